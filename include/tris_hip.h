@@ -1,0 +1,167 @@
+/* tris_hip.h -- C ABI of libtris_hip.so: the MI355X (gfx950) kernels of the TRIS Stage-1 hot path.
+ *
+ * The reference (fawnliu/TRIS) has no native layer and no FFI: its hot path is PyTorch ops called from Python
+ * (SURVEY.md 8b).  This header is therefore the boundary a maintainer binds *beneath* the reference's Python
+ * call sites: each entry point below names the reference op (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (ids: int64) unless noted; no torch types, no hidden allocation:
+ *     scratch is passed in (`workspace`, size from the matching *_workspace_bytes helper or documented inline);
+ *   - activations are channels-last: an NHWC tensor is the row-major matrix [B*H*W, C];
+ *   - conv weights are [Cout][kh][kw][Cin] (= torch.channels_last memory of the reference's [Cout,Cin,kh,kw]);
+ *   - `stream` is a hipStream_t (0 = default stream); launches are asynchronous, stateless and re-entrant;
+ *   - return value: 0 on success, otherwise a hipError_t.
+ */
+#ifndef TRIS_HIP_H
+#define TRIS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dense products -------------------------------------------------------------------------------------------
+ * C[b] = act(alpha * opA(A[b]) . opB(B[b]) + bias) + resid[b]        (f32 MFMA, exact f32 accumulate)
+ *   opA: transA=0 -> A[m*lda+k], 1 -> A[k*lda+m];  opB: transB=0 -> B[k*ldb+n], 1 -> B[n*ldb+k]
+ *   bias_mode 1: bias[n], 2: bias[m];  act 0 none, 1 ReLU, 2 QuickGELU x*sigmoid(1.702x)
+ *   workspace (optional, batch==1): enables split-K for small output grids; any size, used opportunistically.
+ * Replaces nn.Linear / 1x1 nn.Conv2d / torch.bmm / matmul on the path: CLIP/clip/model.py:17,27,45 (1x1 convs),
+ * :369-376 (MHA projections, MLP), :562 (text_projection); model/model_stage1.py:36-37,61-63,75; model/attn.py:73-109,
+ * 118-128. */
+int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
+                  int transA, int transB, int batch, long strideA, long strideB, long strideC, const float* bias,
+                  int bias_mode, const float* resid, long ldr, long strideR, int act, float alpha, float* workspace,
+                  long workspace_bytes, void* stream);
+
+/* 3x3 convolution, pad 1, implicit GEMM (no im2col buffer).  CLIP/clip/model.py:21 (Bottleneck.conv2), :212-229 (stem).
+ * fwd: stride 1 or 2.  dgrad: stride 1 only (the only strided conv on the path, the stem's conv1, reads the image and
+ * needs no input gradient).  wgrad: split-K over output pixels; workspace >= 2 slabs of Cout*9*Cin floats, more = faster. */
+int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout, int stride,
+                         void* stream);
+int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* dX, int B, int H, int W, int Cin, int Cout,
+                           void* stream);
+int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout,
+                           int stride, float* workspace, long workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d (training: batch statistics; CLIP/clip/model.py:18,22,28,39; train_stage1.py:288) ---------------------
+ * stats = [mean | invstd | biased var], 3*C floats.  running_* may be NULL (no update).  workspace:
+ * tris_col_workspace_bytes(M, C).  Eval mode = tris_bn_apply with mean=running_mean, invstd=rsqrt(running_var+eps). */
+long tris_col_workspace_bytes(long M, int C);
+int tris_bn_stats_f32(const float* X, long M, int C, float eps, float momentum, float* stats, float* running_mean,
+                      float* running_var, float* workspace, void* stream);
+/* SyncBatchNorm (train_stage1.py:69): gathered = [world][mean(C) | var(C) | count] from every rank */
+int tris_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* stats,
+                             float* running_mean, float* running_var, void* stream);
+/* Y = (X-mean)*invstd*gamma+beta (+resid) (ReLU) -- also the residual add + relu3 of Bottleneck.forward :52-54 */
+int tris_bn_apply_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* resid, float* Y, long M, int C, int relu, void* stream);
+/* backward: dz = dY * (Y > 0) when Y != NULL.  sum_dz = dbeta, sum_dzx = dgamma. */
+int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
+                           long M, int C, float* sum_dz, float* sum_dzx, float* workspace, void* stream);
+int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
+                          const float* gamma, const float* sum_dz, const float* sum_dzx, float inv_count, float* dX,
+                          long M, int C, void* stream);
+/* out[n] = sum_m X[m*ld+n]  (bias gradients).  workspace: tris_col_workspace_bytes(M, N) */
+int tris_colsum_f32(const float* X, long M, int N, long ld, float* out, float* workspace, void* stream);
+
+/* ---- InstanceNorm2d(affine) [+ReLU] on [B, P, C]  (model/attn.py:75,80,85,106) ---------------------------------------- */
+int tris_instnorm_fwd_f32(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* invstd,
+                          int B, int P, int C, float eps, int relu, void* stream);
+int tris_instnorm_bwd_f32(const float* dY, const float* Y, const float* X, const float* gamma, const float* mean,
+                          const float* invstd, float* dX, float* dgamma_part /*[B,C]*/, float* dbeta_part /*[B,C]*/,
+                          int B, int P, int C, int relu, void* stream);
+
+/* ---- LayerNorm over the last dim W <= 1024  (CLIP/clip/model.py:352-358) ------------------------------------------------ */
+int tris_layernorm_fwd_f32(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* rstd,
+                           long rows, int W, float eps, void* stream);
+long tris_layernorm_bwd_workspace_bytes(long rows, int W);
+int tris_layernorm_bwd_f32(const float* dY, const float* X, const float* gamma, const float* mean, const float* rstd,
+                           float* dX, float* dgamma, float* dbeta, long rows, int W, float* workspace, void* stream);
+
+/* ---- pooling / elementwise / layout -------------------------------------------------------------------------------- */
+int tris_avgpool2_fwd_f32(const float* X, float* Y, int B, int H, int W, int C, void* stream); /* model.py:25,37,231 */
+int tris_avgpool2_bwd_f32(const float* dY, float* dX, int B, int H, int W, int C, void* stream);
+#define TRIS_EW_ADD 0       /* O = A + B */
+#define TRIS_EW_AXPY 1      /* O = s*A + B          (model_stage1.py:73-74, the 0.1 residual mix) */
+#define TRIS_EW_RELU_BWD 2  /* O = A * (B > 0)      A = dY, B = Y */
+#define TRIS_EW_QGELU 3     /* O = A*sigmoid(1.702A) (CLIP/clip/model.py:361-363) */
+#define TRIS_EW_QGELU_BWD 4 /* O = A * d/dB quickgelu(B) */
+#define TRIS_EW_MUL 5       /* O = A * B */
+#define TRIS_EW_SCALE 6     /* O = s * A */
+#define TRIS_EW_RELU 7      /* O = max(A, 0) */
+int tris_elementwise_f32(int op, const float* A, const float* B, float* O, long n, float s, void* stream);
+int tris_nchw_to_nhwc_f32(const float* X, float* Y, int B, int C, int H, int W, void* stream);
+
+/* ---- text / ViT transformer pieces --------------------------------------------------------------------------------- */
+/* nn.MultiheadAttention core on packed QKV [N, L, 3W] -> [N, L, W]; head dim 64, L <= 64; causal = the additive
+ * upper-triangular -inf mask of CLIP/clip/model.py:537-543.  (model.py:380-382) */
+int tris_mha_fwd_f32(const float* qkv, float* out, int N, int L, int W, int heads, int causal, void* stream);
+int tris_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv, int N, int L, int W, int heads, int causal,
+                     void* stream);
+/* token_embedding(ids) + positional_embedding[:L]  (model.py:553-554).  bwd: dtok must be zero-filled by the caller */
+int tris_embed_fwd_f32(const long* ids, const float* tok, const float* pos, float* out, int N, int L, int W,
+                       void* stream);
+int tris_embed_bwd_f32(const long* ids, const float* dout, float* dtok, float* dpos, int N, int L, int W, void* stream);
+/* x[arange(N), ids.argmax(-1)]  (model.py:562) */
+int tris_eot_gather_fwd_f32(const long* ids, const float* x, float* out, int N, int L, int W, void* stream);
+int tris_eot_gather_bwd_f32(const long* ids, const float* dout, float* dx, int N, int L, int W, void* stream);
+
+/* ---- Stage-1 heads ------------------------------------------------------------------------------------------------- */
+/* x / x.norm(dim=-1)  (model_stage1.py:68-69; train_stage1.py:268-269) */
+int tris_l2norm_fwd_f32(const float* X, float* Y, float* inv_norm, long rows, int C, void* stream);
+int tris_l2norm_bwd_f32(const float* dY, const float* Y, const float* inv_norm, float* dX, long rows, int C,
+                        void* stream);
+/* softmax(scale * x) over rows of length n  (model/attn.py:119,122) */
+int tris_softmax_fwd_f32(const float* X, float* Y, long rows, int n, float scale, void* stream);
+int tris_softmax_bwd_f32(const float* dY, const float* Y, float* dX, long rows, int n, float scale, void* stream);
+/* training cls head on score [B,P,N]: bg channel + channel softmax + mean/max pooling + focal term
+ * (model_stage1.py:80-108, focal_loss :122-123).  cls_fg may be NULL. */
+int tris_cls_head_fwd_f32(const float* score, float* cls_out, float* cls_fg, int B, int P, int N, float focal_p,
+                          float focal_c, void* stream);
+int tris_cls_head_bwd_f32(const float* score, const float* g_cls_out, float* dscore, int B, int P, int N, float focal_p,
+                          float focal_c, void* stream);
+/* diagonal response maps score[i,:,i] -> bilinear (align_corners=False) to SxS -> relu / sigmoid
+ * (model_stage1.py:110-119, model/utils.py:5-10).  sig_map may be NULL (eval).  bwd ACCUMULATES into dscore. */
+int tris_maps_fwd_f32(const float* score, float* relu_map, float* sig_map, int B, int h, int w, int N, int S,
+                      void* stream);
+int tris_maps_bwd_f32(const float* score, const float* d_relu, const float* d_sig, float* dscore, int B, int h, int w,
+                      int N, int S, void* stream);
+/* F.interpolate(mode='bilinear') on [planes, Hi, Wi] (train_stage1.py:328-329, validate.py:180) */
+int tris_resize_bilinear_fwd_f32(const float* X, float* Y, int planes, int Hi, int Wi, int Ho, int Wo,
+                                 int align_corners, void* stream);
+int tris_resize_bilinear_bwd_f32(const float* dY, float* dX, int planes, int Hi, int Wi, int Ho, int Wo,
+                                 int align_corners, void* stream);
+/* fg = cam * img written directly as the aux ViT's patch-GEMM operand [B, (R/ps)^2, C*ps*ps]
+ * (train_stage1.py:333-338 + CLIP/clip/model.py:405,420-422) */
+int tris_fg_patch_fwd_f32(const float* cam, const float* img, float* patches, int B, int C, int R, int ps,
+                          void* stream);
+int tris_fg_patch_bwd_f32(const float* dpatches, const float* img, float* dcam, int B, int C, int R, int ps,
+                          void* stream);
+/* class token + positional embedding (CLIP/clip/model.py:423-424) */
+int tris_vit_assemble_fwd_f32(const float* emb, const float* cls, const float* pos, float* x, int B, int T, int W,
+                              void* stream);
+int tris_vit_assemble_bwd_f32(const float* dx, float* demb, int B, int T, int W, void* stream);
+/* The whole loss block: fg_loss = MaxLoss(clip_forward) (train_stage1.py:263-284,340), cbs_loss (:342-353),
+ * cls_loss = multilabel_soft_margin_loss(cls, eye) (:354), loss = w1*l1 + w4*l4 + w5*l5 (:364).
+ * per_img: scratch [B,3]; rowloss: scratch [B]; losses[4] = {total, l1, l4, l5}.  fneg may be NULL when K == 0.
+ * bwd: g3 = device {dL/dl1, dL/dl5, dL/dl4}. */
+int tris_stage1_loss_fwd_f32(const float* cls, const float* fi, const float* ft, const float* fneg, int B, int N, int E,
+                             int K, float w1, float w4, float w5, float* per_img, float* rowloss, float* losses,
+                             void* stream);
+int tris_stage1_loss_bwd_f32(const float* cls, const float* fi, const float* ft, const float* fneg, const float* g3,
+                             int B, int N, int E, int K, float* dcls, float* dfi, void* stream);
+
+/* ---- optimiser ----------------------------------------------------------------------------------------------------- */
+/* torch.optim.AdamW step over a flat arena (train_stage1.py:135-139, 370); step_count is the 1-based t */
+int tris_adamw_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step_count, void* stream);
+
+/* ---- evaluation post-processing (validate.py:180-190, utils/util.py:9-15) ------------------------------------------- */
+/* relu_map [S,S] of ONE (image, sentence) -> cam [oH,oW] = bilinear(align_corners=True)/(max+1e-5); mask = cam > 1e-9;
+ * out_iu (int64[3], device) = {I, U, argmax index of cam}; target: uint8 [oH,oW].  cam may be NULL. */
+int tris_eval_post_f32(const float* relu_map, int S, const unsigned char* target, int oH, int oW, float* cam,
+                       long* out_iu, float* workspace /* >= 2*1024+8 floats */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIS_HIP_H */

@@ -1,0 +1,251 @@
+// Transformer-side kernels: fused multi-head self-attention for short sequences (L <= 64, head dim 64),
+// token embedding, EOT-row gather.  (CLIP text encoder L=20 causal; aux ViT-B/32 L=50 unmasked.)
+//
+// One workgroup per (head, sequence): Q/K/V tiles of the packed QKV activation are staged in LDS (row pad 1 ->
+// conflict-free column walks), scores and probabilities live in LDS, the row softmax is a 64-lane wavefront
+// shuffle reduction.  The FLOPs here are ~1% of the step, so this is VALU f32, not MFMA.
+#include "common.h"
+#include "tris_hip.h"
+
+namespace {
+
+constexpr int HD = 64;       // head dim
+constexpr int HP = HD + 1;   // padded LDS row
+
+// qkv: [N, L, 3W] packed (q | k | v), out: [N, L, W]
+__global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
+                                                      int W, int causal, float scale) {
+  extern __shared__ float sm[];
+  float* q = sm;
+  float* k = q + L * HP;
+  float* v = k + L * HP;
+  float* s = v + L * HP;  // [L][L+1]
+  const int LP = L + 1;
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* base = qkv + (long)n * L * 3 * W + h * HD;
+  for (int idx = tid; idx < L * HD; idx += 256) {
+    int l = idx >> 6, d = idx & 63;
+    const float* r = base + (long)l * 3 * W + d;
+    q[l * HP + d] = r[0];
+    k[l * HP + d] = r[W];
+    v[l * HP + d] = r[2 * W];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * L; idx += 256) {
+    int i = idx / L, j = idx - i * L;
+    float acc = -INFINITY;
+    if (!causal || j <= i) {
+      acc = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < HD; ++d) acc += q[i * HP + d] * k[j * HP + d];
+      acc *= scale;
+    }
+    s[i * LP + j] = acc;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int i = wv; i < L; i += 4) {
+    float x = lane < L ? s[i * LP + lane] : -INFINITY;
+    float m = wave_max(x);
+    float e = lane < L ? expf(x - m) : 0.f;
+    float sum = wave_sum(e);
+    if (lane < L) s[i * LP + lane] = e / sum;
+  }
+  __syncthreads();
+  float* ob = out + (long)n * L * W + h * HD;
+  for (int idx = tid; idx < L * HD; idx += 256) {
+    int i = idx >> 6, d = idx & 63;
+    float acc = 0.f;
+    for (int j = 0; j < L; ++j) acc += s[i * LP + j] * v[j * HP + d];
+    ob[(long)i * W + d] = acc;
+  }
+}
+
+// dqkv: [N, L, 3W]; recomputes P from q,k.
+__global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                      float* __restrict__ dqkv, int L, int W, int causal, float scale) {
+  extern __shared__ float sm[];
+  float* q = sm;
+  float* k = q + L * HP;
+  float* v = k + L * HP;
+  float* g = v + L * HP;   // dO
+  float* s = g + L * HP;   // P  [L][L+1]
+  float* ds = s + L * (L + 1);  // dP -> dS
+  const int LP = L + 1;
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* base = qkv + (long)n * L * 3 * W + h * HD;
+  const float* gb = dout + (long)n * L * W + h * HD;
+  for (int idx = tid; idx < L * HD; idx += 256) {
+    int l = idx >> 6, d = idx & 63;
+    const float* r = base + (long)l * 3 * W + d;
+    q[l * HP + d] = r[0];
+    k[l * HP + d] = r[W];
+    v[l * HP + d] = r[2 * W];
+    g[l * HP + d] = gb[(long)l * W + d];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * L; idx += 256) {
+    int i = idx / L, j = idx - i * L;
+    float acc = -INFINITY, dp = 0.f;
+    if (!causal || j <= i) {
+      acc = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < HD; ++d) {
+        acc += q[i * HP + d] * k[j * HP + d];
+        dp += g[i * HP + d] * v[j * HP + d];
+      }
+      acc *= scale;
+    }
+    s[i * LP + j] = acc;
+    ds[i * LP + j] = dp;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int i = wv; i < L; i += 4) {
+    float x = lane < L ? s[i * LP + lane] : -INFINITY;
+    float m = wave_max(x);
+    float e = lane < L ? expf(x - m) : 0.f;
+    float sum = wave_sum(e);
+    float p = e / sum;
+    float dp = lane < L ? ds[i * LP + lane] : 0.f;
+    float delta = wave_sum(p * dp);
+    if (lane < L) {
+      s[i * LP + lane] = p;
+      ds[i * LP + lane] = p * (dp - delta) * scale;  // dS, pre-multiplied by the 1/sqrt(d) of the logits
+    }
+  }
+  __syncthreads();
+  float* ob = dqkv + (long)n * L * 3 * W + h * HD;
+  for (int idx = tid; idx < L * HD; idx += 256) {
+    int i = idx >> 6, d = idx & 63;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < L; ++j) {
+      dq += ds[i * LP + j] * k[j * HP + d];
+      dk += ds[j * LP + i] * q[j * HP + d];
+      dv += s[j * LP + i] * g[j * HP + d];
+    }
+    float* r = ob + (long)i * 3 * W + d;
+    r[0] = dq;
+    r[W] = dk;
+    r[2 * W] = dv;
+  }
+}
+
+__global__ void embed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ tok,
+                                 const float* __restrict__ pos, float* __restrict__ out, long NL, int L, int W) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W4 = W >> 2;
+  if (i >= NL * W4) return;
+  long t = i / W4;
+  int c = (int)(i - t * W4) * 4;
+  int l = (int)(t % L);
+  float4 a = *reinterpret_cast<const float4*>(tok + ids[t] * W + c);
+  float4 b = *reinterpret_cast<const float4*>(pos + (long)l * W + c);
+  *reinterpret_cast<float4*>(out + t * W + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// dTok must be zero-filled by the caller; dPos[l] = sum_n dOut[n,l] (deterministic, rows >= L untouched).
+__global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ dtok,
+                                 float* __restrict__ dpos, int N, int L, int W) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long NLW = (long)N * L * W;
+  if (i < NLW) {
+    long t = i / W;
+    int c = (int)(i - t * W);
+    atomicAdd(dtok + ids[t] * W + c, dout[i]);
+  }
+  if (i < (long)L * W) {
+    int l = (int)(i / W), c = (int)(i - (long)l * W);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dout[((long)n * L + l) * W + c];
+    dpos[(long)l * W + c] = s;
+  }
+}
+
+// out[n] = x[n, argmax_l ids[n,l]]  (first maximal index, as torch.argmax)
+__global__ void eot_gather_kernel(const long* __restrict__ ids, const float* __restrict__ x, float* __restrict__ out,
+                                  float* __restrict__ dx, const float* __restrict__ dout, int L, int W) {
+  const int n = blockIdx.x;
+  int best = 0;
+  long bv = ids[(long)n * L];
+  for (int l = 1; l < L; ++l) {
+    long vv = ids[(long)n * L + l];
+    if (vv > bv) { bv = vv; best = l; }
+  }
+  if (out) {
+    for (int c = threadIdx.x; c < W; c += blockDim.x) out[(long)n * W + c] = x[((long)n * L + best) * W + c];
+  } else {  // backward: dx is [N,L,W], all rows zero except the gathered one
+    for (int i = threadIdx.x; i < L * W; i += blockDim.x) {
+      int l = i / W, c = i - l * W;
+      dx[(long)n * L * W + i] = (l == best) ? dout[(long)n * W + c] : 0.f;
+    }
+  }
+}
+
+// both kernels may need more than the default 64 KB of dynamic LDS (L = 50..64)
+int mha_init() {
+  static int state = -1;
+  if (state < 0) {
+    hipError_t a = hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipError_t b = hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    state = (a != hipSuccess) ? (int)a : (int)b;
+  }
+  return state;
+}
+
+}  // namespace
+
+extern "C" int tris_mha_fwd_f32(const float* qkv, float* out, int N, int L, int W, int heads, int causal, void* stream) {
+  if (W != heads * HD || L > 64 || L < 1) return (int)hipErrorInvalidValue;
+  size_t lds = (size_t)(3 * L * HP + L * (L + 1)) * sizeof(float);
+  if (int e = mha_init()) return e;
+  hipLaunchKernelGGL(mha_fwd_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, qkv, out, L, W, causal,
+                     0.125f);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv, int N, int L, int W, int heads,
+                                int causal, void* stream) {
+  if (W != heads * HD || L > 64 || L < 1) return (int)hipErrorInvalidValue;
+  size_t lds = (size_t)(4 * L * HP + 2 * L * (L + 1)) * sizeof(float);
+  if (int e = mha_init()) return e;
+  hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, qkv, dout, dqkv, L, W, causal,
+                     0.125f);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_embed_fwd_f32(const long* ids, const float* tok, const float* pos, float* out, int N, int L, int W,
+                                  void* stream) {
+  if (W % 4) return (int)hipErrorInvalidValue;
+  long n = (long)N * L * (W / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, tok, pos, out,
+                     (long)N * L, L, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_embed_bwd_f32(const long* ids, const float* dout, float* dtok, float* dpos, int N, int L, int W,
+                                  void* stream) {
+  long n = (long)N * L * W;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, dout, dtok, dpos, N,
+                     L, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_eot_gather_fwd_f32(const long* ids, const float* x, float* out, int N, int L, int W, void* stream) {
+  hipLaunchKernelGGL(eot_gather_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ids, x, out, (float*)nullptr,
+                     (const float*)nullptr, L, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_eot_gather_bwd_f32(const long* ids, const float* dout, float* dx, int N, int L, int W,
+                                       void* stream) {
+  hipLaunchKernelGGL(eot_gather_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ids, (const float*)nullptr,
+                     (float*)nullptr, dx, dout, L, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}

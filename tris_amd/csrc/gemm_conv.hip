@@ -1,0 +1,496 @@
+// MFMA GEMM / implicit-GEMM convolution core for the TRIS Stage-1 hot path (gfx950).
+//
+// One templated kernel serves every dense product on the path:
+//   * Linear / 1x1 conv (NHWC => plain GEMM), their dgrad (NN) and wgrad (TN, split-K)
+//   * 3x3 conv forward, dgrad and wgrad as implicit GEMM (the im2col gather lives in the tile loaders)
+//   * batched products of the cross-modal attention
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in / f32 accumulate, bit-equal to an fmaf chain.  That is what the
+// 1e-3 fp32 parity bar of the north star needs; roofline = 157.3 TFLOP/s (MI355X_MICROARCH.md).
+//
+// Tile: BM x BN x 16, 256 threads = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2) as 32x32 MFMA fragments.
+// LDS image is k-major (As[k][m], Bs[k][n], row pad 4) so a fragment read is 32 consecutive floats per half-wave
+// (conflict-free ds_read_b32).  Global loads for tile t+1 are issued before the MFMA block of tile t
+// (register staging), stored to LDS after it.
+#include "common.h"
+#include "tris_hip.h"
+
+namespace {
+
+enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2 };
+enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3 };
+enum { EPI_STD = 0, EPI_SLAB = 1 };
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long sA, sB, sC;  // batch strides (elements)
+  const float* bias;
+  int bias_mode;  // 0 none, 1 per column n, 2 per row m
+  const float* resid;
+  long ldr, sR;
+  int act;  // 0 none, 1 relu, 2 quick-gelu
+  float alpha;
+  int vecA, vecB;  // 16-byte vector loads legal for the operand
+  int kchunk, splitk;
+  int tiles_n;
+  // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
+  int gH, gW, gC, gHo, gWo, gStride;
+  int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
+};
+
+constexpr int BK = 16;
+constexpr int PAD = 4;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int BM, int BN, int AK, int BKIND, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 32, FN = WN / 32;
+  constexpr int PA = BM / 64, PB = BN / 64;  // float4 per thread per tile
+  __shared__ float As[BK][BM + PAD];
+  __shared__ float Bs[BK][BN + PAD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
+  const int zb = blockIdx.z / p.splitk;  // batch index
+  const int zs = blockIdx.z % p.splitk;  // k slice
+  const int kbeg = zs * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+
+  const float* __restrict__ A = p.A + (long)zb * p.sA;
+  const float* __restrict__ Bp = p.B + (long)zb * p.sB;
+
+  // ---- per-thread loader state ------------------------------------------------------------------------
+  // A, k-contiguous kinds (ROWK / IM2COL): thread -> (row = tid>>2 + 64*pass, kofs = (tid&3)*4)
+  // A COLK and B KN*: thread -> (k = tid / F4 + pass*RPP, col4 = (tid % F4)*4), F4 = tile_width/4
+  int a_b[PA], a_iy0[PA], a_ix0[PA];
+  bool a_ok[PA];
+  if (AK == A_IM2COL) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      int m = m0 + (tid >> 2) + q * 64;
+      a_ok[q] = m < p.M;
+      int mm = a_ok[q] ? m : 0;
+      int hw = p.gHo * p.gWo;
+      a_b[q] = mm / hw;
+      int r = mm - a_b[q] * hw;
+      int oy = r / p.gWo, ox = r - oy * p.gWo;
+      a_iy0[q] = oy * p.gStride - 1;
+      a_ix0[q] = ox * p.gStride - 1;
+    }
+  }
+  // B_KN_IM2COL: column j = (tap, ci) is fixed per thread
+  int bj_tap = 0, bj_ci = 0;
+  if (BKIND == B_KN_IM2COL) {
+    constexpr int F4 = BN / 4;
+    int j = n0 + (tid % F4) * 4;
+    bj_tap = j / p.gC;
+    bj_ci = j - bj_tap * p.gC;
+  }
+
+  float4 ra[PA], rb[PB];
+
+  auto load_A = [&](int k0) {
+    if (AK == A_ROWK) {
+      const int kk = k0 + (tid & 3) * 4;
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        int m = m0 + (tid >> 2) + q * 64;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < p.M) {
+          const float* src = A + (long)m * p.lda + kk;
+          if (p.vecA && kk + 3 < kend) {
+            v = ld4(src);
+          } else {
+            if (kk + 0 < kend) v.x = src[0];
+            if (kk + 1 < kend) v.y = src[1];
+            if (kk + 2 < kend) v.z = src[2];
+            if (kk + 3 < kend) v.w = src[3];
+          }
+        }
+        ra[q] = v;
+      }
+    } else if (AK == A_COLK) {
+      constexpr int F4 = BM / 4, RPP = 256 / F4;
+      const int mc = m0 + (tid % F4) * 4;
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        int kk = k0 + tid / F4 + q * RPP;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < kend) {
+          const float* src = A + (long)kk * p.lda + mc;
+          if (p.vecA && mc + 3 < p.M) {
+            v = ld4(src);
+          } else {
+            if (mc + 0 < p.M) v.x = src[0];
+            if (mc + 1 < p.M) v.y = src[1];
+            if (mc + 2 < p.M) v.z = src[2];
+            if (mc + 3 < p.M) v.w = src[3];
+          }
+        }
+        ra[q] = v;
+      }
+    } else {  // A_IM2COL: k = tap*gC + ci
+      const int kk = k0 + (tid & 3) * 4;
+      if (p.vecA) {  // gC % 16 == 0: the whole 16-wide k tile sits inside one tap
+        const int tap = kk / p.gC, ci = kk - tap * p.gC;
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+          int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a_ok[q] && kk < kend && (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW)
+            v = ld4(A + ((long)(a_b[q] * p.gH + iy) * p.gW + ix) * p.gC + ci);
+          ra[q] = v;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int k = kk + e;
+            float v = 0.f;
+            if (a_ok[q] && k < kend) {
+              int tap = k / p.gC, ci = k - tap * p.gC;
+              int ky = tap / 3, kx = tap - ky * 3;
+              int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;
+              if ((unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW)
+                v = A[((long)(a_b[q] * p.gH + iy) * p.gW + ix) * p.gC + ci];
+            }
+            t[e] = v;
+          }
+          ra[q] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+    }
+  };
+
+  auto load_B = [&](int k0) {
+    if (BKIND == B_NK) {  // B[n*ldb + k]
+      const int kk = k0 + (tid & 3) * 4;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        int n = n0 + (tid >> 2) + q * 64;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.N) {
+          const float* src = Bp + (long)n * p.ldb + kk;
+          if (p.vecB && kk + 3 < kend) {
+            v = ld4(src);
+          } else {
+            if (kk + 0 < kend) v.x = src[0];
+            if (kk + 1 < kend) v.y = src[1];
+            if (kk + 2 < kend) v.z = src[2];
+            if (kk + 3 < kend) v.w = src[3];
+          }
+        }
+        rb[q] = v;
+      }
+    } else {
+      constexpr int F4 = BN / 4, RPP = 256 / F4;
+      const int nc = n0 + (tid % F4) * 4;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        int kk = k0 + tid / F4 + q * RPP;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < kend) {
+          if (BKIND == B_KN || BKIND == B_KN_DGRAD) {
+            const float* src;
+            if (BKIND == B_KN) {
+              src = Bp + (long)kk * p.ldb + nc;
+            } else {  // k = tap'*Cout + co ; B[k][ci] = W[co][8 - tap'][ci]
+              int tapp = kk / p.wCout, co = kk - tapp * p.wCout;
+              src = Bp + ((long)co * 9 + (8 - tapp)) * p.wCin + nc;
+            }
+            if (p.vecB && nc + 3 < p.N) {
+              v = ld4(src);
+            } else {
+              if (nc + 0 < p.N) v.x = src[0];
+              if (nc + 1 < p.N) v.y = src[1];
+              if (nc + 2 < p.N) v.z = src[2];
+              if (nc + 3 < p.N) v.w = src[3];
+            }
+          } else {  // B_KN_IM2COL: k = output pixel, column = (tap, ci) of the gathered input
+            int hw = p.gHo * p.gWo;
+            int b = kk / hw;
+            int r = kk - b * hw;
+            int oy = r / p.gWo, ox = r - oy * p.gWo;
+            if (p.vecB) {  // gC % 4 == 0: 4 consecutive columns share the tap
+              if (nc < p.N) {
+                int ky = bj_tap / 3, kx = bj_tap - ky * 3;
+                int iy = oy * p.gStride - 1 + ky, ix = ox * p.gStride - 1 + kx;
+                if ((unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW)
+                  v = ld4(Bp + ((long)(b * p.gH + iy) * p.gW + ix) * p.gC + bj_ci);
+              }
+            } else {
+              float t[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                int j = nc + e;
+                float x = 0.f;
+                if (j < p.N) {
+                  int tap = j / p.gC, ci = j - tap * p.gC;
+                  int ky = tap / 3, kx = tap - ky * 3;
+                  int iy = oy * p.gStride - 1 + ky, ix = ox * p.gStride - 1 + kx;
+                  if ((unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW)
+                    x = Bp[((long)(b * p.gH + iy) * p.gW + ix) * p.gC + ci];
+                }
+                t[e] = x;
+              }
+              v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+          }
+        }
+        rb[q] = v;
+      }
+    }
+  };
+
+  auto store_lds = [&]() {
+    if (AK == A_ROWK || AK == A_IM2COL) {
+      const int c = (tid & 3) * 4;
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        int r = (tid >> 2) + q * 64;
+        As[c + 0][r] = ra[q].x;
+        As[c + 1][r] = ra[q].y;
+        As[c + 2][r] = ra[q].z;
+        As[c + 3][r] = ra[q].w;
+      }
+    } else {
+      constexpr int F4 = BM / 4, RPP = 256 / F4;
+#pragma unroll
+      for (int q = 0; q < PA; ++q)
+        *reinterpret_cast<float4*>(&As[tid / F4 + q * RPP][(tid % F4) * 4]) = ra[q];
+    }
+    if (BKIND == B_NK) {
+      const int c = (tid & 3) * 4;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        int r = (tid >> 2) + q * 64;
+        Bs[c + 0][r] = rb[q].x;
+        Bs[c + 1][r] = rb[q].y;
+        Bs[c + 2][r] = rb[q].z;
+        Bs[c + 3][r] = rb[q].w;
+      }
+    } else {
+      constexpr int F4 = BN / 4, RPP = 256 / F4;
+#pragma unroll
+      for (int q = 0; q < PB; ++q)
+        *reinterpret_cast<float4*>(&Bs[tid / F4 + q * RPP][(tid % F4) * 4]) = rb[q];
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kbeg < kend) {
+    load_A(kbeg);
+    load_B(kbeg);
+    store_lds();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = (k0 + BK) < kend;
+      if (more) {
+        load_A(k0 + BK);
+        load_B(k0 + BK);
+      }
+      const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = As[kk + kh][wm * WM + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = Bs[kk + kh][wn * WN + j * 32 + li];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        store_lds();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --------------
+  const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < p.M && col < p.N) {
+          float v = acc[i][j][r];
+          if (EPI == EPI_SLAB) {
+            p.C[((long)blockIdx.z * p.M + row) * p.N + col] = v;
+          } else {
+            v *= p.alpha;
+            if (p.bias_mode == 1) v += p.bias[col];
+            else if (p.bias_mode == 2) v += p.bias[row];
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
+            if (p.resid) v += p.resid[(long)zb * p.sR + (long)row * p.ldr + col];
+            p.C[(long)zb * p.sC + (long)row * p.ldc + col] = v;
+          }
+        }
+      }
+    }
+}
+
+// Sum split-K slabs (ws[s][M][N]) and apply the standard epilogue.
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmParams p) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)p.M * p.N;
+  if (idx >= total) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += ws[(long)s * total + idx];
+  int row = (int)(idx / p.N), col = (int)(idx - (long)row * p.N);
+  v *= p.alpha;
+  if (p.bias_mode == 1) v += p.bias[col];
+  else if (p.bias_mode == 2) v += p.bias[row];
+  if (p.act == 1) v = fmaxf(v, 0.f);
+  else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
+  if (p.resid) v += p.resid[(long)row * p.ldr + col];
+  p.C[(long)row * p.ldc + col] = v;
+}
+
+template <int AK, int BKIND>
+int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
+  // tile choice: biggest tile that still gives the 256 CUs something to do
+  int bm, bn;
+  long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
+  if (p.N <= 64) {
+    bn = 64;
+    bm = ((long)cdiv(p.M, 128) * batch >= 256) ? 128 : 64;
+  } else if (t128 >= 192) {
+    bm = bn = 128;
+  } else {
+    bm = bn = 64;
+  }
+  int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
+  long tiles = (long)tiles_m * tiles_n * batch;
+  p.tiles_n = tiles_n;
+  // split-K when the output grid cannot fill the chip and K is long (wgrad, small-M linears)
+  int splitk = 1;
+  if (batch == 1 && ws != nullptr && tiles < 192 && p.K >= 512) {
+    splitk = (int)min((long)cdiv(384, tiles), (long)(p.K / 256));
+    long per = (long)p.M * p.N * sizeof(float);
+    if ((long)splitk * per > ws_bytes) splitk = (int)(ws_bytes / per);
+    if (splitk < 2) splitk = 1;
+  }
+  p.splitk = splitk;
+  p.kchunk = cdiv(cdiv(p.K, splitk), BK) * BK;
+  if (splitk > 1) splitk = cdiv(p.K, p.kchunk), p.splitk = splitk;
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(batch * splitk));
+  float* Cfinal = p.C;
+#define TRIS_GO(BM_, BN_)                                                                     \
+  do {                                                                                        \
+    if (splitk > 1) {                                                                         \
+      p.C = ws;                                                                               \
+      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AK, BKIND, EPI_SLAB>), grid, dim3(256), 0, st, p); \
+    } else {                                                                                  \
+      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AK, BKIND, EPI_STD>), grid, dim3(256), 0, st, p);  \
+    }                                                                                         \
+  } while (0)
+  if (bm == 128 && bn == 128) TRIS_GO(128, 128);
+  else if (bm == 128 && bn == 64) TRIS_GO(128, 64);
+  else TRIS_GO(64, 64);
+#undef TRIS_GO
+  TRIS_LAUNCH_CHECK();
+  if (splitk > 1) {
+    p.C = Cfinal;
+    long total = (long)p.M * p.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, splitk, p);
+    TRIS_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
+                             long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
+                             const float* bias, int bias_mode, const float* resid, long ldr, long sR, int act,
+                             float alpha, float* workspace, long ws_bytes, void* stream) {
+  if (M <= 0 || N <= 0 || batch <= 0) return 0;
+  if (K <= 0) return (int)hipErrorInvalidValue;
+  GemmParams p = {};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;
+  p.bias = bias; p.bias_mode = bias ? bias_mode : 0;
+  p.resid = resid; p.ldr = ldr; p.sR = sR; p.act = act; p.alpha = alpha;
+  p.vecA = al16(A) && (lda % 4 == 0) && (sA % 4 == 0);
+  p.vecB = al16(B) && (ldb % 4 == 0) && (sB % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (!transA && transB) return launch_cfg<A_ROWK, B_NK>(p, batch, workspace, ws_bytes, st);
+  if (!transA && !transB) return launch_cfg<A_ROWK, B_KN>(p, batch, workspace, ws_bytes, st);
+  if (transA && !transB) return launch_cfg<A_COLK, B_KN>(p, batch, workspace, ws_bytes, st);
+  return launch_cfg<A_COLK, B_NK>(p, batch, workspace, ws_bytes, st);
+}
+
+// Y[B,Ho,Wo,Cout] = conv3x3(X[B,H,W,Cin], Wt[Cout][3][3][Cin]), pad 1, stride 1|2, optional fused ReLU-less epilogue.
+extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout,
+                                    int stride, void* stream) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  GemmParams p = {};
+  p.A = X; p.B = Wt; p.C = Y;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+  p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.vecA = al16(X) && (Cin % 16 == 0);
+  p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
+  return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+// dX[B,H,W,Cin] = conv3x3_transpose(dY[B,H,W,Cout], Wt), stride 1 only: a 3x3 conv of dY with the taps mirrored.
+extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* dX, int B, int H, int W, int Cin,
+                                      int Cout, void* stream) {
+  GemmParams p = {};
+  p.A = dY; p.B = Wt; p.C = dX;
+  p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
+  p.ldc = Cin; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cout; p.gHo = H; p.gWo = W; p.gStride = 1;
+  p.wCin = Cin; p.wCout = Cout;
+  p.vecA = al16(dY) && (Cout % 16 == 0);
+  p.vecB = al16(Wt) && (Cin % 4 == 0);
+  if (Cout % 16 != 0) return (int)hipErrorInvalidValue;  // k tile must not straddle taps for the B loader
+  return launch_cfg<A_IM2COL, B_KN_DGRAD>(p, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+// dW[Cout][3][3][Cin] = sum over output pixels of dY (x) gathered X.  Split-K over pixels through `workspace`.
+extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin,
+                                      int Cout, int stride, float* workspace, long ws_bytes, void* stream) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  GemmParams p = {};
+  p.A = dY; p.B = X; p.C = dW;
+  p.M = Cout; p.N = 9 * Cin; p.K = B * Ho * Wo;
+  p.lda = Cout; p.ldc = 9L * Cin; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.vecA = al16(dY) && (Cout % 4 == 0);
+  p.vecB = al16(X) && (Cin % 4 == 0);
+  return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, (hipStream_t)stream);
+}
