@@ -1,0 +1,373 @@
+"""Per-kernel parity: every HIP op (through the C ABI, via tris_amd.ops) against a plain PyTorch fp32 CPU
+reference of the same op, forward and backward.  Tolerances are fp32-roundoff class (the MFMA path is exact f32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+def dev(t):
+    return t.cuda()
+
+
+def close(a, b, tol=TOL, name=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, f"{name}: max err {err:.3e} (ref scale {ref:.3e})"
+
+
+def leaf(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).requires_grad_(True)
+
+
+def gpu_leaf(t):
+    return t.detach().clone().cuda().requires_grad_(True)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tris_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 48, 1024), (130, 70, 52), (256, 256, 64), (48, 1024, 2048), (7, 5, 27),
+                                   (3000, 64, 64), (1000, 200, 16)])
+def test_linear_fwd_bwd(ops, M, N, K):
+    x, w, b, r = leaf(M, K), leaf(N, K, scale=0.1), leaf(N), leaf(M, N)
+    y = x @ w.t() + b + r
+    y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+    gx, gw, gb, gr = gpu_leaf(x), gpu_leaf(w), gpu_leaf(b), gpu_leaf(r)
+    gy = ops.linear(gx, gw, gb, gr)
+    gy.backward(torch.ones_like(gy) * 0.5 + gy.detach() * 0.1)
+    close(gy, y, name="y")
+    close(gx.grad, x.grad, name="dx")
+    close(gw.grad, w.grad, name="dw")
+    close(gb.grad, b.grad, name="db")
+    close(gr.grad, r.grad, name="dresid")
+
+
+def test_linear_relu_and_gelu_epilogues(ops):
+    x, w, b = leaf(70, 96), leaf(40, 96, scale=0.2), leaf(40)
+    y = F.relu(x @ w.t() + b)
+    y.sum().backward()
+    gx, gw, gb = gpu_leaf(x), gpu_leaf(w), gpu_leaf(b)
+    gy = ops.linear(gx, gw, gb, None, 1)
+    gy.sum().backward()
+    close(gy, y)
+    close(gx.grad, x.grad)
+    close(gw.grad, w.grad)
+    with torch.no_grad():
+        h = x @ w.t() + b
+        close(ops.linear(gx, gw, gb, None, 2), h * torch.sigmoid(1.702 * h))
+
+
+@pytest.mark.parametrize("tB", [False, True])
+def test_matmul_and_bmm(ops, tB):
+    A = leaf(3, 50, 36)
+    B2 = leaf(20, 36) if tB else leaf(36, 20)
+    C = A @ (B2.t() if tB else B2)
+    C.backward(C.detach())
+    gA, gB = gpu_leaf(A), gpu_leaf(B2)
+    gC = ops.matmul(gA, gB, tB)
+    gC.backward(gC.detach())
+    close(gC, C)
+    close(gA.grad, A.grad)
+    close(gB.grad, B2.grad)
+    # batched, and shared-A batched
+    for shared in (False, True):
+        A3 = leaf(12, 40) if shared else leaf(4, 12, 40)
+        B3 = leaf(4, 9, 40) if tB else leaf(4, 40, 9)
+        ref = torch.matmul(A3, B3.transpose(1, 2) if tB else B3) * 0.5
+        ref.backward(ref.detach())
+        gA3, gB3 = gpu_leaf(A3), gpu_leaf(B3)
+        out = ops.bmm(gA3, gB3, tB, 0.5)
+        out.backward(out.detach())
+        close(out, ref)
+        close(gA3.grad, A3.grad, name="dA")
+        close(gB3.grad, B3.grad, name="dB")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 20, 20, 32, 64, 1), (2, 12, 10, 64, 64, 1), (1, 9, 7, 128, 16, 1),
+                                                     (2, 32, 32, 3, 32, 2), (3, 16, 16, 16, 48, 1)])
+def test_conv3x3(ops, B, H, W, Cin, Cout, stride):
+    x, w = leaf(B, Cin, H, W), leaf(Cout, Cin, 3, 3, scale=0.1)
+    y = F.conv2d(x, w, stride=stride, padding=1)
+    y.backward(y.detach() * 0.1 + 1)
+    gx = x.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(stride == 1)
+    gw = w.detach().clone().contiguous(memory_format=torch.channels_last).cuda().requires_grad_(True)
+    gy = ops.conv3x3(gx, gw, stride)
+    gy.backward(gy.detach() * 0.1 + 1)
+    close(gy.permute(0, 3, 1, 2), y, name="y")
+    close(gw.grad, w.grad, name="dw")
+    if stride == 1:
+        close(gx.grad.permute(0, 3, 1, 2), x.grad, name="dx")
+
+
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+@pytest.mark.parametrize("shape", [(2, 10, 10, 64), (3, 40, 40, 32), (2, 5, 5, 2048)])
+def test_batchnorm_train(ops, shape, res, relu):
+    C = shape[-1]
+    x, g, b = leaf(*shape), leaf(C), leaf(C)
+    x.data = x.data * 2 + 3  # large mean: exercises the shifted-variance path
+    r = leaf(*shape, seed=5) if res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.batch_norm(x.permute(0, 3, 1, 2), rm, rv, g, b, True, 0.1, 1e-5).permute(0, 2, 3, 1)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    (y * y).sum().backward()
+    gx, gg, gb = gpu_leaf(x), gpu_leaf(g), gpu_leaf(b)
+    gr = gpu_leaf(r) if res else None
+    grm, grv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    gy = ops.batch_norm(gx, gg, gb, grm, grv, gr, relu, True)
+    (gy * gy).sum().backward()
+    close(gy, y, name="y")
+    close(grm, rm, name="running_mean")
+    close(grv, rv, name="running_var")
+    close(gx.grad, x.grad, 5e-4, name="dx")
+    close(gg.grad, g.grad, 5e-4, name="dgamma")
+    close(gb.grad, b.grad, 5e-4, name="dbeta")
+    if res:
+        close(gr.grad, r.grad, name="dresid")
+    # eval mode
+    with torch.no_grad():
+        ye = F.batch_norm(x.permute(0, 3, 1, 2), rm, rv, g, b, False, 0.1, 1e-5).permute(0, 2, 3, 1)
+        close(ops.batch_norm(gx, gg, gb, grm, grv, None, False, False), ye, name="eval")
+
+
+def test_avgpool_layernorm_gelu(ops):
+    x = leaf(2, 8, 6, 16)
+    y = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    y.backward(y.detach())
+    gx = gpu_leaf(x)
+    gy = ops.avgpool2(gx)
+    gy.backward(gy.detach())
+    close(gy, y)
+    close(gx.grad, x.grad)
+    for W in (512, 768, 100):
+        x, g, b = leaf(37, W), leaf(W), leaf(W)
+        y = F.layer_norm(x, (W,), g, b, 1e-5)
+        (y * y).sum().backward()
+        gx, gg, gb = gpu_leaf(x), gpu_leaf(g), gpu_leaf(b)
+        gy = ops.layer_norm(gx, gg, gb)
+        (gy * gy).sum().backward()
+        close(gy, y)
+        close(gx.grad, x.grad)
+        close(gg.grad, g.grad)
+        close(gb.grad, b.grad)
+    x = leaf(33, 17)
+    y = x * torch.sigmoid(1.702 * x)
+    y.sum().backward()
+    gx = gpu_leaf(x)
+    gy = ops.quick_gelu(gx)
+    gy.sum().backward()
+    close(gy, y)
+    close(gx.grad, x.grad)
+
+
+@pytest.mark.parametrize("N,L,heads,causal", [(3, 20, 8, True), (2, 50, 12, False), (1, 64, 2, True), (2, 7, 1, False)])
+def test_mha(ops, N, L, heads, causal):
+    W = heads * 64
+    qkv = leaf(N, L, 3 * W)
+    q, k, v = qkv.split(W, dim=-1)
+    q = q.view(N, L, heads, 64).transpose(1, 2)
+    k = k.view(N, L, heads, 64).transpose(1, 2)
+    v = v.view(N, L, heads, 64).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(N, L, W)
+    (o * o).sum().backward()
+    g = gpu_leaf(qkv)
+    go = ops.mha(g, heads, causal)
+    (go * go).sum().backward()
+    close(go, o)
+    close(g.grad, qkv.grad)
+
+
+def test_embed_eot(ops):
+    ids = torch.tensor([[49406, 5, 9, 49407, 0, 0], [49406, 9, 9, 9, 49407, 0], [49406, 7, 49407, 0, 0, 0]])
+    tok, pos = leaf(49408, 64, scale=0.1), leaf(10, 64)
+    x = tok[ids] + pos[:6]
+    h = x[torch.arange(3), ids.argmax(-1)]
+    ((x * x).sum() + (h * 3).sum()).backward()
+    gt, gp = gpu_leaf(tok), gpu_leaf(pos)
+    gx = ops.embed(ids.cuda(), gt, gp)
+    gh = ops.eot_gather(ids.cuda(), gx)
+    ((gx * gx).sum() + (gh * 3).sum()).backward()
+    close(gx, x)
+    close(gh, h)
+    close(gt.grad, tok.grad)
+    close(gp.grad, pos.grad)
+
+
+def test_l2norm_softmax_instnorm_axpy(ops):
+    x = leaf(50, 1024)
+    y = x / x.norm(dim=-1, keepdim=True)
+    (y * torch.arange(1024.0)).sum().backward()
+    gx = gpu_leaf(x)
+    gy = ops.l2norm(gx)
+    (gy * torch.arange(1024.0).cuda()).sum().backward()
+    close(gy, y)
+    close(gx.grad, x.grad)
+    for n in (48, 100, 130):
+        x = leaf(20, n)
+        y = torch.softmax(x / 32.0, -1)
+        (y * y).sum().backward()
+        gx = gpu_leaf(x)
+        gy = ops.softmax(gx, 1 / 32.0)
+        (gy * gy).sum().backward()
+        close(gy, y)
+        close(gx.grad, x.grad)
+    for relu in (True, False):
+        x, g, b = leaf(3, 100, 128), leaf(128), leaf(128)
+        y = F.instance_norm(x.permute(0, 2, 1).reshape(3, 128, 10, 10), None, None, g, b, True, 0.1, 1e-5)
+        y = (F.relu(y) if relu else y).reshape(3, 128, 100).permute(0, 2, 1)
+        (y * y).sum().backward()
+        gx, gg, gb = gpu_leaf(x), gpu_leaf(g), gpu_leaf(b)
+        gy = ops.instance_norm(gx, gg, gb, relu)
+        (gy * gy).sum().backward()
+        close(gy, y)
+        close(gx.grad, x.grad, 5e-4)
+        close(gg.grad, g.grad, 5e-4)
+        close(gb.grad, b.grad, 5e-4)
+    a, b = leaf(7, 9), leaf(7, 9, seed=3)
+    y = 0.1 * a + b
+    y.sum().backward()
+    ga, gb = gpu_leaf(a), gpu_leaf(b)
+    gy = ops.axpy(ga, gb, 0.1)
+    gy.sum().backward()
+    close(gy, y)
+    close(ga.grad, a.grad)
+    close(gb.grad, b.grad)
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo,align", [(10, 10, 320, 320, False), (320, 320, 224, 224, True),
+                                                (32, 32, 45, 61, True), (7, 9, 20, 13, False), (40, 40, 11, 17, True)])
+def test_resize(ops, hi, wi, ho, wo, align):
+    x = leaf(2, 3, hi, wi)
+    y = F.interpolate(x, (ho, wo), mode="bilinear", align_corners=align)
+    (y * y).sum().backward()
+    gx = gpu_leaf(x)
+    gy = ops.resize_bilinear(gx, (ho, wo), align)
+    (gy * gy).sum().backward()
+    close(gy, y)
+    close(gx.grad, x.grad)
+
+
+def _ref_heads(score, h, w, S, fp=3.0, fc=0.01):
+    B, P, N = score.shape
+    st = score.transpose(1, 2).reshape(B, N, h, w)
+    st = torch.cat([torch.ones_like(st[:, :1]), st], 1)
+    masks = torch.softmax(st, 1).view(B, N + 1, -1)
+    feats = st.view(B, N + 1, -1)
+    mm = masks.mean(-1)
+    cls = (feats.mean(-1) + feats.max(-1).values + torch.pow(1 - mm, fp) * torch.log(fc + mm))[:, 1:]
+    diag = torch.stack([score[i, :, i].view(1, h, w) for i in range(B)], 0)
+    seg = F.interpolate(diag, size=(S, S), mode="bilinear", align_corners=False)
+    return cls, torch.diagonal(mm[:, 1:]), F.relu(seg), torch.sigmoid(seg)
+
+
+@pytest.mark.parametrize("B,h,w,S", [(4, 10, 10, 320), (3, 5, 5, 64), (48, 10, 10, 320)])
+def test_score_heads(ops, B, h, w, S):
+    score = leaf(B, h * w, B, scale=3.0)
+    cls, fg, r, s = _ref_heads(score, h, w, S)
+    wr, ws = torch.randn(r.shape, generator=torch.Generator().manual_seed(1)), torch.randn(s.shape, generator=torch.Generator().manual_seed(2))
+    ((cls * cls).sum() + (r * wr).sum() + (s * ws).sum()).backward()
+    g = gpu_leaf(score)
+    gcls, gfg, gr, gs = ops.score_heads(g, h, w, S, True)
+    ((gcls * gcls).sum() + (gr * wr.cuda()).sum() + (gs * ws.cuda()).sum()).backward()
+    close(gcls, cls, name="cls")
+    close(gfg, fg, name="cls_fg")
+    close(gr, r, name="relu")
+    close(gs, s, name="sig")
+    close(g.grad, score.grad, 5e-4, name="dscore")
+    with torch.no_grad():
+        close(ops.score_heads(g, h, w, S, False), r, name="eval")
+
+
+def test_fg_patches_and_vit_assemble(ops):
+    cam, img = leaf(2, 1, 64, 64), leaf(2, 3, 64, 64)
+    fg = cam * img
+    ref = fg.reshape(2, 3, 2, 32, 2, 32).permute(0, 2, 4, 1, 3, 5).reshape(2, 4, 3 * 32 * 32)
+    (ref * ref).sum().backward()
+    gc = gpu_leaf(cam)
+    out = ops.fg_patches(gc, img.detach().cuda(), 32)
+    (out * out).sum().backward()
+    close(out, ref)
+    close(gc.grad, cam.grad)
+    emb, cls, pos = leaf(2, 4, 96), leaf(96), leaf(5, 96)
+    x = torch.cat([cls.expand(2, 1, 96), emb], 1) + pos
+    (x * x).sum().backward()
+    ge = gpu_leaf(emb)
+    gx = ops.vit_assemble(ge, cls.detach().cuda(), pos.detach().cuda())
+    (gx * gx).sum().backward()
+    close(gx, x)
+    close(ge.grad, emb.grad)
+
+
+@pytest.mark.parametrize("K", [3, 0])
+def test_stage1_loss(ops, K):
+    B, E = 6, 512
+    cls, fi, ft = leaf(B, B, scale=2.0), leaf(B, E), leaf(B, E, seed=1)
+    ft.data[:3] += 2.0 * fi.data[:3]  # some clearly positive cosines (un-clamped branch)
+    fneg = leaf(B, K, E, seed=2) if K else None
+    a = fi / fi.norm(dim=-1, keepdim=True)
+    t = ft / ft.norm(dim=-1, keepdim=True)
+    l1 = -(torch.log((a * t).sum(-1).clamp(0.0001, 0.9999))).mean()
+    l5 = torch.zeros(())
+    if K:
+        n = fneg / fneg.norm(dim=-1, keepdim=True)
+        l5 = (-(torch.log(1 - (a[:, None] * n).sum(-1)))).mean(1).mean()
+    l4 = F.multilabel_soft_margin_loss(cls, torch.eye(B))
+    loss = l1 + 5 * l4 + 2 * l5
+    loss.backward()
+    gc, gi = gpu_leaf(cls), gpu_leaf(fi)
+    out = ops.stage1_loss(gc, gi, ft.detach().cuda(), fneg.detach().cuda() if K else None, 1.0, 5.0, 2.0)
+    out[0].backward()
+    close(out, torch.stack([loss, l1, l4, l5]), name="losses")
+    close(gc.grad, cls.grad, name="dcls")
+    close(gi.grad, fi.grad, name="dfi")
+
+
+def test_adamw_matches_torch(ops):
+    from tris_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ps = [torch.randn(33, 7), torch.randn(64, 16, 3, 3).contiguous(memory_format=torch.channels_last), torch.randn(5)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    ours = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    o_ref = torch.optim.AdamW([{"params": ref[:2], "lr": 5e-6}, {"params": ref[2:]}], lr=5e-5, weight_decay=0.01)
+    o_our = FusedAdamW([{"params": ours[:2], "lr": 5e-6}, {"params": ours[2:]}], lr=5e-5, weight_decay=0.01)
+    for step in range(3):
+        for r, o in zip(ref, ours):
+            g = torch.randn(r.shape, generator=torch.Generator().manual_seed(step * 10 + r.dim()))
+            r.grad = g.clone()
+            o.grad.copy_(g.cuda())
+        o_ref.step()
+        o_our.step()
+    for r, o in zip(ref, ours):
+        close(o, r, 1e-6)
+
+
+def test_eval_post(ops):
+    from oracle import tris_oracle as O
+    g = torch.Generator().manual_seed(3)
+    m = F.relu(torch.randn(1, 1, 320, 320, generator=g))
+    m[0, 0, :40] = 0
+    tgt = torch.zeros(427, 640, dtype=torch.bool)
+    tgt[100:300, 50:400] = True
+    I, U, mask, cam = O.eval_postprocess(m, tgt)
+    iu, gcam = ops.eval_post(m.cuda(), tgt.to(torch.uint8).cuda())
+    iu = iu.tolist()
+    close(gcam, cam, 1e-5)
+    assert abs(iu[0] - I) <= 2 and abs(iu[1] - U) <= 2  # exact up to pixels sitting on the 1e-9 threshold
+    assert gcam.flatten()[iu[2]].item() == pytest.approx(float(cam.max()), abs=1e-6)

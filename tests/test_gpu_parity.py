@@ -1,0 +1,233 @@
+"""End-to-end parity of the HIP Stage-1 path (through the drop-in modules -> C ABI) against
+ (a) the committed golden vectors generated from the real reference (tests/golden, oracle/gen_golden.py) and
+ (b) the CPU oracle on other seeded inputs.
+Bar (BASELINE.json north_star): response maps and loss within 1e-3 in fp32; masks identical up to threshold ties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3  # north-star tolerance for fp32 response maps / losses
+
+
+def _args(extra=()):
+    from tris_amd.args import get_parser
+    return get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20",
+                                    "--negative_samples", "3", "--batch_size", "2"] + list(extra))
+
+
+@pytest.fixture(scope="module")
+def model():
+    import warnings
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.utils.synth import seed_fill
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = TRIS(_args()).cuda()
+    seed_fill(m.state_dict(), 1234)
+    return m
+
+
+@pytest.fixture(scope="module")
+def aux():
+    import warnings
+    from tris_amd.CLIP import clip
+    from tris_amd.train_stage1 import freeze_aux
+    from tris_amd.utils.synth import seed_fill
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, _ = clip.load("ViT-B-32", device="cuda", txt_length=20)
+    seed_fill(a.state_dict(), 4321)
+    return freeze_aux(a)
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from tris_amd.utils.synth import synthetic_batch
+    return synthetic_batch(2, 320, 20, 3, seed=7)
+
+
+def refill(m, seed=1234):
+    from tris_amd.utils.synth import seed_fill
+    seed_fill(m.state_dict(), seed)
+
+
+def cpu_sd(m):
+    return {k: v.detach().float().cpu().contiguous().clone() for k, v in m.state_dict().items()}
+
+
+def err(a, b):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.abs(a - b).max())
+
+
+def test_g1_text_encoder(model, batch, golden):
+    g = golden("g1_g2_encoders.npz")
+    model.eval()
+    with torch.no_grad():
+        x, hidden = model.backbone.encode_text(batch["word_ids"].cuda())
+    assert err(hidden, g["text_hidden"]) < 1e-4
+    assert abs(float(x.sum()) - g["text_x_sum"][0]) < 5e-2
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_g2_image_encoder(model, batch, golden, mode):
+    g = golden("g1_g2_encoders.npz")
+    refill(model)
+    model.train(mode == "train")
+    with torch.no_grad():
+        c = model.backbone.encode_image(batch["img"].cuda())
+    assert c[4] is None
+    for i in range(4):
+        assert tuple(c[i].shape[:2]) == (2, 256 << i)
+        assert err(c[i][:, :8, :8, :8], g[f"c{i + 1}_{mode}_crop"]) < 2e-4, i
+        st = g[f"c{i + 1}_{mode}_stat"]
+        assert abs(float(c[i].mean()) - st[0]) < 1e-4 and abs(float(c[i].abs().max()) - st[2]) < 1e-3
+    if mode == "train":
+        assert err(model.backbone.visual.bn1.running_mean, g["bn1_running_mean_after"]) < 1e-5
+        assert err(model.backbone.visual.layer4[2].bn3.running_var, g["l4_bn3_running_var_after"]) < 1e-5
+    refill(model)
+
+
+def test_g3_bilateral_prompt(model, golden):
+    g = golden("g3_bilateral_prompt.npz")
+    gen = torch.Generator().manual_seed(11)
+    for B in (1, 2, 4):
+        vis = torch.randn(B, 1024, 10, 10, generator=gen)
+        vis = vis / vis.norm(dim=1, keepdim=True)
+        lan = torch.randn(B, 1024, B, generator=gen)
+        lan = lan / lan.norm(dim=1, keepdim=True)
+        if B > 1:  # golden inputs use per-image sentence sets; the Stage-1 path shares one set -> check via oracle below
+            continue
+        with torch.no_grad():
+            nv, nl = model.attn_fusion(vis.cuda(), lan.cuda())
+        assert err(nl, g[f"B{B}_new_lan"]) < 1e-4
+        assert err(nv[:, :64], g[f"B{B}_new_vis_crop"]) < 1e-4
+    # shared sentence set, B=3 images x N=5 sentences, against the oracle
+    from oracle import tris_oracle as O
+    vis = torch.randn(3, 1024, 10, 10, generator=gen)
+    vis = vis / vis.norm(dim=1, keepdim=True)
+    lan = torch.randn(1, 1024, 5, generator=gen).repeat(3, 1, 1)
+    lan = lan / lan.norm(dim=1, keepdim=True)
+    with torch.no_grad():
+        onv, onl = O.bilateral_prompt(cpu_sd(model), "attn_fusion", vis, lan)
+        nv, nl = model.attn_fusion(vis.cuda(), lan.cuda())
+    assert err(nv, onv) < 1e-4 and err(nl, onl) < 1e-4
+
+
+def test_g4_forward(model, batch, golden):
+    g = golden("g4_tris_forward.npz")
+    img, ids = batch["img"].cuda(), batch["word_ids"].cuda()
+    refill(model)
+    model.eval()
+    with torch.no_grad():
+        for B in (1, 2):
+            o = model(img[:B], ids[:B])
+            assert o.shape == (B, 1, 320, 320)
+            assert err(o[:, :, ::4, ::4], g[f"eval_B{B}_full_ds4"]) < TOL
+            assert err(o[..., :16, :16], g[f"eval_B{B}_crop"]) < TOL
+    model.train()
+    with torch.no_grad():
+        cls, fg, r, s, ls = model(img, ids)
+    assert err(cls, g["train_cls_out"]) < TOL
+    assert err(fg, g["train_cls_fg"]) < 1e-4
+    assert err(r[:, :, ::4, ::4], g["train_relu_ds4"]) < TOL
+    assert err(s[:, :, ::4, ::4], g["train_sig_ds4"]) < 1e-4
+    assert abs(float(ls) - float(g["train_logit_scale"])) < 1e-4
+    refill(model)
+
+
+def test_g5_g6_train_step(model, aux, batch, golden):
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import train_step
+    g = golden("g5_g6_step.npz")
+    refill(model)
+    model.train()
+    args = _args()
+    bb, new = model.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                     weight_decay=args.weight_decay)
+    named = dict(model.named_parameters())
+    losses = train_step(model, aux, opt, batch["img"].cuda(), batch["word_ids"].cuda(), batch["neg_word_ids"].cuda(),
+                        args).tolist()
+    ref = g["losses"]
+    assert abs(losses[0] - ref[0]) < TOL and abs(losses[1] - ref[1]) < TOL
+    assert abs(losses[2] - ref[2]) < 1e-4 and abs(losses[3] - ref[3]) < 1e-4
+    for k in [n[len("grad_norm."):] for n in g.files if n.startswith("grad_norm.")]:
+        p = named[k]
+        assert p.grad is not None, k
+        gn = float(g["grad_norm." + k])
+        assert abs(float(p.grad.norm()) - gn) <= 1e-3 * gn + 1e-6, (k, float(p.grad.norm()), gn)
+        head = p.grad.reshape(-1)[:16]
+        href = g["grad_head." + k]
+        assert err(head, href) <= 1e-3 * max(np.abs(href).max(), 1e-3 * gn) + 1e-6, k
+        if k != "logit_scale":
+            assert err(p.detach().reshape(-1)[:16], g["after_step." + k]) < 1e-6, k
+    used = torch.from_numpy(g["grad_tok_ids"]).cuda()
+    assert err(named["backbone.token_embedding.weight"].grad[used][:, :8], g["grad_tok_rows"]) < 1e-3 * max(
+        1.0, float(np.abs(g["grad_tok_rows"]).max()))
+    assert err(model.backbone.visual.bn1.running_mean, g["after_step_bn1_running_mean"]) < 1e-5
+    for k in g["nograd_keys"].tolist():
+        assert getattr(named[k], "_tris_no_grad_path", False), k
+
+
+def test_step_vs_oracle_other_seed(aux):
+    """B=3, different weights/inputs: losses, maps and a few gradients against the CPU oracle."""
+    import warnings
+    from oracle import tris_oracle as O
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import stage1_forward_losses
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = TRIS(_args()).cuda()
+    seed_fill(m.state_dict(), 99)
+    m.train()
+    b = synthetic_batch(3, 320, 20, 3, seed=21)
+    sd = cpu_sd(m)
+    auxsd = {k: v.detach().cpu().clone() for k, v in aux.state_dict().items()}
+    bbk, newk = O.trainable_split(sd)
+    for k in bbk + newk + ["logit_scale"]:
+        sd[k].requires_grad_(True)
+    ref = O.stage1_losses(sd, auxsd, b, faithful=False)
+    ref["loss"].backward()
+    bb, new = m.trainable_parameters()
+    FusedAdamW([{"params": bb}, {"params": new}], lr=1e-5)
+    args = _args()
+    losses, cls, sig = stage1_forward_losses(m, aux, b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda(), args)
+    losses[0].backward()
+    lv = losses.tolist()
+    for i, k in enumerate(("loss", "l1", "l4", "l5")):
+        assert abs(lv[i] - float(ref[k])) < TOL, (k, lv[i], float(ref[k]))
+    assert err(cls, ref["cls"]) < TOL and err(sig, ref["sig"]) < 1e-4
+    named = dict(m.named_parameters())
+    for k in ("vis_project.weight", "attn_fusion.v_proj2.0.weight", "attn_fusion.t_proj1.0.weight",
+              "backbone.visual.conv1.weight", "backbone.visual.layer3.0.conv2.weight",
+              "backbone.visual.layer2.0.downsample.1.weight", "backbone.transformer.resblocks.3.mlp.c_proj.weight",
+              "backbone.text_projection", "lan_project.bias"):
+        gr, go = named[k].grad, sd[k].grad
+        scale = float(go.abs().max())
+        assert err(gr, go) <= 2e-3 * scale + 1e-7, (k, err(gr, go), scale)
+
+
+def test_g7_eval_postprocess(model, batch, golden):
+    from tris_amd import ops
+    g = golden("g7_eval.npz")
+    refill(model)
+    model.eval()
+    img, ids = batch["img"].cuda(), batch["word_ids"].cuda()
+    with torch.no_grad():
+        for n in range(3):
+            oh, ow, y0, x0, I, U, am = [int(v) for v in g[f"case{n}"]]
+            o = model(img[n % 2:n % 2 + 1], ids[n % 2:n % 2 + 1])
+            tgt = torch.zeros(oh, ow, dtype=torch.uint8)
+            tgt[y0:y0 + oh // 3, x0:x0 + ow // 3] = 1
+            iu, cam = ops.eval_post(o, tgt.cuda())
+            iu = iu.tolist()
+            assert abs(iu[0] - I) <= 3 and abs(iu[1] - U) <= 3, (iu, I, U)
+            assert err(cam[::8, ::8], g[f"case{n}_cam_ds8"]) < 1e-4
+            # synthetic-target IoU within +-0.1 (percent points) of the reference's
+            assert abs(100.0 * iu[0] / iu[1] - 100.0 * I / U) < 0.1

@@ -1,0 +1,398 @@
+"""CLIP encoders of the TRIS Stage-1 path on MI355X kernels.
+
+Mirrors the module tree, constructor signatures and the state-dict keys of the reference's modified
+CLIP (/root/reference/CLIP/clip/model.py) so checkpoints load unchanged, but every forward is built
+from `tris_amd.ops` (HIP kernels, channels-last activations).  Nothing here runs on CPU: modules can
+be constructed, moved and (de)serialised anywhere, `forward` needs the GPU.
+
+  Bottleneck              CLIP/clip/model.py:10-55
+  AttentionPool2d         :58-104   (parameters kept for checkpoints; output is discarded by Stage-1)
+  ModifiedResNet          :195-279  (returns (c1,c2,c3,c4,[global,local]))
+  ResidualAttentionBlock  :366-386,  Transformer :389-397,  VisionTransformer :400-448
+  CLIP                    :451-580  (encode_text returns (all tokens, projected EOT token) :552-564)
+  build_model             :607-644
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+
+
+class Conv2d(nn.Module):
+    """Bias-free conv holding its weight as [Cout,Cin,k,k] in channels_last memory (kernel layout)."""
+
+    def __init__(self, cin, cout, k, stride=1, bias=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        nn.init.kaiming_uniform_(w, a=5 ** 0.5)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+    def forward(self, x):  # x channels-last [B,H,W,Cin]
+        if self.k == 1:
+            return ops.linear(x, self.weight, self.bias)
+        assert self.k == 3 and self.bias is None
+        return ops.conv3x3(x, self.weight, self.stride)
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d-compatible parameters/buffers; `process_group` set => SyncBatchNorm semantics."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.process_group = None
+
+    def forward(self, x, resid=None, relu=False):
+        if self.training:
+            self.num_batches_tracked += 1
+        group = self.process_group if self.training else None
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
+                              self.training, self.momentum, self.eps, group)
+
+
+class AvgPool2d(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        assert k == 2
+        self.k = k
+
+    def forward(self, x):
+        return ops.avgpool2(x)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3)
+        self.bn2 = BatchNorm2d(planes)
+        self.avgpool = AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3 = Conv2d(planes, planes * self.expansion, 1)
+        self.bn3 = BatchNorm2d(planes * self.expansion)
+        self.downsample = None
+        self.stride = stride
+        if stride > 1 or inplanes != planes * Bottleneck.expansion:
+            self.downsample = nn.Sequential(OrderedDict([
+                ("-1", AvgPool2d(stride) if stride > 1 else nn.Identity()),
+                ("0", Conv2d(inplanes, planes * self.expansion, 1)),
+                ("1", BatchNorm2d(planes * self.expansion)),
+            ]))
+
+    def forward(self, x):  # channels-last
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        out = self.avgpool(out)
+        out = self.conv3(out)
+        if self.downsample is not None:
+            idn = self.downsample[0](x)
+            idn = self.downsample[2](self.downsample[1](idn))
+        else:
+            idn = x
+        return self.bn3(out, resid=idn, relu=True)  # relu(bn3(conv3) + identity), fused
+
+
+class Linear(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_features, self.out_features = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def forward(self, x, resid=None, act=0):
+        return ops.linear(x, self.weight, self.bias, resid, act)
+
+
+class AttentionPool2d(nn.Module):
+    """Kept for state-dict compatibility.  Stage-1 discards its output (model/model_stage1.py:59), so the
+    MI355X path never executes it; calling it raises."""
+
+    def __init__(self, spacial_dim, embed_dim, num_heads, output_dim=None):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
+        self.k_proj = Linear(embed_dim, embed_dim)
+        self.q_proj = Linear(embed_dim, embed_dim)
+        self.v_proj = Linear(embed_dim, embed_dim)
+        self.c_proj = Linear(embed_dim, output_dim or embed_dim)
+        self.num_heads, self.embed_dim, self.spacial_dim = num_heads, embed_dim, spacial_dim
+        for p in self.parameters():
+            p._tris_no_grad_path = True  # never receives a gradient in Stage-1
+
+    def forward(self, x):
+        raise NotImplementedError("AttentionPool2d output is unused by TRIS Stage-1 and is not part of the MI355X path")
+
+
+class ModifiedResNet(nn.Module):
+    def __init__(self, layers, output_dim, heads, input_resolution=224, width=64):
+        super().__init__()
+        self.output_dim, self.input_resolution = output_dim, input_resolution
+        self.conv1 = Conv2d(3, width // 2, 3, stride=2)
+        self.bn1 = BatchNorm2d(width // 2)
+        self.conv2 = Conv2d(width // 2, width // 2, 3)
+        self.bn2 = BatchNorm2d(width // 2)
+        self.conv3 = Conv2d(width // 2, width, 3)
+        self.bn3 = BatchNorm2d(width)
+        self.avgpool = AvgPool2d(2)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0])
+        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
+        self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        layers = [Bottleneck(self._inplanes, planes, stride)]
+        self._inplanes = planes * Bottleneck.expansion
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self._inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward_cl(self, x):
+        """x [B,3,H,W] (NCHW, as the reference's callers pass it) -> (c1,c2,c3,c4) channels-last [B,h,w,C]."""
+        x = ops.nchw_to_nhwc(x.float())
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
+        x = self.bn3(self.conv3(x), relu=True)
+        x = self.avgpool(x)
+        outs = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                x = blk(x)
+            outs.append(x)
+        return tuple(outs)
+
+    def forward(self, x):
+        # reference returns NCHW tensors; hand out NCHW-shaped views of the channels-last buffers (no copy)
+        outs = [o.permute(0, 3, 1, 2) for o in self.forward_cl(x)]
+        outs.append(None)  # [x_global, x_local] of attnpool: discarded by every Stage-1 caller
+        return tuple(outs)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, w, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(w))
+        self.bias = nn.Parameter(torch.zeros(w))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        return ops.quick_gelu(x)
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter layout of nn.MultiheadAttention (packed in_proj, out_proj); self-attention only."""
+
+    def __init__(self, d_model, n_head):
+        super().__init__()
+        self.embed_dim, self.num_heads = d_model, n_head
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model, n_head, attn_mask=None):
+        super().__init__()
+        self.attn = MultiheadAttention(d_model, n_head)
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([
+            ("c_fc", Linear(d_model, d_model * 4)),
+            ("gelu", QuickGELU()),
+            ("c_proj", Linear(d_model * 4, d_model)),
+        ]))
+        self.ln_2 = LayerNorm(d_model)
+        self.causal = attn_mask is not None
+
+    def forward(self, x):  # x [N, L, W] batch-first (the reference runs sequence-first; same math)
+        h = self.ln_1(x)
+        qkv = ops.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        a = ops.mha(qkv, self.attn.num_heads, self.causal)
+        x = self.attn.out_proj(a, resid=x)
+        h = self.ln_2(x)
+        if torch.is_grad_enabled():
+            f = self.mlp.gelu(self.mlp.c_fc(h))
+        else:
+            f = self.mlp.c_fc(h, act=2)  # QuickGELU fused into the GEMM epilogue (inference / frozen aux text)
+        return self.mlp.c_proj(f, resid=x)
+
+
+class Transformer(nn.Module):
+    def __init__(self, width, layers, heads, attn_mask=None):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+    def forward(self, x):
+        for blk in self.resblocks:
+            x = blk(x)
+        return x
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim):
+        super().__init__()
+        self.input_resolution, self.output_dim, self.patch_size = input_resolution, output_dim, patch_size
+        # patch conv keeps the standard contiguous [W,3,ps,ps] layout: it is used as a [W, 3*ps*ps] GEMM operand
+        self.conv1 = nn.Module()
+        self.conv1.weight = nn.Parameter(torch.randn(width, 3, patch_size, patch_size) * 0.02)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self.spacial_dim = 7
+
+    def forward_patches(self, patches):
+        """patches [B, G*G, 3*ps*ps] (rows ordered (c,ky,kx), see ops.fg_patches) -> [B, output_dim]"""
+        emb = ops.linear(patches, self.conv1.weight.reshape(self.conv1.weight.shape[0], -1))
+        x = ops.vit_assemble(emb, self.class_embedding, self.positional_embedding)
+        x = self.ln_pre(x)
+        x = self.transformer(x)
+        cls = self.ln_post(x[:, 0, :].contiguous())
+        return ops.matmul(cls, self.proj)
+
+    def forward(self, x):
+        """x [B,3,R,R] NCHW.  Patch extraction = fg_patches with a unit cam."""
+        B, C, R, _ = x.shape
+        ones = torch.ones(B, 1, R, R, device=x.device, dtype=torch.float32)
+        return self.forward_patches(ops.fg_patches(ones, x.float(), self.patch_size))
+
+
+class CLIP(nn.Module):
+    def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 txt_length, vocab_size, transformer_width, transformer_heads, transformer_layers):
+        super().__init__()
+        self.context_length = context_length
+        if isinstance(vision_layers, (tuple, list)):
+            self.visual = ModifiedResNet(layers=vision_layers, output_dim=embed_dim, heads=vision_width * 32 // 64,
+                                         input_resolution=image_resolution, width=vision_width)
+        else:
+            self.visual = VisionTransformer(input_resolution=image_resolution, patch_size=vision_patch_size,
+                                            width=vision_width, layers=vision_layers, heads=vision_width // 64,
+                                            output_dim=embed_dim)
+        self.txt_length = txt_length
+        self.transformer = Transformer(width=transformer_width, layers=transformer_layers, heads=transformer_heads,
+                                       attn_mask=True)  # causal mask applied inside the attention kernel
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, transformer_width))
+        self.ln_final = LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.logit_scale._tris_no_grad_path = True
+        self.initialize_parameters()
+
+    def initialize_parameters(self):
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        if isinstance(self.visual, ModifiedResNet):
+            std = self.visual.attnpool.c_proj.in_features ** -0.5
+            for m in (self.visual.attnpool.q_proj, self.visual.attnpool.k_proj, self.visual.attnpool.v_proj,
+                      self.visual.attnpool.c_proj):
+                nn.init.normal_(m.weight, std=std)
+            for layer in (self.visual.layer1, self.visual.layer2, self.visual.layer3, self.visual.layer4):
+                for name, param in layer.named_parameters():
+                    if name.endswith("bn3.weight"):
+                        nn.init.zeros_(param)
+        proj_std = (self.transformer.width ** -0.5) * ((2 * self.transformer.layers) ** -0.5)
+        attn_std = self.transformer.width ** -0.5
+        fc_std = (2 * self.transformer.width) ** -0.5
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=self.transformer.width ** -0.5)
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def encode_image(self, image):
+        return self.visual(image)
+
+    def encode_text(self, text):
+        """text int [N, L] -> (x [N, L, W], hidden [N, E])"""
+        ids = text.long()
+        if ids.shape[1] > self.txt_length:
+            raise ValueError(f"token length {ids.shape[1]} exceeds txt_length {self.txt_length}")
+        x = ops.embed(ids, self.token_embedding.weight, self.positional_embedding)
+        x = self.transformer(x)
+        x = self.ln_final(x)
+        hidden = ops.matmul(ops.eot_gather(ids, x), self.text_projection)
+        return x, hidden
+
+    def forward(self, image, text):
+        raise NotImplementedError("CLIP.forward (zero-shot logits) is not on the Stage-1 path")
+
+
+def convert_weights(model):
+    """fp16 conversion in the reference (CLIP/clip/model.py:583-604); the MI355X path computes in fp32 -> no-op."""
+    return model
+
+
+def build_model(state_dict, txt_length=40):
+    vit = "visual.proj" in state_dict
+    if vit:
+        vision_width = state_dict["visual.conv1.weight"].shape[0]
+        vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+        grid = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+        image_resolution = vision_patch_size * grid
+    else:
+        counts = [len(set(k.split(".")[2] for k in state_dict if k.startswith(f"visual.layer{b}"))) for b in (1, 2, 3, 4)]
+        vision_layers = tuple(counts)
+        vision_width = state_dict["visual.layer1.0.conv1.weight"].shape[0]
+        out_w = round((state_dict["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+        vision_patch_size = None
+        assert out_w ** 2 + 1 == state_dict["visual.attnpool.positional_embedding"].shape[0]
+        image_resolution = out_w * 32
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    width = state_dict["ln_final.weight"].shape[0]
+    layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 txt_length, vocab_size, width, width // 64, layers)
+    sd = {k: v.float() for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    model.load_state_dict(sd, strict=False)
+    return model.eval()
+
+
+# constructor arguments of the CLIP variants used by Stage-1 (no checkpoint needed to build the architecture)
+ARCH = {
+    "RN50": dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64,
+                 vision_patch_size=None, context_length=77, vocab_size=49408, transformer_width=512,
+                 transformer_heads=8, transformer_layers=12),
+    "RN101": dict(embed_dim=512, image_resolution=224, vision_layers=(3, 4, 23, 3), vision_width=64,
+                  vision_patch_size=None, context_length=77, vocab_size=49408, transformer_width=512,
+                  transformer_heads=8, transformer_layers=12),
+    "ViT-B/32": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+                     context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                     transformer_layers=12),
+    "ViT-B/16": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
+                     context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                     transformer_layers=12),
+}
+ARCH["ViT-B-32"] = ARCH["ViT-B/32"]  # train_stage1.py:167 spells it with a dash

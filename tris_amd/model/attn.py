@@ -1,0 +1,71 @@
+"""`bilateral_prompt` -- the image<->text cross-modal attention of TRIS Stage-1 (reference model/attn.py:68-136),
+rebuilt on MI355X kernels.  Same constructor, parameter names (`v_proj{1,2,3}.{0,1}`, `t_proj{1,2,3}.0`,
+`v_output.{0,1}`, `t_output.0`) and call signature:
+
+    forward(vis [B,C,H,W], lan [B,C,N]) -> (new_vis [B,C,H,W], new_lan [B,N,C])
+
+Internally activations are channels-last ([B,P,C]); `forward_cl` is the copy-free entry TRIS uses.  The sentence set
+is identical for every image of the batch in Stage-1 (model_stage1.py:66 repeats it), so `forward_cl` accepts the
+un-repeated [N,C] sentence matrix and projects it once instead of B times (same values).
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..CLIP.clip.model import Conv2d, Linear
+
+
+class InstanceNorm2d(nn.Module):
+    """affine InstanceNorm2d, instance statistics in train and eval (track_running_stats=False)"""
+
+    def __init__(self, c, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class ReLU(nn.Module):
+    pass
+
+
+def _vbranch(seq, x, relu):
+    """Sequential(Conv2d 1x1 + bias, InstanceNorm2d, [ReLU]) on channels-last [B,P,C]"""
+    y = ops.linear(x, seq[0].weight, seq[0].bias)
+    return ops.instance_norm(y, seq[1].weight, seq[1].bias, relu, seq[1].eps)
+
+
+class bilateral_prompt(nn.Module):
+    def __init__(self, vis_chans, lan_chans, m_chans=None):
+        super().__init__()
+        m = vis_chans if m_chans is None else m_chans
+        for i in (1, 2, 3):
+            setattr(self, f"v_proj{i}", nn.Sequential(Conv2d(vis_chans, m, 1, bias=True), InstanceNorm2d(m), ReLU()))
+        for i in (1, 2, 3):
+            setattr(self, f"t_proj{i}", nn.Sequential(Linear(lan_chans, m), ReLU()))
+        self.v_output = nn.Sequential(Conv2d(m, vis_chans, 1, bias=True), InstanceNorm2d(vis_chans))
+        self.t_output = nn.Sequential(Linear(m, lan_chans))
+
+    def forward_cl(self, vis, lan):
+        """vis [B,P,C] channels-last pixels, lan [N,C] sentences -> (new_vis [B,P,C], new_lan [B,N,C])"""
+        B, Pp, C = vis.shape
+        scale = 1.0 / math.sqrt(lan.shape[-1])
+        Qv, Kv, Vv = (_vbranch(getattr(self, f"v_proj{i}"), vis, True) for i in (1, 2, 3))
+        Qt, Kt, Vt = (getattr(self, f"t_proj{i}")[0](lan, act=1) for i in (1, 2, 3))
+        Av = ops.softmax(ops.matmul(Qv, Kt, tB=True), scale)        # [B,P,N]  softmax over sentences
+        At = ops.softmax(ops.bmm(Qt, Kv, tB=True), scale)           # [B,N,P]  softmax over pixels
+        new_vis = ops.matmul(Av, Vt, tB=False)                      # [B,P,C]
+        new_lan = ops.bmm(At, Vv, tB=False)                         # [B,N,C]
+        new_vis = _vbranch(self.v_output, new_vis, False)
+        new_lan = self.t_output[0](new_lan)
+        return new_vis, new_lan
+
+    def forward(self, vis, lan):
+        B, C, H, W = vis.shape
+        lan_t = lan.transpose(1, 2)  # [B,N,C]
+        if B > 1 and not bool((lan_t[0:1] == lan_t).all()):
+            raise NotImplementedError("per-image sentence sets are not on the Stage-1 path (model_stage1.py:66 repeats one set)")
+        nv, nl = self.forward_cl(vis.permute(0, 2, 3, 1).reshape(B, H * W, C), lan_t[0].contiguous())
+        return nv.reshape(B, H, W, C).permute(0, 3, 1, 2), nl

@@ -1,0 +1,73 @@
+"""TRIS Stage-1 model on MI355X kernels -- drop-in for the reference's `model.model_stage1.TRIS`
+(/root/reference/model/model_stage1.py:14-123): same constructor (`TRIS(args)`), the same 518 state-dict keys,
+`.backbone.encode_text/encode_image`, `.trainable_parameters()`, and
+
+    forward(x [B,3,H,W], word_id [B,L]) -> train: (cls_out [B,B], cls_fg [B], relu_map, sigmoid_map, exp(logit_scale))
+                                           eval : relu_map [B,1,H,W]
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..CLIP import clip
+from ..CLIP.clip.model import Conv2d, Linear
+from .attn import bilateral_prompt
+
+
+class TRIS(nn.Module):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.bert_model = args.bert_tokenizer
+        if args.backbone == "clip-RN50":
+            last_vis_channel, self.textdim = 2048, 1024
+        elif args.backbone == "clip-RN101":
+            last_vis_channel, self.textdim = 2048, 512
+        else:
+            raise ValueError(f"backbone {args.backbone!r} has no Stage-1 definition in the reference "
+                             "(model_stage1.py:20-25 covers clip-RN50 / clip-RN101 only)")
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+        clip_model, _ = clip.load(args.backbone.split("-")[-1], device=device, jit=False,
+                                  txt_length=args.max_query_len)
+        self.backbone = clip_model.float()
+        self.vis_project = Conv2d(last_vis_channel, args.hidden_dim, 1, bias=True)
+        self.lan_project = Linear(self.textdim, args.hidden_dim)
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        if self.args.attn_multi > 0:
+            self.attn_fusion = bilateral_prompt(args.hidden_dim, lan_chans=args.hidden_dim)
+
+    def trainable_parameters(self):
+        new = [self.vis_project, self.lan_project]
+        if hasattr(self, "attn_fusion"):
+            new.append(self.attn_fusion)
+        return list(self.backbone.parameters()), list(nn.ModuleList(new).parameters())
+
+    def forward(self, x, word_id):
+        B, _, H, W = x.shape
+        _, hidden = self.backbone.encode_text(word_id)                 # [B,E]
+        c4 = self.backbone.visual.forward_cl(x)[3]                      # [B,h,w,2048] channels-last
+        h_, w_ = c4.shape[1:3]
+        Pp = h_ * w_
+        lan = self.lan_project(hidden)                                  # [N,C]   (N = B sentences)
+        vis = self.vis_project(c4).reshape(B, Pp, -1)                   # [B,P,C]
+        norm_vis = ops.l2norm(vis)
+        norm_lan = ops.l2norm(lan)
+        if self.args.attn_multi > 0:
+            new_vis, new_lan = self.attn_fusion.forward_cl(norm_vis, norm_lan)
+            norm_vis = ops.axpy(new_vis, norm_vis, 0.1)                 # hard-coded 0.1 (model_stage1.py:73-74)
+            lan_b = ops.axpy(new_lan, norm_lan.unsqueeze(0).expand(B, -1, -1).contiguous(), 0.1)   # [B,N,C]
+        else:
+            lan_b = norm_lan.unsqueeze(0).expand(B, -1, -1).contiguous()
+        score = ops.bmm(norm_vis, lan_b, tB=True)                       # [B,P,N]
+        logit_scale = self.logit_scale.exp()
+        score = score * logit_scale
+        if self.training:
+            cls_out, cls_fg, relu_map, sig_map = ops.score_heads(score, h_, w_, H, True, float(self.args.FOCAL_P),
+                                                                 float(self.args.FOCAL_LAMBDA))
+            return cls_out, cls_fg, relu_map, sig_map, logit_scale
+        return ops.score_heads(score, h_, w_, H, False)
+
+
+def focal_loss(x, p=1, c=0.1):
+    return torch.pow(1 - x, p) * torch.log(c + x)

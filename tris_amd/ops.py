@@ -1,0 +1,832 @@
+"""Host-side operators of the TRIS Stage-1 hot path: thin autograd wrappers over the C ABI (include/tris_hip.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape -- plumbing.  Every
+numeric op below is a kernel from libtris_hip.so; there is no eager / CPU fallback and CPU tensors
+are rejected loudly.
+
+Layout conventions: activations are channels-last, i.e. an image tensor is a contiguous
+[B, H, W, C] array; conv weights keep the reference's [Cout, Cin, kh, kw] *shape* in
+torch.channels_last memory so state dicts stay compatible.
+
+Weight gradients: a parameter may carry a "gradient sink" (`p.grad` is a view into a flat arena,
+see tris_amd.optim).  Backward kernels then write the weight gradient straight into that arena
+(each parameter is used once per step) and return None to autograd.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import CONSTS, call, query
+
+EW = CONSTS
+
+
+class NoGpuError(RuntimeError):
+    pass
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NoGpuError("tris_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.uint8:
+            raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def P(t, off=0):
+    return None if t is None else t.data_ptr() + 4 * off
+
+
+_WS = {}
+
+
+def workspace(nbytes):
+    """Per-device scratch arena (single stream => serial reuse is safe)."""
+    dev = torch.cuda.current_device()
+    cur = _WS.get(dev)
+    if cur is None or cur.numel() * 4 < nbytes:
+        n = max(int(nbytes), 256 << 20)
+        cur = torch.empty(n // 4 + 1, dtype=torch.float32, device="cuda")
+        _WS[dev] = cur
+    return cur
+
+
+def cl_weight(w):
+    """Conv weight in the kernel layout [Cout][kh][kw][Cin] (= channels_last memory)."""
+    if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+        return w.contiguous(memory_format=torch.channels_last)
+    return w
+
+
+def _sink(p):
+    """The arena view a weight gradient should be written into, or None (=> return it to autograd)."""
+    if p is not None and getattr(p, "_tris_sink", False):
+        return p.grad
+    return None
+
+
+def _emit(p, make, needs):
+    """Produce a parameter gradient: into the sink (return None) or as a fresh tensor."""
+    if not needs:
+        return None
+    s = _sink(p)
+    if s is not None:
+        make(s)
+        return None
+    out = torch.empty_like(p, memory_format=torch.preserve_format)
+    make(out)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- raw launches
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
+         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True):
+    _chk(A, B, C, bias, resid)
+    ws = workspace(0) if (use_ws and batch == 1) else None
+    call("tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
+         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream())
+    return C
+
+
+def colsum(X, M, N, out):
+    ws = workspace(query("tris_col_workspace_bytes", M, N))
+    call("tris_colsum_f32", P(X), M, N, N, P(out), P(ws), _stream())
+    return out
+
+
+def ew(op, A, B=None, s=0.0, out=None):
+    _chk(A, B)
+    out = torch.empty_like(A) if out is None else out
+    call("tris_elementwise_f32", EW[op], P(A), P(B), P(out), A.numel(), float(s), _stream())
+    return out
+
+
+def nchw_to_nhwc(x):
+    _chk(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty(B, H, W, C, device=x.device, dtype=x.dtype)
+    call("tris_nchw_to_nhwc_f32", P(x), P(y), B, C, H, W, _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
+class LinearFn(torch.autograd.Function):
+    """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, resid, act):
+        _chk(x, w, b, resid)
+        x = x.contiguous()
+        K = x.shape[-1]
+        N = w.numel() // K
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        if resid is not None:
+            resid = resid.contiguous()
+        gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid, ldr=N,
+             act=act)
+        ctx.act, ctx.dims = act, (M, N, K)
+        ctx.has_b, ctx.has_r = b is not None, resid is not None
+        if act == 2 and any(ctx.needs_input_grad):
+            raise RuntimeError("fused QuickGELU epilogue is forward-only; use QGeluFn when gradients are needed")
+        if act == 1 and resid is not None and any(ctx.needs_input_grad):
+            raise RuntimeError("relu + residual epilogue is forward-only")
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w, b, y if act == 1 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, y = ctx.saved_tensors
+        pw, pb = ctx.params
+        M, N, K = ctx.dims
+        dy = dy.contiguous()
+        d_res = dy if ctx.has_r and ctx.needs_input_grad[3] else None
+        if ctx.act == 1:
+            dy = ew("TRIS_EW_RELU_BWD", dy, y)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dy, w, dx, M, K, N, N, K, K, False, False)
+        dw = _emit(pw, lambda o: gemm(dy, x, o, N, K, M, N, K, K, True, False), ctx.needs_input_grad[1])
+        db = None
+        if ctx.has_b:
+            db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
+        return dx, dw, db, d_res, None
+
+
+def linear(x, w, b=None, resid=None, act=0):
+    return LinearFn.apply(x, w, b, resid, act)
+
+
+class MatmulFn(torch.autograd.Function):
+    """C = A . B (tB False, B [K,N]) or A . B^T (tB True, B [N,K]); A [..., K] flattened to 2-D."""
+
+    @staticmethod
+    def forward(ctx, A, B, tB):
+        _chk(A, B)
+        A, B = A.contiguous(), B.contiguous()
+        K = A.shape[-1]
+        M = A.numel() // K
+        N = B.shape[0] if tB else B.shape[1]
+        C = torch.empty(*A.shape[:-1], N, device=A.device, dtype=torch.float32)
+        gemm(A, B, C, M, N, K, K, B.shape[1], N, False, tB)
+        ctx.tB, ctx.dims = tB, (M, N, K)
+        ctx.params = (B,)
+        ctx.save_for_backward(A, B)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        M, N, K = ctx.dims
+        dC = dC.contiguous()
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty_like(A)
+            if ctx.tB:   # dA = dC . B   (B [N,K])
+                gemm(dC, B, dA, M, K, N, N, K, K, False, False)
+            else:        # dA = dC . B^T (B [K,N])
+                gemm(dC, B, dA, M, K, N, N, N, K, False, True)
+        if ctx.needs_input_grad[1]:
+            if ctx.tB:   # dB [N,K] = dC^T . A
+                dB = _emit(ctx.params[0], lambda o: gemm(dC, A, o, N, K, M, N, K, K, True, False), True)
+            else:        # dB [K,N] = A^T . dC
+                dB = _emit(ctx.params[0], lambda o: gemm(A, dC, o, K, N, M, K, N, N, True, False), True)
+        return dA, dB, None
+
+
+def matmul(A, B, tB=False):
+    return MatmulFn.apply(A, B, tB)
+
+
+class BmmFn(torch.autograd.Function):
+    """C[b] = A[b] . op(B[b]);  A may be 2-D (shared by every batch).  A [Bt,M,K]|[M,K]; B [Bt,N,K] (tB) | [Bt,K,N]."""
+
+    @staticmethod
+    def forward(ctx, A, B, tB, alpha):
+        _chk(A, B)
+        A, B = A.contiguous(), B.contiguous()
+        Bt = B.shape[0]
+        shared = A.dim() == 2
+        M, K = A.shape[-2], A.shape[-1]
+        N = B.shape[1] if tB else B.shape[2]
+        C = torch.empty(Bt, M, N, device=B.device, dtype=torch.float32)
+        gemm(A, B, C, M, N, K, K, B.shape[2], N, False, tB, batch=Bt, sA=0 if shared else M * K,
+             sB=B.shape[1] * B.shape[2], sC=M * N, alpha=alpha)
+        ctx.cfg = (tB, alpha, shared, Bt, M, N, K)
+        ctx.save_for_backward(A, B)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        tB, alpha, shared, Bt, M, N, K = ctx.cfg
+        dC = dC.contiguous()
+        sA = 0 if shared else M * K
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dAp = torch.empty(Bt, M, K, device=B.device, dtype=torch.float32)
+            if tB:   # dA[b] = dC[b] . B[b]       (B[b] is [N,K])
+                gemm(dC, B, dAp, M, K, N, N, K, K, False, False, batch=Bt, sA=M * N, sB=N * K, sC=M * K, alpha=alpha)
+            else:    # dA[b] = dC[b] . B[b]^T     (B[b] is [K,N])
+                gemm(dC, B, dAp, M, K, N, N, N, K, False, True, batch=Bt, sA=M * N, sB=K * N, sC=M * K, alpha=alpha)
+            if shared:
+                dA = torch.empty(M, K, device=B.device, dtype=torch.float32)
+                colsum(dAp, Bt, M * K, dA)
+            else:
+                dA = dAp
+        if ctx.needs_input_grad[1]:
+            dB = torch.empty_like(B)
+            if tB:   # dB[b] [N,K] = dC[b]^T . A[b]
+                gemm(dC, A, dB, N, K, M, N, K, K, True, False, batch=Bt, sA=M * N, sB=sA, sC=N * K, alpha=alpha)
+            else:    # dB[b] [K,N] = A[b]^T . dC[b]
+                gemm(A, dC, dB, K, N, M, K, N, N, True, False, batch=Bt, sA=sA, sB=M * N, sC=K * N, alpha=alpha)
+        return dA, dB, None, None
+
+
+def bmm(A, B, tB=False, alpha=1.0):
+    return BmmFn.apply(A, B, tB, alpha)
+
+
+# ----------------------------------------------------------------------------------------------- 3x3 conv
+class Conv3x3Fn(torch.autograd.Function):
+    """x [B,H,W,Cin] channels-last, w [Cout,Cin,3,3] in channels_last memory, pad 1, stride 1|2."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        _chk(x, w)
+        x = x.contiguous()
+        ctx.params = (w,)
+        w = cl_weight(w)
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+        call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream())
+        ctx.stride = stride
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stride != 1:
+                raise NotImplementedError("dgrad of the strided stem conv is never needed (its input is the image)")
+            dx = torch.empty_like(x)
+            call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream())
+
+        def wgrad(o):
+            ws = workspace(0)
+            call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4,
+                 _stream())
+        dw = _emit(ctx.params[0], wgrad, ctx.needs_input_grad[1])
+        return dx, dw, None
+
+
+def conv3x3(x, w, stride=1):
+    return Conv3x3Fn.apply(x, w, stride)
+
+
+# ----------------------------------------------------------------------------------------------- BatchNorm
+class BatchNormFn(torch.autograd.Function):
+    """BatchNorm2d on channels-last x [..., C] with optional fused residual add and ReLU.
+
+    training=True: batch statistics (+ running-stat update, + cross-rank combine when `group` is given =
+    SyncBatchNorm).  training=False: running statistics (forward only)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group):
+        _chk(x, gamma, beta, rmean, rvar, resid)
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        if resid is not None:
+            resid = resid.contiguous()
+        count = M
+        if training:
+            stats = torch.empty(3 * C, device=x.device, dtype=torch.float32)
+            ws = workspace(query("tris_col_workspace_bytes", M, C))
+            if group is None:
+                call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(stats), P(rmean), P(rvar), P(ws), _stream())
+            else:
+                import torch.distributed as dist
+                call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(stats), None, None, P(ws), _stream())
+                world = dist.get_world_size(group)
+                mine = torch.empty(2 * C + 1, device=x.device, dtype=torch.float32)
+                mine[:C].copy_(stats[:C])
+                mine[C:2 * C].copy_(stats[2 * C:])
+                mine[2 * C] = float(M)
+                allv = torch.empty(world * (2 * C + 1), device=x.device, dtype=torch.float32)
+                dist.all_gather_into_tensor(allv, mine, group=group)
+                call("tris_bn_sync_combine_f32", P(allv), world, C, eps, momentum, P(stats), P(rmean), P(rvar),
+                     _stream())
+                count = M * world  # DistributedSampler gives every rank the same per-step batch
+            mean, invstd = stats[:C], stats[C:2 * C]
+        else:
+            if any(ctx.needs_input_grad):
+                raise NotImplementedError("BatchNorm in eval mode is forward-only on this path")
+            mean = rmean
+            invstd = torch.rsqrt(rvar + eps)
+        call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
+             _stream())
+        ctx.cfg = (M, C, bool(relu), resid is not None, count, group)
+        ctx.params = (gamma, beta)
+        if training:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
+        M, C, relu, has_res, count, group = ctx.cfg
+        dy = dy.contiguous()
+        d_res = None
+        if has_res:
+            # out = relu(bn(x) + resid): both branches see dz = dy * (out > 0)
+            if relu:
+                dy = ew("TRIS_EW_RELU_BWD", dy, y)
+            d_res = dy if ctx.needs_input_grad[5] else None
+            y = None
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ws = workspace(query("tris_col_workspace_bytes", M, C))
+        call("tris_bn_bwd_reduce_f32", P(dy), P(y), P(x), P(mean), P(invstd), M, C, P(sums), P(sums, C), P(ws),
+             _stream())
+        dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
+        db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), P(sums), P(sums, C),
+                 1.0 / float(count), P(dx), M, C, _stream())
+        return dx, dg, db, None, None, d_res, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None):
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group)
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
+        call("tris_avgpool2_fwd_f32", P(x), P(y), B, H, W, C, _stream())
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
+        call("tris_avgpool2_bwd_f32", P(dy), P(dx), B, H, W, C, _stream())
+        return dx
+
+
+def avgpool2(x):
+    return AvgPool2Fn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------- transformer pieces
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        _chk(x, g, b)
+        x = x.contiguous()
+        W = x.shape[-1]
+        rows = x.numel() // W
+        y = torch.empty_like(x)
+        st = torch.empty(2, rows, device=x.device, dtype=torch.float32)
+        call("tris_layernorm_fwd_f32", P(x), P(g), P(b), P(y), P(st), P(st, rows), rows, W, eps, _stream())
+        ctx.dims = (rows, W)
+        ctx.params = (g, b)
+        ctx.save_for_backward(x, g, b, st)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, st = ctx.saved_tensors
+        rows, W = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dgb = torch.empty(2, W, device=x.device, dtype=torch.float32) if need_p else None
+        ws = workspace(query("tris_layernorm_bwd_workspace_bytes", rows, W))
+        call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(dgb), P(dgb, W),
+             rows, W, P(ws), _stream())
+        dg = _emit(ctx.params[0], lambda o: o.copy_(dgb[0]), ctx.needs_input_grad[1])
+        db = _emit(ctx.params[1], lambda o: o.copy_(dgb[1]), ctx.needs_input_grad[2])
+        return dx, dg, db, None
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    return LayerNormFn.apply(x, g, b, eps)
+
+
+class MhaFn(torch.autograd.Function):
+    """qkv [N, L, 3W] -> [N, L, W]; heads of 64."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, causal):
+        _chk(qkv)
+        qkv = qkv.contiguous()
+        N, L, W3 = qkv.shape
+        W = W3 // 3
+        out = torch.empty(N, L, W, device=qkv.device, dtype=torch.float32)
+        call("tris_mha_fwd_f32", P(qkv), P(out), N, L, W, heads, int(causal), _stream())
+        ctx.cfg = (N, L, W, heads, int(causal))
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        N, L, W, heads, causal = ctx.cfg
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        call("tris_mha_bwd_f32", P(qkv), P(do), P(dqkv), N, L, W, heads, causal, _stream())
+        return dqkv, None, None
+
+
+def mha(qkv, heads, causal):
+    return MhaFn.apply(qkv, heads, causal)
+
+
+class QGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ew("TRIS_EW_QGELU", x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ew("TRIS_EW_QGELU_BWD", dy.contiguous(), x)
+
+
+def quick_gelu(x):
+    return QGeluFn.apply(x)
+
+
+class EmbedFn(torch.autograd.Function):
+    """token_embedding[ids] + positional_embedding[:L]"""
+
+    @staticmethod
+    def forward(ctx, ids, tok, pos):
+        _chk(ids, tok, pos)
+        ids = ids.contiguous()
+        N, L = ids.shape
+        W = tok.shape[1]
+        out = torch.empty(N, L, W, device=tok.device, dtype=torch.float32)
+        call("tris_embed_fwd_f32", P(ids), P(tok), P(pos), P(out), N, L, W, _stream())
+        ctx.params = (tok, pos)
+        ctx.save_for_backward(ids, tok, pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, tok, pos = ctx.saved_tensors
+        N, L = ids.shape
+        W = tok.shape[1]
+        dout = dout.contiguous()
+        st = _sink(ctx.params[0]), _sink(ctx.params[1])
+        dtok = st[0] if st[0] is not None else torch.empty_like(tok)
+        dpos = st[1] if st[1] is not None else torch.empty_like(pos)
+        dtok.zero_()
+        dpos.zero_()
+        call("tris_embed_bwd_f32", P(ids), P(dout), P(dtok), P(dpos), N, L, W, _stream())
+        return None, (None if st[0] is not None else dtok), (None if st[1] is not None else dpos)
+
+
+def embed(ids, tok, pos):
+    return EmbedFn.apply(ids, tok, pos)
+
+
+class EotGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, x):
+        _chk(ids, x)
+        ids, x = ids.contiguous(), x.contiguous()
+        N, L, W = x.shape
+        out = torch.empty(N, W, device=x.device, dtype=torch.float32)
+        call("tris_eot_gather_fwd_f32", P(ids), P(x), P(out), N, L, W, _stream())
+        ctx.save_for_backward(ids)
+        ctx.dims = (N, L, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        N, L, W = ctx.dims
+        dx = torch.empty(N, L, W, device=dout.device, dtype=torch.float32)
+        call("tris_eot_gather_bwd_f32", P(ids), P(dout.contiguous()), P(dx), N, L, W, _stream())
+        return None, dx
+
+
+def eot_gather(ids, x):
+    return EotGatherFn.apply(ids, x)
+
+
+# ----------------------------------------------------------------------------------------------- heads
+class L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+        call("tris_l2norm_fwd_f32", P(x), P(y), P(inv), rows, C, _stream())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        call("tris_l2norm_bwd_f32", P(dy.contiguous()), P(y), P(inv), P(dx), inv.numel(), y.shape[-1], _stream())
+        return dx
+
+
+def l2norm(x):
+    return L2NormFn.apply(x)
+
+
+class SoftmaxFn(torch.autograd.Function):
+    """softmax(scale * x) over the last dim"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        _chk(x)
+        x = x.contiguous()
+        n = x.shape[-1]
+        y = torch.empty_like(x)
+        call("tris_softmax_fwd_f32", P(x), P(y), x.numel() // n, n, scale, _stream())
+        ctx.scale = scale
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        n = y.shape[-1]
+        dx = torch.empty_like(y)
+        call("tris_softmax_bwd_f32", P(dy.contiguous()), P(y), P(dx), y.numel() // n, n, ctx.scale, _stream())
+        return dx, None
+
+
+def softmax(x, scale=1.0):
+    return SoftmaxFn.apply(x, scale)
+
+
+class InstNormFn(torch.autograd.Function):
+    """InstanceNorm2d(affine) [+ReLU] on channels-last x [B, P, C]"""
+
+    @staticmethod
+    def forward(ctx, x, g, b, relu, eps):
+        _chk(x, g, b)
+        x = x.contiguous()
+        B, Pp, C = x.shape
+        y = torch.empty_like(x)
+        st = torch.empty(2, B, C, device=x.device, dtype=torch.float32)
+        call("tris_instnorm_fwd_f32", P(x), P(g), P(b), P(y), P(st), P(st, B * C), B, Pp, C, eps, int(relu), _stream())
+        ctx.relu = bool(relu)
+        ctx.params = (g, b)
+        ctx.save_for_backward(x, g, b, st, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, st, y = ctx.saved_tensors
+        B, Pp, C = x.shape
+        dx = torch.empty_like(x)
+        parts = torch.empty(2, B, C, device=x.device, dtype=torch.float32)
+        call("tris_instnorm_bwd_f32", P(dy.contiguous()), P(y), P(x), P(g), P(st), P(st, B * C), P(dx), P(parts),
+             P(parts, B * C), B, Pp, C, int(ctx.relu), _stream())
+        dg = _emit(ctx.params[0], lambda o: colsum(parts[0], B, C, o), ctx.needs_input_grad[1])
+        db = _emit(ctx.params[1], lambda o: colsum(parts[1], B, C, o), ctx.needs_input_grad[2])
+        return dx, dg, db, None, None
+
+
+def instance_norm(x, g, b, relu=False, eps=1e-5):
+    return InstNormFn.apply(x, g, b, relu, eps)
+
+
+class AxpyFn(torch.autograd.Function):
+    """s * a + b"""
+
+    @staticmethod
+    def forward(ctx, a, b, s):
+        ctx.s = s
+        return ew("TRIS_EW_AXPY", a.contiguous(), b.contiguous(), s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        da = ew("TRIS_EW_SCALE", dy, None, ctx.s) if ctx.needs_input_grad[0] else None
+        return da, (dy if ctx.needs_input_grad[1] else None), None
+
+
+def axpy(a, b, s):
+    return AxpyFn.apply(a, b, s)
+
+
+class ScoreHeadsFn(torch.autograd.Function):
+    """score [B, P, N] -> (cls_out [B,N], cls_fg [B], relu_map [B,1,S,S], sig_map [B,1,S,S]) for training,
+    or only relu_map in eval.  model_stage1.py:80-119."""
+
+    @staticmethod
+    def forward(ctx, score, h, w, S, train, focal_p, focal_c):
+        _chk(score)
+        score = score.contiguous()
+        B, Pp, N = score.shape
+        dev = score.device
+        relu_map = torch.empty(B, 1, S, S, device=dev, dtype=torch.float32)
+        ctx.cfg = (B, Pp, N, h, w, S, train, focal_p, focal_c)
+        ctx.save_for_backward(score)
+        if not train:
+            call("tris_maps_fwd_f32", P(score), P(relu_map), None, B, h, w, N, S, _stream())
+            return relu_map
+        cls_out = torch.empty(B, N, device=dev, dtype=torch.float32)
+        cls_fg = torch.zeros(B, device=dev, dtype=torch.float32)
+        sig_map = torch.empty(B, 1, S, S, device=dev, dtype=torch.float32)
+        call("tris_cls_head_fwd_f32", P(score), P(cls_out), P(cls_fg), B, Pp, N, focal_p, focal_c, _stream())
+        call("tris_maps_fwd_f32", P(score), P(relu_map), P(sig_map), B, h, w, N, S, _stream())
+        ctx.mark_non_differentiable(cls_fg)
+        return cls_out, cls_fg, relu_map, sig_map
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (score,) = ctx.saved_tensors
+        B, Pp, N, h, w, S, train, focal_p, focal_c = ctx.cfg
+        if train:
+            g_cls, _, g_relu, g_sig = grads
+        else:
+            g_cls, g_relu, g_sig = None, grads[0], None
+        dscore = torch.empty_like(score)
+        if g_cls is not None:
+            call("tris_cls_head_bwd_f32", P(score), P(g_cls.contiguous()), P(dscore), B, Pp, N, focal_p, focal_c,
+                 _stream())
+        else:
+            dscore.zero_()
+        if g_relu is not None or g_sig is not None:
+            call("tris_maps_bwd_f32", P(score), P(g_relu.contiguous()) if g_relu is not None else None,
+                 P(g_sig.contiguous()) if g_sig is not None else None, P(dscore), B, h, w, N, S, _stream())
+        return dscore, None, None, None, None, None, None
+
+
+def score_heads(score, h, w, S, train, focal_p=3.0, focal_c=0.01):
+    return ScoreHeadsFn.apply(score, h, w, S, train, focal_p, focal_c)
+
+
+class ResizeFn(torch.autograd.Function):
+    """F.interpolate(x [B,C,H,W], size, mode='bilinear', align_corners=align)"""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align):
+        _chk(x)
+        x = x.contiguous()
+        B, C, Hi, Wi = x.shape
+        y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        call("tris_resize_bilinear_fwd_f32", P(x), P(y), B * C, Hi, Wi, Ho, Wo, int(align), _stream())
+        ctx.cfg = (B, C, Hi, Wi, Ho, Wo, int(align))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Hi, Wi, Ho, Wo, align = ctx.cfg
+        dx = torch.empty(B, C, Hi, Wi, device=dy.device, dtype=torch.float32)
+        call("tris_resize_bilinear_bwd_f32", P(dy.contiguous()), P(dx), B * C, Hi, Wi, Ho, Wo, align, _stream())
+        return dx, None, None, None
+
+
+def resize_bilinear(x, size, align_corners):
+    return ResizeFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+
+
+class FgPatchFn(torch.autograd.Function):
+    """(cam [B,1,R,R], img [B,C,R,R]) -> fg = cam*img as ViT patch-GEMM rows [B, (R/ps)^2, C*ps*ps]"""
+
+    @staticmethod
+    def forward(ctx, cam, img, ps):
+        _chk(cam, img)
+        cam, img = cam.contiguous(), img.contiguous()
+        B, C, R, _ = img.shape
+        G = R // ps
+        out = torch.empty(B, G * G, C * ps * ps, device=img.device, dtype=torch.float32)
+        call("tris_fg_patch_fwd_f32", P(cam), P(img), P(out), B, C, R, ps, _stream())
+        ctx.cfg = (B, C, R, ps)
+        ctx.save_for_backward(img)
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        (img,) = ctx.saved_tensors
+        B, C, R, ps = ctx.cfg
+        dcam = torch.empty(B, 1, R, R, device=dp.device, dtype=torch.float32)
+        call("tris_fg_patch_bwd_f32", P(dp.contiguous()), P(img), P(dcam), B, C, R, ps, _stream())
+        return dcam, None, None
+
+
+def fg_patches(cam, img, ps):
+    return FgPatchFn.apply(cam, img, ps)
+
+
+class VitAssembleFn(torch.autograd.Function):
+    """[cls + pos[0]; emb + pos[1:]] -> [B, T, W]  (class/positional embeddings are frozen aux weights)"""
+
+    @staticmethod
+    def forward(ctx, emb, cls, pos):
+        _chk(emb, cls, pos)
+        emb = emb.contiguous()
+        B, T1, W = emb.shape
+        x = torch.empty(B, T1 + 1, W, device=emb.device, dtype=torch.float32)
+        call("tris_vit_assemble_fwd_f32", P(emb), P(cls), P(pos), P(x), B, T1 + 1, W, _stream())
+        ctx.cfg = (B, T1 + 1, W)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, T, W = ctx.cfg
+        demb = torch.empty(B, T - 1, W, device=dx.device, dtype=torch.float32)
+        call("tris_vit_assemble_bwd_f32", P(dx.contiguous()), P(demb), B, T, W, _stream())
+        return demb, None, None
+
+
+def vit_assemble(emb, cls, pos):
+    return VitAssembleFn.apply(emb, cls, pos)
+
+
+class Stage1LossFn(torch.autograd.Function):
+    """(cls [B,N], f_img [B,E], f_txt [B,E], f_neg [B,K,E]|None) -> losses[4] = (total, l1, l4, l5).
+    train_stage1.py:263-284, 340-364.  Text features come from the frozen aux CLIP: no gradient to them."""
+
+    @staticmethod
+    def forward(ctx, cls, fi, ft, fneg, w1, w4, w5):
+        _chk(cls, fi, ft, fneg)
+        cls, fi, ft = cls.contiguous(), fi.contiguous(), ft.contiguous()
+        B, N = cls.shape
+        E = fi.shape[1]
+        K = 0
+        if fneg is not None:
+            fneg = fneg.contiguous()
+            K = fneg.shape[1]
+        dev = cls.device
+        scratch = torch.empty(B * 4, device=dev, dtype=torch.float32)
+        losses = torch.empty(4, device=dev, dtype=torch.float32)
+        call("tris_stage1_loss_fwd_f32", P(cls), P(fi), P(ft), P(fneg), B, N, E, K, w1, w4, w5, P(scratch),
+             P(scratch, 3 * B), P(losses), _stream())
+        ctx.cfg = (B, N, E, K, w1, w4, w5)
+        ctx.save_for_backward(cls, fi, ft, fneg)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        cls, fi, ft, fneg = ctx.saved_tensors
+        B, N, E, K, w1, w4, w5 = ctx.cfg
+        g = g.contiguous()
+        # dL/dl1 = g[0]*w1 + g[1]; dL/dl5 = g[0]*w5 + g[3]; dL/dl4 = g[0]*w4 + g[2]
+        g3 = torch.stack([g[0] * w1 + g[1], g[0] * w5 + g[3], g[0] * w4 + g[2]]).contiguous()
+        dcls = torch.empty_like(cls)
+        dfi = torch.empty_like(fi)
+        call("tris_stage1_loss_bwd_f32", P(cls), P(fi), P(ft), P(fneg), P(g3), B, N, E, K, P(dcls), P(dfi), _stream())
+        return dcls, dfi, None, None, None, None, None
+
+
+def stage1_loss(cls, fi, ft, fneg, w1=1.0, w4=5.0, w5=2.0):
+    return Stage1LossFn.apply(cls, fi, ft, fneg, w1, w4, w5)
+
+
+def eval_post(relu_map, target_u8):
+    """validate.py:180-190 for one (image, sentence): returns (iu int64[3] on device = I, U, argmax; cam [oH,oW])."""
+    _chk(relu_map, target_u8)
+    S = relu_map.shape[-1]
+    oH, oW = target_u8.shape[-2:]
+    cam = torch.empty(oH, oW, device=relu_map.device, dtype=torch.float32)
+    iu = torch.empty(3, device=relu_map.device, dtype=torch.int64)
+    ws = workspace(4 * (2 * 1024 + 8))
+    call("tris_eval_post_f32", P(relu_map.contiguous()), S, P(target_u8.contiguous()), oH, oW, P(cam), P(iu), P(ws),
+         _stream())
+    return iu, cam
