@@ -15,13 +15,19 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // MODE 1: sum(dz), sum(dz * xhat) with dz = dY * (Y > 0 if Y given)  (BN backward).  MODE 2: plain column sum.
 // part layout: [nblocks][2][C].
 // ------------------------------------------------------------------------------------------------------
+struct d4 { double x, y, z, w; };
+__device__ __forceinline__ d4 d4zero() { d4 r; r.x = r.y = r.z = r.w = 0.0; return r; }
+__device__ __forceinline__ void st4d(double* p, d4 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+
+// Accumulators are fp64: these reductions feed train-mode BatchNorm, whose backward cancels large terms, and the
+// CPU oracle (ATen) accumulates them in double as well.  fp64 VALU adds are free next to the HBM stream.
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           const float* __restrict__ Y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, long M, int C, long ld,
-                                                          long rows_per_block, float* __restrict__ part) {
-  __shared__ float4 l0[256];
-  __shared__ float4 l1[256];
+                                                          long rows_per_block, double* __restrict__ part) {
+  __shared__ d4 l0[256];
+  __shared__ d4 l1[256];
   const int CV = C >> 2;
   const int CVB = CV < 256 ? CV : 256;
   const int RS = 256 / CVB;
@@ -31,18 +37,16 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   const long rend = min(M, rbeg + rows_per_block);
   for (int cv0 = 0; cv0 < CV; cv0 += CVB) {
     const int c = (cv0 + cvl) * 4;
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
-    float4 sh = make_float4(0, 0, 0, 0), mu = sh, is = sh;
+    d4 s0 = d4zero(), s1 = d4zero();
+    float4 mu = make_float4(0, 0, 0, 0), is = mu;
     const bool act = (ro < RS) && (cv0 + cvl < CV);
     if (act) {
-      if (MODE == 0) sh = ld4(X + c);  // shift = row 0 (guards the E[x^2]-E[x]^2 cancellation)
       if (MODE == 1) { mu = ld4(mean + c); is = ld4(invstd + c); }
       for (long r = rbeg + ro; r < rend; r += RS) {
         if (MODE == 0) {
           float4 x = ld4(X + r * ld + c);
-          x.x -= sh.x; x.y -= sh.y; x.z -= sh.z; x.w -= sh.w;
           s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
-          s1.x += x.x * x.x; s1.y += x.y * x.y; s1.z += x.z * x.z; s1.w += x.w * x.w;
+          s1.x += (double)x.x * x.x; s1.y += (double)x.y * x.y; s1.z += (double)x.z * x.z; s1.w += (double)x.w * x.w;
         } else if (MODE == 1) {
           float4 g = ld4(dY + r * ld + c);
           if (Y) {
@@ -54,8 +58,8 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           }
           float4 x = ld4(X + r * ld + c);
           s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
-          s1.x += g.x * (x.x - mu.x) * is.x; s1.y += g.y * (x.y - mu.y) * is.y;
-          s1.z += g.z * (x.z - mu.z) * is.z; s1.w += g.w * (x.w - mu.w) * is.w;
+          s1.x += (double)(g.x * ((x.x - mu.x) * is.x)); s1.y += (double)(g.y * ((x.y - mu.y) * is.y));
+          s1.z += (double)(g.z * ((x.z - mu.z) * is.z)); s1.w += (double)(g.w * ((x.w - mu.w) * is.w));
         } else {
           float4 x = ld4(X + r * ld + c);
           s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
@@ -68,54 +72,66 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     __syncthreads();
     if (ro == 0 && cv0 + cvl < CV) {
       for (int q = 1; q < RS; ++q) {
-        float4 a = l0[q * CVB + cvl], b = l1[q * CVB + cvl];
+        d4 a = l0[q * CVB + cvl], b = l1[q * CVB + cvl];
         s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
         s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
       }
-      float* o = part + (long)blockIdx.x * 2 * C;
-      st4(o + c, s0);
-      if (MODE != 2) st4(o + C + c, s1);
+      double* o = part + (long)blockIdx.x * 2 * C;
+      st4d(o + c, s0);
+      if (MODE != 2) st4d(o + C + c, s1);
     }
   }
 }
 
 // BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const float* __restrict__ X, long M, int C,
-                                   float eps, float momentum, float* __restrict__ stats, float* running_mean,
-                                   float* running_var) {
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C, float eps, float momentum,
+                                   float* __restrict__ stats, float* running_mean, float* running_var) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f, ss = 0.f;
+  double s = 0.0, ss = 0.0;
   for (int b = 0; b < nb; ++b) {
     s += part[(long)b * 2 * C + c];
     ss += part[(long)b * 2 * C + C + c];
   }
-  float inv = 1.0f / (float)M;
-  float ms = s * inv;
-  float var = fmaxf(ss * inv - ms * ms, 0.f);
-  float mean = X[c] + ms;
-  stats[c] = mean;
-  stats[C + c] = rsqrtf(var + eps);
-  stats[2 * C + c] = var;
+  double mean = s / (double)M;
+  double var = ss / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  stats[2 * C + c] = (float)var;
   if (running_mean) {
-    float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
 
 // Sum partials [nb][2][C] -> out0[C] (and out1[C] if given).
-__global__ void part_finalize_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out0,
+__global__ void part_finalize_kernel(const double* __restrict__ part, int nb, int C, float* __restrict__ out0,
                                      float* __restrict__ out1) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f, ss = 0.f;
+  double s = 0.0, ss = 0.0;
   for (int b = 0; b < nb; ++b) {
     s += part[(long)b * 2 * C + c];
     if (out1) ss += part[(long)b * 2 * C + C + c];
   }
-  out0[c] = s;
-  if (out1) out1[c] = ss;
+  out0[c] = (float)s;
+  if (out1) out1[c] = (float)ss;
+}
+
+// float-partials variant (LayerNorm backward partials)
+__global__ void part_finalize_f32_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out0,
+                                         float* __restrict__ out1) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s += part[(long)b * 2 * C + c];
+    if (out1) ss += part[(long)b * 2 * C + C + c];
+  }
+  out0[c] = (float)s;
+  if (out1) out1[c] = (float)ss;
 }
 
 // SyncBN: combine per-rank (mean, biased var, count) -> global mean / invstd / var, update running stats.
@@ -124,27 +140,27 @@ __global__ void bn_sync_combine_kernel(const float* __restrict__ gathered, int W
                                        float* __restrict__ stats, float* running_mean, float* running_var) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float n = 0.f, mean = 0.f;
+  double n = 0.0, mean = 0.0;
   for (int w = 0; w < Wn; ++w) {
     const float* g = gathered + (long)w * (2 * C + 1);
     n += g[2 * C];
-    mean += g[c] * g[2 * C];
+    mean += (double)g[c] * g[2 * C];
   }
   mean /= n;
-  float m2 = 0.f;
+  double m2 = 0.0;
   for (int w = 0; w < Wn; ++w) {
     const float* g = gathered + (long)w * (2 * C + 1);
-    float d = g[c] - mean;
-    m2 += (g[C + c] + d * d) * g[2 * C];
+    double d = g[c] - mean;
+    m2 += ((double)g[C + c] + d * d) * g[2 * C];
   }
-  float var = m2 / n;
-  stats[c] = mean;
-  stats[C + c] = rsqrtf(var + eps);
-  stats[2 * C + c] = var;
+  double var = m2 / n;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  stats[2 * C + c] = (float)var;
   if (running_mean) {
-    float unb = n > 1.f ? var * (n / (n - 1.f)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
 
@@ -479,6 +495,15 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ X, float* __restri
   }
 }
 
+// generic column sum for widths that are not a multiple of 4 (rare, small): one thread per column
+__global__ void colsum_scalar_kernel(const float* __restrict__ X, long M, int N, long ld, float* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (long r = 0; r < M; ++r) s += X[r * ld + c];
+  out[c] = s;
+}
+
 inline int grid_for(long n, int block = 256) {
   long g = (n + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -503,7 +528,7 @@ inline ColPlan col_plan(long M, int C) {
 
 extern "C" long tris_col_workspace_bytes(long M, int C) {
   ColPlan p = col_plan(M, C);
-  return (long)p.nb * 2 * C * sizeof(float);
+  return (long)p.nb * 2 * C * sizeof(double);
 }
 
 extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float momentum, float* stats,
@@ -512,10 +537,10 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
   hipStream_t st = (hipStream_t)stream;
   ColPlan p = col_plan(M, C);
   hipLaunchKernelGGL(col_partial_kernel<0>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, C,
-                     (long)C, p.rpb, workspace);
+                     (long)C, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, p.nb, X, M, C, eps, momentum,
-                     stats, running_mean, running_var);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, p.nb, M, C,
+                     eps, momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -546,9 +571,10 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   hipStream_t st = (hipStream_t)stream;
   ColPlan p = col_plan(M, C);
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, Y, mean, invstd, M, C, (long)C, p.rpb,
-                     workspace);
+                     (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, p.nb, C, sum_dz, sum_dzx);
+  hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
+                     sum_dz, sum_dzx);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -564,14 +590,18 @@ extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const floa
 }
 
 extern "C" int tris_colsum_f32(const float* X, long M, int N, long ld, float* out, float* workspace, void* stream) {
-  if (N % 4 || ld % 4) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
+  if (N % 4 || ld % 4 || (((uintptr_t)X) & 15)) {
+    hipLaunchKernelGGL(colsum_scalar_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, X, M, N, ld, out);
+    TRIS_LAUNCH_CHECK();
+    return 0;
+  }
   ColPlan p = col_plan(M, N);
   hipLaunchKernelGGL(col_partial_kernel<2>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, N,
-                     ld, p.rpb, workspace);
+                     ld, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, workspace, p.nb, N, out,
-                     (float*)nullptr);
+  hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const double*)workspace, p.nb, N,
+                     out, (float*)nullptr);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -622,7 +652,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
                      rpb);
   TRIS_LAUNCH_CHECK();
   if (dgamma) {
-    hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(W, 256)), dim3(256), 0, st, workspace, nb, W, dgamma, dbeta);
+    hipLaunchKernelGGL(part_finalize_f32_kernel, dim3(cdiv(W, 256)), dim3(256), 0, st, workspace, nb, W, dgamma, dbeta);
     TRIS_LAUNCH_CHECK();
   }
   return 0;

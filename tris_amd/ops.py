@@ -135,16 +135,16 @@ class LinearFn(torch.autograd.Function):
              act=act)
         ctx.act, ctx.dims = act, (M, N, K)
         ctx.has_b, ctx.has_r = b is not None, resid is not None
-        if act == 2 and any(ctx.needs_input_grad):
-            raise RuntimeError("fused QuickGELU epilogue is forward-only; use QGeluFn when gradients are needed")
-        if act == 1 and resid is not None and any(ctx.needs_input_grad):
-            raise RuntimeError("relu + residual epilogue is forward-only")
         ctx.params = (w, b)
         ctx.save_for_backward(x, w, b, y if act == 1 else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.act == 2:
+            raise RuntimeError("fused QuickGELU epilogue is forward-only; use QGeluFn when gradients are needed")
+        if ctx.act == 1 and ctx.has_r:
+            raise RuntimeError("relu + residual epilogue is forward-only")
         x, w, b, y = ctx.saved_tensors
         pw, pb = ctx.params
         M, N, K = ctx.dims
@@ -338,20 +338,21 @@ class BatchNormFn(torch.autograd.Function):
                 count = M * world  # DistributedSampler gives every rank the same per-step batch
             mean, invstd = stats[:C], stats[C:2 * C]
         else:
-            if any(ctx.needs_input_grad):
-                raise NotImplementedError("BatchNorm in eval mode is forward-only on this path")
             mean = rmean
             invstd = torch.rsqrt(rvar + eps)
         call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
              _stream())
         ctx.cfg = (M, C, bool(relu), resid is not None, count, group)
         ctx.params = (gamma, beta)
+        ctx.training = bool(training)
         if training:
             ctx.save_for_backward(x, gamma, beta, mean, invstd, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("BatchNorm in eval mode is forward-only on this path")
         x, gamma, beta, mean, invstd, y = ctx.saved_tensors
         M, C, relu, has_res, count, group = ctx.cfg
         dy = dy.contiguous()
