@@ -1,0 +1,176 @@
+"""Benchmark of the TRIS Stage-1 training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full Stage-1 training iteration (TRIS forward, CLIP-guided fg / negative-sample / cls losses
+through the frozen aux ViT-B/32, backward, [gradient all-reduce], AdamW, LR schedule) on 48 synthetic 320x320
+images + 20-token sentences + 3 negatives per image PER GPU (weak scaling), fp32, seed-filled weights.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 48
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (metric config: 48)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_b):
+    """The oracle's reference-faithful Stage-1 step (incl. the reference's redundant work) on the host cores."""
+    from oracle import tris_oracle as O
+    from tris_amd.utils.shapes import aux_state_dict_spec, empty_state_dict, tris_state_dict_spec
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    # the GPU node's host is 2 x 64-core EPYC (256 hw threads); PyTorch-CPU throughput on this workload PEAKS at 32
+    # threads there (64 threads: 0.55x, 128 threads: 0.2x -- measured, tools/cpu_probe.py), so 32 is the fair setting
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = seed_fill(empty_state_dict(tris_state_dict_spec()), 1234)
+    aux = seed_fill(empty_state_dict(aux_state_dict_spec()), 4321)
+    b = synthetic_batch(sample_b, 320, 20, 3, seed=7)
+    state = {}
+    O.train_step(sd, aux, b, state=state, faithful=True)  # warm-up
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        O.train_step(sd, aux, b, state=state, faithful=True)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(sample_b / dt, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} timed + 1 warm-up reference-faithful fp32 train steps of oracle/tris_oracle.py at batch "
+                      f"{sample_b} (same synthetic 320px / 20-token / 3-negative workload; {dt:.2f} s/step; host has "
+                      f"{os.cpu_count()} hw threads, 32 used because more threads run slower)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from tris_amd import ops
+    from tris_amd.args import get_parser
+    from tris_amd.CLIP import clip
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.parallel import GradReducer, convert_sync_batchnorm
+    from tris_amd.train_stage1 import freeze_aux, train_step
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+
+    args = get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20",
+                                    "--negative_samples", "3", "--batch_size", str(a.batch), "--epoch", "15"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = TRIS(args).cuda().train()
+        aux, _ = clip.load("ViT-B-32", device="cuda", txt_length=args.max_query_len)
+    seed_fill(model.state_dict(), 1234)
+    seed_fill(aux.state_dict(), 4321)
+    freeze_aux(aux)
+    bb, new = model.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                     weight_decay=args.weight_decay)
+    max_iter = 1000 * args.epoch
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: (1 - x / max_iter) ** 0.9)
+    reducer = None
+    if world > 1:
+        convert_sync_batchnorm(model)
+        reducer = GradReducer([ar.g for ar in opt.arenas])
+    b = synthetic_batch(a.batch, 320, 20, 3, seed=7, rank=rank)
+    img, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
+
+    def step():
+        return train_step(model, aux, opt, img, ids, neg, args, sched, reducer)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_vals = losses.tolist()
+
+    # ---- live roofline measurement of the dominant kernel family (one extra, untimed, instrumented step) ----
+    ops.profile_begin()
+    step()
+    rec = ops.profile_end()
+    fl = sum(r[1] for r in rec)
+    ms = sum(r[2] for r in rec)
+    kinds = {}
+    for k, f, m in rec:
+        e = kinds.setdefault(k, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += f
+        e[2] += m
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    one = (time.perf_counter() - t1) * 1e3
+    ach = fl / (ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_kernel<BM,BN,A,B,EPI> (f32-MFMA GEMM / implicit-GEMM conv family)",
+            "launches_per_step": len(rec), "kernel_ms_per_step": round(ms, 3),
+            "algorithmic_gflop_per_step": round(fl / 1e9, 1),
+            "by_kind": {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
+                            "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
+                        for k, v in kinds.items()}}
+
+    if rank == 0:
+        out = {"metric": "Stage-1 training images/sec @320px bs48 (TRIS clip-RN50, 3 negatives)",
+               "value": round(world * a.batch * a.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Stage-1 train step, RefCOCOg-shaped synthetic batch: 48 img/GPU 320x320, "
+                                      "20-token query + 3 negative queries per image, clip-RN50 trunk + frozen aux "
+                                      "CLIP ViT-B/32, AdamW (BASELINE.json configs[2]/[3])",
+                          "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": 20,
+                          "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
+               "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

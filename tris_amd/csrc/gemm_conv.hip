@@ -378,13 +378,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmPa
 
 template <int AK, int BKIND>
 int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
-  // tile choice: biggest tile that still gives the 256 CUs something to do
+  // tile choice: biggest tile that still gives the 256 CUs something to do.  When split-K is available (wgrad,
+  // small-M linears) prefer the 128-wide tiles (2x2 fragments per wave: half the LDS reads per MFMA of 64x64) and
+  // recover the parallelism along K instead.
   int bm, bn;
+  const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
   long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   if (p.N <= 64) {
     bn = 64;
-    bm = ((long)cdiv(p.M, 128) * batch >= 256) ? 128 : 64;
-  } else if (t128 >= 192) {
+    bm = ((long)cdiv(p.M, 128) * batch >= 256 || (can_split && p.M >= 128)) ? 128 : 64;
+  } else if (t128 >= 192 || (can_split && p.M >= 128 && p.N >= 128)) {
     bm = bn = 128;
   } else {
     bm = bn = 64;
@@ -392,10 +395,10 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   long tiles = (long)tiles_m * tiles_n * batch;
   p.tiles_n = tiles_n;
-  // split-K when the output grid cannot fill the chip and K is long (wgrad, small-M linears)
+  // split-K when the output grid cannot fill the chip and K is long
   int splitk = 1;
-  if (batch == 1 && ws != nullptr && tiles < 192 && p.K >= 512) {
-    splitk = (int)min((long)cdiv(384, tiles), (long)(p.K / 256));
+  if (can_split && tiles < 192) {
+    splitk = (int)min((long)cdiv(512, tiles), (long)(p.K / 256));
     long per = (long)p.M * p.N * sizeof(float);
     if ((long)splitk * per > ws_bytes) splitk = (int)(ws_bytes / per);
     if (splitk < 2) splitk = 1;

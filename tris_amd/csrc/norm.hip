@@ -83,16 +83,42 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   }
 }
 
-// BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
-__global__ void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C, float eps, float momentum,
-                                   float* __restrict__ stats, float* running_mean, float* running_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s += part[(long)b * 2 * C + c];
-    ss += part[(long)b * 2 * C + C + c];
+// Partial-sum finalizers.  Block = 16 channels x 16 slices of the nb partial rows, reduced through LDS, so the
+// fixed-order (deterministic) sum over up to 512 partial blocks is 16-way parallel per channel.
+template <typename T>
+__device__ __forceinline__ void reduce_parts(const T* __restrict__ part, int nb, int C, bool two, double& s, double& ss,
+                                             int& c, bool& lead) {
+  __shared__ double sh0[16][17];
+  __shared__ double sh1[16][17];
+  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
+  s = 0.0;
+  ss = 0.0;
+  if (c < C)
+    for (int b = j; b < nb; b += 16) {
+      s += (double)part[(long)b * 2 * C + c];
+      if (two) ss += (double)part[(long)b * 2 * C + C + c];
+    }
+  sh0[j][cl] = s;
+  sh1[j][cl] = ss;
+  __syncthreads();
+  lead = (j == 0) && (c < C);
+  if (lead) {
+    s = 0.0;
+    ss = 0.0;
+    for (int q = 0; q < 16; ++q) { s += sh0[q][cl]; ss += sh1[q][cl]; }
   }
+}
+
+// BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
+                                                          float eps, float momentum, float* __restrict__ stats,
+                                                          float* running_mean, float* running_var) {
+  double s, ss;
+  int c;
+  bool lead;
+  reduce_parts(part, nb, C, true, s, ss, c, lead);
+  if (!lead) return;
   double mean = s / (double)M;
   double var = ss / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -107,29 +133,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nb, long
 }
 
 // Sum partials [nb][2][C] -> out0[C] (and out1[C] if given).
-__global__ void part_finalize_kernel(const double* __restrict__ part, int nb, int C, float* __restrict__ out0,
-                                     float* __restrict__ out1) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s += part[(long)b * 2 * C + c];
-    if (out1) ss += part[(long)b * 2 * C + C + c];
-  }
-  out0[c] = (float)s;
-  if (out1) out1[c] = (float)ss;
-}
-
-// float-partials variant (LayerNorm backward partials)
-__global__ void part_finalize_f32_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out0,
-                                         float* __restrict__ out1) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s += part[(long)b * 2 * C + c];
-    if (out1) ss += part[(long)b * 2 * C + C + c];
-  }
+template <typename T>
+__global__ __launch_bounds__(256) void part_finalize_kernel(const T* __restrict__ part, int nb, int C,
+                                                            float* __restrict__ out0, float* __restrict__ out1) {
+  double s, ss;
+  int c;
+  bool lead;
+  reduce_parts(part, nb, C, out1 != nullptr, s, ss, c, lead);
+  if (!lead) return;
   out0[c] = (float)s;
   if (out1) out1[c] = (float)ss;
 }
@@ -539,7 +550,7 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
   hipLaunchKernelGGL(col_partial_kernel<0>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, C,
                      (long)C, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, p.nb, M, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, p.nb, M, C,
                      eps, momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -573,7 +584,7 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, Y, mean, invstd, M, C, (long)C, p.rpb,
                      (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
                      sum_dz, sum_dzx);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -600,7 +611,7 @@ extern "C" int tris_colsum_f32(const float* X, long M, int N, long ld, float* ou
   hipLaunchKernelGGL(col_partial_kernel<2>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, N,
                      ld, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const double*)workspace, p.nb, N,
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(cdiv(N, 16)), dim3(256), 0, st, (const double*)workspace, p.nb, N,
                      out, (float*)nullptr);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -652,7 +663,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
                      rpb);
   TRIS_LAUNCH_CHECK();
   if (dgamma) {
-    hipLaunchKernelGGL(part_finalize_f32_kernel, dim3(cdiv(W, 256)), dim3(256), 0, st, workspace, nb, W, dgamma, dbeta);
+    hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(cdiv(W, 16)), dim3(256), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);
     TRIS_LAUNCH_CHECK();
   }
   return 0;

@@ -85,13 +85,44 @@ def _emit(p, make, needs):
     return out
 
 
+# ----------------------------------------------------------------------------------------------- profiling hook
+# bench.py measures the dominant kernel family live: when enabled, every MFMA GEMM / implicit-GEMM conv launch is
+# bracketed by HIP events on the launch stream and logged with its algorithmic FLOPs.
+_PROF = None
+
+
+def profile_begin():
+    global _PROF
+    _PROF = []
+
+
+def profile_end():
+    """-> list of (kind, flops, milliseconds)"""
+    global _PROF
+    rec, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    return [(k, f, a.elapsed_time(b)) for k, f, a, b in rec]
+
+
+def _timed(kind, flops, fn):
+    if _PROF is None:
+        return fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = fn()
+    b.record()
+    _PROF.append((kind, flops, a, b))
+    return r
+
+
 # ----------------------------------------------------------------------------------------------- raw launches
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
          ldr=0, sR=0, act=0, alpha=1.0, use_ws=True):
     _chk(A, B, C, bias, resid)
     ws = workspace(0) if (use_ws and batch == 1) else None
-    call("tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
-         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream())
+    _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
+        "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
+        bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()))
     return C
 
 
@@ -271,7 +302,8 @@ class Conv3x3Fn(torch.autograd.Function):
         Cout = w.shape[0]
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-        call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream())
+        _timed("conv3x3_fwd", 2.0 * B * Ho * Wo * Cout * 9 * Cin,
+               lambda: call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))
         ctx.stride = stride
         ctx.save_for_backward(x, w)
         return y
@@ -287,12 +319,14 @@ class Conv3x3Fn(torch.autograd.Function):
             if ctx.stride != 1:
                 raise NotImplementedError("dgrad of the strided stem conv is never needed (its input is the image)")
             dx = torch.empty_like(x)
-            call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream())
+            _timed("conv3x3_dgrad", 2.0 * B * H * W * Cout * 9 * Cin,
+                   lambda: call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))
 
         def wgrad(o):
             ws = workspace(0)
-            call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4,
-                 _stream())
+            _timed("conv3x3_wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin,
+                   lambda: call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws),
+                                ws.numel() * 4, _stream()))
         dw = _emit(ctx.params[0], wgrad, ctx.needs_input_grad[1])
         return dx, dw, None
 
