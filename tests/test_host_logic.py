@@ -1,0 +1,104 @@
+"""Host-side logic that needs no GPU: drop-in surface (constructor, state-dict keys, argparse defaults, tokenizer),
+synthetic inputs, and the evaluation helpers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_args_defaults_match_reference_recipe():
+    from tris_amd.args import get_parser
+    a = get_parser().parse_args([])
+    assert (a.backbone, a.hidden_dim, a.max_query_len, a.negative_samples) == ("clip-RN50", 1024, 20, 0)
+    assert (a.lr, a.lr_multi, a.weight_decay, a.attn_multi) == (5e-5, 0.1, 0.01, 0.1)
+    assert (a.w1, a.w4, a.w5, a.FOCAL_P, a.FOCAL_LAMBDA) == (1, 5, 2, 3, 0.01)
+    a = get_parser().parse_args(["--weight_decay", "0.1", "--print-freq", "7", "--distributed"])
+    assert a.weight_decay == 0.1 and a.print_freq == 7 and a.distributed
+
+
+def test_tris_module_surface():
+    from tris_amd.utils.shapes import _build_tris
+    m = _build_tris()
+    bb, new = m.trainable_parameters()
+    ids = {id(p) for p in bb + new}
+    assert id(m.logit_scale) not in ids  # never optimised (model_stage1.py:44-52)
+    assert len(bb) == 324 and len(new) == 28
+    nograd = [k for k, p in m.named_parameters() if getattr(p, "_tris_no_grad_path", False)]
+    assert len(nograd) == 10 and all("attnpool" in k or k == "backbone.logit_scale" for k in nograd)
+    w = m.backbone.visual.layer1[0].conv2.weight
+    assert w.shape == (64, 64, 3, 3) and w.is_contiguous(memory_format=torch.channels_last)
+    # a reference-layout (contiguous NCHW) checkpoint loads into the channels_last parameters unchanged in value
+    sd = {k: v.clone().contiguous() for k, v in m.state_dict().items()}
+    sd["backbone.visual.layer1.0.conv2.weight"] = torch.arange(64 * 64 * 9, dtype=torch.float32).view(64, 64, 3, 3)
+    m.load_state_dict(sd)
+    assert m.backbone.visual.layer1[0].conv2.weight.is_contiguous(memory_format=torch.channels_last)
+    assert float(m.backbone.visual.layer1[0].conv2.weight[3, 5, 1, 2]) == float(sd["backbone.visual.layer1.0.conv2.weight"][3, 5, 1, 2])
+    with pytest.raises(ValueError):
+        _build_tris(["--backbone", "clip-ViT-B/16"])  # no Stage-1 definition in the reference either
+
+
+def test_tokenizer_known_answers():
+    from tris_amd.CLIP.clip import simple_tokenizer
+    try:
+        simple_tokenizer.default_bpe()
+    except FileNotFoundError:
+        pytest.skip("CLIP BPE merge table not available on this machine")
+    from tris_amd.CLIP import clip
+    g = np.load(os.path.join(GOLDEN, "g8_tokenizer.npz"))
+    toks = clip.tokenize(list(g["sentences"]), truncate=True)[:, :20].numpy()
+    assert (toks == g["tokens"]).all()
+    assert clip.tokenize("man on the right")[0, :6].tolist() == [49406, 786, 525, 518, 1155, 49407]
+    with pytest.raises(RuntimeError):
+        clip.tokenize("word " * 100)
+
+
+def test_synthetic_batch_is_deterministic_and_rank_sharded():
+    from tris_amd.utils.synth import synthetic_batch
+    a, b = synthetic_batch(3, 32, 20, 3, seed=7), synthetic_batch(3, 32, 20, 3, seed=7)
+    assert torch.equal(a["img"], b["img"]) and torch.equal(a["neg_word_ids"], b["neg_word_ids"])
+    c = synthetic_batch(3, 32, 20, 3, seed=7, rank=1)
+    assert not torch.equal(a["img"], c["img"]) and not torch.equal(a["word_ids"], c["word_ids"])
+    ids = a["word_ids"]
+    assert (ids[:, 0] == 49406).all() and (ids.max(1).values == 49407).all() and ids.shape == (3, 20)
+    assert a["neg_word_ids"].shape == (3, 3, 20)
+
+
+def test_eval_helpers():
+    from tris_amd.utils.util import AverageMeter, compute_mask_IU
+    from tris_amd.validate import isCorrectHit
+    m = torch.zeros(4, 6, dtype=torch.bool)
+    t = torch.zeros(4, 6, dtype=torch.bool)
+    m[:2] = True
+    t[1:3] = True
+    I, U = compute_mask_IU(m, t)
+    assert (int(I), int(U)) == (6, 18)
+    with pytest.raises(ValueError):
+        compute_mask_IU(m, t[:, :3])
+    am = AverageMeter()
+    am.update(2.0, 2)
+    am.update(4.0, 2)
+    assert am.avg == 3.0
+    heat = np.zeros((5, 5), dtype=np.float32)
+    heat[3, 1] = 2.0
+    gt = np.zeros((5, 5), dtype=bool)
+    gt[3, 1] = True
+    assert isCorrectHit([[0, 2, 2, 4]], heat, gt) == (1, (3, 1), 1)
+    assert isCorrectHit([[3, 3, 4, 4]], heat, gt)[0] == 0
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from types import SimpleNamespace
+    from tris_amd.utils.util import load_checkpoint, save_checkpoint
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: 1.0)
+    args = SimpleNamespace(output=str(tmp_path), pretrain="c.pth", eval=False, start_epoch=0)
+    save_checkpoint(4, net, opt, sched, args=args, checkpoint_name="c.pth")
+    ck = torch.load(tmp_path / "c.pth")
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch"}
+    net2 = torch.nn.Linear(3, 2)
+    load_checkpoint(args, net2, torch.optim.AdamW(net2.parameters()), None)
+    assert args.start_epoch == 5 and torch.equal(net2.weight, net.weight)

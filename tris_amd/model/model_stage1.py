@@ -43,16 +43,20 @@ class TRIS(nn.Module):
             new.append(self.attn_fusion)
         return list(self.backbone.parameters()), list(nn.ModuleList(new).parameters())
 
-    def forward(self, x, word_id):
-        B, _, H, W = x.shape
-        _, hidden = self.backbone.encode_text(word_id)                 # [B,E]
+    def encode_visual(self, x):
+        """Image-only half of forward (RN50 trunk -> vis_project -> L2 norm).  Returned state can be reused for every
+        sentence of the same image (validate.py re-runs the trunk per sentence; the values are identical)."""
+        B = x.shape[0]
         c4 = self.backbone.visual.forward_cl(x)[3]                      # [B,h,w,2048] channels-last
         h_, w_ = c4.shape[1:3]
-        Pp = h_ * w_
-        lan = self.lan_project(hidden)                                  # [N,C]   (N = B sentences)
-        vis = self.vis_project(c4).reshape(B, Pp, -1)                   # [B,P,C]
-        norm_vis = ops.l2norm(vis)
-        norm_lan = ops.l2norm(lan)
+        vis = self.vis_project(c4).reshape(B, h_ * w_, -1)              # [B,P,C]
+        return ops.l2norm(vis), h_, w_
+
+    def forward_cached(self, vis_state, word_id, out_size):
+        norm_vis, h_, w_ = vis_state
+        B = norm_vis.shape[0]
+        _, hidden = self.backbone.encode_text(word_id)                 # [N,E]   (N = B sentences)
+        norm_lan = ops.l2norm(self.lan_project(hidden))                 # [N,C]
         if self.args.attn_multi > 0:
             new_vis, new_lan = self.attn_fusion.forward_cl(norm_vis, norm_lan)
             norm_vis = ops.axpy(new_vis, norm_vis, 0.1)                 # hard-coded 0.1 (model_stage1.py:73-74)
@@ -63,10 +67,14 @@ class TRIS(nn.Module):
         logit_scale = self.logit_scale.exp()
         score = score * logit_scale
         if self.training:
-            cls_out, cls_fg, relu_map, sig_map = ops.score_heads(score, h_, w_, H, True, float(self.args.FOCAL_P),
+            cls_out, cls_fg, relu_map, sig_map = ops.score_heads(score, h_, w_, out_size, True,
+                                                                 float(self.args.FOCAL_P),
                                                                  float(self.args.FOCAL_LAMBDA))
             return cls_out, cls_fg, relu_map, sig_map, logit_scale
-        return ops.score_heads(score, h_, w_, H, False)
+        return ops.score_heads(score, h_, w_, out_size, False)
+
+    def forward(self, x, word_id):
+        return self.forward_cached(self.encode_visual(x), word_id, x.shape[2])
 
 
 def focal_loss(x, p=1, c=0.1):

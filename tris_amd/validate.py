@@ -1,0 +1,105 @@
+"""Stage-1 evaluation on MI355X -- `validate` with the reference's signature and return value
+(validate.py:130-249): per (image, sentence) response map -> bilinear to the annotation size (align_corners=True)
+-> max-normalise -> threshold 1e-9 -> I/U, IoU, pointing-game hit.
+
+Differences that do not change the returned numbers:
+  * the RN50 trunk + vis_project run once per image and are reused for all of its sentences (the reference
+    recomputes them per sentence, validate.py:173-179);
+  * resize / normalise / threshold / counting run in one device kernel chain (ops.eval_post) -- one host sync per
+    sentence instead of several;
+  * the box metrics that the reference only prints (cv2 contours + torchvision NMS, validate.py:195-201) are not
+    produced (cv2 / torchvision are not part of this stack);
+  * under torch.distributed the five accumulators are all-reduced so every rank returns the global numbers
+    (the reference returns rank-local meters).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .utils.util import AverageMeter
+
+
+def isCorrectHit(bbox_annot, heatmap, gt_mask=None):
+    """validate.py:106-117: arg-max point inside any GT box (hit) / on the GT mask (hitm)."""
+    max_loc = np.unravel_index(np.argmax(heatmap, axis=None), heatmap.shape)
+    hitm = 1 if (gt_mask is not None and bool(gt_mask[max_loc[0], max_loc[1]])) else 0
+    for bbox in bbox_annot:
+        if bbox[0] <= max_loc[1] <= bbox[2] and bbox[1] <= max_loc[0] <= bbox[3]:
+            return 1, max_loc, hitm
+    return 0, max_loc, hitm
+
+
+def get_scores(clip_model, fg_224_eval, word_id):
+    """validate.py:120-127: cosine logits of aux-CLIP image features vs text features [N1, N2]."""
+    f_i = ops.l2norm(clip_model.encode_image(fg_224_eval))
+    f_t = ops.l2norm(clip_model.encode_text(word_id)[1])
+    return ops.matmul(f_i, f_t, tB=True)
+
+
+@torch.no_grad()
+def validate(args, data_loader, model, local_rank=0, visualize=False, logger=None, save_cam=False):
+    num_steps = len(data_loader)
+    model.eval()
+    net = model.module if hasattr(model, "module") else model
+    say = logger.info if logger is not None else print
+    say("Starting validation without PRMS")
+    if save_cam and args.name_save_dir:
+        os.makedirs(args.name_save_dir, exist_ok=True)
+    if save_cam and args.cam_save_dir:
+        os.makedirs(args.cam_save_dir, exist_ok=True)
+    batch_time, mIOU_meter = AverageMeter(), AverageMeter()
+    I_sum = U_sum = 0
+    n_sent = hit_acc = hitmask_acc = 0
+    cam_out_name = []
+    end = time.time()
+    for idx, (samples, targets) in enumerate(data_loader):
+        img_id = int(np.asarray(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
+        word_ids = samples["word_ids"].squeeze(1).cuda(local_rank, non_blocking=True)      # [1, L, S]
+        img = samples["img"].cuda(local_rank, non_blocking=True)                           # [1, 3, H, W]
+        target = targets["target"].cuda(local_rank, non_blocking=True)
+        tgt = (target.reshape(target.shape[-2:]) != 0).to(torch.uint8)
+        bbox = np.asarray(targets["boxes"]).reshape(-1, 4) if "boxes" in targets else np.zeros((0, 4))
+        vis = net.encode_visual(img)                                                       # once per image
+        for j in range(word_ids.size(-1)):
+            n_sent += 1
+            out = net.forward_cached(vis, word_ids[:, :, j].contiguous(), img.shape[2])    # relu map [1,1,H,W]
+            iu, cam = ops.eval_post(out, tgt)
+            I, U, am = iu.tolist()                                                         # the one host sync
+            I_sum += I
+            U_sum += U
+            mIOU_meter.update(I / U if U > 0 else 0.0, img.size(0))
+            y, x = divmod(am, cam.shape[1])
+            hit = 0
+            for b in bbox:
+                if b[0] <= x <= b[2] and b[1] <= y <= b[3]:
+                    hit = 1
+                    break
+            hit_acc += hit
+            if args.cam_save_dir is not None and save_cam:
+                np.save(os.path.join(args.cam_save_dir, f"{idx}_{j}_{img_id}.npy"), cam.cpu().numpy())
+            if args.name_save_dir is not None and save_cam:
+                cam_out_name.append(f"{idx}_{j}_{img_id}")
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if idx % args.print_freq == 0:
+            say(f"Test: [{idx:4d}/{num_steps}] | mIOU {100 * mIOU_meter.avg:.3f} | Overall IOU "
+                f"{100 * float(I_sum) / max(float(U_sum), 1.0):.3f} | Hit {hit_acc / max(n_sent, 1) * 100:.3f} | "
+                f"Time {batch_time.val:.3f} ({batch_time.avg:.3f})")
+    if args.name_save_dir is not None and save_cam:
+        with open(os.path.join(args.name_save_dir, f"{args.dataset}_train_cam_name.json"), "w") as f:
+            f.write(json.dumps(cam_out_name))
+    acc = torch.tensor([float(I_sum), float(U_sum), float(mIOU_meter.sum), float(mIOU_meter.count), float(hit_acc),
+                        float(n_sent)], dtype=torch.float64, device="cuda")
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(acc)
+    I_t, U_t, iou_sum, iou_cnt, hits, nsent = acc.tolist()
+    overall_IoU = 100 * I_t / max(U_t, 1.0)
+    mIOU = torch.tensor(100 * iou_sum / max(iou_cnt, 1.0))
+    hit = 100 * hits / max(nsent, 1.0)
+    say(f"Test: mIOU {float(mIOU):.5f}  Overall IOU {overall_IoU:.5f}  HiT {hit:.3f}")
+    return overall_IoU, mIOU, hit
