@@ -35,6 +35,7 @@ struct GemmParams {
   int act;  // 0 none, 1 relu, 2 quick-gelu
   float alpha;
   int vecA, vecB;  // 16-byte vector loads legal for the operand
+  int fastA, fastB;  // operand satisfies the preconditions of gemm_fast_kernel
   int kchunk, splitk;
   int tiles_n;
   // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
@@ -376,6 +377,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmPa
   p.C[(long)row * p.ldc + col] = v;
 }
 
+#include "gemm_fast.h"
+
 template <int AK, int BKIND>
 int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
   // tile choice: biggest tile that still gives the 256 CUs something to do.  When split-K is available (wgrad,
@@ -403,19 +406,28 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if ((long)splitk * per > ws_bytes) splitk = (int)(ws_bytes / per);
     if (splitk < 2) splitk = 1;
   }
+  const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
+  const int kalign = fast ? 32 : BK;
   p.splitk = splitk;
-  p.kchunk = cdiv(cdiv(p.K, splitk), BK) * BK;
+  p.kchunk = cdiv(cdiv(p.K, splitk), kalign) * kalign;
   if (splitk > 1) splitk = cdiv(p.K, p.kchunk), p.splitk = splitk;
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(batch * splitk));
   float* Cfinal = p.C;
-#define TRIS_GO(BM_, BN_)                                                                     \
-  do {                                                                                        \
-    if (splitk > 1) {                                                                         \
-      p.C = ws;                                                                               \
+#define TRIS_GO(BM_, BN_)                                                                          \
+  do {                                                                                             \
+    if (fast) {                                                                                    \
+      if (splitk > 1) {                                                                            \
+        p.C = ws;                                                                                  \
+        hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB>), grid, dim3(256), 0, st, p); \
+      } else {                                                                                     \
+        hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD>), grid, dim3(256), 0, st, p);  \
+      }                                                                                            \
+    } else if (splitk > 1) {                                                                       \
+      p.C = ws;                                                                                    \
       hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AK, BKIND, EPI_SLAB>), grid, dim3(256), 0, st, p); \
-    } else {                                                                                  \
+    } else {                                                                                       \
       hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AK, BKIND, EPI_STD>), grid, dim3(256), 0, st, p);  \
-    }                                                                                         \
+    }                                                                                              \
   } while (0)
   if (bm == 128 && bn == 128) TRIS_GO(128, 128);
   else if (bm == 128 && bn == 64) TRIS_GO(128, 64);
@@ -448,6 +460,8 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.resid = resid; p.ldr = ldr; p.sR = sR; p.act = act; p.alpha = alpha;
   p.vecA = al16(A) && (lda % 4 == 0) && (sA % 4 == 0);
   p.vecB = al16(B) && (ldb % 4 == 0) && (sB % 4 == 0);
+  p.fastA = p.vecA && (!transA || M % 4 == 0);
+  p.fastB = p.vecB && (transB || N % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
   if (!transA && transB) return launch_cfg<A_ROWK, B_NK>(p, batch, workspace, ws_bytes, st);
   if (!transA && !transB) return launch_cfg<A_ROWK, B_KN>(p, batch, workspace, ws_bytes, st);
@@ -466,6 +480,8 @@ extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, i
   p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
   p.vecA = al16(X) && (Cin % 16 == 0);
   p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
+  p.fastA = al16(X) && (Cin % 32 == 0);
+  p.fastB = p.vecB;
   return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -480,6 +496,8 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   p.wCin = Cin; p.wCout = Cout;
   p.vecA = al16(dY) && (Cout % 16 == 0);
   p.vecB = al16(Wt) && (Cin % 4 == 0);
+  p.fastA = al16(dY) && (Cout % 32 == 0);
+  p.fastB = p.vecB;
   if (Cout % 16 != 0) return (int)hipErrorInvalidValue;  // k tile must not straddle taps for the B loader
   return launch_cfg<A_IM2COL, B_KN_DGRAD>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
@@ -495,5 +513,7 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
   p.vecA = al16(dY) && (Cout % 4 == 0);
   p.vecB = al16(X) && (Cin % 4 == 0);
+  p.fastA = p.vecA;
+  p.fastB = p.vecB;
   return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, (hipStream_t)stream);
 }

@@ -1,0 +1,245 @@
+// Fast path of the MFMA GEMM / implicit-GEMM core (included by gemm_conv.hip).
+//
+// Same tiling as the generic kernel (BM x BN block, 4 waves 2x2, 32x32 f32 MFMA fragments) but:
+//   * BK = 32 and *branch-free* tile loaders: rows/columns past the edge are clamped (their results are never
+//     stored) and out-of-image im2col taps are loaded from a valid address and zeroed with a select, so the K loop has
+//     no divergent control flow and the accumulators stay pinned in registers;
+//   * k-contiguous operands (row-major A, B^T, im2col) keep a row-major LDS image [rows][32+4]: 16-byte global loads
+//     go to LDS as ds_write_b128, and a fragment read is ONE ds_read_b128 per lane = 4 k-values feeding 4 MFMAs.
+//     Row stride 36 floats puts the 16 lanes of every ds_read_b128 service group on 16 distinct 16-byte slots
+//     (9*i mod 16 is a permutation) -> conflict-free.  The logical k order inside an MFMA is permuted
+//     (lane-half kh, MFMA j  <->  k = 8g + 4kh + j); both operands use the same permutation, the sum is unchanged;
+//   * m-contiguous operands (A^T for wgrad, B for dgrad / NN) keep the k-major image and read 4 scalars.
+// Preconditions (checked on the host, otherwise the generic kernel runs): K % 32 == 0 per k-slice, 16-byte aligned
+// operands, M % 4 == 0 / N % 4 == 0 for the m-/n-contiguous kinds, gathered channels % 32 == 0 for im2col.
+#pragma once
+
+template <int BM, int BN, int AK, int BKIND, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
+  constexpr int FBK = 32;
+  constexpr int LDK = FBK + 4;
+  constexpr bool A_RM = (AK != A_COLK);
+  constexpr bool B_RM = (BKIND == B_NK);
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 32, FN = WN / 32;
+  constexpr int PA = BM / 32, PB = BN / 32;  // float4 per thread per tile
+  constexpr int A_SZ = A_RM ? BM * LDK : FBK * (BM + 4);
+  constexpr int B_SZ = B_RM ? BN * LDK : FBK * (BN + 4);
+  __shared__ __attribute__((aligned(16))) float As[A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
+  const int zb = blockIdx.z / p.splitk;
+  const int zs = blockIdx.z % p.splitk;
+  const int kbeg = zs * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const float* __restrict__ A = p.A + (long)zb * p.sA;
+  const float* __restrict__ Bp = p.B + (long)zb * p.sB;
+
+  // ---- loader state ---------------------------------------------------------------------------------------------
+  // row-major kinds: thread -> (row = tid>>3 + 32*q, kofs = (tid&7)*4);  k-major kinds: (k = tid/F4 + q*RPP, col4)
+  long a_off[PA];  // ROWK: row offset; IM2COL: unused
+  int a_b[PA], a_iy0[PA], a_ix0[PA];
+  if (AK == A_ROWK) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      int m = min(m0 + (tid >> 3) + q * 32, p.M - 1);
+      a_off[q] = (long)m * p.lda + (tid & 7) * 4;
+    }
+  } else if (AK == A_IM2COL) {
+    const int hw = p.gHo * p.gWo;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      int m = min(m0 + (tid >> 3) + q * 32, p.M - 1);
+      a_b[q] = m / hw;
+      int r = m - a_b[q] * hw;
+      int oy = r / p.gWo, ox = r - oy * p.gWo;
+      a_iy0[q] = oy * p.gStride - 1;
+      a_ix0[q] = ox * p.gStride - 1;
+    }
+  }
+  constexpr int AF4 = BM / 4, ARPP = 256 / AF4;
+  const int a_mc = min(m0 + (tid % AF4) * 4, p.M - 4);  // COLK column (clamped)
+  long b_off[PB];
+  if (BKIND == B_NK) {
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      int n = min(n0 + (tid >> 3) + q * 32, p.N - 1);
+      b_off[q] = (long)n * p.ldb + (tid & 7) * 4;
+    }
+  }
+  constexpr int BF4 = BN / 4, BRPP = 256 / BF4;
+  const int b_nc = min(n0 + (tid % BF4) * 4, p.N - 4);  // KN* column (clamped)
+  int bj_tap = 0, bj_ci = 0;
+  if (BKIND == B_KN_IM2COL) {
+    bj_tap = b_nc / p.gC;
+    bj_ci = b_nc - bj_tap * p.gC;
+  }
+  const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
+
+  float4 ra[PA], rb[PB];
+
+  auto load_A = [&](int k0) {
+    if (AK == A_ROWK) {
+#pragma unroll
+      for (int q = 0; q < PA; ++q) ra[q] = ld4(A + a_off[q] + k0);
+    } else if (AK == A_IM2COL) {
+      const int tap = k0 / p.gC;  // whole 32-wide k tile lies inside one tap (gC % 32 == 0)
+      const int ci = k0 - tap * p.gC + (tid & 7) * 4;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;
+        const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
+        const long off = inb ? ((long)(a_b[q] * p.gH + iy) * p.gW + ix) * p.gC + ci : 0;
+        float4 v = ld4(A + off);
+        ra[q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {  // A_COLK: A[k*lda + m]
+#pragma unroll
+      for (int q = 0; q < PA; ++q) ra[q] = ld4(A + (long)(k0 + tid / AF4 + q * ARPP) * p.lda + a_mc);
+    }
+  };
+
+  auto load_B = [&](int k0) {
+    if (BKIND == B_NK) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
+    } else if (BKIND == B_KN) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + (long)(k0 + tid / BF4 + q * BRPP) * p.ldb + b_nc);
+    } else if (BKIND == B_KN_DGRAD) {  // k = tap'*Cout + co ; B[k][ci] = W[co][8 - tap'][ci]
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const int kk = k0 + tid / BF4 + q * BRPP;
+        const int tapp = kk / p.wCout, co = kk - tapp * p.wCout;
+        rb[q] = ld4(Bp + ((long)co * 9 + (8 - tapp)) * p.wCin + b_nc);
+      }
+    } else {  // B_KN_IM2COL: k = output pixel, column = (tap, ci) of the gathered input
+      const int hw = p.gHo * p.gWo;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const int kk = k0 + tid / BF4 + q * BRPP;
+        const int b = kk / hw;
+        const int r = kk - b * hw;
+        const int oy = r / p.gWo, ox = r - oy * p.gWo;
+        const int iy = oy * p.gStride - 1 + bj_ky, ix = ox * p.gStride - 1 + bj_kx;
+        const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
+        const long off = inb ? ((long)(b * p.gH + iy) * p.gW + ix) * p.gC + bj_ci : 0;
+        float4 v = ld4(Bp + off);
+        rb[q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  auto store_lds = [&]() {
+    if (A_RM) {
+#pragma unroll
+      for (int q = 0; q < PA; ++q)
+        *reinterpret_cast<float4*>(&As[((tid >> 3) + q * 32) * LDK + (tid & 7) * 4]) = ra[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < PA; ++q)
+        *reinterpret_cast<float4*>(&As[(tid / AF4 + q * ARPP) * (BM + 4) + (tid % AF4) * 4]) = ra[q];
+    }
+    if (B_RM) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q)
+        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + q * 32) * LDK + (tid & 7) * 4]) = rb[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < PB; ++q)
+        *reinterpret_cast<float4*>(&Bs[(tid / BF4 + q * BRPP) * (BN + 4) + (tid % BF4) * 4]) = rb[q];
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31, kh = lane >> 5;
+  load_A(kbeg);
+  load_B(kbeg);
+  store_lds();
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += FBK) {
+    const bool more = (k0 + FBK) < kend;  // uniform
+    if (more) {
+      load_A(k0 + FBK);
+      load_B(k0 + FBK);
+    }
+#pragma unroll
+    for (int g = 0; g < FBK; g += 8) {
+      float4 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WM + i * 32 + li;
+        if (A_RM) {
+          a[i] = *reinterpret_cast<const float4*>(&As[row * LDK + g + kh * 4]);
+        } else {
+          const float* s = &As[(g + kh * 4) * (BM + 4) + row];
+          a[i] = make_float4(s[0], s[BM + 4], s[2 * (BM + 4)], s[3 * (BM + 4)]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = wn * WN + j * 32 + li;
+        if (B_RM) {
+          b[j] = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + kh * 4]);
+        } else {
+          const float* s = &Bs[(g + kh * 4) * (BN + 4) + col];
+          b[j] = make_float4(s[0], s[BN + 4], s[2 * (BN + 4)], s[3 * (BN + 4)]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) {
+      store_lds();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ---------------------
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < p.M && col < p.N) {
+          float v = acc[i][j][r];
+          if (EPI == EPI_SLAB) {
+            p.C[((long)blockIdx.z * p.M + row) * p.N + col] = v;
+          } else {
+            v *= p.alpha;
+            if (p.bias_mode == 1) v += p.bias[col];
+            else if (p.bias_mode == 2) v += p.bias[row];
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
+            if (p.resid) v += p.resid[(long)zb * p.sR + (long)row * p.ldr + col];
+            p.C[(long)zb * p.sC + (long)row * p.ldc + col] = v;
+          }
+        }
+      }
+    }
+}
