@@ -70,8 +70,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # TRIS_FORCE_DIST=1 exercises the RCCL code path (SyncBN collectives + gradient all-reduce) with a single rank
+    force = os.environ.get("TRIS_FORCE_DIST") == "1"
+    if world > 1 or force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from tris_amd import ops
@@ -98,9 +102,9 @@ def main():
     max_iter = 1000 * args.epoch
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: (1 - x / max_iter) ** 0.9)
     reducer = None
-    if world > 1:
+    if world > 1 or force:
         convert_sync_batchnorm(model)
-        reducer = GradReducer([ar.g for ar in opt.arenas])
+        reducer = GradReducer([ar.g for ar in opt.arenas], force=force)
     b = synthetic_batch(a.batch, 320, 20, 3, seed=7, rank=rank)
     img, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
 
@@ -167,7 +171,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,6 +32,7 @@ for it in range(3):
     opt.step()
     t3 = sync()
     print(f"iter {it}: fwd {1e3*(t1-t0):.1f} ms  bwd {1e3*(t2-t1):.1f} ms  opt {1e3*(t3-t2):.1f} ms  loss {losses.tolist()}", flush=True)
+ops._PROF_SHAPES = True
 ops.profile_begin()
 losses, cls, sig = stage1_forward_losses(m, aux, img, ids, neg, args)
 losses[0].backward()
@@ -39,8 +40,7 @@ rec = ops.profile_end()
 kinds = {}
 for k, f, ms in rec:
     e = kinds.setdefault(k, [0, 0.0, 0.0]); e[0] += 1; e[1] += f; e[2] += ms
-for k, v in kinds.items():
-    print(f"  {k:14s} launches {v[0]:4d}  {v[1]/1e9:9.1f} GF  {v[2]:9.2f} ms  {v[1]/(v[2]*1e-3)/1e12:7.2f} TF/s", flush=True)
-worst = sorted(rec, key=lambda r: -r[2])[:15]
-for k, f, ms in worst:
-    print(f"   slow: {k} {f/1e9:.2f} GF {ms:.3f} ms {f/(ms*1e-3)/1e12:.2f} TF/s", flush=True)
+tot = sum(v[2] for v in kinds.values())
+print(f"total GEMM-family ms {tot:.2f}")
+for k, v in sorted(kinds.items(), key=lambda kv: -kv[1][2])[:45]:
+    print(f"  {v[2]:8.3f} ms {100*v[2]/tot:5.1f}%  x{v[0]:3d}  {v[1]/1e9:8.1f} GF  {v[1]/(v[2]*1e-3)/1e12:7.2f} TF/s  {k}", flush=True)

@@ -89,6 +89,7 @@ def _emit(p, make, needs):
 # bench.py measures the dominant kernel family live: when enabled, every MFMA GEMM / implicit-GEMM conv launch is
 # bracketed by HIP events on the launch stream and logged with its algorithmic FLOPs.
 _PROF = None
+_PROF_SHAPES = False
 
 
 def profile_begin():
@@ -104,14 +105,14 @@ def profile_end():
     return [(k, f, a.elapsed_time(b)) for k, f, a, b in rec]
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, tag=None):
     if _PROF is None:
         return fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     r = fn()
     b.record()
-    _PROF.append((kind, flops, a, b))
+    _PROF.append((kind if tag is None else f"{kind}:{tag}", flops, a, b))
     return r
 
 
@@ -122,7 +123,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
     ws = workspace(0) if (use_ws and batch == 1) else None
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
-        bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()))
+        bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
+        tag=(f"{'T' if tA else 'N'}{'T' if tB else 'N'} M{M} N{N} K{K} b{batch}" if _PROF_SHAPES else None))
     return C
 
 

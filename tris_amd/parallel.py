@@ -26,14 +26,15 @@ def convert_sync_batchnorm(module, process_group=None):
 class GradReducer:
     """Mean-all-reduce flat gradient buffers in `chunk_mb` pieces; `reduce()` after backward, before step."""
 
-    def __init__(self, flats, group=None, chunk_mb=64):
+    def __init__(self, flats, group=None, chunk_mb=64, force=False):
         self.flats = list(flats)
         self.group = group
         self.chunk = chunk_mb * (1 << 20) // 4
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force  # run the collectives even with one rank (code-path test)
 
     def reduce(self):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         handles = []
         for f in self.flats:
