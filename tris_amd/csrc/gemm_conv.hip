@@ -381,31 +381,44 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmPa
 
 template <int AK, int BKIND>
 int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
-  // tile choice: biggest tile that still gives the 256 CUs something to do.  When split-K is available (wgrad,
-  // small-M linears) prefer the 128-wide tiles (2x2 fragments per wave: half the LDS reads per MFMA of 64x64) and
-  // recover the parallelism along K instead.
-  int bm, bn;
+  // Tile / split-K choice by a small cost model (cycles on the f32 MFMA pipe, 64 cycles per 32x32x2 MFMA):
+  //   per-wave cycles per 32-deep k step = (BM/64)*(BN/64)*1024; a block owns a CU's 4 SIMDs; blocks beyond the 256
+  //   CUs queue.  Split-K adds a slab round trip + a reduce launch.  Smaller tiles pay extra LDS / L2 traffic.
   const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
-  long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
-  if (p.N <= 64) {
-    bn = 64;
-    bm = ((long)cdiv(p.M, 128) * batch >= 256 || (can_split && p.M >= 128)) ? 128 : 64;
-  } else if (t128 >= 192 || (can_split && p.M >= 128 && p.N >= 128)) {
-    bm = bn = 128;
-  } else {
-    bm = bn = 64;
-  }
-  int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
-  long tiles = (long)tiles_m * tiles_n * batch;
-  p.tiles_n = tiles_n;
-  // split-K when the output grid cannot fill the chip and K is long
-  int splitk = 1;
-  if (can_split && tiles < 192) {
+  int bm = 64, bn = 64, splitk = 1;
+  if (can_split && p.K >= 4096) {
+    // long-K reductions (wgrad over pixels): 2 co-resident blocks per CU keep the MFMA pipe busy across the
+    // barrier / staging phases, and ~512 blocks smooth the wave quantisation -> split K until there are ~512 blocks
+    if (p.N <= 64) { bn = 64; bm = p.M >= 128 ? 128 : 64; }
+    else if (p.M >= 128 && p.N >= 128) { bm = bn = 128; }
+    const long tiles = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
     splitk = (int)min((long)cdiv(512, tiles), (long)(p.K / 256));
-    long per = (long)p.M * p.N * sizeof(float);
+    const long per = (long)p.M * p.N * (long)sizeof(float);
     if ((long)splitk * per > ws_bytes) splitk = (int)(ws_bytes / per);
     if (splitk < 2) splitk = 1;
+  } else {
+    static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const double pen[3] = {1.0, 1.08, 1.2};
+    double best = 1e30;
+    for (int c = 0; c < 3; ++c) {
+      const int cbm = cand[c][0], cbn = cand[c][1];
+      if (c < 2 && p.M < 96) continue;           // 128-row tiles on a tiny M waste the MFMA
+      if (c == 0 && p.N <= 64) continue;
+      const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
+      const double per_k32 = (cbm / 64) * (cbn / 64) * 1024.0 * pen[c];
+      const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
+      for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
+        if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
+        const double ksteps = (double)cdiv(cdiv(p.K, sk), 32);
+        const double blocks = (double)tiles * sk;
+        double t = (ksteps * per_k32 + 3000.0) * (blocks <= 256.0 ? 1.0 : blocks / 256.0);
+        if (sk > 1) t += 14000.0 + 2.0 * sk * (double)p.M * p.N * 4.0 / 2000.0;  // reduce launch + slab bytes @ ~2 kB/cycle
+        if (t < best) { best = t; bm = cbm; bn = cbn; splitk = sk; }
+      }
+    }
   }
+  int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
+  p.tiles_n = tiles_n;
   const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
   const int kalign = fast ? 32 : BK;
   p.splitk = splitk;
