@@ -132,7 +132,9 @@ def main():
     # ---- live roofline measurement of the dominant kernel family (one extra, untimed, instrumented step) ----
     ops.profile_begin()
     step()
-    rec = ops.profile_end()
+    rec_all = ops.profile_end()
+    xa = [r for r in rec_all if r[0].startswith("xattn")]
+    rec = [r for r in rec_all if not r[0].startswith("xattn")]
     fl = sum(r[1] for r in rec)
     ms = sum(r[2] for r in rec)
     kinds = {}
@@ -156,6 +158,25 @@ def main():
                             "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
                         for k, v in kinds.items()}}
 
+    # PMC-derived HBM traffic of the same kernel family (separate rocprofv3 --pmc passes, committed under profiles/)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_hbm_traffic.json")))["gemm_family"]
+        roof["traffic"] = int((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / pmc["launches_per_step"])
+        roof["traffic_note"] = ("bytes per launch, averaged over the family: (FETCH_SIZE x2 + WRITE_SIZE) per step / launches per "
+                                "step from profiles/r1c_pmc_hbm_traffic.json (rocprofv3 --pmc, B=48 step)")
+    except Exception:
+        pass
+    roof_x = None
+    if xa:
+        P_, N_, C_ = 100, a.batch, 1024
+        xbytes = a.batch * (4 * P_ * C_ + N_ * C_) * 4 + 3 * N_ * C_ * 4
+        xms = sum(r[2] for r in xa)
+        roof_x = {"bound": "hbm", "achieved": round(xbytes / (xms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(xbytes / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                  "kernel": "xattn_scores_kernel + xattn_out_kernel (fused bilateral cross attention, forward, both launches)",
+                  "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
+                  "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
+
     if rank == 0:
         out = {"metric": "Stage-1 training images/sec @320px bs48 (TRIS clip-RN50, 3 negatives)",
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps,
@@ -167,7 +188,7 @@ def main():
                           "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": 20,
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
                "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
-               "roofline": roof}
+               "roofline": roof, "roofline_xattn": roof_x}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(out))

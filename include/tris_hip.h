@@ -113,6 +113,18 @@ int tris_l2norm_bwd_f32(const float* dY, const float* Y, const float* inv_norm, 
 /* softmax(scale * x) over rows of length n  (model/attn.py:119,122) */
 int tris_softmax_fwd_f32(const float* X, float* Y, long rows, int n, float scale, void* stream);
 int tris_softmax_bwd_f32(const float* dY, const float* Y, float* dX, long rows, int n, float scale, void* stream);
+/* Fused image<->text cross attention of bilateral_prompt (model/attn.py:117-128), all images in two launches.
+ * Qv,Kv,Vv [B,P,C] (pixels, channels-last), Qt,Kt,Vt [N,C] (sentences, one set shared by every image -- the reference
+ * repeats it, model_stage1.py:66), scale = 1/sqrt(C); N <= 64, C % 64 == 0.
+ *   new_vis[b] = softmax_n(Qv[b].Kt^T*scale).Vt      [B,P,C]
+ *   new_lan[b] = softmax_p(Qt.Kv[b]^T*scale).Vv[b]   [B,N,C]
+ * probs [B,3,P,N] (scratch + saved for backward): plane 0 = Av, plane 1 = Kv.Qt^T logits, plane 2 = AtT (pixel-major). */
+int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
+                       const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
+                       void* stream);
+/* backward of a softmax taken over the P axis of [B,P,N]: dX = scale*Y*(dY - sum_p Y*dY)  (model/attn.py:122) */
+int tris_softmax_col_bwd_f32(const float* dY, const float* Y, float* dX, int B, int P, int N, float scale,
+                             void* stream);
 /* training cls head on score [B,P,N]: bg channel + channel softmax + mean/max pooling + focal term
  * (model_stage1.py:80-108, focal_loss :122-123).  cls_fg may be NULL. */
 int tris_cls_head_fwd_f32(const float* score, float* cls_out, float* cls_fg, int B, int P, int N, float focal_p,

@@ -371,3 +371,23 @@ def test_eval_post(ops):
     close(gcam, cam, 1e-5)
     assert abs(iu[0] - I) <= 2 and abs(iu[1] - U) <= 2  # exact up to pixels sitting on the 1e-9 threshold
     assert gcam.flatten()[iu[2]].item() == pytest.approx(float(cam.max()), abs=1e-6)
+
+
+@pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64)])
+def test_xattn_fused(ops, B, P, N, C):
+    Qv, Kv, Vv = leaf(B, P, C, seed=1), leaf(B, P, C, seed=2), leaf(B, P, C, seed=3)
+    Qt, Kt, Vt = leaf(N, C, seed=4), leaf(N, C, seed=5), leaf(N, C, seed=6)
+    sc = 1.0 / math.sqrt(C)
+    Av = torch.softmax(Qv @ Kt.t() * sc, dim=2)
+    At = torch.softmax(Qt @ Kv.transpose(1, 2) * sc, dim=2)
+    nv, nl = Av @ Vt, At @ Vv
+    wv = torch.randn(nv.shape, generator=torch.Generator().manual_seed(7))
+    wl = torch.randn(nl.shape, generator=torch.Generator().manual_seed(8))
+    ((nv * wv).sum() + (nl * wl).sum()).backward()
+    g = [gpu_leaf(t) for t in (Qv, Kv, Vv, Qt, Kt, Vt)]
+    gnv, gnl = ops.xattn(*g)
+    ((gnv * wv.cuda()).sum() + (gnl * wl.cuda()).sum()).backward()
+    close(gnv, nv, name="new_vis")
+    close(gnl, nl, name="new_lan")
+    for a, b, name in zip(g, (Qv, Kv, Vv, Qt, Kt, Vt), ("dQv", "dKv", "dVv", "dQt", "dKt", "dVt")):
+        close(a.grad, b.grad, 5e-4, name=name)

@@ -54,10 +54,13 @@ class bilateral_prompt(nn.Module):
         scale = 1.0 / math.sqrt(lan.shape[-1])
         Qv, Kv, Vv = (_vbranch(getattr(self, f"v_proj{i}"), vis, True) for i in (1, 2, 3))
         Qt, Kt, Vt = (getattr(self, f"t_proj{i}")[0](lan, act=1) for i in (1, 2, 3))
-        Av = ops.softmax(ops.matmul(Qv, Kt, tB=True), scale)        # [B,P,N]  softmax over sentences
-        At = ops.softmax(ops.bmm(Qt, Kv, tB=True), scale)           # [B,N,P]  softmax over pixels
-        new_vis = ops.matmul(Av, Vt, tB=False)                      # [B,P,C]
-        new_lan = ops.bmm(At, Vv, tB=False)                         # [B,N,C]
+        if Qt.shape[0] <= 64 and C % 64 == 0 and Pp <= 256:
+            new_vis, new_lan = ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)   # fused cross attention (csrc/xattn.hip)
+        else:  # composed from the GEMM core + row softmax (same math) for shapes outside the fused kernel's limits
+            Av = ops.softmax(ops.matmul(Qv, Kt, tB=True), scale)        # [B,P,N]  softmax over sentences
+            At = ops.softmax(ops.bmm(Qt, Kv, tB=True), scale)           # [B,N,P]  softmax over pixels
+            new_vis = ops.matmul(Av, Vt, tB=False)                      # [B,P,C]
+            new_lan = ops.bmm(At, Vv, tB=False)                         # [B,N,C]
         new_vis = _vbranch(self.v_output, new_vis, False)
         new_lan = self.t_output[0](new_lan)
         return new_vis, new_lan

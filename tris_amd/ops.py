@@ -671,6 +671,61 @@ def instance_norm(x, g, b, relu=False, eps=1e-5):
     return InstNormFn.apply(x, g, b, relu, eps)
 
 
+class XAttnFn(torch.autograd.Function):
+    """Fused bilateral cross attention (model/attn.py:117-128): forward = tris_xattn_fwd (two launches for the whole
+    batch); backward = nine large single GEMMs on the saved probabilities + two softmax-backward kernels."""
+
+    @staticmethod
+    def forward(ctx, Qv, Kv, Vv, Qt, Kt, Vt):
+        _chk(Qv, Kv, Vv, Qt, Kt, Vt)
+        Qv, Kv, Vv, Qt, Kt, Vt = (t.contiguous() for t in (Qv, Kv, Vv, Qt, Kt, Vt))
+        B, Pp, C = Qv.shape
+        N = Qt.shape[0]
+        dev = Qv.device
+        new_vis = torch.empty(B, Pp, C, device=dev, dtype=torch.float32)
+        new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
+        probs = torch.empty(B, 3, Pp, N, device=dev, dtype=torch.float32)
+        _timed("xattn_fwd", 8.0 * B * Pp * N * C,
+               lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
+                            P(probs), B, Pp, N, C, _stream()))
+        ctx.dims = (B, Pp, N, C)
+        ctx.save_for_backward(Qv, Kv, Vv, Qt, Kt, Vt, probs)
+        return new_vis, new_lan
+
+    @staticmethod
+    def backward(ctx, d_vis, d_lan):
+        Qv, Kv, Vv, Qt, Kt, Vt, probs = ctx.saved_tensors
+        B, Pp, N, C = ctx.dims
+        dev = Qv.device
+        scale = 1.0 / math.sqrt(C)
+        d_vis, d_lan = d_vis.contiguous(), d_lan.contiguous()
+        BP = B * Pp
+        Av = probs[:, 0].contiguous().view(BP, N)
+        AtT = probs[:, 2].contiguous().view(B, Pp, N)
+
+        def new(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+        # pixel -> sentence direction:  new_vis = Av . Vt
+        dAv = gemm(d_vis, Vt, new(BP, N), BP, N, C, C, C, N, False, True)                      # [BP,N] = d_vis . Vt^T
+        dVt = gemm(Av, d_vis, new(N, C), N, C, BP, N, C, C, True, False)                       # Av^T . d_vis
+        dS1 = new(BP, N)
+        call("tris_softmax_bwd_f32", P(dAv), P(Av), P(dS1), BP, N, scale, _stream())
+        dQv = gemm(dS1, Kt, new(B, Pp, C), BP, C, N, N, C, C, False, False)                    # dS1 . Kt
+        dKt = gemm(dS1, Qv, new(N, C), N, C, BP, N, C, C, True, False)                         # dS1^T . Qv
+        # sentence -> pixel direction:  new_lan[b] = AtT[b]^T . Vv[b]
+        dAtT = gemm(Vv, d_lan, new(B, Pp, N), Pp, N, C, C, C, N, False, True, batch=B, sA=Pp * C, sB=N * C, sC=Pp * N)
+        dVv = gemm(AtT, d_lan, new(B, Pp, C), Pp, C, N, N, C, C, False, False, batch=B, sA=Pp * N, sB=N * C, sC=Pp * C)
+        dS2 = new(B, Pp, N)
+        call("tris_softmax_col_bwd_f32", P(dAtT), P(AtT), P(dS2), B, Pp, N, scale, _stream())
+        dKv = gemm(dS2, Qt, new(B, Pp, C), BP, C, N, N, C, C, False, False)                    # dS2T . Qt
+        dQt = gemm(dS2, Kv, new(N, C), N, C, BP, N, C, C, True, False)                         # dS2T^T . Kv
+        return dQv, dKv, dVv, dQt, dKt, dVt
+
+
+def xattn(Qv, Kv, Vv, Qt, Kt, Vt):
+    return XAttnFn.apply(Qv, Kv, Vv, Qt, Kt, Vt)
+
+
 class AxpyFn(torch.autograd.Function):
     """s * a + b"""
 
