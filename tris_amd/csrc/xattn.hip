@@ -1,5 +1,5 @@
 // Fused image<->text cross attention of `bilateral_prompt` (reference model/attn.py:117-128) for ALL images of the batch
-// in two launches (gfx950).  This is the kernel pair the north star prices against the HBM roofline:
+// in three launches (gfx950).  This is the kernel pair the north star prices against the HBM roofline:
 // algorithmic traffic per image = Qv,Kv,Vv reads (3 x P x C x 4 B) + new_vis, new_lan writes = 1.84 MB at P=100, N=48, C=1024.
 //
 //   pixels   Qv,Kv,Vv [B,P,C]   (v_proj1..3 outputs, channels-last)
@@ -45,17 +45,36 @@ __global__ __launch_bounds__(256) void xattn_scores_kernel(const float* __restri
   for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int kspan = C / 4;  // channels per wave
   const int kbeg = wave * kspan;
-  for (int k = kbeg; k < kbeg + kspan; k += 16) {
-    const float4 a = ld4(xr + k);
-    float4 t[NF];
+  // 64 channels per trip: all 4*(1+NF) 16-byte loads are issued before the first MFMA consumes one (the loop is
+  // latency-bound otherwise: every MFMA group would wait a full HBM/L2 round trip)
+  int k = kbeg;
+  for (; k + 64 <= kbeg + kspan; k += 64) {
+    float4 a[4], t[NF][4];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) t[f] = ld4(tr[f] + k);
+    for (int u = 0; u < 4; ++u) {
+      a[u] = ld4(xr + k + 16 * u);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) t[f][u] = ld4(tr[f] + k + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, t[f][u].x, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, t[f][u].y, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, t[f][u].z, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, t[f][u].w, acc[f], 0, 0, 0);
+      }
+  }
+  for (; k < kbeg + kspan; k += 16) {  // remainder when C/4 is not a multiple of 64
+    const float4 a = ld4(xr + k);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, t[f].x, acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, t[f].y, acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, t[f].z, acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, t[f].w, acc[f], 0, 0, 0);
+      const float4 t = ld4(tr[f] + k);
+      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, t.x, acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, t.y, acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, t.z, acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, t.w, acc[f], 0, 0, 0);
     }
   }
   // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -80,6 +99,30 @@ __global__ __launch_bounds__(256) void xattn_scores_kernel(const float* __restri
   }
 }
 
+// Pixel softmax of the Kv.Qt^T logits (plane 1 -> AtT probabilities in plane 2); one workgroup per image, so the
+// exponentials are evaluated once per image instead of once per channel tile of launch 3.
+__global__ __launch_bounds__(256) void xattn_colsoftmax_kernel(float* __restrict__ probs, int P, int N) {
+  __shared__ float cm[128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* lg = probs + ((long)b * 3 + 1) * P * N;
+  float* out = probs + ((long)b * 3 + 2) * P * N;
+  const int n = tid >> 2, q = tid & 3;
+  float m = -INFINITY;
+  if (n < N) for (int p = q; p < P; p += 4) m = fmaxf(m, lg[(long)p * N + n]);
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  float s = 0.f;
+  if (n < N) for (int p = q; p < P; p += 4) s += expf(lg[(long)p * N + n] - m);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (q == 0) { cm[n] = m; cm[64 + n] = s; }
+  __syncthreads();
+  for (int i = tid; i < P * N; i += 256) {
+    const int nn = i % N;
+    out[i] = expf(lg[i] - cm[nn]) / cm[64 + nn];
+  }
+}
+
 // grid (C/32, B); block 256; dynamic LDS
 template <int NF>
 __global__ __launch_bounds__(256) void xattn_out_kernel(const float* __restrict__ Vv, const float* __restrict__ Vt,
@@ -93,49 +136,60 @@ __global__ __launch_bounds__(256) void xattn_out_kernel(const float* __restrict_
   float* pT = pA + PR * NP;       // AtT [PR][NP]
   float* vt = pT + PR * NP;       // Vt tile [NF*16][CP] (rows >= N zero)
   float* vv = vt + NF * 16 * CP;  // Vv tile [PR][CP]     (rows >= P zero)
-  float* cm = vv + PR * CP;       // column max / sum scratch [2][64]
   const int c0 = blockIdx.x * CT, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* pb = probs + (long)b * 3 * P * N;
-  for (int i = tid; i < PR * NP; i += 256) {
-    const int p = i / NP, n = i - p * NP;
-    const bool ok = p < P && n < N;
-    pA[i] = ok ? pb[(long)p * N + n] : 0.f;
-    pT[i] = ok ? pb[((long)P + p) * N + n] : -INFINITY;  // logits for now
-  }
-  for (int i = tid; i < NF * 16 * (CT / 4); i += 256) {
-    const int n = i / (CT / 4), c4 = (i - n * (CT / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) v = ld4(Vt + (long)n * C + c0 + c4);
-    *reinterpret_cast<float4*>(&vt[n * CP + c4]) = v;
-  }
-  for (int i = tid; i < PR * (CT / 4); i += 256) {
-    const int p = i / (CT / 4), c4 = (i - p * (CT / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p < P) v = ld4(Vv + ((long)b * P + p) * C + c0 + c4);
-    *reinterpret_cast<float4*>(&vv[p * CP + c4]) = v;
-  }
-  __syncthreads();
-  // softmax over the P pixels of every sentence column of pT (4 threads per column, P/4 rows each)
+  // Fills are written as "issue U independent loads, then store" so the global latency is paid once per batch.
   {
-    const int n = tid >> 2, q = tid & 3;
-    float m = -INFINITY;
-    if (n < N) for (int p = q; p < P; p += 4) m = fmaxf(m, pT[p * NP + n]);
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    m = fmaxf(m, __shfl_xor(m, 2, 64));
-    float s = 0.f;
-    if (n < N) for (int p = q; p < P; p += 4) s += expf(pT[p * NP + n] - m);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (n < 64 && q == 0) { cm[n] = m; cm[64 + n] = s; }
+    const int total = P * N;  // compact [P][N] planes in HBM -> padded [PR][NP] LDS rows; pads pre-set below
+    for (int i = tid; i < PR * NP; i += 256) { pA[i] = 0.f; pT[i] = 0.f; }
+    __syncthreads();
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < total; i0 += 256 * U) {
+      float va[U], vl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + u * 256, total - 1);
+        va[u] = pb[i];
+        vl[u] = pb[(long)2 * total + i];  // plane 2: AtT probabilities (xattn_colsoftmax_kernel)
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total) {
+          const int p = i / N, n = i - p * N;
+          pA[p * NP + n] = va[u];
+          pT[p * NP + n] = vl[u];
+        }
+      }
+    }
   }
-  __syncthreads();
-  for (int i = tid; i < PR * NP; i += 256) {
-    const int p = i / NP, n = i - p * NP;
-    const bool ok = p < P && n < N;
-    const float v = ok ? expf(pT[i] - cm[n]) / cm[64 + n] : 0.f;
-    pT[i] = v;
-    if (ok && blockIdx.x == 0) pb[((long)2 * P + p) * N + n] = v;  // publish AtT (plane 2) for the backward pass
+  {
+    constexpr int F4 = CT / 4;
+    for (int i = tid; i < NF * 16 * F4; i += 256) {
+      const int n = i / F4, c4 = (i - n * F4) * 4;
+      float4 v = ld4(Vt + (long)min(n, N - 1) * C + c0 + c4);
+      if (n >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&vt[n * CP + c4]) = v;
+    }
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < PR * F4; i0 += 256 * U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + u * 256, PR * F4 - 1);
+        const int p = i / F4, c4 = (i - p * F4) * 4;
+        v[u] = ld4(Vv + ((long)b * P + min(p, P - 1)) * C + c0 + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 256;
+        if (i < PR * F4) {
+          const int p = i / F4, c4 = (i - p * F4) * 4;
+          *reinterpret_cast<float4*>(&vv[p * CP + c4]) = p < P ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
   }
   __syncthreads();
   const int li = lane & 15, kq = lane >> 4;
@@ -195,6 +249,8 @@ int launch_fwd(const float* Qv, const float* Kv, const float* Vv, const float* Q
   const float scale = 1.0f / sqrtf((float)C);
   hipLaunchKernelGGL((xattn_scores_kernel<NF>), dim3((P + 15) / 16, 2, B), dim3(256), 0, st, Qv, Kv, Qt, Kt, probs, P, N,
                      C, scale);
+  TRIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(xattn_colsoftmax_kernel, dim3(B), dim3(256), 0, st, probs, P, N);
   TRIS_LAUNCH_CHECK();
   const size_t lds = out_lds_bytes(P, NF);
   static bool attr_done[MAXNF + 1] = {false, false, false, false, false};
