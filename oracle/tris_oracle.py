@@ -374,3 +374,16 @@ def hit_test(cam, boxes, gt_mask):
         if b[0] <= x <= b[2] and b[1] <= y <= b[3]:
             return 1, (y, x), hitm
     return 0, (y, x), hitm
+
+
+def prms_scores(sd, aux, img, ids_all):
+    """validate_same_sentence scoring -- validate.py:299-333 for ONE ref.
+    img [1,3,S,S], ids_all [S_ref, L] -> (maps [S_ref,1,H,W], score[S_ref]); the reference keeps the first arg-max."""
+    maps = torch.cat([tris_forward(sd, img, ids_all[j:j + 1], False) for j in range(ids_all.shape[0])], 0)
+    im = F.interpolate(img, (224, 224), mode="bilinear", align_corners=True)
+    cam = F.interpolate(maps, (224, 224), mode="bilinear", align_corners=True)
+    f_i = encode_image_vit(aux, "", cam * im)
+    f_t = encode_text(aux, "", ids_all)[1]
+    f_i = f_i / f_i.norm(dim=-1, keepdim=True)
+    f_t = f_t / f_t.norm(dim=-1, keepdim=True)
+    return maps, (f_i @ f_t.t()).sum(1)

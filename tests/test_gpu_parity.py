@@ -218,3 +218,61 @@ def test_g7_eval_postprocess(model, batch, golden):
             assert err(cam[::8, ::8], g[f"case{n}_cam_ds8"]) < 1e-4
             # synthetic-target IoU within +-0.1 (percent points) of the reference's
             assert abs(100.0 * iu[0] / iu[1] - 100.0 * I / U) < 0.1
+
+
+class _OneRefLoader(list):
+    pass
+
+
+def test_validate_and_prms_against_oracle(model, aux):
+    """validate() / validate_same_sentence() on a synthetic 2-ref, 3-sentence loader vs the oracle's restatement."""
+    from types import SimpleNamespace
+    from oracle import tris_oracle as O
+    from tris_amd.utils.synth import synthetic_batch, synthetic_ids
+    from tris_amd.validate import validate, validate_same_sentence
+    refill(model)
+    model.eval()
+    args = SimpleNamespace(print_freq=1000, cam_save_dir=None, name_save_dir=None, dataset="refcocog", save_cam=False,
+                           max_query_len=20)
+    rng = np.random.RandomState(3)
+    loader = _OneRefLoader()
+    refs = []
+    for r in range(2):
+        img = synthetic_batch(1, 320, 20, 0, seed=40 + r)["img"]
+        ids = torch.from_numpy(synthetic_ids(3, 20, rng))                     # [S=3, L]
+        oh, ow = (427, 640) if r == 0 else (333, 480)
+        tgt = torch.zeros(1, oh, ow, dtype=torch.int64)
+        tgt[0, 50:200, 100:300] = 1
+        box = torch.tensor([[100, 50, 300, 200]])
+        loader.append(({"img": img, "word_ids": ids.t().reshape(1, 1, 20, 3), "word_masks": torch.ones(1, 1, 20, 3)},
+                       {"target": tgt, "boxes": box, "img_path": torch.tensor([r]), "sentences": []}))
+        refs.append((img, ids, tgt[0].bool(), box))
+    oIoU, mIoU, hit = validate(args, loader, model, 0)
+    sd = cpu_sd(model)
+    Is = Us = 0
+    ious, hits = [], []
+    with torch.no_grad():
+        for img, ids, tgt, box in refs:
+            for j in range(3):
+                o = O.tris_forward(sd, img, ids[j:j + 1], False)
+                I, U, m, cam = O.eval_postprocess(o, tgt)
+                Is += I
+                Us += U
+                ious.append(I / U)
+                hits.append(O.hit_test(cam, box.tolist(), tgt)[0])
+    assert abs(oIoU - 100 * Is / Us) < 0.1 and abs(float(mIoU) - 100 * np.mean(ious)) < 0.1
+    assert abs(hit - 100 * np.mean(hits)) < 1e-6
+    # PRMS
+    o2, m2, h2 = validate_same_sentence(args, loader, model, 0, clip_model=aux)
+    auxsd = {k: v.detach().cpu().clone() for k, v in aux.state_dict().items()}
+    Is = Us = 0.0
+    ious = []
+    with torch.no_grad():
+        for img, ids, tgt, box in refs:
+            maps, score = O.prms_scores(sd, auxsd, img, ids)
+            best = int(torch.argmax(score))
+            I, U, m, cam = O.eval_postprocess(maps[best:best + 1], tgt)
+            Is += I * 9.0
+            Us += U * 9.0
+            ious += [I / U] * 3
+    assert abs(o2 - 100 * Is / Us) < 0.1 and abs(float(m2) - 100 * np.mean(ious)) < 0.1

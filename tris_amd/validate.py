@@ -103,3 +103,79 @@ def validate(args, data_loader, model, local_rank=0, visualize=False, logger=Non
     hit = 100 * hits / max(nsent, 1.0)
     say(f"Test: mIOU {float(mIOU):.5f}  Overall IOU {overall_IoU:.5f}  HiT {hit:.3f}")
     return overall_IoU, mIOU, hit
+
+
+@torch.no_grad()
+def validate_same_sentence(args, data_loader, model, local_rank=0, visualize=False, logger=None, save_cam=False,
+                           clip_model=None):
+    """PRMS evaluation (validate.py:252-387): for every ref, each sentence's response map is scored by the aux CLIP
+    against ALL sentences of the ref (sum of cosines of the CLIP-masked image with each sentence); the best-scoring
+    map is used for every sentence of the ref (so I, U, hit are weighted by the sentence count exactly as the reference
+    does, :336-344).  Here the S foreground images go through the aux ViT as ONE batch and the S sentences through the
+    text tower once (the reference runs S*S single forwards)."""
+    from .CLIP import clip as _clip
+    num_steps = len(data_loader)
+    model.eval()
+    net = model.module if hasattr(model, "module") else model
+    say = logger.info if logger is not None else print
+    say("Starting validation with PRMS")
+    save_cam = bool(getattr(args, "save_cam", save_cam))
+    if save_cam and args.name_save_dir:
+        os.makedirs(args.name_save_dir, exist_ok=True)
+    if save_cam and args.cam_save_dir:
+        os.makedirs(args.cam_save_dir, exist_ok=True)
+    if clip_model is None:
+        clip_model, _ = _clip.load("ViT-B/32", device="cuda", jit=False, txt_length=args.max_query_len)
+    clip_model.eval()
+    R = 224
+    mIOU_meter = AverageMeter()
+    I_sum = U_sum = 0.0
+    n_sent = hit_acc = 0
+    cam_out_name = []
+    for idx, (samples, targets) in enumerate(data_loader):
+        img_id = int(np.asarray(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
+        word_ids = samples["word_ids"].squeeze(1).cuda(local_rank, non_blocking=True)      # [1, L, S]
+        img = samples["img"].cuda(local_rank, non_blocking=True)
+        target = targets["target"].cuda(local_rank, non_blocking=True)
+        tgt = (target.reshape(target.shape[-2:]) != 0).to(torch.uint8)
+        bbox = np.asarray(targets["boxes"].cpu() if torch.is_tensor(targets.get("boxes")) else targets.get("boxes", [])).reshape(-1, 4)
+        S = word_ids.size(-1)
+        n_sent += S
+        ids = word_ids[0].t().contiguous()                                                 # [S, L]
+        vis = net.encode_visual(img)
+        maps = [net.forward_cached(vis, ids[j:j + 1], img.shape[2]) for j in range(S)]     # S x [1,1,H,W]
+        outs = torch.cat(maps, 0)                                                          # [S,1,H,W]
+        img224 = ops.resize_bilinear(img, (R, R), True) if img.shape[2] != R else img
+        cam224 = ops.resize_bilinear(outs, (R, R), True) if img.shape[2] != R else outs
+        patches = ops.fg_patches(cam224, img224.expand(S, -1, -1, -1).contiguous(), clip_model.visual.patch_size)
+        f_i = ops.l2norm(clip_model.visual.forward_patches(patches))                       # [S,E]
+        f_t = ops.l2norm(clip_model.encode_text(ids)[1])                                   # [S,E]
+        score = ops.matmul(f_i, f_t, tB=True).sum(dim=1)                                   # [S]  (validate.py:327-329)
+        best = int(torch.argmax(score).item())                                             # first maximum, as `>` does
+        iu, cam = ops.eval_post(maps[best], tgt)
+        I, U, am = iu.tolist()
+        I_sum += float(I) * S * S
+        U_sum += float(U) * S * S
+        mIOU_meter.update(I / U if U > 0 else 0.0, img.size(0) * S)
+        y, x = divmod(am, cam.shape[1])
+        hit = 0
+        for b in bbox:
+            if b[0] <= x <= b[2] and b[1] <= y <= b[3]:
+                hit = 1
+                break
+        hit_acc += hit * S
+        if args.cam_save_dir is not None and save_cam:
+            np.save(os.path.join(args.cam_save_dir, f"{idx}_{img_id}.npy"), cam.cpu().numpy())
+        if args.name_save_dir is not None and save_cam:
+            cam_out_name.append(f"{idx}_{img_id}")
+        if idx % args.print_freq == 0:
+            say(f"Test: [{idx:4d}/{num_steps}] | mIOU {100 * mIOU_meter.avg:.3f} | Overall IOU "
+                f"{100 * I_sum / max(U_sum, 1.0):.3f} | Hit {hit_acc / max(n_sent, 1) * 100:.3f}")
+    if args.name_save_dir is not None and save_cam:
+        with open(os.path.join(args.name_save_dir, f"{args.dataset}_train_names.json"), "w") as f:
+            f.write(json.dumps(cam_out_name))
+    overall_IoU = 100 * I_sum / max(U_sum, 1.0)
+    mIOU = torch.tensor(100 * mIOU_meter.avg)
+    hit = 100 * hit_acc / max(n_sent, 1)
+    say(f"Test: mIOU {float(mIOU):.5f}  Overall IOU {overall_IoU:.5f}  HiT {hit:.3f}")
+    return overall_IoU, mIOU, hit
