@@ -42,6 +42,17 @@ int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* dX, int B, i
 int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout,
                            int stride, float* workspace, long workspace_bytes, void* stream);
 
+/* Forward conv / 1x1 conv (A[M,K] . B[N,K]^T) with the train-mode BatchNorm statistics of the OUTPUT fused into the
+ * epilogue: stat_part <- [rows][2][N] fp64 partial (sum, sum of squares), *stat_rows (HOST int) <- rows, or 0 when the
+ * shape is not eligible (then call tris_bn_stats_f32).  stat_part capacity: ceil(M/128)*2*N doubles.  Finish with
+ * tris_bn_finalize_f32.  (CLIP/clip/model.py:17-29,45-48: conv -> bn pairs of Bottleneck / stem) */
+int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, int M, int N, int K, double* stat_part,
+                         int* stat_rows, void* stream);
+int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout,
+                                int stride, double* stat_part, int* stat_rows, void* stream);
+int tris_bn_finalize_f32(const double* part, int rows, long M, int C, float eps, float momentum, float* stats,
+                         float* running_mean, float* running_var, void* stream);
+
 /* ---- BatchNorm2d (training: batch statistics; CLIP/clip/model.py:18,22,28,39; train_stage1.py:288) ---------------------
  * stats = [mean | invstd | biased var], 3*C floats.  running_* may be NULL (no update).  workspace:
  * tris_col_workspace_bytes(M, C).  Eval mode = tris_bn_apply with mean=running_mean, invstd=rsqrt(running_var+eps). */

@@ -391,3 +391,26 @@ def test_xattn_fused(ops, B, P, N, C):
     close(gnl, nl, name="new_lan")
     for a, b, name in zip(g, (Qv, Kv, Vv, Qt, Kt, Vt), ("dQv", "dKv", "dVv", "dQt", "dKt", "dVt")):
         close(a.grad, b.grad, 5e-4, name=name)
+
+
+@pytest.mark.parametrize("kind,shape", [("conv3", (2, 20, 20, 32, 64)), ("conv3", (3, 24, 24, 64, 160)), ("conv1", (2, 16, 16, 64, 256)),
+                                        ("conv1", (1, 12, 12, 256, 64))])
+def test_fused_bn_statistics_in_conv_epilogue(ops, kind, shape):
+    """conv -> train-mode BN with the statistics taken from the GEMM epilogue == the two-kernel path."""
+    B, H, W, Cin, Cout = shape
+    x = torch.randn(B, H, W, Cin, generator=torch.Generator().manual_seed(1)).cuda() * 2 + 1
+    k = 3 if kind == "conv3" else 1
+    w = (torch.randn(Cout, Cin, k, k, generator=torch.Generator().manual_seed(2)) * 0.1).contiguous(
+        memory_format=torch.channels_last).cuda()
+    g, b = torch.rand(Cout).cuda() + 0.5, torch.randn(Cout).cuda()
+
+    def run(stats):
+        rm, rv = torch.zeros(Cout).cuda(), torch.ones(Cout).cuda()
+        y = ops.conv3x3(x, w, 1, stats=stats) if k == 3 else ops.linear(x, w, None, stats=stats)
+        assert hasattr(y, "_bn_part") == stats
+        return ops.batch_norm(y, g, b, rm, rv, None, True, True), rm, rv
+    with torch.no_grad():
+        (y0, rm0, rv0), (y1, rm1, rv1) = run(False), run(True)
+    close(y1, y0, 1e-5, name="bn out")
+    close(rm1, rm0, 1e-6, name="running_mean")
+    close(rv1, rv0, 1e-5, name="running_var")

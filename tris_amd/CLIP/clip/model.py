@@ -32,11 +32,11 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x):  # x channels-last [B,H,W,Cin]
+    def forward(self, x, stats=False):  # x channels-last [B,H,W,Cin]; stats: fuse the following BatchNorm's statistics
         if self.k == 1:
-            return ops.linear(x, self.weight, self.bias)
+            return ops.linear(x, self.weight, self.bias, stats=stats and self.bias is None)
         assert self.k == 3 and self.bias is None
-        return ops.conv3x3(x, self.weight, self.stride)
+        return ops.conv3x3(x, self.weight, self.stride, stats=stats)
 
 
 class BatchNorm2d(nn.Module):
@@ -92,13 +92,14 @@ class Bottleneck(nn.Module):
             ]))
 
     def forward(self, x):  # channels-last
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
+        tr = self.training  # train mode: BatchNorm batch statistics come out of the producing conv's epilogue
+        out = self.bn1(self.conv1(x, stats=tr), relu=True)
+        out = self.bn2(self.conv2(out, stats=tr), relu=True)
         out = self.avgpool(out)
-        out = self.conv3(out)
+        out = self.conv3(out, stats=tr)
         if self.downsample is not None:
             idn = self.downsample[0](x)
-            idn = self.downsample[2](self.downsample[1](idn))
+            idn = self.downsample[2](self.downsample[1](idn, stats=tr))
         else:
             idn = x
         return self.bn3(out, resid=idn, relu=True)  # relu(bn3(conv3) + identity), fused
@@ -163,9 +164,10 @@ class ModifiedResNet(nn.Module):
     def forward_cl(self, x):
         """x [B,3,H,W] (NCHW, as the reference's callers pass it) -> (c1,c2,c3,c4) channels-last [B,h,w,C]."""
         x = ops.nchw_to_nhwc(x.float())
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
-        x = self.bn3(self.conv3(x), relu=True)
+        tr = self.training
+        x = self.bn1(self.conv1(x, stats=tr), relu=True)   # (conv1 has Cin=3: not eligible, separate statistics pass)
+        x = self.bn2(self.conv2(x, stats=tr), relu=True)
+        x = self.bn3(self.conv3(x, stats=tr), relu=True)
         x = self.avgpool(x)
         outs = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

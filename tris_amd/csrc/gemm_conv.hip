@@ -36,6 +36,7 @@ struct GemmParams {
   float alpha;
   int vecA, vecB;  // 16-byte vector loads legal for the operand
   int fastA, fastB;  // operand satisfies the preconditions of gemm_fast_kernel
+  double* stat_part;  // optional fused BN statistics partials [tiles_m][2][N] (fast kernel, no split-K)
   int kchunk, splitk;
   int tiles_n;
   // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
@@ -386,7 +387,10 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   //   CUs queue.  Split-K adds a slab round trip + a reduce launch.  Smaller tiles pay extra LDS / L2 traffic.
   const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
   int bm = 64, bn = 64, splitk = 1;
-  if (can_split && p.K >= 4096) {
+  if (p.stat_part != nullptr) {  // fused BN statistics: fixed 128-row tiles (the caller sizes the partial buffer), no split-K
+    bm = 128;
+    bn = p.N <= 64 ? 64 : 128;
+  } else if (can_split && p.K >= 4096) {
     // long-K reductions (wgrad over pixels): 2 co-resident blocks per CU keep the MFMA pipe busy across the
     // barrier / staging phases, and ~512 blocks smooth the wave quantisation -> split K until there are ~512 blocks
     if (p.N <= 64) { bn = 64; bm = p.M >= 128 ? 128 : 64; }
@@ -529,4 +533,42 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   p.fastA = p.vecA;
   p.fastB = p.vecB;
   return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+// Conv / 1x1-conv (GEMM) forward with the BatchNorm batch statistics of the OUTPUT fused into the epilogue.
+// stat_part receives [stat_rows][2][N] fp64 partial (sum, sum of squares); *stat_rows (host) = number of partial rows,
+// or 0 when the shape is not eligible for the fused path (then the caller runs tris_bn_stats_f32 as usual).
+static bool stats_eligible(const GemmParams& p) {
+  return p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 128 && p.N >= 4;
+}
+
+extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, int M, int N, int K, double* stat_part,
+                                    int* stat_rows, void* stream) {
+  GemmParams p = {};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = K; p.ldb = K; p.ldc = N; p.alpha = 1.f;
+  p.vecA = al16(A) && (K % 4 == 0);
+  p.vecB = al16(B) && (K % 4 == 0);
+  p.fastA = p.vecA;
+  p.fastB = p.vecB;
+  p.stat_part = stats_eligible(p) ? stat_part : nullptr;
+  *stat_rows = p.stat_part ? cdiv(M, 128) : 0;
+  return launch_cfg<A_ROWK, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin,
+                                           int Cout, int stride, double* stat_part, int* stat_rows, void* stream) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  GemmParams p = {};
+  p.A = X; p.B = Wt; p.C = Y;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+  p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.vecA = al16(X) && (Cin % 16 == 0);
+  p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
+  p.fastA = al16(X) && (Cin % 32 == 0);
+  p.fastB = p.vecB;
+  p.stat_part = stats_eligible(p) ? stat_part : nullptr;
+  *stat_rows = p.stat_part ? cdiv(p.M, 128) : 0;
+  return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
 }

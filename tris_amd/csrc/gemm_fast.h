@@ -218,6 +218,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
   }
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ---------------------
+  float st_s[FN], st_q[FN];  // fused BatchNorm statistics: per-column sum / sum of squares of this block's rows
+#pragma unroll
+  for (int j = 0; j < FN; ++j) st_s[j] = st_q[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -238,8 +241,32 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
             else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
             if (p.resid) v += p.resid[(long)zb * p.sR + (long)row * p.ldr + col];
             p.C[(long)zb * p.sC + (long)row * p.ldc + col] = v;
+            st_s[j] += v;
+            st_q[j] += v * v;
           }
         }
       }
     }
+  if (EPI == EPI_STD && p.stat_part != nullptr) {
+    // rows of one column live in the 2 lane halves (kh) and the 2 waves along M: shuffle, then LDS, then one fp64
+    // partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
+    float* red = As;  // the k loop ended on a barrier: the staging buffer is free
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a = st_s[j] + __shfl_xor(st_s[j], 32, 64);
+      float b = st_q[j] + __shfl_xor(st_q[j], 32, 64);
+      if (kh == 0) {
+        const int cl = wn * WN + j * 32 + li;
+        red[(wm * BN + cl) * 2 + 0] = a;
+        red[(wm * BN + cl) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      const int tm = tile / p.tiles_n;
+      double* o = p.stat_part + (long)tm * 2 * p.N;
+      o[n0 + tid] = (double)red[tid * 2] + (double)red[(BN + tid) * 2];
+      o[p.N + n0 + tid] = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
+    }
+  }
 }

@@ -556,6 +556,15 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
   return 0;
 }
 
+// finish BN statistics from fp64 partials produced by a fused conv epilogue (tris_*_bnstat_f32)
+extern "C" int tris_bn_finalize_f32(const double* part, int rows, long M, int C, float eps, float momentum, float* stats,
+                                    float* running_mean, float* running_var, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, rows, M, C, eps,
+                     momentum, stats, running_mean, running_var);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tris_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* stats,
                                         float* running_mean, float* running_var, void* stream) {
   hipLaunchKernelGGL(bn_sync_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world, C,

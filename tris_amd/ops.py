@@ -150,12 +150,35 @@ def nchw_to_nhwc(x):
     return y
 
 
+# ----------------------------------------------------------------------------------------------- fused BN statistics
+# A conv forward can emit the BatchNorm batch statistics of its output from the GEMM epilogue (tris_*_bnstat_f32).
+# The fp64 partials travel from the conv Function to the BatchNorm Function as an attribute of the output tensor.
+_LAST_STATS = None
+
+
+def _launch_with_stats(y, M, N, launch):
+    import ctypes
+    global _LAST_STATS
+    part = torch.empty(((M + 127) // 128) * 2 * N, device=y.device, dtype=torch.float64)
+    rows = ctypes.c_int(0)
+    launch(part, ctypes.byref(rows))
+    _LAST_STATS = (part, rows.value) if rows.value > 0 else None
+
+
+def _attach_stats(y):
+    global _LAST_STATS
+    if _LAST_STATS is not None:
+        y._bn_part = _LAST_STATS
+        _LAST_STATS = None
+    return y
+
+
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
 class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, act):
+    def forward(ctx, x, w, b, resid, act, stats=False):
         _chk(x, w, b, resid)
         x = x.contiguous()
         K = x.shape[-1]
@@ -164,8 +187,13 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
         if resid is not None:
             resid = resid.contiguous()
-        gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid, ldr=N,
-             act=act)
+        if stats and b is None and resid is None and act == 0:
+            _launch_with_stats(y, M, N, lambda part, rows: _timed(
+                "gemm", 2.0 * M * N * K, lambda: call("tris_gemm_bnstat_f32", P(x), P(w), P(y), M, N, K, part.data_ptr(),
+                                                      rows, _stream())))
+        else:
+            gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid,
+                 ldr=N, act=act)
         ctx.act, ctx.dims = act, (M, N, K)
         ctx.has_b, ctx.has_r = b is not None, resid is not None
         ctx.params = (w, b)
@@ -193,11 +221,12 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
-        return dx, dw, db, d_res, None
+        return dx, dw, db, d_res, None, None
 
 
-def linear(x, w, b=None, resid=None, act=0):
-    return LinearFn.apply(x, w, b, resid, act)
+def linear(x, w, b=None, resid=None, act=0, stats=False):
+    y = LinearFn.apply(x, w, b, resid, act, stats)
+    return _attach_stats(y) if stats else y
 
 
 class MatmulFn(torch.autograd.Function):
@@ -295,7 +324,7 @@ class Conv3x3Fn(torch.autograd.Function):
     """x [B,H,W,Cin] channels-last, w [Cout,Cin,3,3] in channels_last memory, pad 1, stride 1|2."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, stats=False):
         _chk(x, w)
         x = x.contiguous()
         ctx.params = (w,)
@@ -304,8 +333,14 @@ class Conv3x3Fn(torch.autograd.Function):
         Cout = w.shape[0]
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-        _timed("conv3x3_fwd", 2.0 * B * Ho * Wo * Cout * 9 * Cin,
-               lambda: call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))
+        fl = 2.0 * B * Ho * Wo * Cout * 9 * Cin
+        if stats:
+            _launch_with_stats(y, B * Ho * Wo, Cout, lambda part, rows: _timed(
+                "conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnstat_f32", P(x), P(w), P(y), B, H, W, Cin, Cout,
+                                                stride, part.data_ptr(), rows, _stream())))
+        else:
+            _timed("conv3x3_fwd", fl,
+                   lambda: call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))
         ctx.stride = stride
         ctx.save_for_backward(x, w)
         return y
@@ -330,11 +365,12 @@ class Conv3x3Fn(torch.autograd.Function):
                    lambda: call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws),
                                 ws.numel() * 4, _stream()))
         dw = _emit(ctx.params[0], wgrad, ctx.needs_input_grad[1])
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv3x3(x, w, stride=1):
-    return Conv3x3Fn.apply(x, w, stride)
+def conv3x3(x, w, stride=1, stats=False):
+    y = Conv3x3Fn.apply(x, w, stride, stats)
+    return _attach_stats(y) if stats else y
 
 
 # ----------------------------------------------------------------------------------------------- BatchNorm
@@ -345,7 +381,7 @@ class BatchNormFn(torch.autograd.Function):
     SyncBatchNorm).  training=False: running statistics (forward only)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group):
+    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None):
         _chk(x, gamma, beta, rmean, rvar, resid)
         x = x.contiguous()
         C = x.shape[-1]
@@ -356,12 +392,19 @@ class BatchNormFn(torch.autograd.Function):
         count = M
         if training:
             stats = torch.empty(3 * C, device=x.device, dtype=torch.float32)
-            ws = workspace(query("tris_col_workspace_bytes", M, C))
+
+            def local_stats(rm, rv):
+                if part is not None:  # partial sums came out of the producing conv's epilogue
+                    call("tris_bn_finalize_f32", part[0].data_ptr(), part[1], M, C, eps, momentum, P(stats), P(rm),
+                         P(rv), _stream())
+                else:
+                    ws = workspace(query("tris_col_workspace_bytes", M, C))
+                    call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(stats), P(rm), P(rv), P(ws), _stream())
             if group is None:
-                call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(stats), P(rmean), P(rvar), P(ws), _stream())
+                local_stats(rmean, rvar)
             else:
                 import torch.distributed as dist
-                call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(stats), None, None, P(ws), _stream())
+                local_stats(None, None)
                 world = dist.get_world_size(group)
                 mine = torch.empty(2 * C + 1, device=x.device, dtype=torch.float32)
                 mine[:C].copy_(stats[:C])
@@ -413,11 +456,12 @@ class BatchNormFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), P(sums), P(sums, C),
                  1.0 / float(count), P(dx), M, C, _stream())
-        return dx, dg, db, None, None, d_res, None, None, None, None, None
+        return dx, dg, db, None, None, d_res, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None):
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group)
+    part = getattr(x, "_bn_part", None) if training else None
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part)
 
 
 class AvgPool2Fn(torch.autograd.Function):
