@@ -83,7 +83,7 @@ def main():
     from tris_amd.CLIP import clip
     from tris_amd.model.model_stage1 import TRIS
     from tris_amd.optim import FusedAdamW
-    from tris_amd.parallel import GradReducer, convert_sync_batchnorm
+    from tris_amd.parallel import GradReducer, convert_sync_batchnorm, stage1_segments
     from tris_amd.train_stage1 import freeze_aux, train_step
     from tris_amd.utils.synth import seed_fill, synthetic_batch
 
@@ -105,6 +105,8 @@ def main():
     if world > 1 or force:
         convert_sync_batchnorm(model)
         reducer = GradReducer([ar.g for ar in opt.arenas], force=force)
+        reducer.set_segments(stage1_segments(model, opt))   # all-reduce segments launched from inside backward
+        model.backbone.visual.grad_reducer = reducer
     b = synthetic_batch(a.batch, 320, 20, 3, seed=7, rank=rank)
     img, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
 
@@ -191,10 +193,13 @@ def main():
                "roofline": roof, "roofline_xattn": roof_x}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
-        print(json.dumps(out))
+        line = json.dumps(out)
     if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stderr.flush()
+        print(line, flush=True)  # the ONE JSON line, last thing this process writes
 
 
 if __name__ == "__main__":

@@ -34,6 +34,20 @@ def _worker(rank, world, port, out):
     GradReducer(flats, chunk_mb=1).reduce()
     assert torch.allclose(flats[0], torch.full((1000,), 1.5))
     assert torch.allclose(flats[1], torch.arange(10, dtype=torch.float32) * 1.5)
+    # segmented, backward-overlapped form: boundaries launch their segment when backward passes them
+    flats = [torch.full((100,), float(rank + 1)), torch.full((50,), 10.0 * (rank + 1))]
+    red = GradReducer(flats, chunk_mb=1)
+    red.set_segments({"late": [(0, 0, 40), (1, 0, 50)], "early": [(0, 40, 100)]})
+    x = torch.ones(3, requires_grad=True)
+    y = red.boundary(red.boundary(x * 2, "early") * 3, "late")   # backward: "late" fires first, then "early"
+    order = []
+    orig = red._launch
+    red._launch = lambda k: (order.append(k), orig(k))[1]
+    y.sum().backward()
+    assert order == ["late", "early"] and torch.allclose(x.grad, torch.full((3,), 6.0))
+    red.finish()
+    assert torch.allclose(flats[0], torch.full((100,), 1.5)) and torch.allclose(flats[1], torch.full((50,), 15.0))
+    assert red.pending == [] and red.done == set()
     b = synthetic_batch(2, 8, 20, 3, seed=7, rank=rank)
     g = [torch.zeros_like(b["img"]) for _ in range(world)]
     dist.all_gather(g, b["img"])

@@ -102,3 +102,36 @@ def test_checkpoint_roundtrip(tmp_path):
     net2 = torch.nn.Linear(3, 2)
     load_checkpoint(args, net2, torch.optim.AdamW(net2.parameters()), None)
     assert args.start_epoch == 5 and torch.equal(net2.weight, net.weight)
+
+
+def test_gradient_segments_cover_the_arenas_in_backward_order():
+    """GradReducer.plan on the real parameter list (arena layout emulated on CPU): every arena slot belongs to exactly
+    one segment and the trunk stages map to contiguous ranges."""
+    from types import SimpleNamespace
+    from tris_amd.parallel import GradReducer
+    from tris_amd.utils.shapes import _build_tris
+    m = _build_tris()
+    bb, new = m.trainable_parameters()
+    arenas = []
+    for group in (bb, new):
+        ps = [p for p in group if not getattr(p, "_tris_no_grad_path", False)]
+        offs, n = [], 0
+        for p in ps:
+            offs.append(n)
+            n += (p.numel() + 63) // 64 * 64
+        arenas.append(SimpleNamespace(params=ps, offsets=offs, numel=n))
+    rules = {"heads_text": lambda n: not n.startswith("backbone.visual."),
+             "layer4": lambda n: n.startswith("backbone.visual.layer4."),
+             "layer3": lambda n: n.startswith("backbone.visual.layer3."),
+             "layer2": lambda n: n.startswith("backbone.visual.layer2."),
+             "layer1": lambda n: n.startswith("backbone.visual.layer1."),
+             "stem": lambda n: True}
+    seg = GradReducer.plan(arenas, list(m.named_parameters()), rules)
+    cover = [0, 0]
+    for k, ranges in seg.items():
+        for ai, s, e in ranges:
+            assert e > s
+            cover[ai] += e - s
+    assert cover == [arenas[0].numel, arenas[1].numel]
+    assert len(seg["layer4"]) == 1 and len(seg["layer1"]) == 1 and len(seg["stem"]) == 1
+    assert seg["heads_text"][-1][0] == 1 and seg["heads_text"][-1][1:] == (0, arenas[1].numel)

@@ -170,9 +170,15 @@ class ModifiedResNet(nn.Module):
         x = self.bn3(self.conv3(x, stats=tr), relu=True)
         x = self.avgpool(x)
         outs = []
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+        red = getattr(self, "grad_reducer", None)  # data-parallel: overlap the gradient all-reduce with backward
+        if red is not None:
+            x = red.boundary(x, "layer1")          # backward passing this point => every layer1 gradient is written
+        for name, layer in (("layer2", self.layer1), ("layer3", self.layer2), ("layer4", self.layer3),
+                            ("heads_text", self.layer4)):
             for blk in layer:
                 x = blk(x)
+            if red is not None:
+                x = red.boundary(x, name)          # the boundary AFTER a stage releases the segment of the NEXT one
             outs.append(x)
         return tuple(outs)
 
