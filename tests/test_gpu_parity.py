@@ -247,7 +247,14 @@ def test_validate_and_prms_against_oracle(model, aux):
         loader.append(({"img": img, "word_ids": ids.t().reshape(1, 1, 20, 3), "word_masks": torch.ones(1, 1, 20, 3)},
                        {"target": tgt, "boxes": box, "img_path": torch.tensor([r]), "sentences": []}))
         refs.append((img, ids, tgt[0].bool(), box))
-    oIoU, mIoU, hit = validate(args, loader, model, 0)
+    oIoU, mIoU, hit = validate(args, loader, model, 0)            # hipGraph replay path (default)
+    import os
+    os.environ["TRIS_HIPGRAPH"] = "0"
+    try:
+        e_oIoU, e_mIoU, e_hit = validate(args, loader, model, 0)   # eager launches: identical numbers
+    finally:
+        os.environ.pop("TRIS_HIPGRAPH")
+    assert (e_oIoU, float(e_mIoU), e_hit) == (oIoU, float(mIoU), hit)
     sd = cpu_sd(model)
     Is = Us = 0
     ious, hits = [], []

@@ -1,0 +1,45 @@
+"""hipGraph capture of the Stage-1 inference path (validate.py hot loop at batch 1 is launch-latency bound:
+~450 short kernels per forward).  Two graphs, matching the loop structure of `validate`:
+
+    visual(img)      RN50 trunk -> vis_project -> L2 norm        replayed once per image
+    sentence(ids)    text encoder -> cross attention -> maps     replayed once per sentence of that image
+
+Inputs are copied into static buffers; outputs are static buffers owned by the graphs (consume or clone them before
+the next replay).  Capture uses torch's stream-capture plumbing (torch.cuda.graph); every captured node is one of
+this repo's HIP kernels launched through the C ABI on the capturing stream."""
+import torch
+
+
+class GraphedStage1Eval:
+    def __init__(self, net, img_shape, query_len, warmup=2):
+        assert not net.training, "capture the eval path (model.eval())"
+        self.net = net
+        dev = next(net.parameters()).device
+        self.s_img = torch.zeros(img_shape, device=dev, dtype=torch.float32)
+        self.s_ids = torch.zeros(img_shape[0], query_len, device=dev, dtype=torch.int64)
+        self.s_ids[:, 0] = 49406
+        self.s_ids[:, 1] = 49407
+        H = img_shape[2]
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):  # first-call setup (hipFuncSetAttribute, workspace growth) outside capture
+                    v = net.encode_visual(self.s_img)
+                    net.forward_cached(v, self.s_ids, H)
+            torch.cuda.current_stream().wait_stream(side)
+            self.g_vis = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_vis):
+                self.vis = net.encode_visual(self.s_img)
+            self.g_txt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_txt):
+                self.out = net.forward_cached(self.vis, self.s_ids, H)
+
+    def visual(self, img):
+        self.s_img.copy_(img, non_blocking=True)
+        self.g_vis.replay()
+
+    def sentence(self, ids):
+        self.s_ids.copy_(ids, non_blocking=True)
+        self.g_txt.replay()
+        return self.out

@@ -23,6 +23,17 @@ from . import ops
 from .utils.util import AverageMeter
 
 
+def _graphed(net, img, L, cache):
+    """hipGraph replay of the two halves of the eval forward, one capture per input shape (TRIS_HIPGRAPH=0 disables)."""
+    if os.environ.get("TRIS_HIPGRAPH", "1") == "0":
+        return None
+    key = (tuple(img.shape), int(L))
+    if key not in cache:
+        from .graphs import GraphedStage1Eval
+        cache[key] = GraphedStage1Eval(net, tuple(img.shape), int(L))
+    return cache[key]
+
+
 def isCorrectHit(bbox_annot, heatmap, gt_mask=None):
     """validate.py:106-117: arg-max point inside any GT box (hit) / on the GT mask (hitm)."""
     max_loc = np.unravel_index(np.argmax(heatmap, axis=None), heatmap.shape)
@@ -55,6 +66,7 @@ def validate(args, data_loader, model, local_rank=0, visualize=False, logger=Non
     I_sum = U_sum = 0
     n_sent = hit_acc = hitmask_acc = 0
     cam_out_name = []
+    graphs = {}
     end = time.time()
     for idx, (samples, targets) in enumerate(data_loader):
         img_id = int(np.asarray(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
@@ -63,10 +75,15 @@ def validate(args, data_loader, model, local_rank=0, visualize=False, logger=Non
         target = targets["target"].cuda(local_rank, non_blocking=True)
         tgt = (target.reshape(target.shape[-2:]) != 0).to(torch.uint8)
         bbox = np.asarray(targets["boxes"]).reshape(-1, 4) if "boxes" in targets else np.zeros((0, 4))
-        vis = net.encode_visual(img)                                                       # once per image
+        gr = _graphed(net, img, word_ids.shape[1], graphs)
+        if gr is not None:
+            gr.visual(img)                                                                 # once per image (hipGraph)
+        else:
+            vis = net.encode_visual(img)
         for j in range(word_ids.size(-1)):
             n_sent += 1
-            out = net.forward_cached(vis, word_ids[:, :, j].contiguous(), img.shape[2])    # relu map [1,1,H,W]
+            wid = word_ids[:, :, j].contiguous()
+            out = gr.sentence(wid) if gr is not None else net.forward_cached(vis, wid, img.shape[2])  # [1,1,H,W]
             iu, cam = ops.eval_post(out, tgt)
             I, U, am = iu.tolist()                                                         # the one host sync
             I_sum += I
