@@ -88,27 +88,31 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 template <typename T>
 __device__ __forceinline__ void reduce_parts(const T* __restrict__ part, int nb, int C, bool two, double& s, double& ss,
                                              int& c, bool& lead) {
-  __shared__ double sh0[16][17];
-  __shared__ double sh1[16][17];
-  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
-  c = blockIdx.x * 16 + cl;
+  // CH channels x (256/CH) row slices per block; many partial rows (fused conv-epilogue statistics: one row per
+  // 128-row GEMM tile, up to ~10^4) -> 4 channels x 64 slices, otherwise 16 x 16.  Grid = ceil(C / CH) (see fin_grid).
+  __shared__ double sh0[256];
+  __shared__ double sh1[256];
+  const int CH = nb > 512 ? 4 : 16, SL = 256 / CH;
+  const int cl = threadIdx.x % CH, j = threadIdx.x / CH;
+  c = blockIdx.x * CH + cl;
   s = 0.0;
   ss = 0.0;
   if (c < C)
-    for (int b = j; b < nb; b += 16) {
+    for (int b = j; b < nb; b += SL) {
       s += (double)part[(long)b * 2 * C + c];
       if (two) ss += (double)part[(long)b * 2 * C + C + c];
     }
-  sh0[j][cl] = s;
-  sh1[j][cl] = ss;
+  sh0[threadIdx.x] = s;
+  sh1[threadIdx.x] = ss;
   __syncthreads();
   lead = (j == 0) && (c < C);
   if (lead) {
     s = 0.0;
     ss = 0.0;
-    for (int q = 0; q < 16; ++q) { s += sh0[q][cl]; ss += sh1[q][cl]; }
+    for (int q = 0; q < SL; ++q) { s += sh0[q * CH + cl]; ss += sh1[q * CH + cl]; }
   }
 }
+inline int fin_grid(int C, int nb) { return cdiv(C, nb > 512 ? 4 : 16); }
 
 // BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
@@ -550,7 +554,7 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
   hipLaunchKernelGGL(col_partial_kernel<0>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, C,
                      (long)C, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, p.nb, M, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, M, C,
                      eps, momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -559,7 +563,7 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
 // finish BN statistics from fp64 partials produced by a fused conv epilogue (tris_*_bnstat_f32)
 extern "C" int tris_bn_finalize_f32(const double* part, int rows, long M, int C, float eps, float momentum, float* stats,
                                     float* running_mean, float* running_var, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, rows, M, C, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, rows)), dim3(256), 0, (hipStream_t)stream, part, rows, M, C, eps,
                      momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -593,7 +597,7 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, Y, mean, invstd, M, C, (long)C, p.rpb,
                      (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
                      sum_dz, sum_dzx);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -620,7 +624,7 @@ extern "C" int tris_colsum_f32(const float* X, long M, int N, long ld, float* ou
   hipLaunchKernelGGL(col_partial_kernel<2>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, N,
                      ld, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(cdiv(N, 16)), dim3(256), 0, st, (const double*)workspace, p.nb, N,
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(N, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, N,
                      out, (float*)nullptr);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -672,7 +676,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
                      rpb);
   TRIS_LAUNCH_CHECK();
   if (dgamma) {
-    hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(cdiv(W, 16)), dim3(256), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);
+    hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(fin_grid(W, nb)), dim3(256), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);
     TRIS_LAUNCH_CHECK();
   }
   return 0;

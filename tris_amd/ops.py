@@ -442,19 +442,27 @@ class BatchNormFn(torch.autograd.Function):
                 dy = ew("TRIS_EW_RELU_BWD", dy, y)
             d_res = dy if ctx.needs_input_grad[5] else None
             y = None
-        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         ws = workspace(query("tris_col_workspace_bytes", M, C))
-        call("tris_bn_bwd_reduce_f32", P(dy), P(y), P(x), P(mean), P(invstd), M, C, P(sums), P(sums, C), P(ws),
-             _stream())
-        dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
-        db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
-        if group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=group)
+        sg, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
+        direct = (group is None and sg is not None and sb is not None and ctx.needs_input_grad[1]
+                  and ctx.needs_input_grad[2] and sg.is_contiguous() and sb.is_contiguous())
+        if direct:   # the two reductions ARE dbeta / dgamma: write them straight into the gradient arena
+            p_dz, p_dzx = P(sb), P(sg)
+            dg = db = None
+        else:
+            sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            p_dz, p_dzx = P(sums), P(sums, C)
+        call("tris_bn_bwd_reduce_f32", P(dy), P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws), _stream())
+        if not direct:
+            dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
+            db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
+            if group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(sums, group=group)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), P(sums), P(sums, C),
+            call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
                  1.0 / float(count), P(dx), M, C, _stream())
         return dx, dg, db, None, None, d_res, None, None, None, None, None, None
 
@@ -511,8 +519,13 @@ class LayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        dgb = torch.empty(2, W, device=x.device, dtype=torch.float32) if need_p else None
         ws = workspace(query("tris_layernorm_bwd_workspace_bytes", rows, W))
+        sg, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
+        if need_p and sg is not None and sb is not None and sg.is_contiguous() and sb.is_contiguous():
+            call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(sg), P(sb), rows, W, P(ws),
+                 _stream())
+            return dx, None, None, None
+        dgb = torch.empty(2, W, device=x.device, dtype=torch.float32) if need_p else None
         call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(dgb), P(dgb, W),
              rows, W, P(ws), _stream())
         dg = _emit(ctx.params[0], lambda o: o.copy_(dgb[0]), ctx.needs_input_grad[1])
