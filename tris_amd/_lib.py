@@ -8,6 +8,11 @@ import ctypes
 import os
 import re
 
+# PyTorch bundles its own libamdhip64.so.7.  It must be in the process BEFORE libtris_hip.so is dlopen'ed so that both
+# resolve to the SAME HIP runtime instance (same device context, streams and allocations); loading ours first would pull
+# /opt/rocm's copy and torch would then talk to a second, uninitialised runtime (hipErrorNoDevice on the first launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "tris_hip.h")
