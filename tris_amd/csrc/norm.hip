@@ -208,7 +208,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* _
                                     const float* __restrict__ X, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, float inv_cnt,
-                                    float* __restrict__ dX, long n4, int C) {
+                                    float* __restrict__ dX, float* __restrict__ dZ, long n4, int C) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
@@ -221,6 +221,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* _
       if (!(y.z > 0.f)) g.z = 0.f;
       if (!(y.w > 0.f)) g.w = 0.f;
     }
+    if (dZ) st4(dZ + i * 4, g);  // masked upstream gradient = gradient of the residual branch
     float4 x = ld4(X + i * 4), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
     float4 a = ld4(sum_dz + c), b = ld4(sum_dzx + c);
     float4 o;
@@ -605,10 +606,10 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
 
 extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const float* mean,
                                      const float* invstd, const float* gamma, const float* sum_dz, const float* sum_dzx,
-                                     float inv_count, float* dX, long M, int C, void* stream) {
+                                     float inv_count, float* dX, float* dZ, long M, int C, void* stream) {
   long n4 = M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean, invstd,
-                     gamma, sum_dz, sum_dzx, inv_count, dX, n4, C);
+                     gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

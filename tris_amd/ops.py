@@ -436,12 +436,11 @@ class BatchNormFn(torch.autograd.Function):
         M, C, relu, has_res, count, group = ctx.cfg
         dy = dy.contiguous()
         d_res = None
-        if has_res:
-            # out = relu(bn(x) + resid): both branches see dz = dy * (out > 0)
-            if relu:
-                dy = ew("TRIS_EW_RELU_BWD", dy, y)
-            d_res = dy if ctx.needs_input_grad[5] else None
-            y = None
+        want_dz = has_res and ctx.needs_input_grad[5]
+        if has_res and not relu:
+            d_res, want_dz = (dy if want_dz else None), False
+        # out = relu(bn(x) + resid): both branches see dz = dy * (out > 0); the mask is applied inside the reduce / apply
+        # kernels and the apply kernel emits dz for the residual branch in the same pass
         ws = workspace(query("tris_col_workspace_bytes", M, C))
         sg, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
         direct = (group is None and sg is not None and sb is not None and ctx.needs_input_grad[1]
@@ -460,10 +459,12 @@ class BatchNormFn(torch.autograd.Function):
                 import torch.distributed as dist
                 dist.all_reduce(sums, group=group)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] or want_dz:
             dx = torch.empty_like(x)
+            if want_dz:
+                d_res = torch.empty_like(x)
             call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
-                 1.0 / float(count), P(dx), M, C, _stream())
+                 1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, _stream())
         return dx, dg, db, None, None, d_res, None, None, None, None, None, None
 
 
