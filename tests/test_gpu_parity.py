@@ -283,3 +283,38 @@ def test_validate_and_prms_against_oracle(model, aux):
             Us += U * 9.0
             ious += [I / U] * 3
     assert abs(o2 - 100 * Is / Us) < 0.1 and abs(float(m2) - 100 * np.mean(ious)) < 0.1
+
+
+@pytest.mark.parametrize("B,size,neg", [(1, 224, 0), (3, 384, 2), (2, 256, 3), (5, 320, 1)])
+def test_other_shapes_vs_oracle(aux, B, size, neg):
+    """Edge configurations: single image (N = 1 sentence), CLIP-native 224 px (no resize branch, train_stage1.py:327-333),
+    the reference's default 384 px (12x12 grid), no negatives, odd batch sizes -- losses, cls head and maps vs the oracle."""
+    import warnings
+    from oracle import tris_oracle as O
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.train_stage1 import stage1_forward_losses
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    args = _args(["--size", str(size), "--negative_samples", str(neg)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = TRIS(args).cuda()
+    seed_fill(m.state_dict(), 31 + B)
+    b = synthetic_batch(B, size, 20, neg, seed=60 + B)
+    sd = cpu_sd(m)
+    auxsd = {k: v.detach().cpu().clone() for k, v in aux.state_dict().items()}
+    m.train()
+    with torch.no_grad():
+        ref = O.stage1_losses({k: v.clone() for k, v in sd.items()}, auxsd, b, faithful=False)
+        losses, cls, sig = stage1_forward_losses(m, aux, b["img"].cuda(), b["word_ids"].cuda(),
+                                                 b["neg_word_ids"].cuda() if neg else None, args)
+    lv = losses.tolist()
+    for i, k in enumerate(("loss", "l1", "l4", "l5")):
+        assert abs(lv[i] - float(ref[k])) < TOL, (k, lv[i], float(ref[k]))
+    assert err(cls, ref["cls"]) < TOL and err(sig, ref["sig"]) < 1e-4
+    assert sig.shape == (B, 1, size, size)
+    m.eval()
+    seed_fill(m.state_dict(), 31 + B)
+    with torch.no_grad():
+        want = O.tris_forward(cpu_sd(m), b["img"], b["word_ids"], False)
+        got = m(b["img"].cuda(), b["word_ids"].cuda())
+    assert err(got, want) < TOL
