@@ -32,6 +32,12 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                   int bias_mode, const float* resid, long ldr, long strideR, int act, float alpha, float* workspace,
                   long workspace_bytes, void* stream);
 
+/* Arithmetic of the dense-product kernels (process-wide): 0 = v_mfma_f32_32x32x2_f32 (f32 in, bit-equal to an fmaf chain);
+ * 1 = split-bf16 "x3": every fp32 operand is the exact sum of three bf16 pieces, the six significant piece products
+ * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -> fp32-class accuracy at ~2.6x the f32-MFMA peak. */
+int tris_set_gemm_mode(int mode);
+int tris_get_gemm_mode(void);
+
 /* 3x3 convolution, pad 1, implicit GEMM (no im2col buffer).  CLIP/clip/model.py:21 (Bottleneck.conv2), :212-229 (stem).
  * fwd: stride 1 or 2.  dgrad: stride 1 only (the only strided conv on the path, the stem's conv1, reads the image and
  * needs no input gradient).  wgrad: split-K over output pixels; workspace >= 2 slabs of Cout*9*Cin floats, more = faster. */

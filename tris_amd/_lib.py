@@ -36,6 +36,8 @@ def parse_header(path=HEADER):
         types = []
         for a in args.split(","):
             a = a.strip()
+            if a in ("", "void"):
+                continue
             if "*" in a:
                 types.append(ctypes.c_void_p)
             else:

@@ -378,6 +378,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmPa
   p.C[(long)row * p.ldc + col] = v;
 }
 
+// arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy)
+static int g_gemm_mode = 0;
+
 #include "gemm_fast.h"
 
 template <int AK, int BKIND>
@@ -435,9 +438,15 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if (fast) {                                                                                    \
       if (splitk > 1) {                                                                            \
         p.C = ws;                                                                                  \
-        hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB>), grid, dim3(256), 0, st, p); \
+        if (g_gemm_mode == 1)                                                                      \
+          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 1>), grid, dim3(256), 0, st, p); \
+        else                                                                                       \
+          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 0>), grid, dim3(256), 0, st, p); \
       } else {                                                                                     \
-        hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD>), grid, dim3(256), 0, st, p);  \
+        if (g_gemm_mode == 1)                                                                      \
+          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 1>), grid, dim3(256), 0, st, p);  \
+        else                                                                                       \
+          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 0>), grid, dim3(256), 0, st, p);  \
       }                                                                                            \
     } else if (splitk > 1) {                                                                       \
       p.C = ws;                                                                                    \
@@ -572,3 +581,10 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   *stat_rows = p.stat_part ? cdiv(p.M, 128) : 0;
   return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
+
+extern "C" int tris_set_gemm_mode(int mode) {
+  if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
+  g_gemm_mode = mode;
+  return 0;
+}
+extern "C" int tris_get_gemm_mode(void) { return g_gemm_mode; }

@@ -14,7 +14,43 @@
 // operands, M % 4 == 0 / N % 4 == 0 for the m-/n-contiguous kinds, gathered channels % 32 == 0 for im2col.
 #pragma once
 
-template <int BM, int BN, int AK, int BKIND, int EPI>
+// ---- split-bf16 ("x3") arithmetic -----------------------------------------------------------------------------------------
+// An fp32 value is EXACTLY the sum of three bf16 pieces (round-to-nearest residual splitting: 8 + 8 + 8 significand
+// bits).  a*b = sum of the 9 piece products; the 6 with combined weight >= 2^-24 are kept, each is exact in fp32
+// (8 x 8 bits) and is accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Result: fp32-class accuracy at 6 bf16 MFMAs per
+// 16-deep step (6 x 32 cycles) instead of 8 f32 MFMAs (8 x 64 cycles).  Pieces are produced in registers right after
+// the LDS fragment read (the LDS image stays fp32 and is shared with the f32 path).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, h);
+}
+struct Split8 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Split8 split8(const float4 u, const float4 w) {
+  const float x[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float x0 = x[2 * t], x1 = x[2 * t + 1];
+    h[t] = pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h[t] << 16), r1 = x1 - __builtin_bit_cast(float, h[t] & 0xffff0000u);
+    m[t] = pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m[t] << 16), s1 = r1 - __builtin_bit_cast(float, m[t] & 0xffff0000u);
+    l[t] = pk_bf16(s0, s1);
+  }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  Split8 o;
+  o.hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+  o.mid = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+  o.lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+  return o;
+}
+
+template <int BM, int BN, int AK, int BKIND, int EPI, int PREC>
 __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
   constexpr int FBK = 32;
   constexpr int LDK = FBK + 4;
@@ -177,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
       load_A(k0 + FBK);
       load_B(k0 + FBK);
     }
+    if constexpr (PREC == 0) {
 #pragma unroll
     for (int g = 0; g < FBK; g += 8) {
       float4 a[FM], b[FN];
@@ -209,6 +246,54 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
+    }
+    } else {
+#pragma unroll
+      for (int g = 0; g < FBK; g += 16) {
+        // lane (li, kh) owns MFMA k-slots 8*kh + j: j < 4 <- k = g + 4kh + j, j >= 4 <- k = g + 8 + 4kh + (j-4); same map for A and B
+        Split8 sa[FM], sb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = wm * WM + i * 32 + li;
+          float4 u, w;
+          if (A_RM) {
+            u = *reinterpret_cast<const float4*>(&As[row * LDK + g + kh * 4]);
+            w = *reinterpret_cast<const float4*>(&As[row * LDK + g + 8 + kh * 4]);
+          } else {
+            const float* s0 = &As[(g + kh * 4) * (BM + 4) + row];
+            const float* s1 = s0 + 8 * (BM + 4);
+            u = make_float4(s0[0], s0[BM + 4], s0[2 * (BM + 4)], s0[3 * (BM + 4)]);
+            w = make_float4(s1[0], s1[BM + 4], s1[2 * (BM + 4)], s1[3 * (BM + 4)]);
+          }
+          sa[i] = split8(u, w);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int col = wn * WN + j * 32 + li;
+          float4 u, w;
+          if (B_RM) {
+            u = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + kh * 4]);
+            w = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + 8 + kh * 4]);
+          } else {
+            const float* s0 = &Bs[(g + kh * 4) * (BN + 4) + col];
+            const float* s1 = s0 + 8 * (BN + 4);
+            u = make_float4(s0[0], s0[BN + 4], s0[2 * (BN + 4)], s0[3 * (BN + 4)]);
+            w = make_float4(s1[0], s1[BN + 4], s1[2 * (BN + 4)], s1[3 * (BN + 4)]);
+          }
+          sb[j] = split8(u, w);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {  // smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].lo, sb[j].hi, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].lo, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].mid, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].hi, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].mid, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].hi, acc[i][j], 0, 0, 0);
+          }
+      }
     }
     __syncthreads();
     if (more) {

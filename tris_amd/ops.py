@@ -58,6 +58,26 @@ def workspace(nbytes):
     return cur
 
 
+def set_gemm_mode(mode):
+    """'f32' = f32-input MFMA (bit-equal to an fmaf chain); 'x3' = split-bf16 (three bf16 pieces per fp32 operand, six
+    bf16 MFMAs per product, fp32 accumulate): fp32-class accuracy at ~2.6x the f32-MFMA rate."""
+    call("tris_set_gemm_mode", {"f32": 0, "x3": 1}[mode])
+
+
+def _init_mode_from_env():
+    import os
+    m = os.environ.get("TRIS_GEMM_MODE")
+    if m:
+        set_gemm_mode(m)
+
+
+def get_gemm_mode():
+    return ("f32", "x3")[_lib.load().tris_get_gemm_mode()]
+
+
+_init_mode_from_env()
+
+
 def cl_weight(w):
     """Conv weight in the kernel layout [Cout][kh][kw][Cin] (= channels_last memory)."""
     if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
