@@ -11,7 +11,11 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE"
 pids=()
 for f in gemm_conv norm attn heads optim eval xattn; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/tris_hip.h" -nt "$OBJ/$f.o" ]; then
+  stale=0
+  for dep in "$HERE/$f.hip" "$HERE"/*.h "$ROOT/include/tris_hip.h"; do
+    [ "$dep" -nt "$OBJ/$f.o" ] && stale=1
+  done
+  if [ ! -f "$OBJ/$f.o" ] || [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi

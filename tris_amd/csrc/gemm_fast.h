@@ -50,6 +50,20 @@ __device__ __forceinline__ Split8 split8(const float4 u, const float4 w) {
   return o;
 }
 
+struct Split4 { uint2 hi, mid, lo; };
+__device__ __forceinline__ Split4 split4(const float4 u) {
+  Split4 o;
+  o.hi.x = pk_bf16(u.x, u.y);
+  o.hi.y = pk_bf16(u.z, u.w);
+  const float r0 = u.x - __builtin_bit_cast(float, o.hi.x << 16), r1 = u.y - __builtin_bit_cast(float, o.hi.x & 0xffff0000u);
+  const float r2 = u.z - __builtin_bit_cast(float, o.hi.y << 16), r3 = u.w - __builtin_bit_cast(float, o.hi.y & 0xffff0000u);
+  o.mid.x = pk_bf16(r0, r1);
+  o.mid.y = pk_bf16(r2, r3);
+  o.lo.x = pk_bf16(r0 - __builtin_bit_cast(float, o.mid.x << 16), r1 - __builtin_bit_cast(float, o.mid.x & 0xffff0000u));
+  o.lo.y = pk_bf16(r2 - __builtin_bit_cast(float, o.mid.y << 16), r3 - __builtin_bit_cast(float, o.mid.y & 0xffff0000u));
+  return o;
+}
+
 template <int BM, int BN, int AK, int BKIND, int EPI, int PREC>
 __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
   constexpr int FBK = 32;
@@ -59,8 +73,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PA = BM / 32, PB = BN / 32;  // float4 per thread per tile
-  constexpr int A_SZ = A_RM ? BM * LDK : FBK * (BM + 4);
-  constexpr int B_SZ = B_RM ? BN * LDK : FBK * (BN + 4);
+  // x3 mode: k-contiguous operands are split into their three bf16 pieces ONCE, when the tile is stored: the LDS image is
+  // three bf16 planes [plane][row][32 + 8 pad] (row stride 80 B = 5 sixteen-byte slots -> conflict-free ds_read_b128),
+  // i.e. 60 floats' worth per row.  m-/n-contiguous operands keep the fp32 k-major image and are split after the read.
+  constexpr bool A_PL = (PREC == 1) && A_RM, B_PL = (PREC == 1) && B_RM;
+  constexpr int PLB = 80;  // bytes per row of one bf16 plane
+  constexpr int A_SZ = A_PL ? BM * 60 : (A_RM ? BM * LDK : FBK * (BM + 4));
+  constexpr int B_SZ = B_PL ? BN * 60 : (B_RM ? BN * LDK : FBK * (BN + 4));
   __shared__ __attribute__((aligned(16))) float As[A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
 
@@ -174,7 +193,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
   };
 
   auto store_lds = [&]() {
-    if (A_RM) {
+    if (A_PL) {
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const Split4 sp = split4(ra[q]);
+        char* d = reinterpret_cast<char*>(As) + ((tid >> 3) + q * 32) * PLB + (tid & 7) * 8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
+        *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
+      }
+    } else if (A_RM) {
 #pragma unroll
       for (int q = 0; q < PA; ++q)
         *reinterpret_cast<float4*>(&As[((tid >> 3) + q * 32) * LDK + (tid & 7) * 4]) = ra[q];
@@ -183,7 +211,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
       for (int q = 0; q < PA; ++q)
         *reinterpret_cast<float4*>(&As[(tid / AF4 + q * ARPP) * (BM + 4) + (tid % AF4) * 4]) = ra[q];
     }
-    if (B_RM) {
+    if (B_PL) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const Split4 sp = split4(rb[q]);
+        char* d = reinterpret_cast<char*>(Bs) + ((tid >> 3) + q * 32) * PLB + (tid & 7) * 8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
+        *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
+      }
+    } else if (B_RM) {
 #pragma unroll
       for (int q = 0; q < PB; ++q)
         *reinterpret_cast<float4*>(&Bs[((tid >> 3) + q * 32) * LDK + (tid & 7) * 4]) = rb[q];
@@ -250,37 +287,35 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
     } else {
 #pragma unroll
       for (int g = 0; g < FBK; g += 16) {
-        // lane (li, kh) owns MFMA k-slots 8*kh + j: j < 4 <- k = g + 4kh + j, j >= 4 <- k = g + 8 + 4kh + (j-4); same map for A and B
+        // lane (li, kh) owns MFMA k-slots 8*kh + j  <->  k = g + 8*kh + j, for A and B alike
         Split8 sa[FM], sb[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int row = wm * WM + i * 32 + li;
-          float4 u, w;
-          if (A_RM) {
-            u = *reinterpret_cast<const float4*>(&As[row * LDK + g + kh * 4]);
-            w = *reinterpret_cast<const float4*>(&As[row * LDK + g + 8 + kh * 4]);
+          if (A_PL) {
+            const char* s0 = reinterpret_cast<const char*>(As) + row * PLB + g * 2 + kh * 16;
+            sa[i].hi = *reinterpret_cast<const bf16x8*>(s0);
+            sa[i].mid = *reinterpret_cast<const bf16x8*>(s0 + BM * PLB);
+            sa[i].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BM * PLB);
           } else {
-            const float* s0 = &As[(g + kh * 4) * (BM + 4) + row];
-            const float* s1 = s0 + 8 * (BM + 4);
-            u = make_float4(s0[0], s0[BM + 4], s0[2 * (BM + 4)], s0[3 * (BM + 4)]);
-            w = make_float4(s1[0], s1[BM + 4], s1[2 * (BM + 4)], s1[3 * (BM + 4)]);
+            const float* s0 = &As[(g + kh * 8) * (BM + 4) + row];
+            sa[i] = split8(make_float4(s0[0], s0[BM + 4], s0[2 * (BM + 4)], s0[3 * (BM + 4)]),
+                           make_float4(s0[4 * (BM + 4)], s0[5 * (BM + 4)], s0[6 * (BM + 4)], s0[7 * (BM + 4)]));
           }
-          sa[i] = split8(u, w);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int col = wn * WN + j * 32 + li;
-          float4 u, w;
-          if (B_RM) {
-            u = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + kh * 4]);
-            w = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + 8 + kh * 4]);
+          if (B_PL) {
+            const char* s0 = reinterpret_cast<const char*>(Bs) + col * PLB + g * 2 + kh * 16;
+            sb[j].hi = *reinterpret_cast<const bf16x8*>(s0);
+            sb[j].mid = *reinterpret_cast<const bf16x8*>(s0 + BN * PLB);
+            sb[j].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * PLB);
           } else {
-            const float* s0 = &Bs[(g + kh * 4) * (BN + 4) + col];
-            const float* s1 = s0 + 8 * (BN + 4);
-            u = make_float4(s0[0], s0[BN + 4], s0[2 * (BN + 4)], s0[3 * (BN + 4)]);
-            w = make_float4(s1[0], s1[BN + 4], s1[2 * (BN + 4)], s1[3 * (BN + 4)]);
+            const float* s0 = &Bs[(g + kh * 8) * (BN + 4) + col];
+            sb[j] = split8(make_float4(s0[0], s0[BN + 4], s0[2 * (BN + 4)], s0[3 * (BN + 4)]),
+                           make_float4(s0[4 * (BN + 4)], s0[5 * (BN + 4)], s0[6 * (BN + 4)], s0[7 * (BN + 4)]));
           }
-          sb[j] = split8(u, w);
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i)
