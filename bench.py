@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 PER_GPU_BATCH = 48
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA; the x3 mode spends 6 bf16 MFMAs per fp32-accurate product
 HBM_PEAK_GBS = 8000.0
 
 
@@ -151,9 +152,14 @@ def main():
     torch.cuda.synchronize()
     one = (time.perf_counter() - t1) * 1e3
     ach = fl / (ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_kernel<BM,BN,A,B,EPI> (f32-MFMA GEMM / implicit-GEMM conv family)",
+    mode = ops.get_gemm_mode()
+    peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None,
+            "arithmetic": ("v_mfma_f32_32x32x2_f32 (f32 in)" if mode == "f32" else
+                           "split-bf16 x3: 6 x v_mfma_f32_32x32x16_bf16 per fp32-accurate product; achieved/peak are in "
+                           "fp32-equivalent FLOPs (peak = 2500 TFLOP/s bf16 dense / 6; the f32-input MFMA peak is 157.3)"),
+            "kernel": "gemm_fast_kernel<BM,BN,A,B,EPI,PREC> (MFMA GEMM / implicit-GEMM conv family)",
             "launches_per_step": len(rec), "kernel_ms_per_step": round(ms, 3),
             "algorithmic_gflop_per_step": round(fl / 1e9, 1),
             "by_kind": {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
@@ -183,7 +189,7 @@ def main():
         out = {"metric": "Stage-1 training images/sec @320px bs48 (TRIS clip-RN50, 3 negatives)",
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "gemm_mode": mode, "data": "synthetic",
                "config": {"workload": "Stage-1 train step, RefCOCOg-shaped synthetic batch: 48 img/GPU 320x320, "
                                       "20-token query + 3 negative queries per image, clip-RN50 trunk + frozen aux "
                                       "CLIP ViT-B/32, AdamW (BASELINE.json configs[2]/[3])",

@@ -32,10 +32,15 @@ def gpu_leaf(t):
     return t.detach().clone().cuda().requires_grad_(True)
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["x3", "f32"])
+def ops(request):
+    """Every kernel test runs under both arithmetic modes of the dense-product core: split-bf16 x3 (default) and
+    the f32-input MFMA."""
     from tris_amd import ops as o
-    return o
+    prev = o.get_gemm_mode()
+    o.set_gemm_mode(request.param)
+    yield o
+    o.set_gemm_mode(prev)
 
 
 @pytest.mark.parametrize("M,N,K", [(100, 48, 1024), (130, 70, 52), (256, 256, 64), (48, 1024, 2048), (7, 5, 27),

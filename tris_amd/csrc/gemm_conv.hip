@@ -12,6 +12,9 @@
 // LDS image is k-major (As[k][m], Bs[k][n], row pad 4) so a fragment read is 32 consecutive floats per half-wave
 // (conflict-free ds_read_b32).  Global loads for tile t+1 are issued before the MFMA block of tile t
 // (register staging), stored to LDS after it.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 #include "tris_hip.h"
 
@@ -379,7 +382,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmPa
 }
 
 // arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy)
-static int g_gemm_mode = 0;
+static int g_gemm_mode = 1;
 
 #include "gemm_fast.h"
 
@@ -412,7 +415,8 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
       if (c < 2 && p.M < 96) continue;           // 128-row tiles on a tiny M waste the MFMA
       if (c == 0 && p.N <= 64) continue;
       const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
-      const double per_k32 = (cbm / 64) * (cbn / 64) * 1024.0 * pen[c];
+      // MFMA cycles of one 32x32 fragment pair per 32-deep step: 16 f32 MFMAs x 64, or 12 bf16 MFMAs x 32 (x3 mode)
+      const double per_k32 = (cbm / 64) * (cbn / 64) * (g_gemm_mode == 1 ? 384.0 + 250.0 : 1024.0) * pen[c];
       const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
       for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
         if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
@@ -423,6 +427,16 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
         if (t < best) { best = t; bm = cbm; bn = cbn; splitk = sk; }
       }
     }
+  }
+  {  // developer knob: TRIS_FORCE_TILE=128x128|128x64|64x64 overrides the tile choice (tools/x3_probe.py)
+    static int forced = -1;
+    if (forced < 0) {
+      const char* e = getenv("TRIS_FORCE_TILE");
+      forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : 0);
+    }
+    if (forced == 1 && p.N > 64) { bm = 128; bn = 128; }
+    if (forced == 2) { bm = 128; bn = 64; }
+    if (forced == 3) { bm = 64; bn = 64; }
   }
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
