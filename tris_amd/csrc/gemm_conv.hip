@@ -383,6 +383,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmPa
 
 // arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy)
 static int g_gemm_mode = 1;
+static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")) == 4) ? 4 : 8;  // waves per 128x128 x3 block
 
 #include "gemm_fast.h"
 
@@ -452,12 +453,16 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if (fast) {                                                                                    \
       if (splitk > 1) {                                                                            \
         p.C = ws;                                                                                  \
-        if (g_gemm_mode == 1)                                                                      \
+        if (g_gemm_mode == 1 && BM_ == 128 && BN_ == 128 && g_x3_waves == 8)                       \
+          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 1, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, dim3(512), 0, st, p); \
+        else if (g_gemm_mode == 1)                                                                 \
           hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 1>), grid, dim3(256), 0, st, p); \
         else                                                                                       \
           hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 0>), grid, dim3(256), 0, st, p); \
       } else {                                                                                     \
-        if (g_gemm_mode == 1)                                                                      \
+        if (g_gemm_mode == 1 && BM_ == 128 && BN_ == 128 && g_x3_waves == 8)                       \
+          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 1, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, dim3(512), 0, st, p);  \
+        else if (g_gemm_mode == 1)                                                                 \
           hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 1>), grid, dim3(256), 0, st, p);  \
         else                                                                                       \
           hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 0>), grid, dim3(256), 0, st, p);  \

@@ -64,15 +64,18 @@ __device__ __forceinline__ Split4 split4(const float4 u) {
   return o;
 }
 
-template <int BM, int BN, int AK, int BKIND, int EPI, int PREC>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
+// NW = waves per workgroup: 4 (2x2 wave grid) or 8 (2x4: smaller wave tiles, twice the resident waves per CU -- used by
+// the x3 mode on 128x128 tiles, where the bf16 MFMA time per tile is short and the barrier / staging phases need hiding)
+template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(GemmParams p) {
+  constexpr int NTHR = NW * 64, RPASS = NTHR / 8, NWN = NW / 2;
   constexpr int FBK = 32;
   constexpr int LDK = FBK + 4;
   constexpr bool A_RM = (AK != A_COLK);
   constexpr bool B_RM = (BKIND == B_NK);
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WM = BM / 2, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
-  constexpr int PA = BM / 32, PB = BN / 32;  // float4 per thread per tile
+  constexpr int PA = BM / RPASS, PB = BN / RPASS;  // float4 per thread per tile
   // x3 mode: k-contiguous operands are split into their three bf16 pieces ONCE, when the tile is stored: the LDS image is
   // three bf16 planes [plane][row][32 + 8 pad] (row stride 80 B = 5 sixteen-byte slots -> conflict-free ds_read_b128),
   // i.e. 60 floats' worth per row.  m-/n-contiguous operands keep the fp32 k-major image and are split after the read.
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int tile = blockIdx.x;
   const int m0 = (tile / p.tiles_n) * BM;
   const int n0 = (tile % p.tiles_n) * BN;
@@ -103,14 +106,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
   if (AK == A_ROWK) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      int m = min(m0 + (tid >> 3) + q * 32, p.M - 1);
+      int m = min(m0 + (tid >> 3) + q * RPASS, p.M - 1);
       a_off[q] = (long)m * p.lda + (tid & 7) * 4;
     }
   } else if (AK == A_IM2COL) {
     const int hw = p.gHo * p.gWo;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      int m = min(m0 + (tid >> 3) + q * 32, p.M - 1);
+      int m = min(m0 + (tid >> 3) + q * RPASS, p.M - 1);
       a_b[q] = m / hw;
       int r = m - a_b[q] * hw;
       int oy = r / p.gWo, ox = r - oy * p.gWo;
@@ -118,17 +121,17 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
       a_ix0[q] = ox * p.gStride - 1;
     }
   }
-  constexpr int AF4 = BM / 4, ARPP = 256 / AF4;
+  constexpr int AF4 = BM / 4, ARPP = NTHR / AF4;
   const int a_mc = min(m0 + (tid % AF4) * 4, p.M - 4);  // COLK column (clamped)
   long b_off[PB];
   if (BKIND == B_NK) {
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      int n = min(n0 + (tid >> 3) + q * 32, p.N - 1);
+      int n = min(n0 + (tid >> 3) + q * RPASS, p.N - 1);
       b_off[q] = (long)n * p.ldb + (tid & 7) * 4;
     }
   }
-  constexpr int BF4 = BN / 4, BRPP = 256 / BF4;
+  constexpr int BF4 = BN / 4, BRPP = NTHR / BF4;
   const int b_nc = min(n0 + (tid % BF4) * 4, p.N - 4);  // KN* column (clamped)
   int bj_tap = 0, bj_ci = 0;
   if (BKIND == B_KN_IM2COL) {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
 #pragma unroll
       for (int q = 0; q < PA; ++q) {
         const Split4 sp = split4(ra[q]);
-        char* d = reinterpret_cast<char*>(As) + ((tid >> 3) + q * 32) * PLB + (tid & 7) * 8;
+        char* d = reinterpret_cast<char*>(As) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
         *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
     } else if (A_RM) {
 #pragma unroll
       for (int q = 0; q < PA; ++q)
-        *reinterpret_cast<float4*>(&As[((tid >> 3) + q * 32) * LDK + (tid & 7) * 4]) = ra[q];
+        *reinterpret_cast<float4*>(&As[((tid >> 3) + q * RPASS) * LDK + (tid & 7) * 4]) = ra[q];
     } else {
 #pragma unroll
       for (int q = 0; q < PA; ++q)
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
         const Split4 sp = split4(rb[q]);
-        char* d = reinterpret_cast<char*>(Bs) + ((tid >> 3) + q * 32) * PLB + (tid & 7) * 8;
+        char* d = reinterpret_cast<char*>(Bs) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
         *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmParams p) {
     } else if (B_RM) {
 #pragma unroll
       for (int q = 0; q < PB; ++q)
-        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + q * 32) * LDK + (tid & 7) * 4]) = rb[q];
+        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + q * RPASS) * LDK + (tid & 7) * 4]) = rb[q];
     } else {
 #pragma unroll
       for (int q = 0; q < PB; ++q)
