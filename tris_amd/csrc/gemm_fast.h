@@ -76,10 +76,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   constexpr int WM = BM / 2, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PA = BM / RPASS, PB = BN / RPASS;  // float4 per thread per tile
-  // x3 mode: k-contiguous operands are split into their three bf16 pieces ONCE, when the tile is stored: the LDS image is
-  // three bf16 planes [plane][row][32 + 8 pad] (row stride 80 B = 5 sixteen-byte slots -> conflict-free ds_read_b128),
-  // i.e. 60 floats' worth per row.  m-/n-contiguous operands keep the fp32 k-major image and are split after the read.
-  constexpr bool A_PL = (PREC == 1) && A_RM, B_PL = (PREC == 1) && B_RM;
+  // x3 mode: every operand is split into its three bf16 pieces ONCE, when the tile is stored: the LDS image is three
+  // bf16 planes [plane][row][32 + 8 pad] (row stride 80 B = 5 sixteen-byte slots -> conflict-free ds_read_b128), i.e.
+  // 60 floats' worth per row.
+  constexpr bool A_PL = (PREC == 1), B_PL = (PREC == 1);
+  // x3 staging of the m-/n-contiguous operands ("row per thread"): thread -> one row (m or n) and KPT consecutive k,
+  // loaded with scalar loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), split once, and written as
+  // 16-byte bf16 runs into the same [plane][row][k] image the k-contiguous operands use
+  constexpr bool A_KM = (PREC == 1) && !A_RM, B_KM = (PREC == 1) && !B_RM;
+  constexpr int A_KG = NTHR / BM, A_KPT = 32 / A_KG, B_KG = NTHR / BN, B_KPT = 32 / B_KG;
   constexpr int PLB = 80;  // bytes per row of one bf16 plane
   constexpr int A_SZ = A_PL ? BM * 60 : (A_RM ? BM * LDK : FBK * (BM + 4));
   constexpr int B_SZ = B_PL ? BN * 60 : (B_RM ? BN * LDK : FBK * (BN + 4));
@@ -141,6 +146,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
 
   float4 ra[PA], rb[PB];
+  float rka[A_KM ? A_KPT : 1], rkb[B_KM ? B_KPT : 1];
+  const int a_rm = min(m0 + tid % BM, p.M - 1), a_kg = tid / BM;  // x3 row-per-thread coordinates
+  const int b_rn = min(n0 + tid % BN, p.N - 1), b_kg = tid / BN;
+  int bx_tap = 0, bx_ci = 0;
+  if (BKIND == B_KN_IM2COL) { bx_tap = b_rn / p.gC; bx_ci = b_rn - bx_tap * p.gC; }
+  const int bx_ky = bx_tap / 3, bx_kx = bx_tap - (bx_tap / 3) * 3;
 
   auto load_A = [&](int k0) {
     if (AK == A_ROWK) {
@@ -158,6 +169,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         float4 v = ld4(A + off);
         ra[q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    } else if (A_KM) {  // A_COLK, x3: KPT consecutive k of row a_rm
+      const float* src = A + (long)(k0 + a_kg * A_KPT) * p.lda + a_rm;
+#pragma unroll
+      for (int j = 0; j < A_KPT; ++j) rka[j] = src[(long)j * p.lda];
     } else {  // A_COLK: A[k*lda + m]
 #pragma unroll
       for (int q = 0; q < PA; ++q) ra[q] = ld4(A + (long)(k0 + tid / AF4 + q * ARPP) * p.lda + a_mc);
@@ -168,6 +183,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     if (BKIND == B_NK) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
+    } else if (B_KM) {
+      const int kb = k0 + b_kg * B_KPT;
+      if (BKIND == B_KN) {
+        const float* src = Bp + (long)kb * p.ldb + b_rn;
+#pragma unroll
+        for (int j = 0; j < B_KPT; ++j) rkb[j] = src[(long)j * p.ldb];
+      } else if (BKIND == B_KN_DGRAD) {  // k = tap'*Cout + co (the KPT-run stays inside one tap: Cout % 32 == 0)
+        const int tapp = kb / p.wCout, co = kb - tapp * p.wCout;
+        const float* src = Bp + ((long)co * 9 + (8 - tapp)) * p.wCin + b_rn;
+#pragma unroll
+        for (int j = 0; j < B_KPT; ++j) rkb[j] = src[(long)j * 9 * p.wCin];
+      } else {  // B_KN_IM2COL: k = output pixel (KPT consecutive pixels, walked incrementally), column = (tap, ci)
+        const int hw = p.gHo * p.gWo;
+        int b = kb / hw;
+        const int r = kb - b * hw;
+        int oy = r / p.gWo, ox = r - oy * p.gWo;
+#pragma unroll
+        for (int j = 0; j < B_KPT; ++j) {
+          const int iy = oy * p.gStride - 1 + bx_ky, ix = ox * p.gStride - 1 + bx_kx;
+          const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
+          const long off = inb ? ((long)(b * p.gH + iy) * p.gW + ix) * p.gC + bx_ci : 0;
+          const float v = Bp[off];
+          rkb[j] = inb ? v : 0.f;
+          if (++ox == p.gWo) { ox = 0; if (++oy == p.gHo) { oy = 0; ++b; } }
+        }
+      }
     } else if (BKIND == B_KN) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + (long)(k0 + tid / BF4 + q * BRPP) * p.ldb + b_nc);
@@ -196,7 +237,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   };
 
   auto store_lds = [&]() {
-    if (A_PL) {
+    if (A_KM) {
+#pragma unroll
+      for (int h = 0; h < A_KPT / 8; ++h) {
+        const Split8 sp = split8(make_float4(rka[8 * h], rka[8 * h + 1], rka[8 * h + 2], rka[8 * h + 3]),
+                                 make_float4(rka[8 * h + 4], rka[8 * h + 5], rka[8 * h + 6], rka[8 * h + 7]));
+        char* d = reinterpret_cast<char*>(As) + (tid % BM) * PLB + (a_kg * A_KPT + 8 * h) * 2;
+        *reinterpret_cast<bf16x8*>(d) = sp.hi;
+        *reinterpret_cast<bf16x8*>(d + BM * PLB) = sp.mid;
+        *reinterpret_cast<bf16x8*>(d + 2 * BM * PLB) = sp.lo;
+      }
+    } else if (A_PL) {
 #pragma unroll
       for (int q = 0; q < PA; ++q) {
         const Split4 sp = split4(ra[q]);
@@ -214,7 +265,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
       for (int q = 0; q < PA; ++q)
         *reinterpret_cast<float4*>(&As[(tid / AF4 + q * ARPP) * (BM + 4) + (tid % AF4) * 4]) = ra[q];
     }
-    if (B_PL) {
+    if (B_KM) {
+#pragma unroll
+      for (int h = 0; h < B_KPT / 8; ++h) {
+        const Split8 sp = split8(make_float4(rkb[8 * h], rkb[8 * h + 1], rkb[8 * h + 2], rkb[8 * h + 3]),
+                                 make_float4(rkb[8 * h + 4], rkb[8 * h + 5], rkb[8 * h + 6], rkb[8 * h + 7]));
+        char* d = reinterpret_cast<char*>(Bs) + (tid % BN) * PLB + (b_kg * B_KPT + 8 * h) * 2;
+        *reinterpret_cast<bf16x8*>(d) = sp.hi;
+        *reinterpret_cast<bf16x8*>(d + BN * PLB) = sp.mid;
+        *reinterpret_cast<bf16x8*>(d + 2 * BN * PLB) = sp.lo;
+      }
+    } else if (B_PL) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
         const Split4 sp = split4(rb[q]);
