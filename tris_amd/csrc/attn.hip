@@ -10,12 +10,20 @@
 namespace {
 
 constexpr int HD = 64;       // head dim
-constexpr int HP = HD + 1;   // padded LDS row
+constexpr int HP = HD + 4;   // padded LDS row: 68 floats = 17 sixteen-byte slots -> ds_read_b128 of 16 consecutive rows is
+                             // conflict-free (17 j mod 16 is a permutation) and rows stay 16-byte aligned
 
-// qkv: [N, L, 3W] packed (q | k | v), out: [N, L, W]
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4 v) {
+  acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
+}
+
+// qkv: [N, L, 3W] packed (q | k | v), out: [N, L, W].  All LDS traffic is 16-byte wide: scores read q/k rows as float4,
+// the output phase gives each thread 4 consecutive channels of one row.
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
                                                       int W, int causal, float scale) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* q = sm;
   float* k = q + L * HP;
   float* v = k + L * HP;
@@ -23,21 +31,21 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
   const int LP = L + 1;
   const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const float* base = qkv + (long)n * L * 3 * W + h * HD;
-  for (int idx = tid; idx < L * HD; idx += 256) {
-    int l = idx >> 6, d = idx & 63;
+  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
+    const int l = idx >> 4, d = (idx & 15) * 4;
     const float* r = base + (long)l * 3 * W + d;
-    q[l * HP + d] = r[0];
-    k[l * HP + d] = r[W];
-    v[l * HP + d] = r[2 * W];
+    *reinterpret_cast<float4*>(&q[l * HP + d]) = *reinterpret_cast<const float4*>(r);
+    *reinterpret_cast<float4*>(&k[l * HP + d]) = *reinterpret_cast<const float4*>(r + W);
+    *reinterpret_cast<float4*>(&v[l * HP + d]) = *reinterpret_cast<const float4*>(r + 2 * W);
   }
   __syncthreads();
   for (int idx = tid; idx < L * L; idx += 256) {
-    int i = idx / L, j = idx - i * L;
+    const int i = idx / L, j = idx - i * L;
     float acc = -INFINITY;
     if (!causal || j <= i) {
       acc = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < HD; ++d) acc += q[i * HP + d] * k[j * HP + d];
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) acc += dot4(lds4(&q[i * HP + d]), lds4(&k[j * HP + d]));
       acc *= scale;
     }
     s[i * LP + j] = acc;
@@ -53,18 +61,18 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   float* ob = out + (long)n * L * W + h * HD;
-  for (int idx = tid; idx < L * HD; idx += 256) {
-    int i = idx >> 6, d = idx & 63;
-    float acc = 0.f;
-    for (int j = 0; j < L; ++j) acc += s[i * LP + j] * v[j * HP + d];
-    ob[(long)i * W + d] = acc;
+  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
+    const int i = idx >> 4, d = (idx & 15) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < L; ++j) fma4(acc, s[i * LP + j], lds4(&v[j * HP + d]));
+    *reinterpret_cast<float4*>(&ob[(long)i * W + d]) = acc;
   }
 }
 
 // dqkv: [N, L, 3W]; recomputes P from q,k.
 __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                       float* __restrict__ dqkv, int L, int W, int causal, float scale) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* q = sm;
   float* k = q + L * HP;
   float* v = k + L * HP;
@@ -75,24 +83,24 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
   const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const float* base = qkv + (long)n * L * 3 * W + h * HD;
   const float* gb = dout + (long)n * L * W + h * HD;
-  for (int idx = tid; idx < L * HD; idx += 256) {
-    int l = idx >> 6, d = idx & 63;
+  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
+    const int l = idx >> 4, d = (idx & 15) * 4;
     const float* r = base + (long)l * 3 * W + d;
-    q[l * HP + d] = r[0];
-    k[l * HP + d] = r[W];
-    v[l * HP + d] = r[2 * W];
-    g[l * HP + d] = gb[(long)l * W + d];
+    *reinterpret_cast<float4*>(&q[l * HP + d]) = *reinterpret_cast<const float4*>(r);
+    *reinterpret_cast<float4*>(&k[l * HP + d]) = *reinterpret_cast<const float4*>(r + W);
+    *reinterpret_cast<float4*>(&v[l * HP + d]) = *reinterpret_cast<const float4*>(r + 2 * W);
+    *reinterpret_cast<float4*>(&g[l * HP + d]) = *reinterpret_cast<const float4*>(gb + (long)l * W + d);
   }
   __syncthreads();
   for (int idx = tid; idx < L * L; idx += 256) {
-    int i = idx / L, j = idx - i * L;
+    const int i = idx / L, j = idx - i * L;
     float acc = -INFINITY, dp = 0.f;
     if (!causal || j <= i) {
       acc = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < HD; ++d) {
-        acc += q[i * HP + d] * k[j * HP + d];
-        dp += g[i * HP + d] * v[j * HP + d];
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        acc += dot4(lds4(&q[i * HP + d]), lds4(&k[j * HP + d]));
+        dp += dot4(lds4(&g[i * HP + d]), lds4(&v[j * HP + d]));
       }
       acc *= scale;
     }
@@ -116,18 +124,18 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   float* ob = dqkv + (long)n * L * 3 * W + h * HD;
-  for (int idx = tid; idx < L * HD; idx += 256) {
-    int i = idx >> 6, d = idx & 63;
-    float dq = 0.f, dk = 0.f, dv = 0.f;
+  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
+    const int i = idx >> 4, d = (idx & 15) * 4;
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dk = dq, dv = dq;
     for (int j = 0; j < L; ++j) {
-      dq += ds[i * LP + j] * k[j * HP + d];
-      dk += ds[j * LP + i] * q[j * HP + d];
-      dv += s[j * LP + i] * g[j * HP + d];
+      fma4(dq, ds[i * LP + j], lds4(&k[j * HP + d]));
+      fma4(dk, ds[j * LP + i], lds4(&q[j * HP + d]));
+      fma4(dv, s[j * LP + i], lds4(&g[j * HP + d]));
     }
     float* r = ob + (long)i * 3 * W + d;
-    r[0] = dq;
-    r[W] = dk;
-    r[2 * W] = dv;
+    *reinterpret_cast<float4*>(r) = dq;
+    *reinterpret_cast<float4*>(r + W) = dk;
+    *reinterpret_cast<float4*>(r + 2 * W) = dv;
   }
 }
 
