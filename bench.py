@@ -168,10 +168,11 @@ def main():
 
     # PMC-derived HBM traffic of the same kernel family (separate rocprofv3 --pmc passes, committed under profiles/)
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_hbm_traffic.json")))["gemm_family"]
+        pmc_file = "r1j_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["gemm_family"]
         roof["traffic"] = int((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / pmc["launches_per_step"])
         roof["traffic_note"] = ("bytes per launch, averaged over the family: (FETCH_SIZE x2 + WRITE_SIZE) per step / launches per "
-                                "step from profiles/r1c_pmc_hbm_traffic.json (rocprofv3 --pmc, B=48 step)")
+                                f"step from profiles/{pmc_file} (rocprofv3 --pmc, B=48 step)")
     except Exception:
         pass
     roof_x = None
