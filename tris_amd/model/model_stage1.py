@@ -15,6 +15,21 @@ from ..CLIP.clip.model import Conv2d, Linear
 from .attn import bilateral_prompt
 
 
+_SIDE = {}
+
+
+def _overlap_enabled():
+    import os
+    return os.environ.get("TRIS_TEXT_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
+
+
 class TRIS(nn.Module):
     def __init__(self, args=None):
         super().__init__()
@@ -52,10 +67,11 @@ class TRIS(nn.Module):
         vis = self.vis_project(c4).reshape(B, h_ * w_, -1)              # [B,P,C]
         return ops.l2norm(vis), h_, w_
 
-    def forward_cached(self, vis_state, word_id, out_size):
+    def forward_cached(self, vis_state, word_id, out_size, hidden=None):
         norm_vis, h_, w_ = vis_state
         B = norm_vis.shape[0]
-        _, hidden = self.backbone.encode_text(word_id)                 # [N,E]   (N = B sentences)
+        if hidden is None:
+            _, hidden = self.backbone.encode_text(word_id)             # [N,E]   (N = B sentences)
         norm_lan = ops.l2norm(self.lan_project(hidden))                 # [N,C]
         if self.args.attn_multi > 0:
             new_vis, new_lan = self.attn_fusion.forward_cl(norm_vis, norm_lan)
@@ -74,7 +90,20 @@ class TRIS(nn.Module):
         return ops.score_heads(score, h_, w_, out_size, False)
 
     def forward(self, x, word_id):
-        return self.forward_cached(self.encode_visual(x), word_id, x.shape[2])
+        if not _overlap_enabled():
+            return self.forward_cached(self.encode_visual(x), word_id, x.shape[2])
+        # The text encoder (short GEMMs that cannot fill 256 CUs) runs on a second HIP stream, concurrently with the
+        # RN50 trunk; autograd replays each branch's backward on the stream its forward ran on, so the overlap holds
+        # in both directions.  Joined before the heads.
+        main = torch.cuda.current_stream()
+        side = _side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _, hidden = self.backbone.encode_text(word_id)
+        vis = self.encode_visual(x)
+        main.wait_stream(side)
+        hidden.record_stream(main)
+        return self.forward_cached(vis, word_id, x.shape[2], hidden=hidden)
 
 
 def focal_loss(x, p=1, c=0.1):

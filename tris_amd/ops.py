@@ -48,13 +48,14 @@ _WS = {}
 
 
 def workspace(nbytes):
-    """Per-device scratch arena (single stream => serial reuse is safe)."""
-    dev = torch.cuda.current_device()
-    cur = _WS.get(dev)
+    """Scratch arena per (device, stream): kernels on one stream run in order, so serial reuse is safe; work issued on
+    a second stream (the text encoders overlap the RN50 trunk, tris_amd.model.model_stage1) gets its own arena."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    cur = _WS.get(key)
     if cur is None or cur.numel() * 4 < nbytes:
         n = max(int(nbytes), 256 << 20)
         cur = torch.empty(n // 4 + 1, dtype=torch.float32, device="cuda")
-        _WS[dev] = cur
+        _WS[key] = cur
     return cur
 
 

@@ -25,8 +25,22 @@ def MaxLoss(x):
 
 def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     """train_stage1.py:317-364.  Returns (losses[4] = total,l1,l4,l5 ; cls ; sig_out)."""
-    cls, _, _, sig_out, _ = model(img, word_ids)
     B = img.shape[0]
+    # frozen aux text tower (positives + negatives in one batch, no gradient): issued first, on the side stream, so it
+    # overlaps the RN50 trunk of the model forward
+    from .model.model_stage1 import _overlap_enabled, _side_stream
+    f_all = None
+    ids_all = word_ids.long()
+    K = 0
+    if neg_word_ids is not None and args.negative_samples > 0:
+        K = neg_word_ids.shape[1]
+        ids_all = torch.cat([ids_all, neg_word_ids.long().reshape(B * K, -1)], 0)
+    if _overlap_enabled():
+        main, side = torch.cuda.current_stream(), _side_stream(img.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            f_all = clip_model.encode_text(ids_all)[1]
+    cls, _, _, sig_out, _ = model(img, word_ids)
     if img.shape[2] != CLIP_INPUT:
         cam = ops.resize_bilinear(sig_out, (CLIP_INPUT, CLIP_INPUT), True)
         with torch.no_grad():
@@ -36,12 +50,11 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     vit = clip_model.visual
     f_i = vit.forward_patches(ops.fg_patches(cam, im, vit.patch_size))
     with torch.no_grad():
-        ids = word_ids.long()
-        K = 0
-        if neg_word_ids is not None and args.negative_samples > 0:
-            K = neg_word_ids.shape[1]
-            ids = torch.cat([ids, neg_word_ids.long().reshape(B * K, -1)], 0)
-        f_all = clip_model.encode_text(ids)[1]
+        if f_all is None:
+            f_all = clip_model.encode_text(ids_all)[1]
+        else:
+            torch.cuda.current_stream().wait_stream(_side_stream(img.device))
+            f_all.record_stream(torch.cuda.current_stream())
         f_t = f_all[:B].contiguous()
         f_neg = f_all[B:].reshape(B, K, -1).contiguous() if K > 0 else None
     losses = ops.stage1_loss(cls, f_i, f_t, f_neg, float(args.w1), float(args.w4), float(args.w5))
