@@ -86,6 +86,45 @@ def cl_weight(w):
     return w
 
 
+# ----------------------------------------------------------------------------------------------- weight-gradient stream
+# Weight gradients are consumed only by the optimiser (or the data-parallel reducer), never by the rest of backward.
+# They are issued on their own HIP stream so a wgrad (split-K, often HBM-bound in the early layers) overlaps the dgrad /
+# BatchNorm-backward chain that continues on the main stream.  `wgrad_join()` makes the current stream wait for them.
+_WG = {}
+
+
+def _wgrad_enabled():
+    import os
+    return os.environ.get("TRIS_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+
+
+def _wgrad_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _WG:
+        _WG[dev] = torch.cuda.Stream(device=dev)
+    return _WG[dev]
+
+
+def on_wgrad_stream(fn, *tensors):
+    """Run `fn()` (kernel launches only) on the weight-gradient stream after everything queued so far on the current
+    stream; `tensors` are the buffers it reads (kept alive for the side stream via record_stream)."""
+    if not _wgrad_enabled():
+        return fn()
+    main, side = torch.cuda.current_stream(), _wgrad_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        r = fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    return r
+
+
+def wgrad_join():
+    if _WG:
+        torch.cuda.current_stream().wait_stream(_wgrad_stream())
+
+
 def _sink(p):
     """The arena view a weight gradient should be written into, or None (=> return it to autograd)."""
     if p is not None and getattr(p, "_tris_sink", False):
@@ -232,13 +271,22 @@ class LinearFn(torch.autograd.Function):
         M, N, K = ctx.dims
         dy = dy.contiguous()
         d_res = dy if ctx.has_r and ctx.needs_input_grad[3] else None
+        if d_res is not None and _wgrad_enabled() and ctx.needs_input_grad[1]:
+            # dy is about to be read by the weight-gradient stream; autograd may accumulate IN PLACE into a gradient
+            # tensor it is handed back (InputBuffer steals sole-owner tensors), so the residual branch gets its own copy
+            d_res = dy.clone()
         if ctx.act == 1:
             dy = ew("TRIS_EW_RELU_BWD", dy, y)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(dy, w, dx, M, K, N, N, K, K, False, False)
-        dw = _emit(pw, lambda o: gemm(dy, x, o, N, K, M, N, K, K, True, False), ctx.needs_input_grad[1])
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
+                on_wgrad_stream(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False), dy, x)
+            else:
+                dw = _emit(pw, lambda o: gemm(dy, x, o, N, K, M, N, K, K, True, False), True)
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
@@ -385,7 +433,13 @@ class Conv3x3Fn(torch.autograd.Function):
             _timed("conv3x3_wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin,
                    lambda: call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws),
                                 ws.numel() * 4, _stream()))
-        dw = _emit(ctx.params[0], wgrad, ctx.needs_input_grad[1])
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sk = _sink(ctx.params[0])
+            if sk is not None:
+                on_wgrad_stream(lambda: wgrad(sk), dy, x)
+            else:
+                dw = _emit(ctx.params[0], wgrad, True)
         return dx, dw, None, None
 
 

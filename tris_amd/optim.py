@@ -67,6 +67,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         self._steps += 1
+        ops.wgrad_join()  # weight gradients are produced on their own stream
         st = torch.cuda.current_stream().cuda_stream
         for g, a in zip(self.param_groups, self.arenas):
             b1, b2 = g["betas"]

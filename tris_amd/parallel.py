@@ -78,6 +78,8 @@ class GradReducer:
         if key in self.done or not self.active:
             return
         self.done.add(key)
+        from . import ops
+        ops.wgrad_join()  # the segment's weight gradients may still be in flight on the weight-gradient stream
         for ai, s, e in self.segments.get(key, []):
             f = self.flats[ai]
             for c in range(s, e, self.chunk):
