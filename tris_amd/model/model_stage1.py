@@ -24,10 +24,7 @@ def _overlap_enabled():
 
 
 def _side_stream(device):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=key)
-    return _SIDE[key]
+    return ops.side_stream("text")
 
 
 class TRIS(nn.Module):

@@ -120,9 +120,27 @@ def on_wgrad_stream(fn, *tensors):
     return r
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(name):
+    """Named auxiliary HIP stream of the current device (e.g. "text": the text encoders overlap the RN50 trunk)."""
+    key = (torch.cuda.current_device(), name)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+    return _SIDE_STREAMS[key]
+
+
 def wgrad_join():
-    if _WG:
-        torch.cuda.current_stream().wait_stream(_wgrad_stream())
+    """Make the current stream wait for every auxiliary stream that may still be producing gradients (the weight-gradient
+    stream and the named side streams): call before anything consumes the gradient arenas (optimiser, all-reduce)."""
+    cur = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    if dev in _WG and _WG[dev] != cur:
+        cur.wait_stream(_WG[dev])
+    for (d, _), st in _SIDE_STREAMS.items():
+        if d == dev and st != cur:
+            cur.wait_stream(st)
 
 
 def _sink(p):
