@@ -134,6 +134,8 @@ def side_stream(name):
 def wgrad_join():
     """Make the current stream wait for every auxiliary stream that may still be producing gradients (the weight-gradient
     stream and the named side streams): call before anything consumes the gradient arenas (optimiser, all-reduce)."""
+    if not _WG and not _SIDE_STREAMS:
+        return  # nothing was ever issued on an auxiliary stream (also: host-only / CPU test contexts)
     cur = torch.cuda.current_stream()
     dev = torch.cuda.current_device()
     if dev in _WG and _WG[dev] != cur:
