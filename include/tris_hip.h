@@ -66,9 +66,10 @@ int tris_bn_finalize_f32(const double* part, int rows, long M, int C, float eps,
 long tris_col_workspace_bytes(long M, int C);
 int tris_bn_stats_f32(const float* X, long M, int C, float eps, float momentum, float* stats, float* running_mean,
                       float* running_var, float* workspace, void* stream);
-/* SyncBatchNorm (train_stage1.py:69): gathered = [world][mean(C) | var(C) | count] from every rank */
-int tris_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* stats,
-                             float* running_mean, float* running_var, void* stream);
+/* SyncBatchNorm (train_stage1.py:69): gathered = [world][3*C] = every rank's `stats` block [mean | invstd | var] as written
+ * by tris_bn_stats_f32 / tris_bn_finalize_f32 (all_gather it as is); each rank contributed count_per_rank rows. */
+int tris_bn_sync_combine_f32(const float* gathered, int world, int C, long count_per_rank, float eps, float momentum,
+                             float* stats, float* running_mean, float* running_var, void* stream);
 /* Y = (X-mean)*invstd*gamma+beta (+resid) (ReLU) -- also the residual add + relu3 of Bottleneck.forward :52-54 */
 int tris_bn_apply_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* resid, float* Y, long M, int C, int relu, void* stream);

@@ -54,15 +54,14 @@ def _worker(rank, world, port, out):
     assert not torch.equal(g[0], g[1])
     # SyncBN combine (the formula of bn_sync_combine_kernel): per-rank (mean, biased var, count) -> statistics of the
     # concatenated batch, which is the N-rank correctness oracle of SURVEY.md 8(e)
-    def data(r):
-        return torch.randn(5 + r, 3, generator=torch.Generator().manual_seed(100 + r)) * (r + 1) + r
+    def data(r):  # equal per-rank counts, as DistributedSampler guarantees
+        return torch.randn(6, 3, generator=torch.Generator().manual_seed(100 + r)) * (r + 1) + r
     x = data(rank)
-    mine = torch.cat([x.mean(0), x.var(0, unbiased=False), torch.tensor([float(x.shape[0])])])
-    allv = [torch.zeros(7) for _ in range(world)]
+    mine = torch.cat([x.mean(0), x.var(0, unbiased=False)])
+    allv = [torch.zeros(6) for _ in range(world)]
     dist.all_gather(allv, mine)
-    n = sum(v[6] for v in allv)
-    mean = sum(v[:3] * v[6] for v in allv) / n
-    var = sum((v[3:6] + (v[:3] - mean) ** 2) * v[6] for v in allv) / n
+    mean = sum(v[:3] for v in allv) / world
+    var = sum(v[3:6] + (v[:3] - mean) ** 2 for v in allv) / world
     full = torch.cat([data(r) for r in range(world)], 0)
     assert torch.allclose(mean, full.mean(0), atol=1e-5) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-4)
     if rank == 0:

@@ -163,26 +163,25 @@ __global__ __launch_bounds__(256) void part_finalize_kernel(const T* __restrict_
   if (out1) out1[c] = (float)ss;
 }
 
-// SyncBN: combine per-rank (mean, biased var, count) -> global mean / invstd / var, update running stats.
-// gathered layout: [W][2*C + 1] = mean[C], var[C], count.
-__global__ void bn_sync_combine_kernel(const float* __restrict__ gathered, int Wn, int C, float eps, float momentum,
-                                       float* __restrict__ stats, float* running_mean, float* running_var) {
+// SyncBN: combine the per-rank statistics blocks [mean | invstd | biased var] (3*C floats each, exactly what
+// bn_finalize_kernel writes, so the all_gather needs no repacking) -> global mean / invstd / var, running-stat update.
+// Every rank contributes `count` rows (DistributedSampler gives equal per-rank batches).
+__global__ void bn_sync_combine_kernel(const float* __restrict__ gathered, int Wn, int C, float count, float eps,
+                                       float momentum, float* __restrict__ stats, float* running_mean,
+                                       float* running_var) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double n = 0.0, mean = 0.0;
-  for (int w = 0; w < Wn; ++w) {
-    const float* g = gathered + (long)w * (2 * C + 1);
-    n += g[2 * C];
-    mean += (double)g[c] * g[2 * C];
-  }
-  mean /= n;
+  double mean = 0.0;
+  for (int w = 0; w < Wn; ++w) mean += (double)gathered[(long)w * 3 * C + c];
+  mean /= (double)Wn;
   double m2 = 0.0;
   for (int w = 0; w < Wn; ++w) {
-    const float* g = gathered + (long)w * (2 * C + 1);
+    const float* g = gathered + (long)w * 3 * C;
     double d = g[c] - mean;
-    m2 += ((double)g[C + c] + d * d) * g[2 * C];
+    m2 += (double)g[2 * C + c] + d * d;
   }
-  double var = m2 / n;
+  double var = m2 / (double)Wn;
+  double n = (double)count * Wn;
   stats[c] = (float)mean;
   stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
   stats[2 * C + c] = (float)var;
@@ -617,10 +616,11 @@ extern "C" int tris_bn_finalize_f32(const double* part, int rows, long M, int C,
   return 0;
 }
 
-extern "C" int tris_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* stats,
-                                        float* running_mean, float* running_var, void* stream) {
+extern "C" int tris_bn_sync_combine_f32(const float* gathered, int world, int C, long count_per_rank, float eps,
+                                        float momentum, float* stats, float* running_mean, float* running_var,
+                                        void* stream) {
   hipLaunchKernelGGL(bn_sync_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world, C,
-                     eps, momentum, stats, running_mean, running_var);
+                     (float)count_per_rank, eps, momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -501,13 +501,9 @@ class BatchNormFn(torch.autograd.Function):
                 import torch.distributed as dist
                 local_stats(None, None)
                 world = dist.get_world_size(group)
-                mine = torch.empty(2 * C + 1, device=x.device, dtype=torch.float32)
-                mine[:C].copy_(stats[:C])
-                mine[C:2 * C].copy_(stats[2 * C:])
-                mine[2 * C] = float(M)
-                allv = torch.empty(world * (2 * C + 1), device=x.device, dtype=torch.float32)
-                dist.all_gather_into_tensor(allv, mine, group=group)
-                call("tris_bn_sync_combine_f32", P(allv), world, C, eps, momentum, P(stats), P(rmean), P(rvar),
+                allv = torch.empty(world * 3 * C, device=x.device, dtype=torch.float32)
+                dist.all_gather_into_tensor(allv, stats, group=group)   # the stats block travels as is
+                call("tris_bn_sync_combine_f32", P(allv), world, C, M, eps, momentum, P(stats), P(rmean), P(rvar),
                      _stream())
                 count = M * world  # DistributedSampler gives every rank the same per-step batch
             mean, invstd = stats[:C], stats[C:2 * C]
