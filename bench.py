@@ -133,9 +133,19 @@ def main():
     loss_vals = losses.tolist()
 
     # ---- live roofline measurement of the dominant kernel family (one extra, untimed, instrumented step) ----
+    # (kernels are timed one at a time: the stream overlap of the production step is switched off for this pass so that a
+    # launch's HIP-event bracket measures that kernel alone, not whatever else shares the GPU with it)
+    saved_env = {k: os.environ.get(k) for k in ("TRIS_TEXT_STREAM", "TRIS_WGRAD_STREAM")}
+    os.environ["TRIS_TEXT_STREAM"] = os.environ["TRIS_WGRAD_STREAM"] = "0"
+    step()
     ops.profile_begin()
     step()
     rec_all = ops.profile_end()
+    for k, v in saved_env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     xa = [r for r in rec_all if r[0].startswith("xattn")]
     rec = [r for r in rec_all if not r[0].startswith("xattn")]
     fl = sum(r[1] for r in rec)
@@ -197,6 +207,8 @@ def main():
                           "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": 20,
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
                "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
+               "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
+                           "weight_gradients_on_side_stream": os.environ.get("TRIS_WGRAD_STREAM", "1") != "0"},
                "roofline": roof, "roofline_xattn": roof_x}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
