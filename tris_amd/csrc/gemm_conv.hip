@@ -14,6 +14,9 @@
 // (register staging), stored to LDS after it.
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "common.h"
 #include "tris_hip.h"
@@ -387,11 +390,13 @@ static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")
 
 #include "gemm_fast.h"
 
-template <int AK, int BKIND>
-int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
-  // Tile / split-K choice by a small cost model (cycles on the f32 MFMA pipe, 64 cycles per 32x32x2 MFMA):
-  //   per-wave cycles per 32-deep k step = (BM/64)*(BN/64)*1024; a block owns a CU's 4 SIMDs; blocks beyond the 256
-  //   CUs queue.  Split-K adds a slab round trip + a reduce launch.  Smaller tiles pay extra LDS / L2 traffic.
+// ---- configuration = (tile, split-K) ----------------------------------------------------------------------------------
+struct Cfg { int bm, bn, splitk; };
+
+// Tile / split-K choice by a small cost model (cycles on the MFMA pipe); also the starting point of the autotuner.
+//   per-wave cycles per 32-deep k step = (BM/64)*(BN/64)*c; a block owns a CU's 4 SIMDs; blocks beyond the 256 CUs queue.
+//   Split-K adds a slab round trip + a reduce launch.  Smaller tiles pay extra LDS / L2 traffic.
+static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long ws_bytes) {
   const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
   int bm = 64, bn = 64, splitk = 1;
   if (p.stat_part != nullptr) {  // fused BN statistics: fixed 128-row tiles (the caller sizes the partial buffer), no split-K
@@ -439,6 +444,14 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if (forced == 2) { bm = 128; bn = 64; }
     if (forced == 3) { bm = 64; bn = 64; }
   }
+  Cfg c = {bm, bn, splitk};
+  return c;
+}
+
+// launch one configuration (+ split-K reduce)
+template <int AK, int BKIND>
+int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
+  int bm = cfg.bm, bn = cfg.bn, splitk = cfg.splitk;
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
   const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
@@ -487,6 +500,83 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   }
   return 0;
 }
+
+// ---- autotuner ------------------------------------------------------------------------------------------------------------
+// The first time a (kind, M, N, K, batch, mode) product is seen, every admissible (tile, split-K) pair is launched on the
+// caller's buffers (the kernels are idempotent), timed with HIP events, and the fastest is cached for the life of the
+// process.  Host-synchronising, so only outside stream capture; TRIS_AUTOTUNE=0 keeps the cost model.
+struct TuneKey {
+  int ak, bk, M, N, K, batch, mode;
+  bool operator<(const TuneKey& o) const {
+    return std::tie(ak, bk, M, N, K, batch, mode) < std::tie(o.ak, o.bk, o.M, o.N, o.K, o.batch, o.mode);
+  }
+};
+static std::map<TuneKey, Cfg> g_tuned;
+static std::mutex g_tune_mu;
+
+static bool autotune_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("TRIS_AUTOTUNE"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+
+template <int AK, int BKIND>
+int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
+  Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
+  if (p.stat_part != nullptr || !autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return run_cfg<AK, BKIND>(p, batch, ws, st, h);
+  const TuneKey key = {AK, BKIND, p.M, p.N, p.K, batch, g_gemm_mode};
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) return run_cfg<AK, BKIND>(p, batch, ws, st, it->second);
+  }
+  // candidates
+  static const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
+  hipDeviceSynchronize();  // drain the other streams: candidates are timed on an otherwise idle device
+  Cfg best = h;
+  float best_ms = 1e30f;
+  auto time_cfg = [&](Cfg c) -> float {
+    float ms_min = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0, st);
+      if (run_cfg<AK, BKIND>(p, batch, ws, st, c) != 0) return 1e30f;
+      hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+      float ms = 1e30f;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms_min = ms < ms_min ? ms : ms_min;
+    }
+    return ms_min;
+  };
+  for (int t = 0; t < 3; ++t) {
+    const int cbm = tiles[t][0], cbn = tiles[t][1];
+    if (t < 2 && p.M < 96) continue;
+    if (t == 0 && p.N <= 64) continue;
+    const long ntiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
+    for (int sk : sks) {
+      if (sk > 1 && (!can_split || sk > p.K / 256 || (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes)) break;
+      if (sk > 1 && ntiles * sk > 1536) break;  // more than ~6 blocks per CU buys nothing
+      const Cfg c = {cbm, cbn, sk};
+      const float ms = time_cfg(c);
+      if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = best;
+  }
+  return run_cfg<AK, BKIND>(p, batch, ws, st, best);  // leave the outputs of the chosen configuration
+}
+
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
