@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "tris_hip.h")
-LIBPATH = os.path.join(_HERE, "libtris_hip.so")
+LIBPATH = os.environ.get("TRIS_HIP_LIB") or os.path.join(_HERE, "libtris_hip.so")  # env: developer knob (kernel experiments)
 
 _CT = {
     "int": ctypes.c_int,

@@ -53,6 +53,12 @@ __device__ __forceinline__ Split8 split8(const float4 u, const float4 w) {
 struct Split4 { uint2 hi, mid, lo; };
 __device__ __forceinline__ Split4 split4(const float4 u) {
   Split4 o;
+#ifdef TRIS_EXP_NOSPLIT
+  o.hi.x = __builtin_bit_cast(unsigned, u.x); o.hi.y = __builtin_bit_cast(unsigned, u.y);
+  o.mid.x = __builtin_bit_cast(unsigned, u.z); o.mid.y = __builtin_bit_cast(unsigned, u.w);
+  o.lo = o.hi;
+  return o;
+#endif
   o.hi.x = pk_bf16(u.x, u.y);
   o.hi.y = pk_bf16(u.z, u.w);
   const float r0 = u.x - __builtin_bit_cast(float, o.hi.x << 16), r1 = u.y - __builtin_bit_cast(float, o.hi.x & 0xffff0000u);
@@ -310,10 +316,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += FBK) {
     const bool more = (k0 + FBK) < kend;  // uniform
+#ifndef TRIS_EXP_NOLOAD
     if (more) {
       load_A(k0 + FBK);
       load_B(k0 + FBK);
     }
+#endif
     if constexpr (PREC == 0) {
 #pragma unroll
     for (int g = 0; g < FBK; g += 8) {
@@ -395,10 +403,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
       }
     }
     __syncthreads();
+#ifndef TRIS_EXP_NOSTORE
     if (more) {
       store_lds();
       __syncthreads();
     }
+#endif
   }
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ---------------------
