@@ -193,6 +193,27 @@ int tris_adamw_f32(float* p, const float* g, float* m, float* v, long n, float l
 int tris_eval_post_f32(const float* relu_map, int S, const unsigned char* target, int oH, int oW, float* cam,
                        long* out_iu, float* workspace /* >= 2*1024+8 floats */, void* stream);
 
+/* ---- input pipeline (dataset/transform.py:23-63, dataset/ReferDataset.py:125-252) ---------------------
+ * The decoded dataset is kept in HBM as uint8; everything below is bit-exact against Pillow / torchvision semantics. */
+/* Pillow's antialiased two-pass resampling of an 8-bit image [Hin][Win][C] -> [Hout][Wout][C] (F.resize on a PIL image,
+ * dataset/transform.py:29).  bounds_* int32[out][2] = {first source index, tap count}, kk_* int32[out][ksize] taps in
+ * 22-bit fixed point (built on the host exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do); a NULL
+ * bounds pointer skips that pass (size unchanged along it).  tmp: Hin*Wout*C bytes when both passes run. */
+int tris_resample_u8(const unsigned char* in, int Hin, int Win, int C, const int* bounds_h, const int* kk_h, int ksize_h,
+                     const int* bounds_v, const int* kk_v, int ksize_v, int Hout, int Wout, unsigned char* tmp,
+                     unsigned char* out, void* stream);
+/* Pillow NEAREST resize (dataset/transform.py:32, ReferDataset.py:187): out[y][x] = in[yidx[y]][xidx[x]] (index < 0 -> 0) */
+int tris_gather2d_u8(const unsigned char* in, int Hin, int Win, int C, const int* yidx, const int* xidx, int Hout,
+                     int Wout, unsigned char* out, void* stream);
+/* batch assembly: out[b] = lut[c][cache[index[b]][p][c]]  (to_tensor + normalize, dataset/transform.py:41-53, with the
+ * 3x256 float table computed by the host with the reference's float ops).  cache: uint8 [N][HW][3]; index: int64[B];
+ * out: fp32 [B][HW][3] (planar=0, channels-last) or [B][3][HW] (planar=1, the reference's NCHW).  HW % 4 == 0. */
+int tris_u8_gather_normalize_f32(const unsigned char* cache, const long* index, int B, long HW, const float* lut,
+                                 float* out, int planar, void* stream);
+/* out[r] = table[index[r]]  for rows of row_bytes (multiple of 4) bytes: token ids of the sampled sentences
+ * (ReferDataset.py:172-229) */
+int tris_gather_rows(const void* table, const long* index, long rows, long row_bytes, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,8 +59,9 @@ def install():
     tv = _stub("torchvision")
     tv.__path__ = []
 
-    class _IM:
+    class _IM:   # values = Pillow's resampling constants, so the functional stub can hand them to Image.resize
         BICUBIC = 3
+        BILINEAR = 2
         NEAREST = 0
 
     tvt = _stub("torchvision.transforms", Compose=_Dummy, Resize=_Dummy, CenterCrop=_Dummy,
@@ -83,6 +84,51 @@ def install():
     clip.load = _load
     clip.clip.load = _load
     return clip
+
+
+def install_dataset():
+    """Additionally make `dataset.ReferDataset` / `dataset.transform` of the reference importable.
+
+    torchvision is absent, so the three functional ops the reference calls on PIL inputs are supplied here with
+    torchvision 0.9's documented behaviour (transforms/functional_pil.py resize = Image.resize((w, h), interpolation);
+    functional.to_tensor = uint8 HWC -> float CHW / 255; functional.normalize = (x - mean) / std).  pycocotools is
+    absent too: `pycocotools.mask` is served by tris_amd.dataset.cocomask, so target masks are NOT independently pinned
+    by anything that goes through this shim (cocomask's header says so)."""
+    install()
+    import numpy as np
+    import torch
+
+    tvf = sys.modules["torchvision.transforms.functional"]
+
+    def resize(img, size, interpolation=2):
+        return img.resize(tuple(size[::-1]), interpolation)
+
+    def to_tensor(pic):
+        a = np.asarray(pic)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(a.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    def normalize(tensor, mean, std, inplace=False):
+        t = tensor if inplace else tensor.clone()
+        m = torch.as_tensor(mean, dtype=t.dtype).view(-1, 1, 1)
+        sd = torch.as_tensor(std, dtype=t.dtype).view(-1, 1, 1)
+        return t.sub_(m).div_(sd)
+
+    tvf.resize, tvf.to_tensor, tvf.normalize = resize, to_tensor, normalize
+    sys.modules["torchvision.transforms"].functional = tvf
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from tris_amd.dataset import cocomask
+    pc = _stub("pycocotools")
+    pc.__path__ = []
+    pc.mask = _stub("pycocotools.mask", frPyObjects=cocomask.frPyObjects, decode=cocomask.decode, area=cocomask.area)
+    sk = _stub("skimage")
+    sk.__path__ = []
+    sk.io = _stub("skimage.io")
+    _stub("transformers")   # imported but unused by dataset/ReferDataset.py:12; the real one probes torchvision's spec
+    from dataset.ReferDataset import ReferDataset   # noqa: E402  (the reference's)
+    from dataset.transform import get_transform     # noqa: E402
+    return ReferDataset, get_transform
 
 
 def make_args(extra=()):

@@ -223,6 +223,8 @@ def ew(op, A, B=None, s=0.0, out=None):
 
 def nchw_to_nhwc(x):
     _chk(x)
+    if x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous():   # already channels-last in memory (tris_amd.dataset.hbm)
+        return x.permute(0, 2, 3, 1)
     x = x.contiguous()
     B, C, H, W = x.shape
     y = torch.empty(B, H, W, C, device=x.device, dtype=x.dtype)
@@ -1071,3 +1073,94 @@ def eval_post(relu_map, target_u8):
     call("tris_eval_post_f32", P(relu_map.contiguous()), S, P(target_u8.contiguous()), oH, oW, P(cam), P(iu), P(ws),
          _stream())
     return iu, cam
+
+
+# ------------------------------------------------------------------------------------------------------ input pipeline
+#  uint8 dataset resident in HBM; see tris_amd/dataset/hbm.py
+_PIL_TABLES = {}
+
+
+def _pil_tables(kind, n_in, n_out, device):
+    key = (kind, n_in, n_out, str(device))
+    t = _PIL_TABLES.get(key)
+    if t is None:
+        from .dataset import pil_tables
+        if kind == "bilinear":
+            bounds, kk, ksize = pil_tables.resample_tables(n_in, n_out)
+            t = (torch.from_numpy(bounds.copy()).to(device), torch.from_numpy(kk.copy()).to(device), ksize)
+        else:
+            t = (torch.from_numpy(pil_tables.nearest_index(n_in, n_out).copy()).to(device),)
+        _PIL_TABLES[key] = t
+    return t
+
+
+def _chk_u8(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise NoGpuError("tris_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.uint8:
+            raise TypeError(f"expected uint8, got {t.dtype}")
+
+
+def resample_u8(img, out_h, out_w, out=None):
+    """Pillow `resize((out_w, out_h), BILINEAR)` of a uint8 [H,W,C] device image, bit-exact (dataset/transform.py:29)."""
+    _chk_u8(img)
+    img = img.contiguous()
+    H, W, C = img.shape
+    if out is None:
+        out = torch.empty(out_h, out_w, C, dtype=torch.uint8, device=img.device)
+    if (H, W) == (out_h, out_w):
+        out.copy_(img)
+        return out
+    th = _pil_tables("bilinear", W, out_w, img.device) if W != out_w else (None, None, 0)
+    tv = _pil_tables("bilinear", H, out_h, img.device) if H != out_h else (None, None, 0)
+    tmp = torch.empty(H * out_w * C, dtype=torch.uint8, device=img.device) if (th[0] is not None and tv[0] is not None) \
+        else None
+    call("tris_resample_u8", P(img), H, W, C, P(th[0]), P(th[1]), th[2], P(tv[0]), P(tv[1]), tv[2], out_h, out_w,
+         P(tmp), P(out), _stream())
+    return out
+
+
+def resize_nearest_u8(img, out_h, out_w, out=None):
+    """Pillow `resize((out_w, out_h), NEAREST)` of a uint8 [H,W] / [H,W,C] device image (dataset/transform.py:32)."""
+    _chk_u8(img)
+    img = img.contiguous()
+    H, W = img.shape[:2]
+    C = img.shape[2] if img.dim() == 3 else 1
+    if out is None:
+        out = torch.empty((out_h, out_w) + tuple(img.shape[2:]), dtype=torch.uint8, device=img.device)
+    if (H, W) == (out_h, out_w):
+        out.copy_(img)
+        return out
+    yi, = _pil_tables("nearest", H, out_h, img.device)
+    xi, = _pil_tables("nearest", W, out_w, img.device)
+    call("tris_gather2d_u8", P(img), H, W, C, P(yi), P(xi), out_h, out_w, P(out), _stream())
+    return out
+
+
+def gather_normalize(cache, index, lut, planar=False):
+    """cache uint8 [N,H,W,3], index int64 [B], lut float32 [3,256] -> float32 batch of ToTensor+Normalize'd images:
+    planar=False: memory [B,H,W,3], returned as the [B,3,H,W] channels-last view;  planar=True: contiguous [B,3,H,W]."""
+    _chk_u8(cache)
+    _chk(index, lut)
+    N, H, W, C = cache.shape
+    assert C == 3 and cache.is_contiguous() and index.dtype == torch.int64
+    B = index.numel()
+    if planar:
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=cache.device)
+    else:
+        out = torch.empty(B, H, W, 3, dtype=torch.float32, device=cache.device)
+    call("tris_u8_gather_normalize_f32", P(cache), P(index), B, H * W, P(lut.contiguous()), P(out), int(planar), _stream())
+    return out if planar else out.permute(0, 3, 1, 2)
+
+
+def gather_rows(table, index):
+    """table [N, ...] (any dtype, row size a multiple of 4 bytes), index int64 [R] -> [R, ...]"""
+    if not table.is_cuda:
+        raise NoGpuError("tris_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback")
+    assert table.is_contiguous() and index.dtype == torch.int64 and index.is_cuda
+    row_bytes = table[0].numel() * table.element_size()
+    out = torch.empty((index.numel(),) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+    if index.numel():
+        call("tris_gather_rows", P(table), P(index), index.numel(), row_bytes, P(out), _stream())
+    return out
