@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (metric config: 48)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the bounded CPU-baseline sample")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the input-pipeline measurement (SURVEY.md 8f-1)")
     return ap.parse_args()
 
 
@@ -210,6 +211,13 @@ def main():
                "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
                            "weight_gradients_on_side_stream": os.environ.get("TRIS_WGRAD_STREAM", "1") != "0"},
                "roofline": roof, "roofline_xattn": roof_x}
+        if world == 1 and not a.no_pipeline:
+            # input pipeline ahead of the step (HBM-resident uint8 dataset -> batch), measured apart from `value`
+            try:
+                from tools.pipeline_bench import measure as pipeline_measure
+                out["input_pipeline"] = pipeline_measure(batch=a.batch)
+            except Exception as e:  # reported, never hidden
+                out["input_pipeline"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         line = json.dumps(out)

@@ -157,3 +157,34 @@ def test_train_step_from_hbm_batch_equals_planar_batch(tmp_path):
         b = model(s_pl["img"], ids)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_script_level_main_trains_validates_checkpoints_and_resumes(tmp_path):
+    """python -m tris_amd.train_stage1 equivalent on the synthetic dataset: HBM loader -> train_one_epoch -> validate ->
+    best checkpoint; then --resume --eval reproduces the stored validation numbers (train_stage1.py:44-262)."""
+    import os
+    from tris_amd.args import get_parser
+    from tris_amd.train_stage1 import main, setup_seed
+    from tris_amd.utils.synth import make_mini_refer, word_hash_tokenize
+    root = make_mini_refer(str(tmp_path / "data"), n_images=8, seed=6)
+    out = str(tmp_path / "out")
+    argv = ["--refer_data_root", root, "--dataset", "refcocog", "--splitBy", "umd", "--size", "64", "--batch_size", "4",
+            "--epoch", "2", "--test_split", "val", "--output", out, "--negative_samples", "3", "--print-freq", "1",
+            "--backbone", "clip-RN50", "--max_query_len", "20"]
+    setup_seed(1234)
+    best = main(get_parser().parse_args(argv), tokenizer=word_hash_tokenize)
+    assert best["epoch"] >= 0 and os.path.exists(best["path"]) and os.path.exists(best["hit_path"])
+    ck = torch.load(best["path"], map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch"} and len(ck["model"]) == 518
+    res = main(get_parser().parse_args(argv + ["--resume", "--eval", "--pretrain", os.path.basename(best["path"])]),
+               tokenizer=word_hash_tokenize)
+    oIoU, mIoU, hit = res[0]
+    assert abs(float(mIoU) - best["val_acc"]) < 1e-3 and hit == best["val_hit"]
+    # the CPU DataLoader path (the reference's loader) feeds the same loop
+    os.environ["TRIS_HBM_LOADER"] = "0"
+    try:
+        res2 = main(get_parser().parse_args(argv + ["--resume", "--eval", "--pretrain", os.path.basename(best["path"])]),
+                    tokenizer=word_hash_tokenize)
+    finally:
+        del os.environ["TRIS_HBM_LOADER"]
+    assert abs(float(res2[0][1]) - float(mIoU)) < 1e-4 and res2[0][2] == hit

@@ -44,7 +44,7 @@ class ReferDataset(data.Dataset):
         for r in self.ref_ids:
             ids, masks, raws = [], [], []
             for sent in self.refer.Refs[r]["sentences"]:
-                row = np.array(self.tokenizer(sent["sent"]).squeeze(0)[: self.max_tokens])
+                row = self.tokenizer(sent["sent"]).squeeze(0)[: self.max_tokens].numpy()
                 ids.append(torch.tensor(row).unsqueeze(0))
                 masks.append(torch.tensor(np.array(row > 0, dtype=int)).unsqueeze(0))
                 raws.append(sent["sent"])

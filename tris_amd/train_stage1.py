@@ -8,8 +8,13 @@ the same input, :340 and :344), all positive + negative sentences go through the
 (the reference loops over images, :346-347), no weight gradients are computed for the frozen aux CLIP, and the unused
 attention pool of the RN50 is skipped.  Loss values and gradients are identical (tests/test_gpu_parity.py).
 """
+import datetime
+import logging
+import os
+import random
 import time
 
+import numpy as np
 import torch
 
 from . import ops
@@ -106,3 +111,154 @@ def train_one_epoch(train_loader, model, optimizer, epoch, local_rank, args, ite
                     writer.add_scalar(name, val, iteration)
         iteration += 1
     return iteration
+
+
+# ---- script level: python -m tris_amd.train_stage1 <reference flags>  (train_stage1.py:33-262, 413-437) --------------------
+def setup_seed(seed):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def _logger(args, rank):
+    log = logging.getLogger("tris_amd")
+    if not log.handlers:
+        log.setLevel(logging.INFO if rank == 0 else logging.WARNING)
+        h = logging.StreamHandler()
+        h.setFormatter(logging.Formatter("[%(asctime)s] %(message)s", "%H:%M:%S"))
+        log.addHandler(h)
+        if rank == 0 and getattr(args, "output", None):
+            os.makedirs(args.output, exist_ok=True)
+            log.addHandler(logging.FileHandler(os.path.join(args.output, f"log_rank{rank}.txt")))
+    return log
+
+
+def build_dataset(args, split, train, eval_mode, tokenizer=None):
+    """ReferDataset with the reference's arguments (train_stage1.py:82-106, validate.py:50-62)"""
+    from .dataset.ReferDataset import ReferDataset
+    from .dataset.transform import get_transform
+    return ReferDataset(refer_data_root=args.refer_data_root, dataset=args.dataset, splitBy=args.splitBy,
+                        bert_tokenizer=args.bert_tokenizer, split=split, size=args.size, max_tokens=args.max_query_len,
+                        image_transforms=get_transform(args.size, train=train), eval_mode=eval_mode,
+                        negative_samples=args.negative_samples if not eval_mode else 0,
+                        positive_samples=args.positive_samples, scales=getattr(args, "scales", False),
+                        tokenizer=tokenizer)
+
+
+def build_loader(args, dataset, batch_size, shuffle, distributed):
+    """The HBM-resident loader (tris_amd.dataset.hbm) by default; TRIS_HBM_LOADER=0 selects the reference's
+    DataLoader(num_workers=2, pin_memory=True) over the same dataset."""
+    sampler = None
+    if distributed:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, shuffle=shuffle)
+    if os.environ.get("TRIS_HBM_LOADER", "1") != "0":
+        from .dataset.hbm import HbmLoader, HbmReferCache
+        return HbmLoader(HbmReferCache(dataset, args.size), batch_size=batch_size, sampler=sampler,
+                         shuffle=shuffle and sampler is None)
+    from torch.utils.data import DataLoader
+    return DataLoader(dataset, batch_size=batch_size, num_workers=2, pin_memory=True, sampler=sampler,
+                      shuffle=shuffle and sampler is None)
+
+
+def main(args, tokenizer=None):
+    """Training driver with the reference's flow: build model / data / AdamW(2 groups) / poly LR, optional resume or
+    --eval, then per epoch train_one_epoch -> validate on every test split -> keep the best-mIoU and best-hit checkpoints."""
+    import torch.distributed as dist
+    from .CLIP import clip
+    from .model.model_stage1 import TRIS
+    from .optim import FusedAdamW
+    from .parallel import DataParallel, GradReducer, convert_sync_batchnorm, stage1_segments
+    from .utils.util import load_checkpoint, load_pretrained_checkpoint, save_checkpoint
+    from .validate import validate
+    if args.distributed:
+        if not dist.is_initialized():
+            dist.init_process_group("nccl")
+        local_rank = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+        torch.cuda.set_device(local_rank)
+    else:
+        local_rank = 0
+    log = _logger(args, local_rank)
+    net = TRIS(args).cuda(local_rank)
+    param_groups = net.trainable_parameters()
+    if args.distributed:
+        convert_sync_batchnorm(net)
+    model = DataParallel(net)
+    log.info(f"number of params: {sum(p.numel() for p in net.parameters() if p.requires_grad) / 1e6: .2f}M")
+
+    train_set = build_dataset(args, "train", train=True, eval_mode=args.eval, tokenizer=tokenizer)
+    val_sets = [build_dataset(args, sp, train=False, eval_mode=True, tokenizer=tokenizer)
+                for sp in args.test_split.split(",")]
+    val_loaders = [build_loader(args, v, 1, False, args.distributed) for v in val_sets]
+
+    optimizer = FusedAdamW([
+        {"params": param_groups[0], "lr": args.lr * args.lr_multi, "weight_decay": args.weight_decay},
+        {"params": param_groups[1], "lr": args.lr, "weight_decay": args.weight_decay},
+    ], lr=args.lr, weight_decay=args.weight_decay)
+    reducer = None
+    if args.distributed:
+        reducer = GradReducer([a.g for a in optimizer.arenas])
+        reducer.set_segments(stage1_segments(net, optimizer))
+        net.backbone.visual.grad_reducer = reducer
+
+    def evaluate():
+        res = [validate(args, vl, model, local_rank, logger=log) for vl in val_loaders]
+        return res   # [(oIoU, mIoU, hit)] per split
+
+    if args.resume and args.eval:
+        if args.pretrain is not None:
+            load_checkpoint(args, net, logger=log)
+        t0 = time.time()
+        res = evaluate()
+        names = ("val", "testA", "testB")
+        log.info(", ".join(f"{names[min(i, 2)]}: {float(r[1]):.4f}" for i, r in enumerate(res)))
+        log.info(f"Testing time:  {datetime.timedelta(seconds=int(time.time() - t0))}")
+        return res
+
+    train_loader = build_loader(args, train_set, args.batch_size, True, args.distributed)
+    steps_total = max(len(train_loader) * args.epoch, 1)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda x: (1 - x / steps_total) ** 0.9)
+    if args.resume and args.pretrain is not None:
+        load_checkpoint(args, net, optimizer, scheduler, log)
+
+    log.info("Start training")
+    clip_model, _ = clip.load("ViT-B-32", device=f"cuda:{local_rank}", jit=False, txt_length=args.max_query_len)
+    freeze_aux(clip_model)
+    best = {"val_acc": -1, "val_hit": -1, "epoch": -1, "path": "", "hit": -1, "hit_path": "", "testA": -1, "testB": -1}
+    iteration, train_time, start = 0, 0.0, time.time()
+    for epoch in range(args.start_epoch, args.epoch):
+        t0 = time.time()
+        if args.distributed and getattr(train_loader, "sampler", None) is not None:
+            train_loader.sampler.set_epoch(epoch)
+        iteration = train_one_epoch(train_loader, model, optimizer, epoch, local_rank, args, iteration, clip_model,
+                                    lr_scheduler=scheduler, reducer=reducer, logger=log)
+        torch.cuda.synchronize()
+        train_time += time.time() - t0
+        res = evaluate()
+        oIoU, val_acc, hit = res[0]
+        if float(val_acc) > best["val_acc"] and local_rank == 0:
+            if os.path.exists(best["path"]):
+                os.remove(best["path"])
+            best.update(path=save_checkpoint(epoch, net, optimizer, scheduler, log, args,
+                                             f"ckpt_320_epoch_{epoch}_best.pth"),
+                        val_acc=float(val_acc), val_hit=hit, epoch=epoch,
+                        testA=float(res[1][1]) if len(res) > 1 else 0, testB=float(res[2][1]) if len(res) > 2 else 0)
+        if hit > best["hit"] and local_rank == 0:
+            if os.path.exists(best["hit_path"]):
+                os.remove(best["hit_path"])
+            best.update(hit_path=save_checkpoint(epoch, net, optimizer, scheduler, log, args,
+                                                 f"ckpt_320_epoch_{epoch}_hit.pth"), hit=hit)
+        log.info(str(best))
+    if best["path"] and local_rank == 0:
+        load_pretrained_checkpoint(best["path"], net)
+    log.info(f"Training time {train_time:.1f}s; training + testing "
+             f"{datetime.timedelta(seconds=int(time.time() - start))}")
+    return best
+
+
+if __name__ == "__main__":
+    from .args import get_parser
+    _a = get_parser().parse_args()
+    setup_seed(1234)
+    main(_a)

@@ -23,6 +23,11 @@ from . import ops
 from .utils.util import AverageMeter
 
 
+def _host(x):
+    """batch-dict field -> numpy (DataLoader gives CPU tensors / arrays, the HBM loader device tensors)"""
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
 def _graphed(net, img, L, cache):
     """hipGraph replay of the two halves of the eval forward, one capture per input shape (TRIS_HIPGRAPH=0 disables)."""
     if os.environ.get("TRIS_HIPGRAPH", "1") == "0":
@@ -69,12 +74,12 @@ def validate(args, data_loader, model, local_rank=0, visualize=False, logger=Non
     graphs = {}
     end = time.time()
     for idx, (samples, targets) in enumerate(data_loader):
-        img_id = int(np.asarray(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
+        img_id = int(_host(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
         word_ids = samples["word_ids"].squeeze(1).cuda(local_rank, non_blocking=True)      # [1, L, S]
         img = samples["img"].cuda(local_rank, non_blocking=True)                           # [1, 3, H, W]
         target = targets["target"].cuda(local_rank, non_blocking=True)
         tgt = (target.reshape(target.shape[-2:]) != 0).to(torch.uint8)
-        bbox = np.asarray(targets["boxes"]).reshape(-1, 4) if "boxes" in targets else np.zeros((0, 4))
+        bbox = _host(targets["boxes"]).reshape(-1, 4) if "boxes" in targets else np.zeros((0, 4))
         gr = _graphed(net, img, word_ids.shape[1], graphs)
         if gr is not None:
             gr.visual(img)                                                                 # once per image (hipGraph)
@@ -150,7 +155,7 @@ def validate_same_sentence(args, data_loader, model, local_rank=0, visualize=Fal
     n_sent = hit_acc = 0
     cam_out_name = []
     for idx, (samples, targets) in enumerate(data_loader):
-        img_id = int(np.asarray(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
+        img_id = int(_host(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
         word_ids = samples["word_ids"].squeeze(1).cuda(local_rank, non_blocking=True)      # [1, L, S]
         img = samples["img"].cuda(local_rank, non_blocking=True)
         target = targets["target"].cuda(local_rank, non_blocking=True)
