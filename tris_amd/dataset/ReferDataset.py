@@ -61,17 +61,23 @@ class ReferDataset(data.Dataset):
         img_id = self.refer.getImgIds(ref_id)
         return ref_id, img_id[0], self.refer.Imgs[img_id[0]]
 
-    def load_pil(self, index):
-        """-> (RGB PIL image, 'P' PIL mask of the ref's pixels covered by exactly one polygon, bbox x1y1x2y2)"""
-        ref_id, _, rec = self.image_record(index)
-        img = Image.open(os.path.join(self.refer.IMAGE_DIR, rec["file_name"])).convert("RGB")
-        ref = self.refer.loadRefs(ref_id)[0]
+    def load_image(self, index):
+        _, _, rec = self.image_record(index)
+        return Image.open(os.path.join(self.refer.IMAGE_DIR, rec["file_name"])).convert("RGB")
+
+    def load_mask(self, index):
+        """-> ('P' PIL mask of the ref's pixels covered by exactly one polygon, bbox x1y1x2y2)"""
+        ref = self.refer.loadRefs(self.ref_ids[index])[0]
         bbox = np.array(self.refer.Anns[ref["ann_id"]]["bbox"], dtype=int)
         bbox[2], bbox[3] = bbox[0] + bbox[2], bbox[1] + bbox[3]
         ref_mask = np.array(self.refer.getMask(ref)["mask"])
         annot = np.zeros(ref_mask.shape)
         annot[ref_mask == 1] = 1
-        return img, Image.fromarray(annot.astype(np.uint8), mode="P"), bbox
+        return Image.fromarray(annot.astype(np.uint8), mode="P"), bbox
+
+    def load_pil(self, index):
+        """-> (RGB PIL image, mask, bbox)"""
+        return (self.load_image(index),) + self.load_mask(index)
 
     # ---- text side (all the randomness of a sample, in the reference's call order) ---------------------------------
     def negative_pool(self, index):

@@ -17,6 +17,8 @@ HBM: the whole dataset, decoded and resized ONCE to the network resolution, is a
 Batches carry the reference's keys, shapes and dtypes (what default_collate makes of ReferDataset samples), so
 train_one_epoch / validate take either loader.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -42,28 +44,36 @@ class HbmReferCache:
         self.targets = torch.empty(n, S, S, dtype=torch.uint8, device=dev) if train else None
         self.eval_targets = []            # evaluation: masks at their original sizes
         boxes, paths, sizes, self.files = [], [], [], []
-        done = set()
+        # decode (once per image) and mask rasterisation (once per ref) on a few host threads -- Pillow releases the
+        # GIL while decoding --, uploads and the resize kernels in order on this thread
+        from concurrent.futures import ThreadPoolExecutor
+        first_ref = {}
         for i in range(n):
-            img, annot, bbox = ds.load_pil(i)
-            s = int(self.slot_of[i])
-            if s not in done:
-                done.add(s)
+            first_ref.setdefault(int(self.slot_of[i]), i)
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+            for s, img in zip(first_ref, pool.map(ds.load_image, first_ref.values())):
                 ops.resample_u8(torch.from_numpy(np.asarray(img).copy()).to(dev), S, S, out=self.images[s])
-            m = torch.from_numpy(np.asarray(annot).copy()).to(dev)
-            if train:
-                ops.resize_nearest_u8(m, S, S, out=self.targets[i])
-            else:
-                self.eval_targets.append(m)
-            w, h = annot.size
-            fname = recs[i][2]["file_name"]
-            boxes.append(bbox)
-            sizes.append((h, w))
-            paths.append(int(fname.split(".")[0].split("_")[-1]))
-            self.files.append(fname)
+            for i, (annot, bbox) in enumerate(pool.map(ds.load_mask, range(n))):
+                m = torch.from_numpy(np.asarray(annot).copy()).to(dev)
+                if train:
+                    ops.resize_nearest_u8(m, S, S, out=self.targets[i])
+                else:
+                    self.eval_targets.append(m)
+                w, h = annot.size
+                fname = recs[i][2]["file_name"]
+                boxes.append(bbox)
+                sizes.append((h, w))
+                paths.append(int(fname.split(".")[0].split("_")[-1]))
+                self.files.append(fname)
         self.boxes = torch.from_numpy(np.stack(boxes).astype(np.int64)).to(dev)
         self.orig_size = torch.from_numpy(np.array(sizes, np.int64)).to(dev)
         self.img_path = torch.tensor(paths, dtype=torch.int64, device=dev).view(-1, 1)
+        self._index_tokens(n)
+        torch.cuda.synchronize(dev)
+
+    def _index_tokens(self, n):
         # token rows of every sentence, ref-major
+        ds, dev = self.dataset, self.device
         self.sent_base = np.zeros(n + 1, np.int64)
         for i in range(n):
             self.sent_base[i + 1] = self.sent_base[i] + len(ds.input_ids[i])
@@ -72,7 +82,6 @@ class HbmReferCache:
         assert rows.shape[1] * rows.element_size() % 4 == 0
         self.tokens = rows.contiguous().to(dev)
         self.token_masks = mrows.contiguous().to(dev)
-        torch.cuda.synchronize(dev)
 
     def nbytes(self):
         t = self.images.numel() + self.tokens.numel() * self.tokens.element_size()
