@@ -37,6 +37,10 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
  * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -> fp32-class accuracy (measured: error vs fp64 <= the f32-MFMA
  * path's) at up to 2.6x the f32-MFMA peak.  Default: 1. */
 int tris_set_gemm_mode(int mode);
+/* (tile, split-K) selection of the dense-product kernels: 1 (default; env TRIS_AUTOTUNE) = every admissible pair is timed
+ * once per product shape on first use and the fastest is cached for the process; 0 = the static cycle model (deterministic
+ * run-to-run rounding). */
+int tris_set_autotune(int on);
 int tris_get_gemm_mode(void);
 
 /* 3x3 convolution, pad 1, implicit GEMM (no im2col buffer).  CLIP/clip/model.py:21 (Bottleneck.conv2), :212-229 (stem).

@@ -68,5 +68,47 @@ def main():
     print("g9:", {k: v.shape for k, v in g.items()}, os.path.getsize(os.path.join(OUT, "g9_dataset.npz")))
 
 
+def pixel_attention_case(seed, N, Ci, Ct, H, W, T):
+    """deterministic inputs + weights for the PixelAttention fixture / tests (weights 0.25*randn so the softmax is not flat)"""
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"Wk.weight": (Ci, Ct, 1), "Wk.bias": (Ci,), "Wv.weight": (Ci, Ct, 1), "Wv.bias": (Ci,)}
+    for n in ("Wq", "Wm", "Ww", "Wo"):
+        shapes[n + ".weight"] = (Ci, Ci, 1, 1)
+        shapes[n + ".bias"] = (Ci,)
+    for n in ("ins_q", "ins_w"):
+        shapes[n + ".weight"] = (Ci,)
+        shapes[n + ".bias"] = (Ci,)
+    sd = {}
+    for k in sorted(shapes):
+        v = torch.randn(shapes[k], generator=g)
+        sd[k] = (1.0 + 0.1 * v) if k.startswith("ins_") and k.endswith("weight") else 0.25 * v
+    vis = torch.randn(N, Ci, H, W, generator=g)
+    lan = torch.randn(N, Ct, T, generator=g)
+    return sd, vis, lan
+
+
+def main_pixel_attention():
+    """g10: the REAL reference PixelAttention (model/attn.py:9-65) forward + backward on a small case"""
+    from oracle import ref_shim
+    ref_shim.install()
+    from model.attn import PixelAttention
+    N, Ci, Ct, H, W, T = 2, 64, 32, 6, 5, 7
+    sd, vis, lan = pixel_attention_case(3, N, Ci, Ct, H, W, T)
+    m = PixelAttention(Ci, Ct)
+    m.load_state_dict(sd)
+    vis.requires_grad_(True)
+    lan.requires_grad_(True)
+    out = m(vis, lan)
+    gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
+    out.backward(gout)
+    g = {"dims": np.array([N, Ci, Ct, H, W, T]), "out": out.detach().numpy(), "gout": gout.numpy(),
+         "dvis": vis.grad.numpy(), "dlan": lan.grad.numpy()}
+    for k, p in m.named_parameters():
+        g["d_" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g10_pixel_attention.npz"), **g)
+    print("g10:", {k: v.shape for k, v in g.items()})
+
+
 if __name__ == "__main__":
     main()
+    main_pixel_attention()

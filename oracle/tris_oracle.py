@@ -181,6 +181,23 @@ def bilateral_prompt(sd, p, vis, lan):
     return new_vis, new_lan
 
 
+def pixel_attention(sd, p, vis, lan):
+    """PixelAttention.forward (Stage-2 pixel x token cross attention) -- model/attn.py:37-65.
+    vis [N,Ci,H,W], lan [N,Ct,T] -> [N,Ci,H,W]."""
+    N, Ci, H, W = vis.shape
+    Lk = F.conv1d(lan, sd[p + ".Wk.weight"], sd[p + ".Wk.bias"])
+    Lv = F.conv1d(lan, sd[p + ".Wv.weight"], sd[p + ".Wv.bias"])
+    Vq = F.instance_norm(F.conv2d(vis, sd[p + ".Wq.weight"], sd[p + ".Wq.bias"]), weight=sd[p + ".ins_q.weight"],
+                         bias=sd[p + ".ins_q.bias"], eps=1e-5)
+    Vq = Vq.view(N, Ci, H * W).permute(0, 2, 1)
+    attn = torch.softmax(Vq.matmul(Lk) / math.sqrt(Ci), dim=2)
+    G = attn.matmul(Lv.permute(0, 2, 1)).permute(0, 2, 1).reshape(N, Ci, H, W)
+    Gi = F.instance_norm(F.conv2d(G, sd[p + ".Ww.weight"], sd[p + ".Ww.bias"]), weight=sd[p + ".ins_w.weight"],
+                         bias=sd[p + ".ins_w.bias"], eps=1e-5)
+    Vo = F.relu(F.conv2d(vis, sd[p + ".Wm.weight"], sd[p + ".Wm.bias"]))
+    return F.relu(F.conv2d(Vo * Gi, sd[p + ".Wo.weight"], sd[p + ".Wo.bias"]))
+
+
 def tris_forward(sd, img, word_id, train, focal_p=3.0, focal_c=0.01, attn_multi=0.1,
                  with_attnpool=False, return_score=False):
     """TRIS.forward -- model/model_stage1.py:54-119 (focal_loss :122-123, Upsample model/utils.py:5-10)."""

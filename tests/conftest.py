@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Deterministic rounding for the parity suite: the GEMM autotuner picks (tile, split-K) by timing, which changes the
+# summation order from run to run; tests that sit on the fp32 noise floor (ReLU-kink flips) need a fixed order.  The
+# autotuned configuration is exercised explicitly by tests/test_gpu_ops.py::test_gemm_autotune_*.
+os.environ.setdefault("TRIS_AUTOTUNE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

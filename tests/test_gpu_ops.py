@@ -419,3 +419,36 @@ def test_fused_bn_statistics_in_conv_epilogue(ops, kind, shape):
     close(y1, y0, 1e-5, name="bn out")
     close(rm1, rm0, 1e-6, name="running_mean")
     close(rv1, rv0, 1e-5, name="running_var")
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB", [(2400, 768, 3072, False, True), (960, 512, 512, False, True),
+                                         (1024, 256, 19200, True, False), (19200, 1024, 256, False, True),
+                                         (300, 100, 4096, False, False)])
+def test_gemm_autotune_every_candidate_and_the_cached_choice(ops, M, N, K, tA, tB):
+    """The first-encounter autotuner launches every admissible (tile, split-K) pair on the caller's buffers: after the
+    tuning call AND on the cached path the result must be the product; each tile shape is also forced individually."""
+    import os
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    ref = ((A.t() if tA else A).double() @ (B.t() if tB else B).double()).float()
+    dA, dB = A.cuda(), B.cuda()
+
+    def run():
+        C = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(dA, dB, C, M, N, K, dA.shape[1], dB.shape[1], N, tA, tB)
+        return C.cpu()
+    scale = float(ref.abs().max())
+    ops.set_autotune(True)
+    try:
+        first, cached = run(), run()
+    finally:
+        ops.set_autotune(False)
+    assert float((first - ref).abs().max()) <= 2e-4 * scale and float((cached - ref).abs().max()) <= 2e-4 * scale
+    for tile in ("128x128", "128x64", "64x64"):
+        os.environ["TRIS_FORCE_TILE"] = tile
+        try:
+            out = run()
+        finally:
+            del os.environ["TRIS_FORCE_TILE"]
+        assert float((out - ref).abs().max()) <= 2e-4 * scale, tile

@@ -130,3 +130,21 @@ def test_g7_eval(sd, batch, golden):
             oI, oU, m, cam = O.eval_postprocess(o, tgt)
             assert (oI, oU) == (I, U)
             assert np.abs(cam[::8, ::8].numpy() - g[f"case{n}_cam_ds8"]).max() < TOL
+
+
+def test_g10_pixel_attention_oracle_matches_reference(golden):
+    """Stage-2 PixelAttention: oracle restatement vs the real reference module, forward + all gradients"""
+    from oracle.gen_golden_data import pixel_attention_case
+    g = golden("g10_pixel_attention.npz")
+    N, Ci, Ct, H, W, T = (int(v) for v in g["dims"])
+    sd, vis, lan = pixel_attention_case(3, N, Ci, Ct, H, W, T)
+    sd = {"pa." + k: v.requires_grad_(True) for k, v in sd.items()}
+    vis.requires_grad_(True)
+    lan.requires_grad_(True)
+    out = O.pixel_attention(sd, "pa", vis, lan)
+    assert torch.allclose(out, torch.from_numpy(g["out"]), atol=1e-5, rtol=1e-5)
+    out.backward(torch.from_numpy(g["gout"]))
+    assert torch.allclose(vis.grad, torch.from_numpy(g["dvis"]), atol=1e-5, rtol=1e-4)
+    assert torch.allclose(lan.grad, torch.from_numpy(g["dlan"]), atol=1e-5, rtol=1e-4)
+    for k, v in sd.items():
+        assert torch.allclose(v.grad, torch.from_numpy(g["d_" + k[3:]]), atol=1e-5, rtol=1e-4), k

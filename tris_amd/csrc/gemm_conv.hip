@@ -435,11 +435,8 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
     }
   }
   {  // developer knob: TRIS_FORCE_TILE=128x128|128x64|64x64 overrides the tile choice (tools/x3_probe.py)
-    static int forced = -1;
-    if (forced < 0) {
-      const char* e = getenv("TRIS_FORCE_TILE");
-      forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : 0);
-    }
+    const char* e = getenv("TRIS_FORCE_TILE");  // read per call: tests switch it at run time
+    const int forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : 0);
     if (forced == 1 && p.N > 64) { bm = 128; bn = 128; }
     if (forced == 2) { bm = 128; bn = 64; }
     if (forced == 3) { bm = 64; bn = 64; }
@@ -514,10 +511,10 @@ struct TuneKey {
 static std::map<TuneKey, Cfg> g_tuned;
 static std::mutex g_tune_mu;
 
+static int g_autotune = -1;  // -1: read TRIS_AUTOTUNE on first use
 static bool autotune_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("TRIS_AUTOTUNE"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on == 1;
+  if (g_autotune < 0) { const char* e = getenv("TRIS_AUTOTUNE"); g_autotune = (e && e[0] == '0') ? 0 : 1; }
+  return g_autotune == 1;
 }
 
 template <int AK, int BKIND>
@@ -696,4 +693,9 @@ extern "C" int tris_set_gemm_mode(int mode) {
   g_gemm_mode = mode;
   return 0;
 }
+extern "C" int tris_set_autotune(int on) {
+  g_autotune = on ? 1 : 0;
+  return 0;
+}
+
 extern "C" int tris_get_gemm_mode(void) { return g_gemm_mode; }

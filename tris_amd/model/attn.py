@@ -1,4 +1,7 @@
-"""`bilateral_prompt` -- the image<->text cross-modal attention of TRIS Stage-1 (reference model/attn.py:68-136),
+"""Cross-modal attention modules of TRIS on MI355X kernels: `bilateral_prompt` (Stage-1) and `PixelAttention`
+(Stage-2's pixel x token attention, reference model/attn.py:9-65).
+
+`bilateral_prompt` -- the image<->text cross-modal attention of TRIS Stage-1 (reference model/attn.py:68-136),
 rebuilt on MI355X kernels.  Same constructor, parameter names (`v_proj{1,2,3}.{0,1}`, `t_proj{1,2,3}.0`,
 `v_output.{0,1}`, `t_output.0`) and call signature:
 
@@ -72,3 +75,57 @@ class bilateral_prompt(nn.Module):
             raise NotImplementedError("per-image sentence sets are not on the Stage-1 path (model_stage1.py:66 repeats one set)")
         nv, nl = self.forward_cl(vis.permute(0, 2, 3, 1).reshape(B, H * W, C), lan_t[0].contiguous())
         return nv.reshape(B, H, W, C).permute(0, 3, 1, 2), nl
+
+
+class Conv1d(nn.Module):
+    """kernel-size-1 Conv1d (a per-token Linear) keeping the reference's [Cout, Cin, 1] weight shape"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        w = torch.empty(cout, cin, 1)
+        nn.init.kaiming_uniform_(w, a=5 ** 0.5)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+    def forward(self, x, act=0):  # x [..., Cin] token-major
+        return ops.linear(x, self.weight, self.bias, act=act)
+
+
+class PixelAttention(nn.Module):
+    """Stage-2 pixel x token attention (model/attn.py:9-65): every pixel attends over the T word features of its own
+    sentence, the attended language feature gates the visual feature.  Same constructor, parameter names
+    (Wk, Wv, Wq, Wm, Ww, Wo, ins_q, ins_w) and call signature:
+
+        forward(vis_feat [N,Ci,H,W], lan_feat [N,Ct,T]) -> [N,Ci,H,W]
+
+    Built from the Stage-1 kernel family: the six 1x1 projections are MFMA GEMMs with fused bias / ReLU, the two
+    [P,T] / [T,Ci] products run as batched GEMMs, softmax / InstanceNorm / gating are the Stage-1 kernels."""
+
+    def __init__(self, visual_channel, language_channel):
+        super().__init__()
+        self.Ci, self.Ct = visual_channel, language_channel
+        self.Wk = Conv1d(self.Ct, self.Ci)
+        self.Wv = Conv1d(self.Ct, self.Ci)
+        self.Wq = Conv2d(self.Ci, self.Ci, 1, bias=True)
+        self.Wm = Conv2d(self.Ci, self.Ci, 1, bias=True)
+        self.Ww = Conv2d(self.Ci, self.Ci, 1, bias=True)
+        self.Wo = Conv2d(self.Ci, self.Ci, 1, bias=True)
+        self.ins_q = InstanceNorm2d(self.Ci)
+        self.ins_w = InstanceNorm2d(self.Ci)
+
+    def forward_cl(self, x, lan):
+        """x [N,P,Ci] channels-last pixels, lan [N,T,Ct] token-major words -> [N,P,Ci]"""
+        Lk, Lv = self.Wk(lan), self.Wv(lan)                                             # [N,T,Ci]
+        Vq = ops.instance_norm(ops.linear(x, self.Wq.weight, self.Wq.bias), self.ins_q.weight, self.ins_q.bias, False,
+                               self.ins_q.eps)
+        attn = ops.softmax(ops.bmm(Vq, Lk, tB=True), 1.0 / math.sqrt(self.Ci))          # [N,P,T] over the words
+        G = ops.bmm(attn, Lv, tB=False)                                                 # [N,P,Ci]
+        Gi = ops.instance_norm(ops.linear(G, self.Ww.weight, self.Ww.bias), self.ins_w.weight, self.ins_w.bias, False,
+                               self.ins_w.eps)
+        Vo = ops.linear(x, self.Wm.weight, self.Wm.bias, act=1)
+        return ops.linear(ops.mul(Vo, Gi), self.Wo.weight, self.Wo.bias, act=1)
+
+    def forward(self, vis_feat, lan_feat):
+        N, Ci, H, W = vis_feat.shape
+        out = self.forward_cl(vis_feat.permute(0, 2, 3, 1).reshape(N, H * W, Ci), lan_feat.transpose(1, 2).contiguous())
+        return out.reshape(N, H, W, Ci).permute(0, 3, 1, 2)

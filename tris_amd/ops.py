@@ -72,6 +72,11 @@ def _init_mode_from_env():
         set_gemm_mode(m)
 
 
+def set_autotune(on):
+    """per-shape (tile, split-K) autotuning of the GEMM core on/off (include/tris_hip.h: tris_set_autotune)"""
+    call("tris_set_autotune", int(bool(on)))
+
+
 def get_gemm_mode():
     return ("f32", "x3")[_lib.load().tris_get_gemm_mode()]
 
@@ -894,6 +899,27 @@ class AxpyFn(torch.autograd.Function):
 
 def axpy(a, b, s):
     return AxpyFn.apply(a, b, s)
+
+
+class MulFn(torch.autograd.Function):
+    """a * b (same shape)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ew("TRIS_EW_MUL", a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ew("TRIS_EW_MUL", dy, b) if ctx.needs_input_grad[0] else None,
+                ew("TRIS_EW_MUL", dy, a) if ctx.needs_input_grad[1] else None)
+
+
+def mul(a, b):
+    return MulFn.apply(a, b)
 
 
 class ScoreHeadsFn(torch.autograd.Function):
