@@ -193,7 +193,9 @@ def main():
         xms = sum(r[2] for r in xa)
         roof_x = {"bound": "hbm", "achieved": round(xbytes / (xms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(xbytes / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                  "kernel": "xattn_scores_kernel + xattn_out_kernel (fused bilateral cross attention, forward, both launches)",
+                  "kernel": ("xattn_scores_x3_kernel + xattn_out_x3_kernel" if mode == "x3" else
+                             "xattn_scores_kernel + xattn_colsoftmax_kernel + xattn_out_kernel") +
+                            " (fused bilateral cross attention, forward, all launches, HIP events around the call)",
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
 

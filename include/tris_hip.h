@@ -137,12 +137,14 @@ int tris_l2norm_bwd_f32(const float* dY, const float* Y, const float* inv_norm, 
 /* softmax(scale * x) over rows of length n  (model/attn.py:119,122) */
 int tris_softmax_fwd_f32(const float* X, float* Y, long rows, int n, float scale, void* stream);
 int tris_softmax_bwd_f32(const float* dY, const float* Y, float* dX, long rows, int n, float scale, void* stream);
-/* Fused image<->text cross attention of bilateral_prompt (model/attn.py:117-128), all images in two launches.
+/* Fused image<->text cross attention of bilateral_prompt (model/attn.py:117-128), all images in two (x3 arithmetic) or
+ * three (f32 arithmetic) launches.
  * Qv,Kv,Vv [B,P,C] (pixels, channels-last), Qt,Kt,Vt [N,C] (sentences, one set shared by every image -- the reference
  * repeats it, model_stage1.py:66), scale = 1/sqrt(C); N <= 64, C % 64 == 0.
  *   new_vis[b] = softmax_n(Qv[b].Kt^T*scale).Vt      [B,P,C]
  *   new_lan[b] = softmax_p(Qt.Kv[b]^T*scale).Vv[b]   [B,N,C]
- * probs [B,3,P,N] (scratch + saved for backward): plane 0 = Av, plane 1 = Kv.Qt^T logits, plane 2 = AtT (pixel-major). */
+ * probs [B,4,P,N] (scratch + saved for backward): plane 0 = Av, plane 1 = Kv.Qt^T logits, plane 2 = AtT (pixel-major),
+ * plane 3 = Qv.Kt^T logits (x3 path only). */
 int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                        const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
                        void* stream);

@@ -1,0 +1,55 @@
+// split-bf16 ("x3") helpers shared by the GEMM core (gemm_fast.h) and the fused cross attention (xattn.hip).
+// An fp32 value is EXACTLY the sum of three bf16 pieces (round-to-nearest residual splitting: 8 + 8 + 8 significand bits).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, h);
+}
+struct Split8 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Split8 split8(const float4 u, const float4 w) {
+  const float x[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float x0 = x[2 * t], x1 = x[2 * t + 1];
+    h[t] = pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h[t] << 16), r1 = x1 - __builtin_bit_cast(float, h[t] & 0xffff0000u);
+    m[t] = pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m[t] << 16), s1 = r1 - __builtin_bit_cast(float, m[t] & 0xffff0000u);
+    l[t] = pk_bf16(s0, s1);
+  }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  Split8 o;
+  o.hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+  o.mid = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+  o.lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+  return o;
+}
+
+struct Split4 { uint2 hi, mid, lo; };
+__device__ __forceinline__ Split4 split4(const float4 u) {
+  Split4 o;
+#ifdef TRIS_EXP_NOSPLIT
+  o.hi.x = __builtin_bit_cast(unsigned, u.x); o.hi.y = __builtin_bit_cast(unsigned, u.y);
+  o.mid.x = __builtin_bit_cast(unsigned, u.z); o.mid.y = __builtin_bit_cast(unsigned, u.w);
+  o.lo = o.hi;
+  return o;
+#endif
+  o.hi.x = pk_bf16(u.x, u.y);
+  o.hi.y = pk_bf16(u.z, u.w);
+  const float r0 = u.x - __builtin_bit_cast(float, o.hi.x << 16), r1 = u.y - __builtin_bit_cast(float, o.hi.x & 0xffff0000u);
+  const float r2 = u.z - __builtin_bit_cast(float, o.hi.y << 16), r3 = u.w - __builtin_bit_cast(float, o.hi.y & 0xffff0000u);
+  o.mid.x = pk_bf16(r0, r1);
+  o.mid.y = pk_bf16(r2, r3);
+  o.lo.x = pk_bf16(r0 - __builtin_bit_cast(float, o.mid.x << 16), r1 - __builtin_bit_cast(float, o.mid.x & 0xffff0000u));
+  o.lo.y = pk_bf16(r2 - __builtin_bit_cast(float, o.mid.y << 16), r3 - __builtin_bit_cast(float, o.mid.y & 0xffff0000u));
+  return o;
+}
+

@@ -1,5 +1,6 @@
 // Fused image<->text cross attention of `bilateral_prompt` (reference model/attn.py:117-128) for ALL images of the batch
-// in three launches (gfx950).  This is the kernel pair the north star prices against the HBM roofline:
+// in two (split-bf16 arithmetic, default) or three (f32 arithmetic) launches (gfx950).  This is the kernel pair the north
+// star prices against the HBM roofline:
 // algorithmic traffic per image = Qv,Kv,Vv reads (3 x P x C x 4 B) + new_vis, new_lan writes = 1.84 MB at P=100, N=48, C=1024.
 //
 //   pixels   Qv,Kv,Vv [B,P,C]   (v_proj1..3 outputs, channels-last)
@@ -17,10 +18,12 @@
 //   the f32 MFMA.  ~65 KB LDS -> 2 workgroups per CU, 32*B workgroups >> 256 CUs.
 #include "common.h"
 #include "tris_hip.h"
+#include "x3_split.h"
 
 namespace {
 
 constexpr int MAXNF = 4;  // N <= 64 sentences (16 per MFMA fragment)
+constexpr int NPL = 4;    // planes of the probability scratch: 0 Av, 1 Kv.Qt^T logits, 2 AtT, 3 Qv.Kt^T logits (x3 path)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void xattn_scores_kernel(const float* __restri
     for (int r = 0; r < 4; ++r) part[wave][kq * 4 + r][f * 16 + li] = acc[f][r];
   __syncthreads();
   // 4 waves x 4 rows each: sum the partials, then (Qv half) softmax over the N sentences of a row
-  float* out = probs + (((long)b * 3 + which) * P) * N;  // plane 0: Av, plane 1: Kv.Qt^T logits, plane 2: AtT
+  float* out = probs + (((long)b * NPL + which) * P) * N;  // plane 0: Av, plane 1: Kv.Qt^T logits, plane 2: AtT
   for (int r = wave * 4; r < wave * 4 + 4; ++r) {
     const int p = tile * 16 + r;
     float v = -INFINITY;
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void xattn_scores_kernel(const float* __restri
 __global__ __launch_bounds__(256) void xattn_colsoftmax_kernel(float* __restrict__ probs, int P, int N) {
   __shared__ float cm[128];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* lg = probs + ((long)b * 3 + 1) * P * N;
-  float* out = probs + ((long)b * 3 + 2) * P * N;
+  const float* lg = probs + ((long)b * NPL + 1) * P * N;
+  float* out = probs + ((long)b * NPL + 2) * P * N;
   const int n = tid >> 2, q = tid & 3;
   float m = -INFINITY;
   if (n < N) for (int p = q; p < P; p += 4) m = fmaxf(m, lg[(long)p * N + n]);
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void xattn_out_kernel(const float* __restrict_
   float* vv = vt + NF * 16 * CP;  // Vv tile [PR][CP]     (rows >= P zero)
   const int c0 = blockIdx.x * CT, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* pb = probs + (long)b * 3 * P * N;
+  float* pb = probs + (long)b * NPL * P * N;
   // Fills are written as "issue U independent loads, then store" so the global latency is paid once per batch.
   {
     const int total = P * N;  // compact [P][N] planes in HBM -> padded [PR][NP] LDS rows; pads pre-set below
@@ -266,6 +269,386 @@ int launch_fwd(const float* Qv, const float* Kv, const float* Vv, const float* Q
   return 0;
 }
 
+// ---- split-bf16 ("x3") path: two launches, HBM-streaming --------------------------------------------------------------------
+// The f32-input MFMA makes this pair MFMA-co-bound (21 FLOP/B sits on the f32 ridge).  With every fp32 operand split into
+// three exact bf16 pieces (x3_split.h) the six significant piece products run on v_mfma_f32_16x16x32_bf16 at 2.5x the rate
+// and the kernels become HBM streams:
+//   scores (xattn_scores_x3_kernel): one wave = 16 pixel rows x a quarter of C.  The rows go HBM -> registers (32 B per
+//     lane per step, a full 128-B line per row), the sentence tile comes from L2 the same way, both are split in
+//     registers; no LDS, no barrier in the loop; the 4 waves' partial 16 x N tiles meet in LDS once.  Pixel rows are
+//     taken from the flat [B*P, C] matrix (the sentence set is shared), so there is no per-image padding.
+//   outputs (xattn_out_x3_kernel): one workgroup per (64-channel tile, image).  Both logit planes of the image -> LDS,
+//     row softmax (over sentences) and column softmax (over pixels) in place, then new_vis = Av.Vt and new_lan = At.Vv
+//     on the MFMA with the probabilities read from LDS and the Vt / Vv fragments loaded straight from global in MFMA
+//     operand order (issued before the softmax so their latency hides behind it).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4v mfma6(const Split8& a, const Split8& b, f32x4v c) {  // smallest terms first
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.mid, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.mid, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+  return c;
+}
+
+// Wave-local LDS transposition: global loads are issued row-contiguous (8 rows x 128 B per instruction, so every 16-lane
+// group reads whole lines -- fragment-shaped loads cost 4-8x the address/tag work for the same bytes), parked in a
+// per-wave LDS tile [rows][32 + 4 floats] and read back as MFMA fragments (8 consecutive k per lane, two conflict-free
+// ds_read_b128).  Only the owning wave touches its tile: program order + a wave-scope fence, no workgroup barrier.
+constexpr int TLD = 36;
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// grid (ceil(B*P / 32), 2); block 256.  y = 0: Qv.Kt^T -> plane 3, y = 1: Kv.Qt^T -> plane 1 (both scaled logits).
+// Wave w reduces over channels [w*C/4, (w+1)*C/4): its whole share of the pixel rows (16 rows x C/4 floats <= 16 KB) is
+// requested from HBM up front, the sentence tile (L2) is fetched one 32-channel step ahead.  Requires C <= 1024, C % 128 == 0.
+template <int NT, int KS>
+__global__ __launch_bounds__(256) void xattn_scores_x3_kernel(const float* __restrict__ Qv, const float* __restrict__ Kv,
+                                                              const float* __restrict__ Qt, const float* __restrict__ Kt,
+                                                              float* __restrict__ probs, long R, int P, int N, int C,
+                                                              float scale) {
+  // 32 pixel rows per workgroup (two MFMA row tiles share every sentence fragment); wave w reduces over channels
+  // [w*C/4, (w+1)*C/4).  Pixel rows are requested 4 steps (4 x 128 B per row) ahead, the sentence tile (L2) one step.
+  __shared__ __attribute__((aligned(16))) float At[4][32 * TLD];
+  __shared__ __attribute__((aligned(16))) float Bt[4][NT * 16 * TLD];
+  f32x4v(*red)[2 * NT][64] = reinterpret_cast<f32x4v(*)[2 * NT][64]>(&Bt[0][0]);  // [3][2 NT][64], reuses the tiles after the loop
+  static_assert(sizeof(float) * 4 * NT * 16 * TLD >= sizeof(f32x4v) * 3 * 2 * NT * 64, "reduction scratch must fit");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kg = lane >> 4;       // fragment coordinates
+  const int lr = lane >> 3, lc = (lane & 7) * 4;  // loader coordinates: row within an 8-row pass, float offset in the 128-B segment
+  const int m = blockIdx.y;
+  const float* __restrict__ A = m == 0 ? Qv : Kv;
+  const float* __restrict__ T = m == 0 ? Kt : Qt;
+  const long row0 = (long)blockIdx.x * 32;
+  const int kq = C >> 2;  // = 32 * KS (compile-time step count: no control flow around the prefetches, so the waits are exact)
+  const float* ap[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ap[q] = A + min(row0 + q * 8 + lr, R - 1) * C + wave * kq + lc;
+  // Issue order matters: the vector-memory counter retires in order, so what is needed soonest is requested first (step 0's
+  // rows and sentence tile), the deep row prefetch last -- a wait for the sentence tile then leaves the prefetch in flight.
+  float4 a[4][4];  // [step & 3][8-row pass]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[0][q] = ld4(ap[q]);
+  const float* tp[2 * NT];
+#pragma unroll
+  for (int q = 0; q < 2 * NT; ++q) tp[q] = T + (long)min(q * 8 + lr, N - 1) * C + wave * kq + lc;
+  float4 bq[2 * NT];
+#pragma unroll
+  for (int q = 0; q < 2 * NT; ++q) bq[q] = ld4(tp[q]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 1; s < 4; ++s)
+    if (s < KS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[s][q] = ld4(ap[q] + s * 32);
+    }
+  f32x4v acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  float* at = At[wave];
+  float* bt = Bt[wave];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < KS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(at + (q * 8 + lr) * TLD + lc) = a[s & 3][q];
+#pragma unroll
+      for (int q = 0; q < 2 * NT; ++q) *reinterpret_cast<float4*>(bt + (q * 8 + lr) * TLD + lc) = bq[q];
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int q = 0; q < 2 * NT; ++q) bq[q] = ld4(tp[q] + (s + 1) * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the request order (see above)
+      if (s + 4 < KS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[s & 3][q] = ld4(ap[q] + (s + 4) * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence();
+      Split8 sa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        sa[i] = split8(*reinterpret_cast<const float4*>(at + (i * 16 + r) * TLD + kg * 8),
+                       *reinterpret_cast<const float4*>(at + (i * 16 + r) * TLD + kg * 8 + 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float* bs = bt + (j * 16 + r) * TLD + kg * 8;
+        const Split8 sb = split8(*reinterpret_cast<const float4*>(bs), *reinterpret_cast<const float4*>(bs + 4));
+        acc[0][j] = mfma6(sa[0], sb, acc[0][j]);
+        acc[1][j] = mfma6(sa[1], sb, acc[1][j]);
+      }
+      wave_lds_fence();
+    }
+  }
+  __syncthreads();  // every wave is done with its tiles
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) red[wave - 1][i * NT + j][lane] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int plane = m == 0 ? 3 : 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const f32x4v v = acc[i][j] + red[0][i * NT + j][lane] + red[1][i * NT + j][lane] + red[2][i * NT + j][lane];
+        const int n = j * 16 + r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // D[4*kg + t][r]
+          const long row = row0 + i * 16 + 4 * kg + t;
+          if (row < R && n < N) {
+            const long b = row / P;
+            const int p = (int)(row - b * P);
+            probs[((b * NPL + plane) * P + p) * N + n] = v[t] * scale;
+          }
+        }
+      }
+  }
+}
+
+constexpr int XLD = 68;    // row stride (floats) of the Av plane [p][n]: 16-byte aligned, conflict-free b128 fragments
+constexpr int XLT = 132;   // row stride (floats) of the At plane [n][p]
+
+// grid (C / 128, B); block 256 (wave w owns channels c0 + 32w .. +31: two MFMA column tiles share every probability
+// fragment); dynamic LDS (round16(P) * XLD + 64 * XLT) floats
+__global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restrict__ Vv, const float* __restrict__ Vt,
+                                                           float* __restrict__ probs, float* __restrict__ new_vis,
+                                                           float* __restrict__ new_lan, int P, int N, int C) {
+  extern __shared__ __attribute__((aligned(16))) float xlds[];
+  const int PR = (P + 15) / 16 * 16;
+  float* Sa = xlds;             // S1 logits -> Av  [p][n]   (softmax over n)
+  float* St = xlds + PR * XLD;  // S2 logits -> At  [n][p]   (softmax over p)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 128 + wave * 32 + r;  // first of this lane's two channels (the other is c + 16)
+  const int PT = PR / 16, NT = (N + 15) / 16, NK = (N + 31) / 32, PK = (P + 31) / 32;
+
+  // operand fragments straight from global, in MFMA order (8 consecutive k per lane): issued first, consumed last
+  float vv[2][4][8], vt[2][2][8];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = ks * 32 + kg * 8 + i;
+        vv[ct][ks][i] = (ks < PK && p < P) ? Vv[((long)b * P + p) * C + c + ct * 16] : 0.f;
+      }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int n = ks * 32 + kg * 8 + i;
+        vt[ct][ks][i] = (ks < NK && n < N) ? Vt[(long)n * C + c + ct * 16] : 0.f;
+      }
+
+  // both logit planes of the image -> LDS (all requests in flight before the first LDS write)
+  const float* s1 = probs + ((long)b * NPL + 3) * P * N;
+  const float* s2 = probs + ((long)b * NPL + 1) * P * N;
+  const int tot = P * N;
+  if ((N & 3) == 0 && tot <= 8 * 1024) {
+    float4 u[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = (q * 256 + tid) * 4;
+      if (i < tot) { u[q] = ld4(s1 + i); w[q] = ld4(s2 + i); }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = (q * 256 + tid) * 4;
+      if (i < tot) {
+        const int p = i / N, n = i - p * N;
+        *reinterpret_cast<float4*>(Sa + p * XLD + n) = u[q];
+        St[(n + 0) * XLT + p] = w[q].x;
+        St[(n + 1) * XLT + p] = w[q].y;
+        St[(n + 2) * XLT + p] = w[q].z;
+        St[(n + 3) * XLT + p] = w[q].w;
+      }
+    }
+  } else {
+    for (int i = tid; i < tot; i += 256) {
+      const int p = i / N, n = i - p * N;
+      Sa[p * XLD + n] = s1[i];
+      St[n * XLT + p] = s2[i];
+    }
+  }
+  __syncthreads();
+  if (tid < PR) {  // Av: softmax over the sentences of pixel `tid`; k padding (n >= N) and pad rows become exact zeros
+    float* row = Sa + tid * XLD;
+    float4 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const float4*>(row + q * 4);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* e = reinterpret_cast<float*>(&v[q]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (q * 4 + t >= N || tid >= P) e[t] = -INFINITY;
+        mx = fmaxf(mx, e[t]);
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* e = reinterpret_cast<float*>(&v[q]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        e[t] = (q * 4 + t < N && tid < P) ? __expf(e[t] - mx) : 0.f;
+        sum += e[t];
+      }
+    }
+    const float inv = tid < P ? 1.f / sum : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      v[q].x *= inv; v[q].y *= inv; v[q].z *= inv; v[q].w *= inv;
+      *reinterpret_cast<float4*>(row + q * 4) = v[q];
+    }
+  }
+  {  // At: softmax over the pixels of sentence n -- 4 threads per sentence, 32 pixels each (p = q4 + 4 i)
+    const int n = tid >> 2, q4 = tid & 3;
+    float* row = St + n * XLT;
+    float e[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int p = q4 + 4 * i;
+      e[i] = (n < N && p < P) ? row[p] : -INFINITY;
+      mx = fmaxf(mx, e[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int p = q4 + 4 * i;
+      e[i] = (n < N && p < P) ? __expf(e[i] - mx) : 0.f;
+      sum += e[i];
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float inv = n < N ? 1.f / sum : 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) row[q4 + 4 * i] = e[i] * inv;  // pixels >= P and sentences >= N become exact zeros
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {  // probabilities for backward: plane 0 = Av [p][n], plane 2 = AtT [p][n]
+    float* o0 = probs + ((long)b * NPL + 0) * P * N;
+    float* o2 = probs + ((long)b * NPL + 2) * P * N;
+    for (int i = tid; i < tot; i += 256) {
+      const int p = i / N, n = i - p * N;
+      o0[i] = Sa[p * XLD + n];
+      o2[i] = St[n * XLT + p];
+    }
+  }
+
+  // new_vis[b][p][c] = sum_n Av[p][n] Vt[n][c]
+  {
+    f32x4v acc[2][8];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) acc[ct][rt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < NK) {
+        Split8 sb[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          sb[ct] = split8(make_float4(vt[ct][ks][0], vt[ct][ks][1], vt[ct][ks][2], vt[ct][ks][3]),
+                          make_float4(vt[ct][ks][4], vt[ct][ks][5], vt[ct][ks][6], vt[ct][ks][7]));
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+          if (rt < PT) {
+            const float* s = Sa + (rt * 16 + r) * XLD + ks * 32 + kg * 8;
+            const Split8 sa = split8(ld4(s), ld4(s + 4));
+            acc[0][rt] = mfma6(sa, sb[0], acc[0][rt]);
+            acc[1][rt] = mfma6(sa, sb[1], acc[1][rt]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int p = rt * 16 + 4 * kg + t;
+          if (rt < PT && p < P) new_vis[((long)b * P + p) * C + c + ct * 16] = acc[ct][rt][t];
+        }
+  }
+  // new_lan[b][n][c] = sum_p At[n][p] Vv[b][p][c]
+  {
+    f32x4v acc[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < PK) {
+        Split8 sb[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          sb[ct] = split8(make_float4(vv[ct][ks][0], vv[ct][ks][1], vv[ct][ks][2], vv[ct][ks][3]),
+                          make_float4(vv[ct][ks][4], vv[ct][ks][5], vv[ct][ks][6], vv[ct][ks][7]));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          if (nt < NT) {
+            const float* s = St + (nt * 16 + r) * XLT + ks * 32 + kg * 8;
+            const Split8 sa = split8(ld4(s), ld4(s + 4));
+            acc[0][nt] = mfma6(sa, sb[0], acc[0][nt]);
+            acc[1][nt] = mfma6(sa, sb[1], acc[1][nt]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int n = nt * 16 + 4 * kg + t;
+          if (nt < NT && n < N) new_lan[((long)b * N + n) * C + c + ct * 16] = acc[ct][nt][t];
+        }
+  }
+}
+
+template <int NT, int KS>
+int launch_fwd_x3(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt, const float* Vt,
+                  float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C, hipStream_t st) {
+  const float scale = 1.0f / sqrtf((float)C);
+  const long R = (long)B * P;
+  hipLaunchKernelGGL((xattn_scores_x3_kernel<NT, KS>), dim3(cdiv(R, 32), 2), dim3(256), 0, st, Qv, Kv, Qt, Kt, probs, R, P, N,
+                     C, scale);
+  TRIS_LAUNCH_CHECK();
+  const size_t lds = (size_t)(((P + 15) / 16 * 16) * XLD + 64 * XLT) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)xattn_out_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       96 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(xattn_out_x3_kernel, dim3(C / 128, B), dim3(256), lds, st, Vv, Vt, probs, new_vis, new_lan, P, N, C);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
@@ -274,6 +657,19 @@ extern "C" int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float*
   if (N < 1 || N > 16 * MAXNF || P < 1 || C % 64 != 0 || out_lds_bytes(P, (N + 15) / 16) > 150 * 1024)
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
+  if (tris_get_gemm_mode() == 1 && P <= 128 && (C == 1024 || C == 512 || C == 256)) {  // split-bf16: two-launch streaming path
+#define TRIS_X3(NT_)                                                                                                \
+  (C == 1024 ? launch_fwd_x3<NT_, 8>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st)               \
+             : C == 512 ? launch_fwd_x3<NT_, 4>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st)     \
+                        : launch_fwd_x3<NT_, 2>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st))
+    switch ((N + 15) / 16) {
+      case 1: return TRIS_X3(1);
+      case 2: return TRIS_X3(2);
+      case 3: return TRIS_X3(3);
+      default: return TRIS_X3(4);
+    }
+#undef TRIS_X3
+  }
   switch ((N + 15) / 16) {
     case 1: return launch_fwd<1>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st);
     case 2: return launch_fwd<2>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st);

@@ -840,7 +840,7 @@ class XAttnFn(torch.autograd.Function):
         dev = Qv.device
         new_vis = torch.empty(B, Pp, C, device=dev, dtype=torch.float32)
         new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
-        probs = torch.empty(B, 3, Pp, N, device=dev, dtype=torch.float32)
+        probs = torch.empty(B, 4, Pp, N, device=dev, dtype=torch.float32)
         _timed("xattn_fwd", 8.0 * B * Pp * N * C,
                lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
                             P(probs), B, Pp, N, C, _stream()))
