@@ -560,6 +560,7 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     for (int sk : sks) {
       if (sk > 1 && (!can_split || sk > p.K / 256 || (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes)) break;
       if (sk > 1 && ntiles * sk > 1536) break;  // more than ~6 blocks per CU buys nothing
+      if (sk * 8 < h.splitk && ntiles * sk < 256) continue;  // a handful of blocks walking a huge K serially: not worth timing
       const Cfg c = {cbm, cbn, sk};
       const float ms = time_cfg(c);
       if (ms < best_ms) { best_ms = ms; best = c; }
