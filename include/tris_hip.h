@@ -121,6 +121,13 @@ int tris_nchw_to_nhwc_f32(const float* X, float* Y, int B, int C, int H, int W, 
 int tris_mha_fwd_f32(const float* qkv, float* out, int N, int L, int W, int heads, int causal, void* stream);
 int tris_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv, int N, int L, int W, int heads, int causal,
                      void* stream);
+/* The same attention for ANY sequence length, flash-style on the f32 MFMA (no L x L matrix in memory): used for L > 64
+ * (a ViT-B/16 trunk at 320 px has L = 401) and, where faster, for the short sequences too.  lse [N, heads, L] receives
+ * the per-query log-sum-exp (saved for backward); delta [N, heads, L] is backward scratch (rowsum(dO * O)). */
+int tris_mha_mfma_fwd_f32(const float* qkv, float* out, float* lse, int N, int L, int W, int heads, int causal,
+                          void* stream);
+int tris_mha_mfma_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
+                          float* dqkv, int N, int L, int W, int heads, int causal, void* stream);
 /* token_embedding(ids) + positional_embedding[:L]  (model.py:553-554).  bwd: dtok must be zero-filled by the caller */
 int tris_embed_fwd_f32(const long* ids, const float* tok, const float* pos, float* out, int N, int L, int W,
                        void* stream);

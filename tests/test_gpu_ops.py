@@ -179,8 +179,14 @@ def test_avgpool_layernorm_gelu(ops):
     close(gx.grad, x.grad)
 
 
-@pytest.mark.parametrize("N,L,heads,causal", [(3, 20, 8, True), (2, 50, 12, False), (1, 64, 2, True), (2, 7, 1, False)])
-def test_mha(ops, N, L, heads, causal):
+@pytest.mark.parametrize("impl", ["mfma", "valu"])
+@pytest.mark.parametrize("N,L,heads,causal", [(3, 20, 8, True), (2, 50, 12, False), (1, 64, 2, True), (2, 7, 1, False),
+                                             (2, 65, 2, True), (1, 401, 3, False), (2, 130, 2, True), (1, 1, 1, True),
+                                             (2, 16, 1, False), (1, 200, 1, False)])
+def test_mha(ops, N, L, heads, causal, impl, monkeypatch):
+    if impl == "valu" and L > 64:
+        pytest.skip("the LDS-resident kernel holds the whole sequence: L <= 64")
+    monkeypatch.setenv("TRIS_MHA", impl)
     W = heads * 64
     qkv = leaf(N, L, 3 * W)
     q, k, v = qkv.split(W, dim=-1)

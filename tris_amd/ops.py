@@ -661,8 +661,52 @@ class MhaFn(torch.autograd.Function):
         return dqkv, None, None
 
 
+class MhaMfmaFn(torch.autograd.Function):
+    """Flash-style attention on the f32 MFMA, any L (csrc/attn_mfma.hip); saves the per-query log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, causal):
+        _chk(qkv)
+        qkv = qkv.contiguous()
+        N, L, W3 = qkv.shape
+        W = W3 // 3
+        out = torch.empty(N, L, W, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(N, heads, L, device=qkv.device, dtype=torch.float32)
+        _timed("mha_fwd", 4.0 * N * heads * L * L * 64 * (0.5 if causal else 1.0),
+               lambda: call("tris_mha_mfma_fwd_f32", P(qkv), P(out), P(lse), N, L, W, heads, int(causal), _stream()))
+        ctx.cfg = (N, L, W, heads, int(causal))
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, out, lse = ctx.saved_tensors
+        N, L, W, heads, causal = ctx.cfg
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        call("tris_mha_mfma_bwd_f32", P(qkv), P(out), P(do), P(lse), P(delta), P(dqkv), N, L, W, heads, causal, _stream())
+        return dqkv, None, None
+
+
+def _mha_impl(L):
+    """'valu' = the LDS-resident kernel for L <= 64 (csrc/attn.hip), 'mfma' = the flash-style MFMA kernel (any L).
+    TRIS_MHA=valu|mfma forces one; default 'auto' takes the measured faster one: at L = 20 (text) the op is an HBM stream
+    of the packed QKV and the single-launch backward of the LDS-resident kernel wins (654 vs 806 us at N = 3840), from
+    L = 50 (aux ViT) on the MFMA kernel does (fwd 47 vs 53 us, bwd 126 vs 159 us; L = 401: 73 / 84 TFLOP/s)."""
+    import os
+    mode = os.environ.get("TRIS_MHA", "auto")
+    if L > 64 or mode == "mfma":
+        return "mfma"
+    if mode == "valu":
+        return "valu"
+    return "valu" if L < 40 else "mfma"
+
+
 def mha(qkv, heads, causal):
-    return MhaFn.apply(qkv, heads, causal)
+    if _mha_impl(qkv.shape[1]) == "valu":
+        return MhaFn.apply(qkv, heads, causal)
+    return MhaMfmaFn.apply(qkv, heads, causal)
 
 
 class QGeluFn(torch.autograd.Function):
