@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (metric config: 48)")
+    ap.add_argument("--backbone", default="clip-RN50", choices=["clip-RN50", "clip-ViT-B/16"],
+                    help="clip-RN50 = the metric configuration (BASELINE configs[2]/[3]); clip-ViT-B/16 = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the bounded CPU-baseline sample")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the input-pipeline measurement (SURVEY.md 8f-1)")
@@ -89,7 +91,7 @@ def main():
     from tris_amd.train_stage1 import freeze_aux, train_step
     from tris_amd.utils.synth import seed_fill, synthetic_batch
 
-    args = get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20",
+    args = get_parser().parse_args(["--backbone", a.backbone, "--size", "320", "--max_query_len", "20",
                                     "--negative_samples", "3", "--batch_size", str(a.batch), "--epoch", "15"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -200,13 +202,15 @@ def main():
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
 
     if rank == 0:
-        out = {"metric": "Stage-1 training images/sec @320px bs48 (TRIS clip-RN50, 3 negatives)",
+        out = {"metric": f"Stage-1 training images/sec @320px bs48 (TRIS {a.backbone}, 3 negatives)",
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "gemm_mode": mode, "data": "synthetic",
                "config": {"workload": "Stage-1 train step, RefCOCOg-shaped synthetic batch: 48 img/GPU 320x320, "
-                                      "20-token query + 3 negative queries per image, clip-RN50 trunk + frozen aux "
-                                      "CLIP ViT-B/32, AdamW (BASELINE.json configs[2]/[3])",
+                                      f"20-token query + 3 negative queries per image, {a.backbone} trunk + frozen aux "
+                                      "CLIP ViT-B/32, AdamW (BASELINE.json " +
+                                      ("configs[2]/[3])" if a.backbone == "clip-RN50" else
+                                       "configs[4]; the reference defines no such model: parity unpinned, DESIGN.md)"),
                           "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": 20,
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
                "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
@@ -220,7 +224,7 @@ def main():
                 out["input_pipeline"] = pipeline_measure(batch=a.batch)
             except Exception as e:  # reported, never hidden
                 out["input_pipeline"] = {"error": repr(e)}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.backbone == "clip-RN50":
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         line = json.dumps(out)
     if world > 1 or force:

@@ -109,6 +109,74 @@ def main_pixel_attention():
     print("g10:", {k: v.shape for k, v in g.items()})
 
 
+VIT_CASE = dict(input_resolution=64, patch_size=16, width=128, layers=2, heads=2, output_dim=64, image=96, batch=2)
+
+
+def main_vit_spatial():
+    """g11: the dense-trunk ViT variant the reference keeps in comments (CLIP/clip/model.py:427-441), executed with the
+    REAL reference sub-modules (conv1, ln_pre, transformer) and those commented lines as glue -- small configuration."""
+    from oracle import ref_shim
+    ref_shim.install()
+    import torch.nn.functional as F
+    from CLIP.clip.model import VisionTransformer
+    from tris_amd.utils.synth import seed_fill
+    c = VIT_CASE
+    v = VisionTransformer(c["input_resolution"], c["patch_size"], c["width"], c["layers"], c["heads"], c["output_dim"]).float()
+    sd = v.state_dict()
+    seed_fill(sd, 77)
+    with torch.no_grad():   # widen the spread so the softmax is not flat
+        for k in sd:
+            if sd[k].dim() > 1 or k == "class_embedding":
+                sd[k].mul_(8.0)
+    v.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(c["batch"], 3, c["image"], c["image"], generator=g)
+    x = v.conv1(img)
+    H, W = x.shape[-2:]
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    x = torch.cat([v.class_embedding.to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype), x], dim=1)
+    sdim = c["input_resolution"] // c["patch_size"]
+    cls_pos = v.positional_embedding[0:1, :]
+    spatial_pos = F.interpolate(v.positional_embedding[1:, ].reshape(1, sdim, sdim, c["width"]).permute(0, 3, 1, 2),
+                                size=(H, W), mode="bilinear")
+    spatial_pos = spatial_pos.reshape(c["width"], H * W).permute(1, 0)
+    x = x + torch.cat([cls_pos, spatial_pos], dim=0)
+    x = v.ln_pre(x)
+    x = v.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+    cls_feats = x[:, 0, :]
+    spa = x[:, 1:, :].permute(0, 2, 1).reshape(x.shape[0], -1, H, W)
+    gs = torch.randn(spa.shape, generator=g)
+    gc = torch.randn(cls_feats.shape, generator=g)
+    ((spa * gs).sum() + (cls_feats * gc).sum()).backward()
+    out = {"cls": cls_feats.detach().numpy(), "spa": spa.detach().numpy(), "img": img.numpy(), "gs": gs.numpy(),
+           "gc": gc.numpy()}
+    keep = ("class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
+            "transformer.resblocks.0.attn.in_proj_weight", "transformer.resblocks.1.mlp.c_proj.weight")
+    for k, p_ in v.named_parameters():
+        if k in keep:
+            out["d_" + k] = p_.grad.numpy()
+    out["d_conv1.weight_norm"] = np.array(float(v.conv1.weight.grad.norm()))
+    out["d_conv1.weight_head"] = v.conv1.weight.grad.reshape(-1)[:512].numpy()
+    np.savez_compressed(os.path.join(OUT, "g11_vit_spatial.npz"), **out)
+    print("g11:", {k: v_.shape for k, v_ in out.items() if not k.startswith("d_transformer")},
+          os.path.getsize(os.path.join(OUT, "g11_vit_spatial.npz")))
+
+
+def vit_case_state_dict():
+    """the seed-filled weights of the g11 case as a flat {'visual.<key>': tensor} dict (shapes from VIT_CASE)"""
+    from tris_amd.CLIP.clip.model import VisionTransformer
+    from tris_amd.utils.synth import seed_fill
+    c = VIT_CASE
+    v = VisionTransformer(c["input_resolution"], c["patch_size"], c["width"], c["layers"], c["heads"], c["output_dim"])
+    sd = {k: torch.empty(t.shape) for k, t in v.state_dict().items()}
+    seed_fill(sd, 77)
+    for k in sd:
+        if sd[k].dim() > 1 or k == "class_embedding":
+            sd[k].mul_(8.0)
+    return sd
+
+
 if __name__ == "__main__":
     main()
     main_pixel_attention()
+    main_vit_spatial()

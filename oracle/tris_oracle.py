@@ -150,6 +150,27 @@ def encode_image_vit(sd, p, x):
     return x @ sd[v + ".proj"]
 
 
+def encode_image_vit_spatial(sd, p, x):
+    """The dense-trunk variant the reference sketches in comments (CLIP/clip/model.py:427-441): interpolated spatial
+    positional embedding, spatial tokens after the last block reshaped to [N, width, H/ps, W/ps] (no ln_post).
+    PARITY UNPINNED as a whole (the reference never runs it); built only from pieces that are pinned (G1/G2)."""
+    v = p + "visual"
+    w = sd[v + ".conv1.weight"]
+    x = F.conv2d(x, w, stride=w.shape[-1])
+    N, Wd, H, W = x.shape
+    x = x.reshape(N, Wd, -1).permute(0, 2, 1)
+    cls = sd[v + ".class_embedding"].expand(N, 1, Wd)
+    x = torch.cat([cls, x], dim=1)
+    pos = sd[v + ".positional_embedding"]
+    sdim = int(round(math.sqrt(pos.shape[0] - 1)))
+    spatial = F.interpolate(pos[1:].reshape(1, sdim, sdim, Wd).permute(0, 3, 1, 2), size=(H, W), mode="bilinear")
+    pos = torch.cat([pos[0:1], spatial.reshape(Wd, H * W).permute(1, 0)], dim=0)
+    x = _ln(sd, v + ".ln_pre", x + pos)
+    for i in range(_n_layers(sd, v + ".transformer")):
+        x = _resblock(sd, f"{v}.transformer.resblocks.{i}", x, Wd // 64, None)
+    return x[:, 0, :], x[:, 1:, :].permute(0, 2, 1).reshape(N, Wd, H, W)
+
+
 # --------------------------------------------------------------------------------------
 # Stage-1 model (model/model_stage1.py, model/attn.py)
 # --------------------------------------------------------------------------------------
@@ -199,12 +220,15 @@ def pixel_attention(sd, p, vis, lan):
 
 
 def tris_forward(sd, img, word_id, train, focal_p=3.0, focal_c=0.01, attn_multi=0.1,
-                 with_attnpool=False, return_score=False):
+                 with_attnpool=False, return_score=False, vit_trunk=False):
     """TRIS.forward -- model/model_stage1.py:54-119 (focal_loss :122-123, Upsample model/utils.py:5-10)."""
     B = img.shape[0]
     size = img.shape[2:]
     _, hidden = encode_text(sd, "backbone.", word_id)
-    c4 = encode_image_rn(sd, "backbone.", img, train, with_attnpool)[3]
+    if vit_trunk:
+        c4 = encode_image_vit_spatial(sd, "backbone.", img)[1]
+    else:
+        c4 = encode_image_rn(sd, "backbone.", img, train, with_attnpool)[3]
     lan = hidden @ sd["lan_project.weight"].t() + sd["lan_project.bias"]
     vis = F.conv2d(c4, sd["vis_project.weight"], sd["vis_project.bias"])
     h_, w_ = vis.shape[2:]

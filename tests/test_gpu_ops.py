@@ -288,7 +288,7 @@ def _ref_heads(score, h, w, S, fp=3.0, fc=0.01):
     return cls, torch.diagonal(mm[:, 1:]), F.relu(seg), torch.sigmoid(seg)
 
 
-@pytest.mark.parametrize("B,h,w,S", [(4, 10, 10, 320), (3, 5, 5, 64), (48, 10, 10, 320)])
+@pytest.mark.parametrize("B,h,w,S", [(4, 10, 10, 320), (3, 5, 5, 64), (48, 10, 10, 320), (48, 20, 20, 320)])
 def test_score_heads(ops, B, h, w, S):
     score = leaf(B, h * w, B, scale=3.0)
     cls, fg, r, s = _ref_heads(score, h, w, S)

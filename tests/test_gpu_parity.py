@@ -475,3 +475,61 @@ def test_pixel_attention_stage2_shapes_vs_oracle(Ci, HW):
         e_hip = float((h - ref).norm() / ref.norm())
         e_f32 = float((g32[k].double() - ref).norm() / ref.norm())
         assert e_hip <= 3.0 * e_f32 + 2e-5, (k, e_hip, e_f32)
+
+
+# ---- dense ViT trunk (BASELINE config 5) -- parity unpinned as a model, pieces pinned ------------------
+def test_vit_spatial_trunk_matches_reference_modules(golden):
+    from oracle.gen_golden_data import VIT_CASE, vit_case_state_dict
+    from tris_amd import ops
+    from tris_amd.CLIP.clip.model import VisionTransformer
+    g = golden("g11_vit_spatial.npz")
+    c = VIT_CASE
+    v = VisionTransformer(c["input_resolution"], c["patch_size"], c["width"], c["layers"], c["heads"], c["output_dim"]).cuda()
+    v.load_state_dict(vit_case_state_dict())
+    cls, spa = v.forward_spatial(torch.from_numpy(g["img"]).cuda())
+    ref_spa = torch.from_numpy(g["spa"]).permute(0, 2, 3, 1)                      # ours is channels-last
+    assert err(cls, g["cls"]) <= 1e-3 * float(np.abs(g["cls"]).max())
+    assert float((spa.cpu() - ref_spa).abs().max()) <= 1e-3 * float(ref_spa.abs().max())
+    gs = torch.from_numpy(g["gs"]).permute(0, 2, 3, 1).contiguous().cuda()
+    ((spa * gs).sum() + (cls * torch.from_numpy(g["gc"]).cuda()).sum()).backward()
+    ops.wgrad_join()
+    named = dict(v.named_parameters())
+    for k in [n[2:] for n in g.files if n.startswith("d_") and not n.startswith("d_conv1")]:
+        ref = torch.from_numpy(g["d_" + k])
+        got = named[k].grad.cpu()
+        assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (k, float((got - ref).abs().max()))
+    gw = named["conv1.weight"].grad
+    assert abs(float(gw.norm()) - float(g["d_conv1.weight_norm"])) <= 1e-3 * float(g["d_conv1.weight_norm"])
+    assert err(gw.reshape(-1)[:512], g["d_conv1.weight_head"]) <= 2e-3 * float(np.abs(g["d_conv1.weight_head"]).max())
+
+
+def test_tris_vit_b16_forward_matches_oracle_and_trains(aux):
+    """TRIS with the ViT-B/16 trunk at 320 px (401 tokens, flash-style MFMA attention): train-mode forward vs the oracle,
+    then one optimisation step end to end."""
+    import warnings
+    from oracle import tris_oracle as O
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import train_step
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    args = _args(["--backbone", "clip-ViT-B/16"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = TRIS(args).cuda().train()
+    sd = m.state_dict()
+    seed_fill(sd, 4242)
+    b = synthetic_batch(2, 320, 20, 3, seed=3)
+    cls, fg, relu_map, sig, ls = m(b["img"].cuda(), b["word_ids"].cuda())
+    cpu = {k: v.detach().cpu().contiguous() for k, v in sd.items()}
+    with torch.no_grad():
+        o = O.tris_forward(cpu, b["img"], b["word_ids"], True, vit_trunk=True)
+    assert relu_map.shape == (2, 1, 320, 320)
+    assert float((cls.cpu() - o[0]).abs().max()) < TOL and float((fg.cpu() - o[1]).abs().max()) < 1e-4
+    assert float((relu_map.cpu() - o[2]).abs().max()) < TOL * max(1.0, float(o[2].abs().max()))
+    bb, new = m.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                     weight_decay=args.weight_decay)
+    before = m.backbone.visual.positional_embedding.detach().clone()
+    losses = train_step(m, aux, opt, b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda(), args).tolist()
+    assert all(np.isfinite(losses))
+    assert float((m.backbone.visual.positional_embedding.detach() - before).abs().max()) > 0   # the trunk is trained

@@ -148,3 +148,19 @@ def test_g10_pixel_attention_oracle_matches_reference(golden):
     assert torch.allclose(lan.grad, torch.from_numpy(g["dlan"]), atol=1e-5, rtol=1e-4)
     for k, v in sd.items():
         assert torch.allclose(v.grad, torch.from_numpy(g["d_" + k[3:]]), atol=1e-5, rtol=1e-4), k
+
+
+def test_g11_vit_spatial_oracle_matches_reference_modules(golden):
+    """dense ViT trunk (BASELINE config 5): oracle vs the reference's sub-modules glued by its commented variant"""
+    from oracle.gen_golden_data import vit_case_state_dict
+    g = golden("g11_vit_spatial.npz")
+    sd = {"visual." + k: v.requires_grad_(True) for k, v in vit_case_state_dict().items()}
+    cls, spa = O.encode_image_vit_spatial(sd, "", torch.from_numpy(g["img"]))
+    assert torch.allclose(cls, torch.from_numpy(g["cls"]), atol=1e-4, rtol=1e-5)
+    assert torch.allclose(spa, torch.from_numpy(g["spa"]), atol=1e-4, rtol=1e-5)
+    ((spa * torch.from_numpy(g["gs"])).sum() + (cls * torch.from_numpy(g["gc"])).sum()).backward()
+    for k in [n[2:] for n in g.files if n.startswith("d_") and not n.startswith("d_conv1")]:
+        ref = torch.from_numpy(g["d_" + k])
+        assert float((sd["visual." + k].grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6, k
+    gw = sd["visual.conv1.weight"].grad
+    assert abs(float(gw.norm()) - float(g["d_conv1.weight_norm"])) <= 1e-5 * float(g["d_conv1.weight_norm"])

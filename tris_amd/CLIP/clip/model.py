@@ -280,6 +280,27 @@ class VisionTransformer(nn.Module):
         cls = self.ln_post(x[:, 0, :].contiguous())
         return ops.matmul(cls, self.proj)
 
+    def forward_spatial(self, x):
+        """ViT as a dense trunk (BASELINE config 5; the reference sketches it in comments, CLIP/clip/model.py:427-441):
+        x [B,3,H,W] -> (cls [B,width], spa [B, H/ps, W/ps, width] channels-last) taken after the last block (no ln_post).
+        The spatial positional embedding is bilinearly interpolated from its training grid to the input's grid."""
+        B, C, H, Wd = x.shape
+        ps = self.patch_size
+        ones = torch.ones(B, 1, H, Wd, device=x.device, dtype=torch.float32)
+        emb = ops.linear(ops.fg_patches(ones, x.float(), ps), self.conv1.weight.reshape(self.conv1.weight.shape[0], -1))
+        gh, gw = H // ps, Wd // ps
+        sd = self.input_resolution // ps
+        width = self.positional_embedding.shape[1]
+        pos = self.positional_embedding
+        if (gh, gw) != (sd, sd):
+            grid = pos[1:].reshape(1, sd, sd, width).permute(0, 3, 1, 2)                       # [1,width,sd,sd]
+            grid = ops.resize_bilinear(grid, (gh, gw), False)                                  # align_corners=False
+            pos = torch.cat([pos[0:1], grid.reshape(width, gh * gw).permute(1, 0)], dim=0)
+        x = ops.vit_assemble(emb, self.class_embedding, pos.contiguous())
+        x = self.ln_pre(x)
+        x = self.transformer(x)
+        return x[:, 0, :], x[:, 1:, :].reshape(B, gh, gw, width)
+
     def forward(self, x):
         """x [B,3,R,R] NCHW.  Patch extraction = fg_patches with a unit cam."""
         B, C, R, _ = x.shape

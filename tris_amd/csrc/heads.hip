@@ -522,7 +522,13 @@ extern "C" int tris_softmax_bwd_f32(const float* dY, const float* Y, float* dX, 
 extern "C" int tris_cls_head_fwd_f32(const float* score, float* cls_out, float* cls_fg, int B, int P, int N,
                                      float focal_p, float focal_c, void* stream) {
   size_t lds = (size_t)(P * (N + 1) + 2 * P) * sizeof(float);
-  if (lds > 60000) return (int)hipErrorInvalidValue;
+  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+  static bool big_ok = false;  // more than the default 64 KB of dynamic LDS (a 20 x 20 ViT grid with 48 sentences: 82 KB)
+  if (lds > 60000 && !big_ok) {
+    hipError_t e = hipFuncSetAttribute((const void*)cls_head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    big_ok = true;
+  }
   hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, score, cls_out, cls_fg, P, N,
                      focal_p, focal_c);
   TRIS_LAUNCH_CHECK();
@@ -531,7 +537,13 @@ extern "C" int tris_cls_head_fwd_f32(const float* score, float* cls_out, float* 
 extern "C" int tris_cls_head_bwd_f32(const float* score, const float* g, float* dscore, int B, int P, int N,
                                      float focal_p, float focal_c, void* stream) {
   size_t lds = (size_t)(P * (N + 1) + 3 * P + 3 * N) * sizeof(float);
-  if (lds > 60000) return (int)hipErrorInvalidValue;
+  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+  static bool big_ok = false;
+  if (lds > 60000 && !big_ok) {
+    hipError_t e = hipFuncSetAttribute((const void*)cls_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    big_ok = true;
+  }
   hipLaunchKernelGGL(cls_head_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, score, g, dscore, P, N, focal_p,
                      focal_c);
   TRIS_LAUNCH_CHECK();

@@ -36,12 +36,18 @@ class TRIS(nn.Module):
             last_vis_channel, self.textdim = 2048, 1024
         elif args.backbone == "clip-RN101":
             last_vis_channel, self.textdim = 2048, 512
+        elif args.backbone in ("clip-ViT-B/16", "clip-ViT-B/32"):
+            # BASELINE config 5.  NOT defined by the reference (model_stage1.py:20-25 leaves last_vis_channel unbound for
+            # it): the definition here follows the variant sketched in comments at CLIP/clip/model.py:427-441 -- spatial
+            # tokens after the last block, interpolated positional embedding -- with the text width of the ViT-B CLIPs.
+            last_vis_channel, self.textdim = 768, 512
         else:
             raise ValueError(f"backbone {args.backbone!r} has no Stage-1 definition in the reference "
                              "(model_stage1.py:20-25 covers clip-RN50 / clip-RN101 only)")
+        self.vit_trunk = "ViT" in args.backbone
         device = "cuda" if torch.cuda.is_available() else "cpu"
-        clip_model, _ = clip.load(args.backbone.split("-")[-1], device=device, jit=False,
-                                  txt_length=args.max_query_len)
+        clip_model, _ = clip.load(args.backbone.split("-", 1)[-1] if self.vit_trunk else args.backbone.split("-")[-1],
+                                  device=device, jit=False, txt_length=args.max_query_len)
         self.backbone = clip_model.float()
         self.vis_project = Conv2d(last_vis_channel, args.hidden_dim, 1, bias=True)
         self.lan_project = Linear(self.textdim, args.hidden_dim)
@@ -59,7 +65,10 @@ class TRIS(nn.Module):
         """Image-only half of forward (RN50 trunk -> vis_project -> L2 norm).  Returned state can be reused for every
         sentence of the same image (validate.py re-runs the trunk per sentence; the values are identical)."""
         B = x.shape[0]
-        c4 = self.backbone.visual.forward_cl(x)[3]                      # [B,h,w,2048] channels-last
+        if self.vit_trunk:
+            c4 = self.backbone.visual.forward_spatial(x)[1]             # [B,h,w,768] channels-last
+        else:
+            c4 = self.backbone.visual.forward_cl(x)[3]                  # [B,h,w,2048] channels-last
         h_, w_ = c4.shape[1:3]
         vis = self.vis_project(c4).reshape(B, h_ * w_, -1)              # [B,P,C]
         return ops.l2norm(vis), h_, w_

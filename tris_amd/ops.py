@@ -1068,7 +1068,7 @@ def fg_patches(cam, img, ps):
 
 
 class VitAssembleFn(torch.autograd.Function):
-    """[cls + pos[0]; emb + pos[1:]] -> [B, T, W]  (class/positional embeddings are frozen aux weights)"""
+    """[cls + pos[0]; emb + pos[1:]] -> [B, T, W]; gradients for cls / pos only where they are trained (ViT trunk)"""
 
     @staticmethod
     def forward(ctx, emb, cls, pos):
@@ -1083,9 +1083,15 @@ class VitAssembleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx):
         B, T, W = ctx.cfg
+        dx = dx.contiguous()
         demb = torch.empty(B, T - 1, W, device=dx.device, dtype=torch.float32)
-        call("tris_vit_assemble_bwd_f32", P(dx.contiguous()), P(demb), B, T, W, _stream())
-        return demb, None, None
+        call("tris_vit_assemble_bwd_f32", P(dx), P(demb), B, T, W, _stream())
+        dcls = dpos = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dpos = colsum(dx, B, T * W, torch.empty(T, W, device=dx.device, dtype=torch.float32))   # sum over the batch
+            dcls = dpos[0].clone() if ctx.needs_input_grad[1] else None
+            dpos = dpos if ctx.needs_input_grad[2] else None
+        return demb, dcls, dpos
 
 
 def vit_assemble(emb, cls, pos):
