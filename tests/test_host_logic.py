@@ -37,7 +37,10 @@ def test_tris_module_surface():
     assert m.backbone.visual.layer1[0].conv2.weight.is_contiguous(memory_format=torch.channels_last)
     assert float(m.backbone.visual.layer1[0].conv2.weight[3, 5, 1, 2]) == float(sd["backbone.visual.layer1.0.conv2.weight"][3, 5, 1, 2])
     with pytest.raises(ValueError):
-        _build_tris(["--backbone", "clip-ViT-B/16"])  # no Stage-1 definition in the reference either
+        _build_tris(["--backbone", "clip-RN50x4"])  # no Stage-1 definition in the reference either
+    v = _build_tris(["--backbone", "clip-ViT-B/16"])  # BASELINE configs[4]: the dense ViT trunk (self-defined)
+    assert v.vit_trunk and v.vis_project.weight.shape[:2] == (1024, 768) and v.lan_project.weight.shape == (1024, 512)
+    assert v.backbone.visual.positional_embedding.shape == (14 * 14 + 1, 768)
 
 
 def test_tokenizer_known_answers():
