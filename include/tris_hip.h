@@ -37,6 +37,21 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
  * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -> fp32-class accuracy (measured: error vs fp64 <= the f32-MFMA
  * path's) at up to 2.6x the f32-MFMA peak.  Default: 1. */
 int tris_set_gemm_mode(int mode);
+/* Pre-split weight operands (x3 arithmetic).  tris_weight_planes_f32 splits weight matrices once per optimiser step into
+ * three bf16 planes P[pl][r*ld + c] (same indexing as the fp32 source) and the transposed planes PT[pl][c*pt_ld + r] the
+ * data-gradient products use; `table` is a device int64[entries][10] = {src, src row stride, rows, cols, P, P plane
+ * stride, PT (or 0), PT row stride, PT plane stride, first 32x32-tile index}, total_tiles = sum of the entries' tiles.
+ * The *_wp products take such planes for their B operand ([3][N][K], plane stride `bpl` elements) and return
+ * TRIS_WP_UNSUPPORTED (no launch) when planes cannot serve the shape / arithmetic mode -- the caller then uses the fp32
+ * entry point.  Replaces the same reference lines as tris_gemm_f32 / tris_conv3x3_fwd_f32 / tris_conv3x3_dgrad_f32. */
+#define TRIS_WP_UNSUPPORTED (-2)
+int tris_weight_planes_f32(const long* table, int entries, long total_tiles, void* stream);
+int tris_gemm_wp_f32(const float* A, const void* Bplanes, long bpl, float* C, int M, int N, int K, const float* bias,
+                     const float* resid, int act, float* workspace, long workspace_bytes, double* stat_part,
+                     int* stat_rows, void* stream);
+int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long bpl, float* Y, int B, int H, int W, int Cin, int Cout,
+                            int stride, double* stat_part, int* stat_rows, void* stream);
+
 /* (tile, split-K) selection of the dense-product kernels: 1 (default; env TRIS_AUTOTUNE) = every admissible pair is timed
  * once per product shape on first use and the fastest is cached for the process; 0 = the static cycle model (deterministic
  * run-to-run rounding). */

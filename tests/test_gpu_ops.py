@@ -458,3 +458,74 @@ def test_gemm_autotune_every_candidate_and_the_cached_choice(ops, M, N, K, tA, t
         finally:
             del os.environ["TRIS_FORCE_TILE"]
         assert float((out - ref).abs().max()) <= 2e-4 * scale, tile
+
+
+def _unsplit(planes, shape):
+    """bf16 planes [3, numel] -> the fp32 tensor they represent (hi + mid + lo, exact in fp32)"""
+    p = planes.float()
+    return ((p[0] + p[1]) + p[2]).view(shape)
+
+
+def test_weight_planes_are_exact_and_transposed():
+    """tris_weight_planes_f32: the three bf16 pieces sum back to the fp32 weight bit for bit; the transposed planes are
+    W^T (linear) and the tap-mirrored Wd[ci][8-tap][co] (3x3 convolution)"""
+    from tris_amd.planes import WeightPlanes
+    torch.manual_seed(0)
+    lin = torch.nn.Parameter((torch.randn(136, 72) * 3).cuda())
+    c1 = torch.nn.Parameter(torch.randn(64, 40, 1, 1).cuda().contiguous(memory_format=torch.channels_last))
+    c3 = torch.nn.Parameter((torch.randn(48, 24, 3, 3) * 0.1).cuda().contiguous(memory_format=torch.channels_last))
+    odd = torch.nn.Parameter(torch.randn(30, 7).cuda())                     # not a multiple of 8: skipped
+    wp = WeightPlanes([("a.weight", lin), ("b.weight", c1), ("c.weight", c3), ("d.weight", odd)])
+    assert len(wp.items) == 3
+    wp.refresh()
+    torch.cuda.synchronize()
+    for p in (lin, c1, c3):
+        _, _, _, _, ver, planes, planes_t = p._tris_wp
+        mem = p.detach().permute(0, 2, 3, 1).contiguous() if p.dim() == 4 else p.detach()   # memory order [N][...]
+        assert torch.equal(_unsplit(planes, mem.shape), mem)
+        if p is c3:
+            wd = p.detach().permute(1, 2, 3, 0).flip(1, 2).contiguous()                      # [ci][2-ky][2-kx][co]
+            assert torch.equal(_unsplit(planes_t, wd.shape), wd)
+        else:
+            m2 = mem.reshape(mem.shape[0], -1)
+            assert torch.equal(_unsplit(planes_t, m2.t().shape), m2.t().contiguous())
+    assert not hasattr(odd, "_tris_wp")
+
+
+def test_linear_and_conv_with_weight_planes_match_plain_path():
+    """inside WeightPlanes.active() the products read pre-split weights; same results as the in-kernel split"""
+    from tris_amd import ops as o
+    from tris_amd.planes import WeightPlanes
+    if o.get_gemm_mode() != "x3":
+        o.set_gemm_mode("x3")
+    torch.manual_seed(1)
+    w = torch.nn.Parameter((torch.randn(256, 128) * 0.2).cuda())
+    b = torch.nn.Parameter(torch.randn(256).cuda())
+    cw = torch.nn.Parameter((torch.randn(64, 32, 3, 3) * 0.1).cuda().contiguous(memory_format=torch.channels_last))
+    x = torch.randn(3, 50, 128).cuda().requires_grad_(True)
+    xi = torch.randn(2, 12, 10, 32).cuda().requires_grad_(True)
+    wp = WeightPlanes([("l.weight", w), ("c.weight", cw)])
+
+    def run():
+        for t in (x, xi, w, b, cw):
+            t.grad = None
+        y = o.linear(x, w, b, act=1)
+        z = o.conv3x3(xi, cw, 1)
+        ((y * y).sum() + (z * z).sum()).backward()
+        o.wgrad_join()
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in (y, z, x.grad, xi.grad, w.grad, cw.grad)]
+    plain = run()
+    wp.refresh()
+    with WeightPlanes.active():
+        pre = run()
+    for a, b_ in zip(plain, pre):
+        assert float((a - b_).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7
+    assert torch.equal(plain[0], pre[0]) and torch.equal(plain[1], pre[1])     # forward: the very same pieces, same order
+    # a parameter written to in place invalidates its planes (version guard): the plain path is taken again
+    with torch.no_grad():
+        w.mul_(2.0)
+    with WeightPlanes.active():
+        y2 = o.linear(x, w, b, act=1)
+    ref = torch.relu(x.detach() @ w.detach().t() + b.detach())
+    assert float((y2 - ref).abs().max()) <= 2e-4 * float(ref.abs().max())

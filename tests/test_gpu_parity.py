@@ -205,6 +205,31 @@ def test_g5_losses_with_autotuned_gemm(model, aux, batch, golden):
     refill(model)
 
 
+def test_g5_losses_with_weight_planes(model, aux, batch, golden, monkeypatch):
+    """opt-in pre-split weight operands (tris_amd.planes, TRIS_WEIGHT_PLANES=1): same losses as the reference, and the
+    planes really are consulted (every eligible trunk weight carries them after the step)"""
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import train_step
+    monkeypatch.setenv("TRIS_WEIGHT_PLANES", "1")
+    g = golden("g5_g6_step.npz")
+    refill(model)
+    model.train()
+    args = _args()
+    bb, new = model.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                     weight_decay=args.weight_decay)
+    losses = train_step(model, aux, opt, batch["img"].cuda(), batch["word_ids"].cuda(), batch["neg_word_ids"].cuda(),
+                        args).tolist()
+    ref = g["losses"]
+    assert abs(losses[0] - ref[0]) < TOL and abs(losses[1] - ref[1]) < TOL
+    assert abs(losses[2] - ref[2]) < 1e-4 and abs(losses[3] - ref[3]) < 1e-4
+    assert hasattr(model.backbone.visual.layer2[0].conv2.weight, "_tris_wp")
+    assert hasattr(aux.visual.transformer.resblocks[0].mlp.c_fc.weight, "_tris_wp")
+    model._tris_weight_planes = None
+    aux._tris_weight_planes = None
+    refill(model)
+
+
 @pytest.mark.parametrize("B,seed", [(2, 1234), (3, 99)])
 def test_gradients_vs_fp64_noise_floor(B, seed):
     """Whole-step check calibrated against round-off: the HIP path and the fp32 CPU oracle are both compared with

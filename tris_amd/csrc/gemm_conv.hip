@@ -24,7 +24,7 @@
 namespace {
 
 enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2 };
-enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3 };
+enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3, B_NK_PRE = 4 };  // B_NK_PRE: pre-split bf16 planes (fast x3 kernel only)
 enum { EPI_STD = 0, EPI_SLAB = 1 };
 
 struct GemmParams {
@@ -48,6 +48,7 @@ struct GemmParams {
   // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
   int gH, gW, gC, gHo, gWo, gStride;
   int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
+  long bpl;         // B_NK_PRE: elements between the bf16 planes of B
 };
 
 constexpr int BK = 16;
@@ -519,6 +520,8 @@ static bool autotune_enabled() {
 
 template <int AK, int BKIND>
 int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
+  if (BKIND == B_NK_PRE && !(g_gemm_mode == 1 && p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4 && batch == 1))
+    return TRIS_WP_UNSUPPORTED;  // pre-split operands exist only for the fast x3 kernel: the caller falls back to fp32 B
   Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
   if (p.stat_part != nullptr || !autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -687,6 +690,114 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   *stat_rows = p.stat_part ? cdiv(p.M, 128) : 0;
   return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+// ---- pre-split weight operands ("weight planes") ---------------------------------------------------------------------------
+// In x3 arithmetic every block re-splits the tile of B it stages -- for a weight matrix that is the same work repeated by
+// every M tile (2400 times in layer1).  tris_weight_planes_f32 splits the weights ONCE per optimiser step into three bf16
+// planes (and the transposed planes the data-gradient products need); the *_wp entry points stage those planes straight
+// into LDS (16-byte loads, no VALU).
+
+// table (device, int64[entries][10]): src fp32 ptr, src row stride, rows, cols, P ptr, P plane stride, PT ptr, PT row
+// stride, PT plane stride, first tile index.  P[pl][r*src_ld + c] = piece pl of src[r*src_ld + c];
+// PT[pl][c*pt_ld + r] = the same piece transposed.  rows % 4 == 0, cols % 4 == 0.
+__global__ __launch_bounds__(256) void weight_planes_kernel(const long* __restrict__ table, int entries) {
+  __shared__ unsigned short tile[3][32][34];
+  int lo = 0, hi = entries - 1;
+  const long blk = blockIdx.x;
+  while (lo < hi) {  // last entry whose first tile <= blk
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long)mid * 10 + 9] <= blk) lo = mid; else hi = mid - 1;
+  }
+  const long* e = table + (long)lo * 10;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  const long src_ld = e[1];
+  const int rows = (int)e[2], cols = (int)e[3];
+  unsigned short* P = reinterpret_cast<unsigned short*>(e[4]);
+  const long ppl = e[5];
+  unsigned short* PT = reinterpret_cast<unsigned short*>(e[6]);
+  const long pt_ld = e[7], ptpl = e[8];
+  const int t = (int)(blk - e[9]);
+  const int tiles_c = (cols + 31) / 32;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const int tid = threadIdx.x, tr = tid >> 3, tc = (tid & 7) * 4;
+  if (r0 + tr < rows && c0 + tc < cols) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (long)(r0 + tr) * src_ld + c0 + tc);
+    const Split4 sp = split4(v);
+    const long o = (long)(r0 + tr) * src_ld + c0 + tc;
+    *reinterpret_cast<uint2*>(P + o) = sp.hi;
+    *reinterpret_cast<uint2*>(P + ppl + o) = sp.mid;
+    *reinterpret_cast<uint2*>(P + 2 * ppl + o) = sp.lo;
+    const uint2 pc[3] = {sp.hi, sp.mid, sp.lo};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      tile[pl][tr][tc] = (unsigned short)(pc[pl].x & 0xffffu);
+      tile[pl][tr][tc + 1] = (unsigned short)(pc[pl].x >> 16);
+      tile[pl][tr][tc + 2] = (unsigned short)(pc[pl].y & 0xffffu);
+      tile[pl][tr][tc + 3] = (unsigned short)(pc[pl].y >> 16);
+    }
+  }
+  __syncthreads();
+  if (PT != nullptr && c0 + tr < cols && r0 + tc < rows) {  // transposed: row = original column c0+tr, 4 original rows
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      uint2 w;
+      w.x = (unsigned)tile[pl][tc][tr] | ((unsigned)tile[pl][tc + 1][tr] << 16);
+      w.y = (unsigned)tile[pl][tc + 2][tr] | ((unsigned)tile[pl][tc + 3][tr] << 16);
+      *reinterpret_cast<uint2*>(PT + pl * ptpl + (long)(c0 + tr) * pt_ld + r0 + tc) = w;
+    }
+  }
+}
+
+extern "C" int tris_weight_planes_f32(const long* table, int entries, long total_tiles, void* stream) {
+  if (entries <= 0 || total_tiles <= 0) return 0;
+  hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table, entries);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+// C[M,N] = act(A[M,K] . B^T + bias[n]) + resid[M,N] with B given as bf16 planes [3][N][K] (plane stride bpl elements).
+// Optional fused BN statistics of C (stat_part / stat_rows as in tris_gemm_bnstat_f32; pass NULL for none).
+// Returns TRIS_WP_UNSUPPORTED when the planes cannot be used for this shape / arithmetic mode.
+extern "C" int tris_gemm_wp_f32(const float* A, const void* Bplanes, long bpl, float* C, int M, int N, int K,
+                                const float* bias, const float* resid, int act, float* workspace, long ws_bytes,
+                                double* stat_part, int* stat_rows, void* stream) {
+  GemmParams p = {};
+  p.A = A; p.B = reinterpret_cast<const float*>(Bplanes); p.bpl = bpl; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = K; p.ldb = K; p.ldc = N; p.alpha = 1.f;
+  p.bias = bias; p.bias_mode = bias ? 1 : 0; p.resid = resid; p.ldr = N; p.act = act;
+  p.vecA = al16(A) && (K % 4 == 0);
+  p.vecB = al16(Bplanes) && (K % 8 == 0) && (bpl % 8 == 0);
+  p.fastA = p.vecA;
+  p.fastB = p.vecB;
+  if (stat_part != nullptr) {
+    const bool ok = stats_eligible(p) && bias == nullptr && resid == nullptr && act == 0;
+    p.stat_part = ok ? stat_part : nullptr;
+    *stat_rows = ok ? cdiv(M, 128) : 0;
+    return launch_cfg<A_ROWK, B_NK_PRE>(p, 1, nullptr, 0, (hipStream_t)stream);
+  }
+  return launch_cfg<A_ROWK, B_NK_PRE>(p, 1, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+// tris_conv3x3_fwd[_bnstat]_f32 with the weights given as planes [3][Cout][9*Cin].  With the transposed + tap-mirrored
+// planes Wd[ci][tap'][co] = W[co][8-tap'][ci] and (Cin, Cout) swapped this is also the data gradient of a stride-1 conv.
+extern "C" int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long bpl, float* Y, int B, int H, int W, int Cin,
+                                       int Cout, int stride, double* stat_part, int* stat_rows, void* stream) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  GemmParams p = {};
+  p.A = X; p.B = reinterpret_cast<const float*>(Wplanes); p.bpl = bpl; p.C = Y;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+  p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.vecA = al16(X) && (Cin % 16 == 0);
+  p.vecB = al16(Wplanes) && ((9 * Cin) % 8 == 0) && (bpl % 8 == 0);
+  p.fastA = al16(X) && (Cin % 32 == 0);
+  p.fastB = p.vecB;
+  if (stat_part != nullptr) {
+    p.stat_part = stats_eligible(p) ? stat_part : nullptr;
+    *stat_rows = p.stat_part ? cdiv(p.M, 128) : 0;
+  }
+  return launch_cfg<A_IM2COL, B_NK_PRE>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int tris_set_gemm_mode(int mode) {

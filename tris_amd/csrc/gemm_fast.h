@@ -30,7 +30,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   constexpr int FBK = 32;
   constexpr int LDK = FBK + 4;
   constexpr bool A_RM = (AK != A_COLK);
-  constexpr bool B_RM = (BKIND == B_NK);
+  // B_NK_PRE: the B operand arrives already split -- three bf16 planes [plane][N][K] (weights, split once per step by
+  // tris_weight_planes_f32): 16-byte loads go straight to the LDS planes, no VALU work (x3 only).  MEASURED SLOWER than the
+  // in-kernel split at this kernel's operating point: three half-line (64 B) streams per row triple the
+  // address/tag work of the fp32 full-line stream, and the 8-wave kernel has no registers left to fetch 64-k windows.
+  constexpr bool B_PRE = (BKIND == B_NK_PRE);
+  constexpr bool B_RM = (BKIND == B_NK) || B_PRE;
   constexpr int WM = BM / 2, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PA = BM / RPASS, PB = BN / RPASS;  // float4 per thread per tile
@@ -104,6 +109,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
 
   float4 ra[PA], rb[PB];
+  constexpr int PBP = B_PRE ? (BN * 4 + NTHR - 1) / NTHR : 1;  // 16-byte pieces (8 bf16) per thread per plane per tile
+  uint4 rbp[3][PBP];
+  const unsigned short* bp_src[PBP];
+  if (B_PRE) {
+#pragma unroll
+    for (int q = 0; q < PBP; ++q) {
+      const int row = min(n0 + (tid >> 2) + q * (NTHR / 4), p.N - 1);
+      bp_src[q] = reinterpret_cast<const unsigned short*>(p.B) + (long)row * p.ldb + (tid & 3) * 8;
+    }
+  }
   float rka[A_KM ? A_KPT : 1], rkb[B_KM ? B_KPT : 1];
   const int a_rm = min(m0 + tid % BM, p.M - 1), a_kg = tid / BM;  // x3 row-per-thread coordinates
   const int b_rn = min(n0 + tid % BN, p.N - 1), b_kg = tid / BN;
@@ -138,7 +153,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   };
 
   auto load_B = [&](int k0) {
-    if (BKIND == B_NK) {
+    if (B_PRE) {
+#pragma unroll
+      for (int q = 0; q < PBP; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rbp[pl][q] = *reinterpret_cast<const uint4*>(bp_src[q] + pl * p.bpl + k0);
+    } else if (BKIND == B_NK) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
     } else if (B_KM) {
@@ -223,7 +243,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
       for (int q = 0; q < PA; ++q)
         *reinterpret_cast<float4*>(&As[(tid / AF4 + q * ARPP) * (BM + 4) + (tid % AF4) * 4]) = ra[q];
     }
-    if (B_KM) {
+    if (B_PRE) {
+#pragma unroll
+      for (int q = 0; q < PBP; ++q) {
+        const int row = (tid >> 2) + q * (NTHR / 4);
+        if (PBP * (NTHR / 4) == BN || row < BN) {
+          char* d = reinterpret_cast<char*>(Bs) + row * PLB + (tid & 3) * 16;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(d + pl * BN * PLB) = rbp[pl][q];
+        }
+      }
+    } else if (B_KM) {
 #pragma unroll
       for (int h = 0; h < B_KPT / 8; ++h) {
         const Split8 sp = split8(make_float4(rkb[8 * h], rkb[8 * h + 1], rkb[8 * h + 2], rkb[8 * h + 3]),
@@ -236,7 +266,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     } else if (B_PL) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
+#ifdef TRIS_EXP_NOBSPLIT   // experiment: what a pre-split (weight) operand would save -- raw bits instead of the split
+        Split4 sp;
+        sp.hi = make_uint2(__builtin_bit_cast(unsigned, rb[q].x), __builtin_bit_cast(unsigned, rb[q].y));
+        sp.mid = make_uint2(__builtin_bit_cast(unsigned, rb[q].z), __builtin_bit_cast(unsigned, rb[q].w));
+        sp.lo = sp.hi;
+#else
         const Split4 sp = split4(rb[q]);
+#endif
         char* d = reinterpret_cast<char*>(Bs) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;

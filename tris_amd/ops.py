@@ -197,7 +197,8 @@ def _timed(kind, flops, fn, tag=None):
     a.record()
     r = fn()
     b.record()
-    _PROF.append((kind if tag is None else f"{kind}:{tag}", flops, a, b))
+    if r is not False:   # (False = a *_wp entry point declined the shape: nothing was launched)
+        _PROF.append((kind if tag is None else f"{kind}:{tag}", flops, a, b))
     return r
 
 
@@ -260,6 +261,21 @@ def _attach_stats(y):
     return y
 
 
+def _wp_call(name, *args):
+    """call a *_wp entry point: True if it ran, False if the planes cannot serve this shape (caller falls back)"""
+    err = getattr(_lib.load(), name)(*args)
+    if err == -2:   # TRIS_WP_UNSUPPORTED
+        return False
+    if err != 0:
+        raise _lib.TrisHipError(f"{name} failed with hipError_t {err}")
+    return True
+
+
+def _planes(w):
+    from . import planes
+    return planes.lookup(w)
+
+
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
 class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
@@ -274,7 +290,25 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
         if resid is not None:
             resid = resid.contiguous()
-        if stats and b is None and resid is None and act == 0:
+        wp = _planes(w)
+        want_stats = stats and b is None and resid is None and act == 0
+        done = False
+        if wp is not None:   # weights pre-split into bf16 planes (tris_amd.planes)
+            if want_stats:
+                def launch(part, rows):
+                    nonlocal done
+                    done = _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
+                        "tris_gemm_wp_f32", P(x), wp[0], wp[1], P(y), M, N, K, None, None, 0, None, 0, part.data_ptr(),
+                        rows, _stream()))
+                _launch_with_stats(y, M, N, launch)
+            else:
+                ws = workspace(0)
+                done = _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
+                    "tris_gemm_wp_f32", P(x), wp[0], wp[1], P(y), M, N, K, P(b), P(resid), act, P(ws), ws.numel() * 4,
+                    None, None, _stream()))
+        if done:
+            pass
+        elif want_stats:
             _launch_with_stats(y, M, N, lambda part, rows: _timed(
                 "gemm", 2.0 * M * N * K, lambda: call("tris_gemm_bnstat_f32", P(x), P(w), P(y), M, N, K, part.data_ptr(),
                                                       rows, _stream())))
@@ -307,7 +341,12 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dy, w, dx, M, K, N, N, K, K, False, False)
+            wp = _planes(pw)
+            ws = workspace(0)
+            if wp is None or not _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
+                    "tris_gemm_wp_f32", P(dy), wp[2], wp[3], P(dx), M, K, N, None, None, 0, P(ws), ws.numel() * 4, None,
+                    None, _stream())):
+                gemm(dy, w, dx, M, K, N, N, K, K, False, False)
         dw = None
         if ctx.needs_input_grad[1]:
             if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
@@ -430,7 +469,22 @@ class Conv3x3Fn(torch.autograd.Function):
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
         fl = 2.0 * B * Ho * Wo * Cout * 9 * Cin
-        if stats:
+        wp = _planes(ctx.params[0])
+        done = False
+        if wp is not None:
+            if stats:
+                def launch(part, rows):
+                    nonlocal done
+                    done = _timed("conv3x3_fwd", fl, lambda: _wp_call(
+                        "tris_conv3x3_wp_fwd_f32", P(x), wp[0], wp[1], P(y), B, H, W, Cin, Cout, stride, part.data_ptr(),
+                        rows, _stream()))
+                _launch_with_stats(y, B * Ho * Wo, Cout, launch)
+            else:
+                done = _timed("conv3x3_fwd", fl, lambda: _wp_call(
+                    "tris_conv3x3_wp_fwd_f32", P(x), wp[0], wp[1], P(y), B, H, W, Cin, Cout, stride, None, None, _stream()))
+        if done:
+            pass
+        elif stats:
             _launch_with_stats(y, B * Ho * Wo, Cout, lambda part, rows: _timed(
                 "conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnstat_f32", P(x), P(w), P(y), B, H, W, Cin, Cout,
                                                 stride, part.data_ptr(), rows, _stream())))
@@ -452,8 +506,13 @@ class Conv3x3Fn(torch.autograd.Function):
             if ctx.stride != 1:
                 raise NotImplementedError("dgrad of the strided stem conv is never needed (its input is the image)")
             dx = torch.empty_like(x)
-            _timed("conv3x3_dgrad", 2.0 * B * H * W * Cout * 9 * Cin,
-                   lambda: call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))
+            wp = _planes(ctx.params[0])
+            fl = 2.0 * B * H * W * Cout * 9 * Cin
+            # with the transposed, tap-mirrored planes the data gradient is a plain 3x3 convolution of dY
+            if wp is None or not _timed("conv3x3_dgrad", fl, lambda: _wp_call(
+                    "tris_conv3x3_wp_fwd_f32", P(dy), wp[2], wp[3], P(dx), B, H, W, Cout, Cin, 1, None, None, _stream())):
+                _timed("conv3x3_dgrad", fl,
+                       lambda: call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))
 
         def wgrad(o):
             ws = workspace(0)

@@ -66,11 +66,34 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     return losses, cls, sig_out
 
 
+def _weight_planes(module, frozen):
+    """pre-split bf16 planes of a module's weight matrices (tris_amd.planes), built on first use.  Opt-in
+    (TRIS_WEIGHT_PLANES=1): correct and tested, but measured slower than the in-kernel split with the current GEMM core."""
+    from .planes import WeightPlanes
+    if os.environ.get("TRIS_WEIGHT_PLANES", "0") != "1" or ops.get_gemm_mode() != "x3":
+        return None
+    net = module.module if hasattr(module, "module") else module
+    wp = getattr(net, "_tris_weight_planes", None)
+    if wp is None:
+        wp = WeightPlanes(list(net.named_parameters()), frozen=frozen)
+        net._tris_weight_planes = wp
+    return wp
+
+
 def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, lr_scheduler=None, reducer=None):
     """One optimisation step; returns the device tensor losses[4] (no host sync)."""
-    losses, _, _ = stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args)
-    optimizer.zero_grad()
-    losses[0].backward()
+    import contextlib
+    from .planes import WeightPlanes
+    wp = _weight_planes(model, frozen=False)
+    wa = _weight_planes(clip_model, frozen=True)
+    if wp is not None:
+        wp.refresh()          # trainable set: every step (the weights are constant from here to the end of backward)
+    if wa is not None:
+        wa.ensure()           # frozen set: once, or again if its storage moved / a parameter was written to
+    with (WeightPlanes.active() if (wp is not None or wa is not None) else contextlib.nullcontext()):
+        losses, _, _ = stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args)
+        optimizer.zero_grad()
+        losses[0].backward()
     if reducer is not None:
         reducer.reduce()
     optimizer.step()
