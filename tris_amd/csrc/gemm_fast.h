@@ -31,9 +31,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   constexpr int LDK = FBK + 4;
   constexpr bool A_RM = (AK != A_COLK);
   // B_NK_PRE: the B operand arrives already split -- three bf16 planes [plane][N][K] (weights, split once per step by
-  // tris_weight_planes_f32): 16-byte loads go straight to the LDS planes, no VALU work (x3 only).  MEASURED SLOWER than the
-  // in-kernel split at this kernel's operating point: three half-line (64 B) streams per row triple the
-  // address/tag work of the fp32 full-line stream, and the 8-wave kernel has no registers left to fetch 64-k windows.
+  // tris_weight_planes_f32): 16-byte loads go straight to the LDS planes, no VALU work (x3 only).  Measured ON PAR with the
+  // in-kernel split at this kernel's operating point: three half-line (64 B) streams per row cost in address/tag
+  // work what the split saves in VALU, and the 8-wave kernel has no registers left to fetch full-line 64-k windows.
   constexpr bool B_PRE = (BKIND == B_NK_PRE);
   constexpr bool B_RM = (BKIND == B_NK) || B_PRE;
   constexpr int WM = BM / 2, WN = BN / NWN;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 
   float4 ra[PA], rb[PB];
   constexpr int PBP = B_PRE ? (BN * 4 + NTHR - 1) / NTHR : 1;  // 16-byte pieces (8 bf16) per thread per plane per tile
-  uint4 rbp[3][PBP];
+  float4 rbp[3 * PBP];  // (a flat float4 array: the 2-D uint4 form was not promoted to registers)
   const unsigned short* bp_src[PBP];
   if (B_PRE) {
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
       for (int q = 0; q < PBP; ++q)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rbp[pl][q] = *reinterpret_cast<const uint4*>(bp_src[q] + pl * p.bpl + k0);
+        for (int pl = 0; pl < 3; ++pl) rbp[pl * PBP + q] = ld4(reinterpret_cast<const float*>(bp_src[q] + pl * p.bpl + k0));
     } else if (BKIND == B_NK) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         if (PBP * (NTHR / 4) == BN || row < BN) {
           char* d = reinterpret_cast<char*>(Bs) + row * PLB + (tid & 3) * 16;
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(d + pl * BN * PLB) = rbp[pl][q];
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
         }
       }
     } else if (B_KM) {
