@@ -181,11 +181,19 @@ def main():
 
     # PMC-derived HBM traffic of the same kernel family (separate rocprofv3 --pmc passes, committed under profiles/)
     try:
-        pmc_file = "r1j_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
+        pmc_file = "r1o_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["gemm_family"]
         roof["traffic"] = int((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / pmc["launches_per_step"])
         roof["traffic_note"] = ("bytes per launch, averaged over the family: (FETCH_SIZE x2 + WRITE_SIZE) per step / launches per "
                                 f"step from profiles/{pmc_file} (rocprofv3 --pmc, B=48 step)")
+    except Exception:
+        pass
+    try:   # matrix-pipe utilisation of the family from the SQ counters (separate --pmc pass, committed under profiles/)
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r1o_pmc_mfma_util.json")))
+        if mode == "x3":
+            roof["mfma_utilisation_pmc"] = sq["families"]["gemm_family"]["mfma_utilisation"]
+            roof["mfma_utilisation_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family, "
+                                             "profiles/r1o_pmc_mfma_util.json (rocprofv3 --pmc, kernels serialised)")
     except Exception:
         pass
     roof_x = None
