@@ -55,6 +55,7 @@ constexpr int BK = 16;
 constexpr int PAD = 4;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <int BM, int BN, int AK, int BKIND, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
@@ -368,21 +369,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-// Sum split-K slabs (ws[s][M][N]) and apply the standard epilogue.
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmParams p) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)p.M * p.N;
+// Sum split-K slabs (ws[s][M][N]) and apply the standard epilogue.  VEC = 4: one thread owns 4 consecutive columns of a
+// row (16-byte loads, 4 slabs in flight per trip) -- the reduce is a pure HBM/L2 stream and runs a few hundred times per step.
+template <int VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmParams p) {
+  const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  const long total = (long)p.M * p.N;
   if (idx >= total) return;
-  float v = 0.f;
-  for (int s = 0; s < S; ++s) v += ws[(long)s * total + idx];
-  int row = (int)(idx / p.N), col = (int)(idx - (long)row * p.N);
-  v *= p.alpha;
-  if (p.bias_mode == 1) v += p.bias[col];
-  else if (p.bias_mode == 2) v += p.bias[row];
-  if (p.act == 1) v = fmaxf(v, 0.f);
-  else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
-  if (p.resid) v += p.resid[(long)row * p.ldr + col];
-  p.C[(long)row * p.ldc + col] = v;
+  float v[VEC];
+#pragma unroll
+  for (int t = 0; t < VEC; ++t) v[t] = 0.f;
+  if (VEC == 4) {
+    int s = 0;
+    for (; s + 3 < S; s += 4) {  // fixed summation order s = 0, 1, 2, ... (deterministic)
+      const float4 a = ld4(ws + (long)s * total + idx), b = ld4(ws + (long)(s + 1) * total + idx);
+      const float4 c = ld4(ws + (long)(s + 2) * total + idx), d = ld4(ws + (long)(s + 3) * total + idx);
+      v[0] = (((v[0] + a.x) + b.x) + c.x) + d.x;
+      v[1] = (((v[1] + a.y) + b.y) + c.y) + d.y;
+      v[2] = (((v[2] + a.z) + b.z) + c.z) + d.z;
+      v[3] = (((v[3] + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; s < S; ++s) {
+      const float4 a = ld4(ws + (long)s * total + idx);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    }
+  } else {
+    for (int s = 0; s < S; ++s) v[0] += ws[(long)s * total + idx];
+  }
+  const int row = (int)(idx / p.N), col0 = (int)(idx - (long)row * p.N);
+#pragma unroll
+  for (int t = 0; t < VEC; ++t) {
+    const int col = col0 + t;
+    float x = v[t] * p.alpha;
+    if (p.bias_mode == 1) x += p.bias[col];
+    else if (p.bias_mode == 2) x += p.bias[row];
+    if (p.act == 1) x = fmaxf(x, 0.f);
+    else if (p.act == 2) x = x / (1.0f + expf(-1.702f * x));
+    if (p.resid) x += p.resid[(long)row * p.ldr + col];
+    v[t] = x;
+  }
+  if (VEC == 4 && (p.ldc & 3) == 0)
+    *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+  else
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) p.C[(long)row * p.ldc + col0 + t] = v[t];
 }
 
 // arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy)
@@ -493,7 +523,11 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   if (splitk > 1) {
     p.C = Cfinal;
     long total = (long)p.M * p.N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, splitk, p);
+    static const bool vec_ok = !(getenv("TRIS_REDUCE_VEC") && getenv("TRIS_REDUCE_VEC")[0] == '0');  // developer A/B knob
+    if (vec_ok && (p.N & 3) == 0 && al16(ws) && al16(p.C))
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, ws, splitk, p);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, splitk, p);
     TRIS_LAUNCH_CHECK();
   }
   return 0;
@@ -579,7 +613,6 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
 }
 
 
-inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
