@@ -558,3 +558,83 @@ def test_tris_vit_b16_forward_matches_oracle_and_trains(aux):
     losses = train_step(m, aux, opt, b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda(), args).tolist()
     assert all(np.isfinite(losses))
     assert float((m.backbone.visual.positional_embedding.detach() - before).abs().max()) > 0   # the trunk is trained
+
+
+# ---- (e) multi-GPU exchange steps on the GPU box ---------------------------------------------------------------------
+def test_sync_bn_combine_kernel_equals_full_batch_statistics():
+    """tris_bn_sync_combine_f32: per-rank (mean | invstd | biased var) blocks of W equal shards -> the statistics of the
+    concatenated batch (what SyncBatchNorm computes), for 2 and 8 simulated ranks"""
+    from tris_amd import ops
+    torch.manual_seed(0)
+    C, per = 64, 600
+    for world in (2, 8):
+        x = torch.randn(world * per, C, dtype=torch.float64) * 2.0 + 0.5
+        shards = x.view(world, per, C)
+        mean_r = shards.mean(1)
+        var_r = shards.var(1, unbiased=False)
+        gathered = torch.cat([mean_r, 1.0 / torch.sqrt(var_r + 1e-5), var_r], dim=1).float().contiguous().cuda()  # [W, 3C]
+        stats = torch.empty(3 * C, device="cuda")
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        ops.call("tris_bn_sync_combine_f32", ops.P(gathered), world, C, per, 1e-5, 0.1, ops.P(stats), ops.P(rm), ops.P(rv),
+                 ops._stream())
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+        s = stats.cpu().double()
+        assert float((s[:C] - mean).abs().max()) < 1e-5
+        assert float((s[2 * C:] - var).abs().max()) < 1e-4
+        assert float((s[C:2 * C] - 1.0 / torch.sqrt(var + 1e-5)).abs().max()) < 1e-4
+        n = world * per
+        assert float((rm.cpu().double() - 0.1 * mean).abs().max()) < 1e-5
+        assert float((rv.cpu().double() - (0.9 + 0.1 * var * n / (n - 1))).abs().max()) < 1e-4
+
+
+def test_rccl_code_path_single_rank(model, aux, batch, golden):
+    """SyncBatchNorm collectives + the backward-overlapped gradient all-reduce executed over RCCL with a one-rank group
+    (the multi-GPU code path, on the one GPU the test box has): same losses as the golden step, same gradients as the
+    plain path."""
+    import os
+    import torch.distributed as dist
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.parallel import GradReducer, stage1_segments
+    from tris_amd.CLIP.clip.model import BatchNorm2d
+    from tris_amd.train_stage1 import train_step
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = golden("g5_g6_step.npz")
+        args = _args()
+        grads = {}
+        for sync in (False, True):
+            refill(model)
+            model.train()
+            for m in model.modules():
+                if isinstance(m, BatchNorm2d):
+                    m.process_group = dist.group.WORLD if sync else None
+            bb, new = model.trainable_parameters()
+            opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                             weight_decay=args.weight_decay)
+            reducer = None
+            if sync:
+                reducer = GradReducer([a.g for a in opt.arenas], force=True)
+                reducer.set_segments(stage1_segments(model, opt))
+                model.backbone.visual.grad_reducer = reducer
+            losses = train_step(model, aux, opt, batch["img"].cuda(), batch["word_ids"].cuda(),
+                                batch["neg_word_ids"].cuda(), args, reducer=reducer).tolist()
+            ref = g["losses"]
+            assert abs(losses[0] - ref[0]) < TOL and abs(losses[2] - ref[2]) < 1e-4 and abs(losses[3] - ref[3]) < 1e-4
+            grads[sync] = [a.g.detach().clone() for a in opt.arenas]
+        for a, b in zip(grads[False], grads[True]):
+            # same step through the collectives.  Not bit-equal: the synced statistics are combined from per-rank
+            # (mean, var) in a different arithmetic order, and ~50 train-mode BatchNorms at batch 2 amplify that round-off
+            # to the percent level element-wise (see test_gradients_vs_fp64_noise_floor) -- direction and size must agree
+            cos = float((a * b).sum() / (a.norm() * b.norm()))
+            assert cos > 0.999 and float((a - b).norm()) <= 5e-2 * float(a.norm()), (cos, float((a - b).norm()), float(a.norm()))
+    finally:
+        for m in model.modules():
+            if isinstance(m, BatchNorm2d):
+                m.process_group = None
+        model.backbone.visual.grad_reducer = None
+        dist.destroy_process_group()
+        refill(model)
