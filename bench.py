@@ -117,6 +117,7 @@ def main():
     def step():
         return train_step(model, aux, opt, img, ids, neg, args, sched, reducer)
 
+    step()   # one untimed priming step, always: first-encounter GEMM autotuning, allocator growth, RCCL channel set-up
     for _ in range(a.warmup):
         step()
     if world > 1:
@@ -221,7 +222,7 @@ def main():
                                        "configs[4]; the reference defines no such model: parity unpinned, DESIGN.md)"),
                           "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": 20,
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
-               "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
+               "untimed_priming_steps": 1, "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
                "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
                            "weight_gradients_on_side_stream": os.environ.get("TRIS_WGRAD_STREAM", "1") != "0"},
                "roofline": roof, "roofline_xattn": roof_x}
