@@ -14,6 +14,8 @@ be constructed, moved and (de)serialised anywhere, `forward` needs the GPU.
 """
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -32,9 +34,10 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, stats=False):  # x channels-last [B,H,W,Cin]; stats: fuse the following BatchNorm's statistics
+    def forward(self, x, stats=False, grad_box=None):
+        """x channels-last [B,H,W,Cin]; stats: fuse the following BatchNorm's statistics; grad_box: ops.GradBox of the block"""
         if self.k == 1:
-            return ops.linear(x, self.weight, self.bias, stats=stats and self.bias is None)
+            return ops.linear(x, self.weight, self.bias, stats=stats and self.bias is None, grad_box=grad_box)
         assert self.k == 3 and self.bias is None
         return ops.conv3x3(x, self.weight, self.stride, stats=stats)
 
@@ -52,12 +55,12 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.process_group = None
 
-    def forward(self, x, resid=None, relu=False):
+    def forward(self, x, resid=None, relu=False, grad_box=None):
         if self.training:
             self.num_batches_tracked += 1
         group = self.process_group if self.training else None
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
-                              self.training, self.momentum, self.eps, group)
+                              self.training, self.momentum, self.eps, group, grad_box)
 
 
 class AvgPool2d(nn.Module):
@@ -93,7 +96,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):  # channels-last
         tr = self.training  # train mode: BatchNorm batch statistics come out of the producing conv's epilogue
-        out = self.bn1(self.conv1(x, stats=tr), relu=True)
+        # identity block: x feeds conv1 and the residual add; the residual gradient rides conv1's data-gradient epilogue
+        box = ops.GradBox() if (self.downsample is None and tr and torch.is_grad_enabled() and x.requires_grad
+                               and os.environ.get("TRIS_GRAD_BOX", "1") != "0") else None
+        out = self.bn1(self.conv1(x, stats=tr, grad_box=box), relu=True)
         out = self.bn2(self.conv2(out, stats=tr), relu=True)
         out = self.avgpool(out)
         out = self.conv3(out, stats=tr)
@@ -102,7 +108,7 @@ class Bottleneck(nn.Module):
             idn = self.downsample[2](self.downsample[1](idn, stats=tr))
         else:
             idn = x
-        return self.bn3(out, resid=idn, relu=True)  # relu(bn3(conv3) + identity), fused
+        return self.bn3(out, resid=idn, relu=True, grad_box=box)  # relu(bn3(conv3) + identity), fused
 
 
 class Linear(nn.Module):

@@ -276,13 +276,26 @@ def _planes(w):
     return planes.lookup(w)
 
 
+class GradBox:
+    """Hand-off of a residual-branch gradient inside one block.  In `out = relu(bn3(f(x)) + x)` the tensor x has two
+    consumers (f's first conv and the residual input of bn3); autograd would sum their two gradients with an extra
+    elementwise pass over the activation.  Instead bn3's backward -- which always runs before the first conv's, because
+    the latter depends on it through f -- leaves its residual gradient here, and the first conv's data-gradient GEMM adds
+    it in its epilogue (`resid`).  Used by the identity Bottlenecks of the RN50 trunk."""
+    __slots__ = ("value",)
+
+    def __init__(self):
+        self.value = None
+
+
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
 class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, act, stats=False):
+    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None):
         _chk(x, w, b, resid)
+        ctx.grad_box = grad_box
         x = x.contiguous()
         K = x.shape[-1]
         N = w.numel() // K
@@ -339,14 +352,20 @@ class LinearFn(torch.autograd.Function):
         if ctx.act == 1:
             dy = ew("TRIS_EW_RELU_BWD", dy, y)
         dx = None
+        box = ctx.grad_box
+        extra = None   # a residual-branch gradient left by a later layer of the same block: added in the GEMM epilogue
+        if box is not None and box.value is not None:
+            extra, box.value = box.value, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp = _planes(pw)
             ws = workspace(0)
             if wp is None or not _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
-                    "tris_gemm_wp_f32", P(dy), wp[2], wp[3], P(dx), M, K, N, None, None, 0, P(ws), ws.numel() * 4, None,
+                    "tris_gemm_wp_f32", P(dy), wp[2], wp[3], P(dx), M, K, N, None, P(extra), 0, P(ws), ws.numel() * 4, None,
                     None, _stream())):
-                gemm(dy, w, dx, M, K, N, N, K, K, False, False)
+                gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K)
+        elif extra is not None:
+            raise RuntimeError("a residual gradient was handed to a layer whose input needs no gradient")
         dw = None
         if ctx.needs_input_grad[1]:
             if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
@@ -356,11 +375,11 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
-        return dx, dw, db, d_res, None, None
+        return dx, dw, db, d_res, None, None, None
 
 
-def linear(x, w, b=None, resid=None, act=0, stats=False):
-    y = LinearFn.apply(x, w, b, resid, act, stats)
+def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None):
+    y = LinearFn.apply(x, w, b, resid, act, stats, grad_box)
     return _attach_stats(y) if stats else y
 
 
@@ -542,7 +561,7 @@ class BatchNormFn(torch.autograd.Function):
     SyncBatchNorm).  training=False: running statistics (forward only)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None):
+    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None, grad_box=None):
         _chk(x, gamma, beta, rmean, rvar, resid)
         x = x.contiguous()
         C = x.shape[-1]
@@ -579,6 +598,7 @@ class BatchNormFn(torch.autograd.Function):
         call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
              _stream())
         ctx.cfg = (M, C, bool(relu), resid is not None, count, group)
+        ctx.grad_box = grad_box
         ctx.params = (gamma, beta)
         ctx.training = bool(training)
         if training:
@@ -622,12 +642,15 @@ class BatchNormFn(torch.autograd.Function):
                 d_res = torch.empty_like(x)
             call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
                  1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, _stream())
-        return dx, dg, db, None, None, d_res, None, None, None, None, None, None
+        if ctx.grad_box is not None and d_res is not None:   # hand the residual gradient to the block's first conv
+            ctx.grad_box.value, d_res = d_res, None
+        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None):
+def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
+               grad_box=None):
     part = getattr(x, "_bn_part", None) if training else None
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part)
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box)
 
 
 class AvgPool2Fn(torch.autograd.Function):
