@@ -138,3 +138,15 @@ def test_gradient_segments_cover_the_arenas_in_backward_order():
     assert cover == [arenas[0].numel, arenas[1].numel]
     assert len(seg["layer4"]) == 1 and len(seg["layer1"]) == 1 and len(seg["stem"]) == 1
     assert seg["heads_text"][-1][0] == 1 and seg["heads_text"][-1][1:] == (0, arenas[1].numel)
+
+
+def test_batchnorm_step_counter_is_flushed_when_observed():
+    """num_batches_tracked is counted on the host during training and materialised in state_dict / reset by load"""
+    from tris_amd.CLIP.clip.model import BatchNorm2d
+    m = BatchNorm2d(8)
+    m._nbt_pending = 3                      # what three training forwards leave behind
+    sd = m.state_dict()
+    assert int(sd["num_batches_tracked"]) == 3 and m._nbt_pending == 0
+    m._nbt_pending = 2
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert int(m.num_batches_tracked) == 3 and m._nbt_pending == 0

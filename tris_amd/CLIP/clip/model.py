@@ -54,10 +54,21 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.process_group = None
+        # The step counter is bookkeeping only (momentum is fixed): a 1-element device add per layer per step is 55 extra
+        # launches on the critical stream, so forward counts on the host and the buffer is brought up to date whenever
+        # it can be observed (state_dict / checkpoint) or replaced (load_state_dict).
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m.flush_batches_tracked())
+        self.register_load_state_dict_post_hook(lambda m, incompatible: setattr(m, "_nbt_pending", 0))
+
+    def flush_batches_tracked(self):
+        if self._nbt_pending:
+            self.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
 
     def forward(self, x, resid=None, relu=False, grad_box=None):
         if self.training:
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1
         group = self.process_group if self.training else None
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
                               self.training, self.momentum, self.eps, group, grad_box)
