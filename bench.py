@@ -167,12 +167,15 @@ def main():
     one = (time.perf_counter() - t1) * 1e3
     ach = fl / (ms * 1e-3) / 1e12
     mode = ops.get_gemm_mode()
-    peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
+    peak = F32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / (6.0 if mode == "x3" else 3.0)
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": None,
             "arithmetic": ("v_mfma_f32_32x32x2_f32 (f32 in)" if mode == "f32" else
                            "split-bf16 x3: 6 x v_mfma_f32_32x32x16_bf16 per fp32-accurate product; achieved/peak are in "
-                           "fp32-equivalent FLOPs (peak = 2500 TFLOP/s bf16 dense / 6; the f32-input MFMA peak is 157.3)"),
+                           "fp32-equivalent FLOPs (peak = 2500 TFLOP/s bf16 dense / 6; the f32-input MFMA peak is 157.3)"
+                           if mode == "x3" else
+                           "split-bf16 x2 (opt-in throughput mode): 3 x v_mfma_f32_32x32x16_bf16 per product, 16-bit significands; "
+                           "peak = 2500 / 3"),
             "kernel": "gemm_fast_kernel<BM,BN,A,B,EPI,PREC> (MFMA GEMM / implicit-GEMM conv family)",
             "launches_per_step": len(rec), "kernel_ms_per_step": round(ms, 3),
             "algorithmic_gflop_per_step": round(fl / 1e9, 1),
@@ -204,7 +207,7 @@ def main():
         xms = sum(r[2] for r in xa)
         roof_x = {"bound": "hbm", "achieved": round(xbytes / (xms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(xbytes / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                  "kernel": ("xattn_scores_x3_kernel + xattn_out_x3_kernel" if mode == "x3" else
+                  "kernel": ("xattn_scores_x3_kernel + xattn_out_x3_kernel" if mode in ("x3", "x2") else
                              "xattn_scores_kernel + xattn_colsoftmax_kernel + xattn_out_kernel") +
                             " (fused bilateral cross attention, forward, all launches, HIP events around the call)",
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),

@@ -35,7 +35,8 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
 /* Arithmetic of the dense-product kernels (process-wide): 0 = v_mfma_f32_32x32x2_f32 (f32 in, bit-equal to an fmaf chain);
  * 1 = split-bf16 "x3": every fp32 operand is the exact sum of three bf16 pieces, the six significant piece products
  * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -> fp32-class accuracy (measured: error vs fp64 <= the f32-MFMA
- * path's) at up to 2.6x the f32-MFMA peak.  Default: 1. */
+ * path's) at up to 2.6x the f32-MFMA peak;  2 = split-bf16 "x2": two pieces, three products (16-bit significands, relative
+ * product error <= 2^-15 -- between fp32 and TF32): an opt-in throughput mode.  Default: 1. */
 int tris_set_gemm_mode(int mode);
 /* Pre-split weight operands (x3 arithmetic).  tris_weight_planes_f32 splits weight matrices once per optimiser step into
  * three bf16 planes P[pl][r*ld + c] (same indexing as the fp32 source) and the transposed planes PT[pl][c*pt_ld + r] the

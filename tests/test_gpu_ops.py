@@ -529,3 +529,30 @@ def test_linear_and_conv_with_weight_planes_match_plain_path():
         y2 = o.linear(x, w, b, act=1)
     ref = torch.relu(x.detach() @ w.detach().t() + b.detach())
     assert float((y2 - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_x2_throughput_mode_is_tf32_class_accurate():
+    """The opt-in 'x2' arithmetic (two bf16 pieces per operand, three MFMAs per product): products carry 16-bit significands,
+    so dense results sit between fp32 and TF32 accuracy -- checked against an fp64 product, and against the x3 default."""
+    from tris_amd import ops as o
+    prev = o.get_gemm_mode()
+    torch.manual_seed(0)
+    A, B = torch.randn(384, 1024), torch.randn(256, 1024)
+    ref = (A.double() @ B.double().t())
+    x = torch.randn(2, 16, 16, 64)
+    w = (torch.randn(64, 64, 3, 3) * 0.05).contiguous(memory_format=torch.channels_last)
+    cref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    errs = {}
+    try:
+        for mode in ("x3", "x2"):
+            o.set_gemm_mode(mode)
+            C = torch.empty(384, 256, device="cuda")
+            o.gemm(A.cuda(), B.cuda(), C, 384, 256, 1024, 1024, 1024, 256, False, True)
+            y = o.conv3x3(x.cuda(), w.cuda(), 1)
+            errs[mode] = (float((C.cpu().double() - ref).abs().max() / ref.abs().max()),
+                          float((y.cpu().double() - cref).abs().max() / cref.abs().max()))
+    finally:
+        o.set_gemm_mode(prev)
+    assert errs["x3"][0] < 2e-6 and errs["x3"][1] < 2e-6          # fp32 class
+    assert errs["x2"][0] < 1e-4 and errs["x2"][1] < 1e-4          # ~2^-15 per product, averaged down over K
+    assert errs["x2"][0] > errs["x3"][0]                          # (and really is the coarser mode)

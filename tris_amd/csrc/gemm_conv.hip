@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int t = 0; t < VEC; ++t) p.C[(long)row * p.ldc + col0 + t] = v[t];
 }
 
-// arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy)
+// arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy),
+// 2 = split-bf16 x2 (3 bf16 MFMAs per product, 16-bit significands: between fp32 and TF32)
 static int g_gemm_mode = 1;
 static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")) == 4) ? 4 : 8;  // waves per 128x128 x3 block
 
@@ -453,7 +454,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
       if (c == 0 && p.N <= 64) continue;
       const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
       // MFMA cycles of one 32x32 fragment pair per 32-deep step: 16 f32 MFMAs x 64, or 12 bf16 MFMAs x 32 (x3 mode)
-      const double per_k32 = (cbm / 64) * (cbn / 64) * (g_gemm_mode == 1 ? 384.0 + 250.0 : 1024.0) * pen[c];
+      const double per_k32 = (cbm / 64) * (cbn / 64) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 2 ? 192.0 + 200.0 : 1024.0) * pen[c];
       const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
       for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
         if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
@@ -489,24 +490,26 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   if (splitk > 1) splitk = cdiv(p.K, p.kchunk), p.splitk = splitk;
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(batch * splitk));
   float* Cfinal = p.C;
+#define TRIS_FAST(BM_, BN_, EPI_, PREC_)                                                                              \
+  do {                                                                                                                 \
+    if (BM_ == 128 && BN_ == 128 && g_x3_waves == 8)                                                                    \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, \
+                         dim3(512), 0, st, p);                                                                         \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_>), grid, dim3(256), 0, st, p);               \
+  } while (0)
 #define TRIS_GO(BM_, BN_)                                                                          \
   do {                                                                                             \
     if (fast) {                                                                                    \
       if (splitk > 1) {                                                                            \
         p.C = ws;                                                                                  \
-        if (g_gemm_mode == 1 && BM_ == 128 && BN_ == 128 && g_x3_waves == 8)                       \
-          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 1, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, dim3(512), 0, st, p); \
-        else if (g_gemm_mode == 1)                                                                 \
-          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 1>), grid, dim3(256), 0, st, p); \
-        else                                                                                       \
-          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 0>), grid, dim3(256), 0, st, p); \
+        if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_SLAB, 1);                                    \
+        else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_SLAB, 2);                               \
+        else hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 0>), grid, dim3(256), 0, st, p); \
       } else {                                                                                     \
-        if (g_gemm_mode == 1 && BM_ == 128 && BN_ == 128 && g_x3_waves == 8)                       \
-          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 1, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, dim3(512), 0, st, p);  \
-        else if (g_gemm_mode == 1)                                                                 \
-          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 1>), grid, dim3(256), 0, st, p);  \
-        else                                                                                       \
-          hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 0>), grid, dim3(256), 0, st, p);  \
+        if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_STD, 1);                                     \
+        else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_STD, 2);                                \
+        else hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 0>), grid, dim3(256), 0, st, p);  \
       }                                                                                            \
     } else if (splitk > 1) {                                                                       \
       p.C = ws;                                                                                    \
@@ -519,6 +522,7 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   else if (bm == 128 && bn == 64) TRIS_GO(128, 64);
   else TRIS_GO(64, 64);
 #undef TRIS_GO
+#undef TRIS_FAST
   TRIS_LAUNCH_CHECK();
   if (splitk > 1) {
     p.C = Cfinal;
@@ -554,7 +558,7 @@ static bool autotune_enabled() {
 
 template <int AK, int BKIND>
 int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
-  if (BKIND == B_NK_PRE && !(g_gemm_mode == 1 && p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4 && batch == 1))
+  if (BKIND == B_NK_PRE && !(g_gemm_mode >= 1 && p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4 && batch == 1))
     return TRIS_WP_UNSUPPORTED;  // pre-split operands exist only for the fast x3 kernel: the caller falls back to fp32 B
   Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
   if (p.stat_part != nullptr || !autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
@@ -834,7 +838,7 @@ extern "C" int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long
 }
 
 extern "C" int tris_set_gemm_mode(int mode) {
-  if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
+  if (mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
   g_gemm_mode = mode;
   return 0;
 }

@@ -42,15 +42,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   // x3 mode: every operand is split into its three bf16 pieces ONCE, when the tile is stored: the LDS image is three
   // bf16 planes [plane][row][32 + 8 pad] (row stride 80 B = 5 sixteen-byte slots -> conflict-free ds_read_b128), i.e.
   // 60 floats' worth per row.
-  constexpr bool A_PL = (PREC == 1), B_PL = (PREC == 1);
+  // PREC 1 = x3 (three bf16 pieces, six products: fp32-class); PREC 2 = x2 (two pieces, three products hi.hi + hi.mid + mid.hi:
+  // 16 significand bits per operand, relative product error <= 2^-15 -- between fp32 and TF32; planes shrink to 4 B/element)
+  constexpr bool A_PL = (PREC >= 1), B_PL = (PREC >= 1);
+  constexpr int NPLN = PREC == 2 ? 2 : 3;  // bf16 planes per operand
   // x3 staging of the m-/n-contiguous operands ("row per thread"): thread -> one row (m or n) and KPT consecutive k,
   // loaded with scalar loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), split once, and written as
   // 16-byte bf16 runs into the same [plane][row][k] image the k-contiguous operands use
-  constexpr bool A_KM = (PREC == 1) && !A_RM, B_KM = (PREC == 1) && !B_RM;
+  constexpr bool A_KM = (PREC >= 1) && !A_RM, B_KM = (PREC >= 1) && !B_RM;
   constexpr int A_KG = NTHR / BM, A_KPT = 32 / A_KG, B_KG = NTHR / BN, B_KPT = 32 / B_KG;
   constexpr int PLB = 80;  // bytes per row of one bf16 plane
-  constexpr int A_SZ = A_PL ? BM * 60 : (A_RM ? BM * LDK : FBK * (BM + 4));
-  constexpr int B_SZ = B_PL ? BN * 60 : (B_RM ? BN * LDK : FBK * (BN + 4));
+  constexpr int A_SZ = A_PL ? BM * 20 * NPLN : (A_RM ? BM * LDK : FBK * (BM + 4));
+  constexpr int B_SZ = B_PL ? BN * 20 * NPLN : (B_RM ? BN * LDK : FBK * (BN + 4));
   __shared__ __attribute__((aligned(16))) float As[A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
 
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
       for (int q = 0; q < PBP; ++q)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rbp[pl * PBP + q] = ld4(reinterpret_cast<const float*>(bp_src[q] + pl * p.bpl + k0));
+        for (int pl = 0; pl < NPLN; ++pl) rbp[pl * PBP + q] = ld4(reinterpret_cast<const float*>(bp_src[q] + pl * p.bpl + k0));
     } else if (BKIND == B_NK) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         char* d = reinterpret_cast<char*>(As) + (tid % BM) * PLB + (a_kg * A_KPT + 8 * h) * 2;
         *reinterpret_cast<bf16x8*>(d) = sp.hi;
         *reinterpret_cast<bf16x8*>(d + BM * PLB) = sp.mid;
-        *reinterpret_cast<bf16x8*>(d + 2 * BM * PLB) = sp.lo;
+        if (NPLN == 3) *reinterpret_cast<bf16x8*>(d + 2 * BM * PLB) = sp.lo;
       }
     } else if (A_PL) {
 #pragma unroll
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         char* d = reinterpret_cast<char*>(As) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
-        *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
+        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
       }
     } else if (A_RM) {
 #pragma unroll
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         if (PBP * (NTHR / 4) == BN || row < BN) {
           char* d = reinterpret_cast<char*>(Bs) + row * PLB + (tid & 3) * 16;
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
+          for (int pl = 0; pl < NPLN; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
         }
       }
     } else if (B_KM) {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         char* d = reinterpret_cast<char*>(Bs) + (tid % BN) * PLB + (b_kg * B_KPT + 8 * h) * 2;
         *reinterpret_cast<bf16x8*>(d) = sp.hi;
         *reinterpret_cast<bf16x8*>(d + BN * PLB) = sp.mid;
-        *reinterpret_cast<bf16x8*>(d + 2 * BN * PLB) = sp.lo;
+        if (NPLN == 3) *reinterpret_cast<bf16x8*>(d + 2 * BN * PLB) = sp.lo;
       }
     } else if (B_PL) {
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         char* d = reinterpret_cast<char*>(Bs) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
-        *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
+        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
       }
     } else if (B_RM) {
 #pragma unroll
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
             const char* s0 = reinterpret_cast<const char*>(As) + row * PLB + g * 2 + kh * 16;
             sa[i].hi = *reinterpret_cast<const bf16x8*>(s0);
             sa[i].mid = *reinterpret_cast<const bf16x8*>(s0 + BM * PLB);
-            sa[i].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BM * PLB);
+            if (NPLN == 3) sa[i].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BM * PLB);
           } else {
             const float* s0 = &As[(g + kh * 8) * (BM + 4) + row];
             sa[i] = split8(make_float4(s0[0], s0[BM + 4], s0[2 * (BM + 4)], s0[3 * (BM + 4)]),
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
             const char* s0 = reinterpret_cast<const char*>(Bs) + col * PLB + g * 2 + kh * 16;
             sb[j].hi = *reinterpret_cast<const bf16x8*>(s0);
             sb[j].mid = *reinterpret_cast<const bf16x8*>(s0 + BN * PLB);
-            sb[j].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * PLB);
+            if (NPLN == 3) sb[j].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * PLB);
           } else {
             const float* s0 = &Bs[(g + kh * 8) * (BN + 4) + col];
             sb[j] = split8(make_float4(s0[0], s0[BN + 4], s0[2 * (BN + 4)], s0[3 * (BN + 4)]),
@@ -382,9 +385,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j) {  // smallest terms first
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].lo, sb[j].hi, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].lo, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].mid, acc[i][j], 0, 0, 0);
+            if (NPLN == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].lo, sb[j].hi, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].lo, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].mid, acc[i][j], 0, 0, 0);
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].hi, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].mid, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].hi, acc[i][j], 0, 0, 0);

@@ -657,7 +657,7 @@ extern "C" int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float*
   if (N < 1 || N > 16 * MAXNF || P < 1 || C % 64 != 0 || out_lds_bytes(P, (N + 15) / 16) > 150 * 1024)
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  if (tris_get_gemm_mode() == 1 && P <= 128 && (C == 1024 || C == 512 || C == 256)) {  // split-bf16: two-launch streaming path
+  if (tris_get_gemm_mode() >= 1 && P <= 128 && (C == 1024 || C == 512 || C == 256)) {  // split-bf16: two-launch streaming path
 #define TRIS_X3(NT_)                                                                                                \
   (C == 1024 ? launch_fwd_x3<NT_, 8>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st)               \
              : C == 512 ? launch_fwd_x3<NT_, 4>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st)     \
