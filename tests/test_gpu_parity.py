@@ -638,3 +638,31 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
         model.backbone.visual.grad_reducer = None
         dist.destroy_process_group()
         refill(model)
+
+
+def test_backward_x2_knob_leaves_forward_bit_identical(model, aux, batch):
+    """TRIS_BWD_GEMM_MODE / ops.set_backward_gemm_mode('x2'): only the gradient products change arithmetic -- losses
+    (forward) are bit-identical, gradients agree in direction and size with the default"""
+    from tris_amd import ops
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import train_step
+    args = _args()
+    res = {}
+    try:
+        for mode in (None, "x2"):
+            ops.set_backward_gemm_mode(mode)
+            refill(model)
+            model.train()
+            bb, new = model.trainable_parameters()
+            opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                             weight_decay=args.weight_decay)
+            losses = train_step(model, aux, opt, batch["img"].cuda(), batch["word_ids"].cuda(),
+                                batch["neg_word_ids"].cuda(), args)
+            res[mode] = (losses.clone(), [a.g.detach().clone() for a in opt.arenas])
+    finally:
+        ops.set_backward_gemm_mode(None)
+        refill(model)
+    assert torch.equal(res[None][0], res["x2"][0])
+    for a, b in zip(res[None][1], res["x2"][1]):
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.999 and abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (cos, float(a.norm()), float(b.norm()))

@@ -66,11 +66,45 @@ def set_gemm_mode(mode):
     call("tris_set_gemm_mode", {"f32": 0, "x3": 1, "x2": 2}[mode])
 
 
+_BWD_MODE = None
+
+
+def set_backward_gemm_mode(mode):
+    """Arithmetic of the dense products launched from backward (data and weight gradients): None = same as forward,
+    or 'x2' / 'x3' / 'f32'.  Forward results (response maps, losses -- the parity bar) do not depend on it.  Env:
+    TRIS_BWD_GEMM_MODE."""
+    global _BWD_MODE
+    assert mode in (None, "f32", "x3", "x2")
+    _BWD_MODE = mode
+
+
+def _bwd_arith(fn):
+    """decorator for the backward of GEMM-bearing Functions: run it under the configured backward arithmetic"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *grads):
+        if _BWD_MODE is None:
+            return fn(ctx, *grads)
+        prev = get_gemm_mode()
+        if prev == _BWD_MODE or prev == "f32":
+            return fn(ctx, *grads)
+        set_gemm_mode(_BWD_MODE)   # host-side flag read at launch time: affects exactly the launches issued below
+        try:
+            return fn(ctx, *grads)
+        finally:
+            set_gemm_mode(prev)
+    return wrapper
+
+
 def _init_mode_from_env():
     import os
     m = os.environ.get("TRIS_GEMM_MODE")
     if m:
         set_gemm_mode(m)
+    b = os.environ.get("TRIS_BWD_GEMM_MODE")
+    if b:
+        set_backward_gemm_mode(b)
 
 
 def set_autotune(on):
@@ -336,6 +370,7 @@ class LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd_arith
     def backward(ctx, dy):
         if ctx.act == 2:
             raise RuntimeError("fused QuickGELU epilogue is forward-only; use QGeluFn when gradients are needed")
@@ -402,6 +437,7 @@ class MatmulFn(torch.autograd.Function):
         return C
 
     @staticmethod
+    @_bwd_arith
     def backward(ctx, dC):
         A, B = ctx.saved_tensors
         M, N, K = ctx.dims
@@ -444,6 +480,7 @@ class BmmFn(torch.autograd.Function):
         return C
 
     @staticmethod
+    @_bwd_arith
     def backward(ctx, dC):
         A, B = ctx.saved_tensors
         tB, alpha, shared, Bt, M, N, K = ctx.cfg
@@ -516,6 +553,7 @@ class Conv3x3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd_arith
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         B, H, W, Cin = x.shape
@@ -976,6 +1014,7 @@ class XAttnFn(torch.autograd.Function):
         return new_vis, new_lan
 
     @staticmethod
+    @_bwd_arith
     def backward(ctx, d_vis, d_lan):
         Qv, Kv, Vv, Qt, Kt, Vt, probs = ctx.saved_tensors
         B, Pp, N, C = ctx.dims
