@@ -640,6 +640,25 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
         refill(model)
 
 
+def test_wgrad_x2_knob_stays_on_the_fp32_noise_floor(monkeypatch):
+    """TRIS_WGRAD_GEMM_MODE=x2 / ops.set_wgrad_gemm_mode('x2'): weight-gradient products with 16-bit-significand inputs --
+    the whole-step fp64-calibrated check must still hold (same criteria as test_gradients_vs_fp64_noise_floor)"""
+    import statistics
+    from tris_amd import ops
+    from tools.noise_study import study
+    ops.set_wgrad_gemm_mode("x2")
+    try:
+        r = study(2, 1234)
+    finally:
+        ops.set_wgrad_gemm_mode(None)
+    for i in range(4):
+        assert abs(r["hip"][i] - r["f64"][i]) < TOL
+    for x in r["rows"]:
+        assert x["cos"] > 0.998, x
+        assert x["hip_normrel"] <= max(20 * x["f32_normrel"], 1e-2), x
+    assert statistics.median([x["hip_maxrel"] / (x["f32_maxrel"] + 1e-12) for x in r["rows"]]) < 3.0
+
+
 def test_backward_x2_knob_leaves_forward_bit_identical(model, aux, batch):
     """TRIS_BWD_GEMM_MODE / ops.set_backward_gemm_mode('x2'): only the gradient products change arithmetic -- losses
     (forward) are bit-identical, gradients agree in direction and size with the default"""

@@ -78,6 +78,32 @@ def set_backward_gemm_mode(mode):
     _BWD_MODE = mode
 
 
+_WGRAD_MODE = None
+
+
+def set_wgrad_gemm_mode(mode):
+    """Arithmetic of the WEIGHT-gradient products only (Linear / 1x1 / 3x3 conv): None = same as the rest, or 'x2'.
+    A weight gradient is a leaf of the backward graph -- its rounding error is not propagated or amplified any further --
+    and a long reduction (>= B*L or B*H*W terms) in which per-term errors average down.  Env: TRIS_WGRAD_GEMM_MODE."""
+    global _WGRAD_MODE
+    assert mode in (None, "f32", "x3", "x2")
+    _WGRAD_MODE = mode
+
+
+def _wgrad_arith(fn):
+    """run a weight-gradient launch (a callable) under the configured weight-gradient arithmetic"""
+    if _WGRAD_MODE is None:
+        return fn()
+    prev = get_gemm_mode()
+    if prev == _WGRAD_MODE or prev == "f32":
+        return fn()
+    set_gemm_mode(_WGRAD_MODE)
+    try:
+        return fn()
+    finally:
+        set_gemm_mode(prev)
+
+
 def _bwd_arith(fn):
     """decorator for the backward of GEMM-bearing Functions: run it under the configured backward arithmetic"""
     import functools
@@ -105,6 +131,9 @@ def _init_mode_from_env():
     b = os.environ.get("TRIS_BWD_GEMM_MODE")
     if b:
         set_backward_gemm_mode(b)
+    w = os.environ.get("TRIS_WGRAD_GEMM_MODE")
+    if w:
+        set_wgrad_gemm_mode(w)
 
 
 def set_autotune(on):
@@ -405,9 +434,9 @@ class LinearFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
-                on_wgrad_stream(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False), dy, x)
+                on_wgrad_stream(lambda: _wgrad_arith(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False)), dy, x)
             else:
-                dw = _emit(pw, lambda o: gemm(dy, x, o, N, K, M, N, K, K, True, False), True)
+                dw = _emit(pw, lambda o: _wgrad_arith(lambda: gemm(dy, x, o, N, K, M, N, K, K, True, False)), True)
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
@@ -574,9 +603,10 @@ class Conv3x3Fn(torch.autograd.Function):
 
         def wgrad(o):
             ws = workspace(0)
-            _timed("conv3x3_wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin,
-                   lambda: call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws),
-                                ws.numel() * 4, _stream()))
+            _wgrad_arith(lambda: _timed(
+                "conv3x3_wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin,
+                lambda: call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws),
+                             ws.numel() * 4, _stream())))
         dw = None
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
