@@ -423,7 +423,7 @@ static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")
 #include "gemm_fast.h"
 
 // ---- configuration = (tile, split-K) ----------------------------------------------------------------------------------
-struct Cfg { int bm, bn, splitk; };
+struct Cfg { int bm, bn, splitk, nw; };  // nw: waves per 128x128 block of the split-bf16 kernels (8 = 2x4 wave grid, 4 = 2x2)
 
 // Tile / split-K choice by a small cost model (cycles on the MFMA pipe); also the starting point of the autotuner.
 //   per-wave cycles per 32-deep k step = (BM/64)*(BN/64)*c; a block owns a CU's 4 SIMDs; blocks beyond the 256 CUs queue.
@@ -473,7 +473,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
     if (forced == 2) { bm = 128; bn = 64; }
     if (forced == 3) { bm = 64; bn = 64; }
   }
-  Cfg c = {bm, bn, splitk};
+  Cfg c = {bm, bn, splitk, g_x3_waves};
   return c;
 }
 
@@ -481,6 +481,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
 template <int AK, int BKIND>
 int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   int bm = cfg.bm, bn = cfg.bn, splitk = cfg.splitk;
+  const int nw = cfg.nw;
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
   const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
@@ -492,7 +493,7 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   float* Cfinal = p.C;
 #define TRIS_FAST(BM_, BN_, EPI_, PREC_)                                                                              \
   do {                                                                                                                 \
-    if (BM_ == 128 && BN_ == 128 && g_x3_waves == 8)                                                                    \
+    if (BM_ == 128 && BN_ == 128 && nw == 8)                                                                            \
       hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, \
                          dim3(512), 0, st, p);                                                                         \
     else                                                                                                               \
@@ -602,9 +603,13 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
       if (sk > 1 && (!can_split || sk > p.K / 256 || (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes)) break;
       if (sk > 1 && ntiles * sk > 1536) break;  // more than ~6 blocks per CU buys nothing
       if (sk * 8 < h.splitk && ntiles * sk < 256) continue;  // a handful of blocks walking a huge K serially: not worth timing
-      const Cfg c = {cbm, cbn, sk};
-      const float ms = time_cfg(c);
-      if (ms < best_ms) { best_ms = ms; best = c; }
+      for (int nw = 8; nw >= 4; nw -= 4) {
+        static const bool tune_nw = getenv("TRIS_TUNE_WAVES") && getenv("TRIS_TUNE_WAVES")[0] == '1';  // off: measured no gain (-0.3%)
+        if (nw == 4 && !(tune_nw && g_gemm_mode >= 1 && t == 0 && g_x3_waves == 8)) break;  // the 4-wave variant exists for 128x128 x3/x2 only
+        const Cfg c = {cbm, cbn, sk, nw};
+        const float ms = time_cfg(c);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+      }
     }
   }
   hipEventDestroy(e0);
