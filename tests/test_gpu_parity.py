@@ -685,3 +685,48 @@ def test_backward_x2_knob_leaves_forward_bit_identical(model, aux, batch):
     for a, b in zip(res[None][1], res["x2"][1]):
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         assert cos > 0.999 and abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (cos, float(a.norm()), float(b.norm()))
+
+
+def test_three_step_training_trajectory_matches_oracle(model, aux):
+    """Training dynamics, not just one step: three optimisation steps on three different batches, HIP path vs the CPU
+    oracle from the same initial weights -- the loss of every step agrees (the later ones depend on the earlier AdamW
+    updates), and the two trained models then produce the same evaluation masks (mask IoU >= 0.98; the mIoU criterion of
+    the north star transplanted to synthetic data)."""
+    from oracle import tris_oracle as O
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import train_step
+    from tris_amd.utils.synth import synthetic_batch
+    args = _args()
+    refill(model)
+    model.train()
+    sd = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+    sd_aux = {k: v.detach().cpu().clone().contiguous() for k, v in aux.state_dict().items()}
+    bb, new = model.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                     weight_decay=args.weight_decay)
+    state = {}
+    try:
+        for step in range(3):
+            b = synthetic_batch(2, 320, 20, 3, seed=100 + step)
+            hip = train_step(model, aux, opt, b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda(),
+                             args).tolist()
+            ref, _ = O.train_step(sd, sd_aux, b, lr=args.lr, lr_multi=args.lr_multi, wd=args.weight_decay, state=state)
+            for i, k in enumerate(("loss", "l1", "l4", "l5")):
+                # (AdamW's first updates are +-lr per element whatever the gradient size: elements whose tiny gradient
+                # rounds to the other sign differ by 2*lr between two correct implementations, so the trajectories drift
+                # apart slowly -- the bound is 1e-3 for the first two steps, 5e-3 for the third)
+                tol = (1e-3 if step < 2 else 5e-3) * max(1.0, abs(ref[k]))
+                assert abs(hip[i] - ref[k]) < tol, (step, k, hip[i], ref[k])
+        model.eval()
+        b = synthetic_batch(2, 320, 20, 3, seed=7)
+        with torch.no_grad():
+            m_hip = model(b["img"].cuda(), b["word_ids"].cuda()).cpu()
+            m_ref = O.tris_forward(sd, b["img"], b["word_ids"], False)
+        m_ref = m_ref if torch.is_tensor(m_ref) else m_ref[2]
+        for i in range(2):
+            a = m_hip[i, 0] / (m_hip[i, 0].max() + 1e-5) > 1e-9
+            r = m_ref[i, 0] / (m_ref[i, 0].max() + 1e-5) > 1e-9
+            iou = float((a & r).sum()) / max(float((a | r).sum()), 1.0)
+            assert iou >= 0.98, (i, iou)
+    finally:
+        refill(model)
