@@ -94,12 +94,15 @@ int tris_bn_sync_combine_f32(const float* gathered, int world, int C, long count
 int tris_bn_apply_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* resid, float* Y, long M, int C, int relu, void* stream);
 /* backward: dz = dY * (Y > 0) when Y != NULL.  sum_dz = dbeta, sum_dzx = dgamma.  apply: dZ (optional) receives dz,
- * the gradient of the fused residual branch (Bottleneck identity path). */
+ * the gradient of the fused residual branch (Bottleneck identity path).  gamma_mask / beta_mask != NULL (BatchNorm + ReLU
+ * without a residual input): the ReLU mask is recomputed from X with tris_bn_apply_f32's own expression -- same sign bit
+ * for bit -- and Y is not read (one 4-byte stream less in each of the two passes). */
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
-                           long M, int C, float* sum_dz, float* sum_dzx, float* workspace, void* stream);
+                           long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,
+                           const float* beta_mask, void* stream);
 int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                           const float* gamma, const float* sum_dz, const float* sum_dzx, float inv_count, float* dX,
-                          float* dZ, long M, int C, void* stream);
+                          float* dZ, long M, int C, const float* beta_mask, void* stream);
 /* out[n] = sum_m X[m*ld+n]  (bias gradients).  workspace: tris_col_workspace_bytes(M, N) */
 int tris_colsum_f32(const float* X, long M, int N, long ld, float* out, float* workspace, void* stream);
 

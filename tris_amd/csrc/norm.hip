@@ -25,7 +25,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           const float* __restrict__ Y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, long M, int C, long ld,
-                                                          long rows_per_block, double* __restrict__ part) {
+                                                          long rows_per_block, double* __restrict__ part,
+                                                          const float* __restrict__ gamma = nullptr,
+                                                          const float* __restrict__ beta = nullptr) {
   __shared__ d4 l0[256];
   __shared__ d4 l1[256];
   const int CV = C >> 2;
@@ -38,16 +40,29 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   for (int cv0 = 0; cv0 < CV; cv0 += CVB) {
     const int c = (cv0 + cvl) * 4;
     d4 s0 = d4zero(), s1 = d4zero();
-    float4 mu = make_float4(0, 0, 0, 0), is = mu;
+    float4 mu = make_float4(0, 0, 0, 0), is = mu, sc = mu, be = mu;
     const bool act = (ro < RS) && (cv0 + cvl < CV);
+    // MODE 1, gamma != NULL: the ReLU mask is recomputed from X with bn_apply_kernel's own expression (same sign bit for
+    // bit) instead of being read from Y -- one 4-byte stream less for every BatchNorm+ReLU without a residual input
+    const bool mask_x = (MODE == 1) && (gamma != nullptr);
     if (act) {
       if (MODE == 1) { mu = ld4(mean + c); is = ld4(invstd + c); }
+      if (mask_x) {
+        const float4 ga = ld4(gamma + c);
+        be = ld4(beta + c);
+        sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+      }
       auto accum = [&](const float4 x, float4 g, const float4 y) {
         if (MODE == 0) {
           s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
           s1.x += (double)x.x * x.x; s1.y += (double)x.y * x.y; s1.z += (double)x.z * x.z; s1.w += (double)x.w * x.w;
         } else if (MODE == 1) {
-          if (Y) {
+          if (mask_x) {
+            if (!((x.x - mu.x) * sc.x + be.x > 0.f)) g.x = 0.f;
+            if (!((x.y - mu.y) * sc.y + be.y > 0.f)) g.y = 0.f;
+            if (!((x.z - mu.z) * sc.z + be.z > 0.f)) g.z = 0.f;
+            if (!((x.w - mu.w) * sc.w + be.w > 0.f)) g.w = 0.f;
+          } else if (Y) {
             if (!(y.x > 0.f)) g.x = 0.f;
             if (!(y.y > 0.f)) g.y = 0.f;
             if (!(y.z > 0.f)) g.z = 0.f;
@@ -231,11 +246,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sum_dz,
                                                            const float* __restrict__ sum_dzx, float inv_cnt,
                                                            float* __restrict__ dX, float* __restrict__ dZ, long n4,
-                                                           int C) {
+                                                           int C, const float* __restrict__ beta_mask) {
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)((i * 4) % C);
   const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), a = ld4(sum_dz + c), b = ld4(sum_dzx + c);
+  // beta_mask != NULL: ReLU mask recomputed from X (bn_apply_kernel's expression) instead of read from Y
+  const float4 be = beta_mask ? ld4(beta_mask + c) : make_float4(0, 0, 0, 0);
   // dx = k1 * (g - k2 - (x - mu) * k3)   with k1 = gamma*invstd, k2 = sum_dz/cnt, k3 = invstd * sum_dzx/cnt
   const float4 k1 = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
   const float4 k2 = make_float4(a.x * inv_cnt, a.y * inv_cnt, a.z * inv_cnt, a.w * inv_cnt);
@@ -243,7 +260,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   auto one = [&](long j) {
     float4 g = ld4(dY + j * 4);
     const float4 x = ld4(X + j * 4);
-    if (Y) {
+    if (beta_mask) {
+      if (!((x.x - mu.x) * k1.x + be.x > 0.f)) g.x = 0.f;   // k1 = invstd * gamma = the forward's scale
+      if (!((x.y - mu.y) * k1.y + be.y > 0.f)) g.y = 0.f;
+      if (!((x.z - mu.z) * k1.z + be.z > 0.f)) g.z = 0.f;
+      if (!((x.w - mu.w) * k1.w + be.w > 0.f)) g.w = 0.f;
+    } else if (Y) {
       const float4 y = ld4(Y + j * 4);
       if (!(y.x > 0.f)) g.x = 0.f;
       if (!(y.y > 0.f)) g.y = 0.f;
@@ -638,12 +660,13 @@ extern "C" int tris_bn_apply_f32(const float* X, const float* mean, const float*
 
 extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean,
                                       const float* invstd, long M, int C, float* sum_dz, float* sum_dzx,
-                                      float* workspace, void* stream) {
+                                      float* workspace, const float* gamma_mask, const float* beta_mask, void* stream) {
   if (C % 4) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   ColPlan p = col_plan(M, C);
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, Y, mean, invstd, M, C, (long)C, p.rpb,
-                     (double*)workspace);
+  if ((gamma_mask == nullptr) != (beta_mask == nullptr)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, gamma_mask ? nullptr : Y, mean, invstd, M, C,
+                     (long)C, p.rpb, (double*)workspace, gamma_mask, beta_mask);
   TRIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
                      sum_dz, sum_dzx);
@@ -653,10 +676,11 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
 
 extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const float* mean,
                                      const float* invstd, const float* gamma, const float* sum_dz, const float* sum_dzx,
-                                     float inv_count, float* dX, float* dZ, long M, int C, void* stream) {
+                                     float inv_count, float* dX, float* dZ, long M, int C, const float* beta_mask,
+                                     void* stream) {
   long n4 = M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean, invstd,
-                     gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C);
+                     gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -13,6 +13,7 @@ see tris_amd.optim).  Backward kernels then write the weight gradient straight i
 (each parameter is used once per step) and return None to autograd.
 """
 import math
+import os
 
 import torch
 
@@ -671,7 +672,8 @@ class BatchNormFn(torch.autograd.Function):
         ctx.params = (gamma, beta)
         ctx.training = bool(training)
         if training:
-            ctx.save_for_backward(x, gamma, beta, mean, invstd, y if relu else None)
+            keep_y = relu and (resid is not None or os.environ.get("TRIS_BN_MASK_X", "1") == "0")   # (env: developer A/B knob)
+            ctx.save_for_backward(x, gamma, beta, mean, invstd, y if keep_y else None)
         return y
 
     @staticmethod
@@ -697,7 +699,10 @@ class BatchNormFn(torch.autograd.Function):
         else:
             sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             p_dz, p_dzx = P(sums), P(sums, C)
-        call("tris_bn_bwd_reduce_f32", P(dy), P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws), _stream())
+        # BatchNorm + ReLU without a residual: the mask is recomputed from x inside the kernels, y is not read
+        mask_x = relu and not has_res and y is None
+        call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
+             P(gamma) if mask_x else None, P(beta) if mask_x else None, _stream())
         if not direct:
             dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
             db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
@@ -709,8 +714,8 @@ class BatchNormFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             if want_dz:
                 d_res = torch.empty_like(x)
-            call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
-                 1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, _stream())
+            call("tris_bn_bwd_apply_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
+                 1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
         if ctx.grad_box is not None and d_res is not None:   # hand the residual gradient to the block's first conv
             ctx.grad_box.value, d_res = d_res, None
         return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None
