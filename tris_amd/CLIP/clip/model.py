@@ -34,10 +34,12 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, stats=False, grad_box=None):
-        """x channels-last [B,H,W,Cin]; stats: fuse the following BatchNorm's statistics; grad_box: ops.GradBox of the block"""
+    def forward(self, x, stats=False, grad_box=None, grad_box_out=None):
+        """x channels-last [B,H,W,Cin]; stats: fuse the following BatchNorm's statistics; grad_box / grad_box_out: the
+        block's ops.GradBox (consume a deposited gradient in the dgrad epilogue / deposit this layer's input gradient)"""
         if self.k == 1:
-            return ops.linear(x, self.weight, self.bias, stats=stats and self.bias is None, grad_box=grad_box)
+            return ops.linear(x, self.weight, self.bias, stats=stats and self.bias is None, grad_box=grad_box,
+                              grad_box_out=grad_box_out)
         assert self.k == 3 and self.bias is None
         return ops.conv3x3(x, self.weight, self.stride, stats=stats)
 
@@ -80,8 +82,8 @@ class AvgPool2d(nn.Module):
         assert k == 2
         self.k = k
 
-    def forward(self, x):
-        return ops.avgpool2(x)
+    def forward(self, x, grad_box_out=None):
+        return ops.avgpool2(x, grad_box_out)
 
 
 class Bottleneck(nn.Module):
@@ -108,18 +110,21 @@ class Bottleneck(nn.Module):
     def forward(self, x):  # channels-last
         tr = self.training  # train mode: BatchNorm batch statistics come out of the producing conv's epilogue
         # identity block: x feeds conv1 and the residual add; the residual gradient rides conv1's data-gradient epilogue
-        box = ops.GradBox() if (self.downsample is None and tr and torch.is_grad_enabled() and x.requires_grad
+        # down-sampling block: the shortcut's input gradient (avg-pool or 1x1 conv backward) rides along the same way
+        box = ops.GradBox() if (tr and torch.is_grad_enabled() and x.requires_grad
                                and os.environ.get("TRIS_GRAD_BOX", "1") != "0") else None
         out = self.bn1(self.conv1(x, stats=tr, grad_box=box), relu=True)
         out = self.bn2(self.conv2(out, stats=tr), relu=True)
         out = self.avgpool(out)
         out = self.conv3(out, stats=tr)
         if self.downsample is not None:
-            idn = self.downsample[0](x)
-            idn = self.downsample[2](self.downsample[1](idn, stats=tr))
-        else:
-            idn = x
-        return self.bn3(out, resid=idn, relu=True, grad_box=box)  # relu(bn3(conv3) + identity), fused
+            if isinstance(self.downsample[0], AvgPool2d):
+                idn = self.downsample[1](self.downsample[0](x, grad_box_out=box), stats=tr)
+            else:
+                idn = self.downsample[1](self.downsample[0](x), stats=tr, grad_box_out=box)
+            idn = self.downsample[2](idn)
+            return self.bn3(out, resid=idn, relu=True)
+        return self.bn3(out, resid=x, relu=True, grad_box=box)  # relu(bn3(conv3) + identity), fused
 
 
 class Linear(nn.Module):

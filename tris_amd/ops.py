@@ -346,11 +346,23 @@ class GradBox:
     consumers (f's first conv and the residual input of bn3); autograd would sum their two gradients with an extra
     elementwise pass over the activation.  Instead bn3's backward -- which always runs before the first conv's, because
     the latter depends on it through f -- leaves its residual gradient here, and the first conv's data-gradient GEMM adds
-    it in its epilogue (`resid`).  Used by the identity Bottlenecks of the RN50 trunk."""
-    __slots__ = ("value",)
+    it in its epilogue (`resid`).  Used by the identity Bottlenecks of the RN50 trunk.
+
+    In the down-sampling Bottlenecks the second consumer of x is the shortcut (avg-pool / 1x1 conv); its backward normally
+    runs before conv1's too (autograd schedules later-created nodes first) but nothing guarantees it, so the depositor
+    checks `consumed` and simply returns its gradient to autograd if conv1 has already run."""
+    __slots__ = ("value", "consumed")
 
     def __init__(self):
         self.value = None
+        self.consumed = False
+
+    def deposit(self, g):
+        """-> True if the gradient was taken over (the caller must then return None for that input)"""
+        if self.consumed or self.value is not None:
+            return False
+        self.value = g
+        return True
 
 
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
@@ -358,9 +370,9 @@ class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None):
+    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None):
         _chk(x, w, b, resid)
-        ctx.grad_box = grad_box
+        ctx.grad_box, ctx.grad_box_out = grad_box, grad_box_out
         x = x.contiguous()
         K = x.shape[-1]
         N = w.numel() // K
@@ -420,8 +432,10 @@ class LinearFn(torch.autograd.Function):
         dx = None
         box = ctx.grad_box
         extra = None   # a residual-branch gradient left by a later layer of the same block: added in the GEMM epilogue
-        if box is not None and box.value is not None:
-            extra, box.value = box.value, None
+        if box is not None:
+            box.consumed = True
+            if box.value is not None:
+                extra, box.value = box.value, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp = _planes(pw)
@@ -432,6 +446,8 @@ class LinearFn(torch.autograd.Function):
                 gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K)
         elif extra is not None:
             raise RuntimeError("a residual gradient was handed to a layer whose input needs no gradient")
+        if dx is not None and ctx.grad_box_out is not None and ctx.grad_box_out.deposit(dx):
+            dx = None   # the block's first conv adds it in its data-gradient epilogue
         dw = None
         if ctx.needs_input_grad[1]:
             if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
@@ -441,11 +457,11 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
-        return dx, dw, db, d_res, None, None, None
+        return dx, dw, db, d_res, None, None, None, None
 
 
-def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None):
-    y = LinearFn.apply(x, w, b, resid, act, stats, grad_box)
+def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None):
+    y = LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out)
     return _attach_stats(y) if stats else y
 
 
@@ -716,8 +732,8 @@ class BatchNormFn(torch.autograd.Function):
                 d_res = torch.empty_like(x)
             call("tris_bn_bwd_apply_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
                  1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
-        if ctx.grad_box is not None and d_res is not None:   # hand the residual gradient to the block's first conv
-            ctx.grad_box.value, d_res = d_res, None
+        if ctx.grad_box is not None and d_res is not None and ctx.grad_box.deposit(d_res):
+            d_res = None   # handed to the block's first conv
         return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None
 
 
@@ -729,8 +745,9 @@ def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=Tru
 
 class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, grad_box_out=None):
         _chk(x)
+        ctx.grad_box_out = grad_box_out
         x = x.contiguous()
         B, H, W, C = x.shape
         y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
@@ -744,11 +761,13 @@ class AvgPool2Fn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
         call("tris_avgpool2_bwd_f32", P(dy), P(dx), B, H, W, C, _stream())
-        return dx
+        if ctx.grad_box_out is not None and ctx.grad_box_out.deposit(dx):
+            dx = None
+        return dx, None
 
 
-def avgpool2(x):
-    return AvgPool2Fn.apply(x)
+def avgpool2(x, grad_box_out=None):
+    return AvgPool2Fn.apply(x, grad_box_out)
 
 
 # ----------------------------------------------------------------------------------------------- transformer pieces
