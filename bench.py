@@ -91,7 +91,8 @@ def main():
     from tris_amd.train_stage1 import freeze_aux, train_step
     from tris_amd.utils.synth import seed_fill, synthetic_batch
 
-    args = get_parser().parse_args(["--backbone", a.backbone, "--size", "320", "--max_query_len", "20",
+    QL = int(os.environ.get("TRIS_BENCH_QUERY_LEN", "20"))   # developer knob (what-if runs); the metric configuration is 20
+    args = get_parser().parse_args(["--backbone", a.backbone, "--size", "320", "--max_query_len", str(QL),
                                     "--negative_samples", "3", "--batch_size", str(a.batch), "--epoch", "15"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -111,7 +112,7 @@ def main():
         reducer = GradReducer([ar.g for ar in opt.arenas], force=force)
         reducer.set_segments(stage1_segments(model, opt))   # all-reduce segments launched from inside backward
         model.backbone.visual.grad_reducer = reducer
-    b = synthetic_batch(a.batch, 320, 20, 3, seed=7, rank=rank)
+    b = synthetic_batch(a.batch, 320, QL, 3, seed=7, rank=rank)
     img, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
 
     def step():
@@ -223,7 +224,7 @@ def main():
                                       "CLIP ViT-B/32, AdamW (BASELINE.json " +
                                       ("configs[2]/[3])" if a.backbone == "clip-RN50" else
                                        "configs[4]; the reference defines no such model: parity unpinned, DESIGN.md)"),
-                          "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": 20,
+                          "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": QL,
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
                "untimed_priming_steps": 1, "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
                "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
