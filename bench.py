@@ -214,6 +214,19 @@ def main():
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
 
+    if roof_x is not None and mode == "x3":
+        try:   # HBM bytes of the two cross-attention launches from the same --pmc passes (profiles/r1o_pmc_hbm_traffic.csv)
+            import csv as _csv
+            tr = 0
+            for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", "r1o_pmc_hbm_traffic.csv"))):
+                if "xattn_" in r["Kernel"]:
+                    tr += int(r["FetchBytesPerStep(x2 corrected)"]) + int(r["WriteBytesPerStep"])
+            if tr:
+                roof_x["traffic"] = tr
+                roof_x["traffic_note"] = ("FETCH_SIZE x2 + WRITE_SIZE of xattn_scores_x3_kernel + xattn_out_x3_kernel, one forward "
+                                          "(rocprofv3 --pmc, B=48): 1.27x the algorithmic bytes (logit planes round trip, sentence tiles)")
+        except Exception:
+            pass
     if rank == 0:
         out = {"metric": f"Stage-1 training images/sec @320px bs48 (TRIS {a.backbone}, 3 negatives)",
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps,
