@@ -101,7 +101,8 @@ def test_matmul_and_bmm(ops, tB):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 20, 20, 32, 64, 1), (2, 12, 10, 64, 64, 1), (1, 9, 7, 128, 16, 1),
-                                                     (2, 32, 32, 3, 32, 2), (3, 16, 16, 16, 48, 1)])
+                                                     (2, 32, 32, 3, 32, 2), (3, 16, 16, 16, 48, 1), (3, 33, 31, 3, 32, 2),
+                                                     (1, 9, 7, 3, 16, 1), (4, 320, 320, 3, 32, 2)])
 def test_conv3x3(ops, B, H, W, Cin, Cout, stride):
     x, w = leaf(B, Cin, H, W), leaf(Cout, Cin, 3, 3, scale=0.1)
     y = F.conv2d(x, w, stride=stride, padding=1)

@@ -12,6 +12,7 @@
 // LDS image is k-major (As[k][m], Bs[k][n], row pad 4) so a fragment read is 32 consecutive floats per half-wave
 // (conflict-free ds_read_b32).  Global loads for tile t+1 are issued before the MFMA block of tile t
 // (register staging), stored to LDS after it.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -680,10 +681,88 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   return launch_cfg<A_IM2COL, B_KN_DGRAD>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
+// ---- weight gradient of the stem's first convolution (Cin = 3: the 27-wide "N" does not fit the tiled kernels) -----------
+// dW[co][tap][ci] = sum over output pixels of dY[p][co] * X[in(p, tap)][ci] is ONE 32 x 32 output tile with a reduction
+// over ~10^6 pixels.  Each wave walks a contiguous pixel range with v_mfma_f32_32x32x2_f32 (2 pixels per step: lane
+// (m = co, kh) reads dY[p + kh][co] -- one 128-byte line per pixel --, lane (n = (tap, ci), kh) gathers its input value
+// with incrementally maintained coordinates, no divisions in the loop); the block's four tiles meet in LDS, per-block
+// partials are summed in fixed order by a second launch.  HBM-bound on the dY stream.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                         float* __restrict__ part, int Bn, int H, int W, int Cin, int Cout,
+                                                         int Ho, int Wo, int stride, long pix_per_wave) {
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mn = lane & 31, kh = lane >> 5;
+  const long total = (long)Bn * Ho * Wo;
+  const long p_beg = ((long)blockIdx.x * 4 + wave) * pix_per_wave;
+  const long p_end = min(total, p_beg + pix_per_wave);
+  const int tap = mn / Cin, ci = mn - tap * Cin;
+  const bool nv = mn < 9 * Cin;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const bool mv = mn < Cout;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // this lane's pixel (p_beg + kh) in (b, oy, ox) form; advanced by 2 per step
+  long p = p_beg + kh;
+  int b = (int)(p / ((long)Ho * Wo));
+  int rem = (int)(p - (long)b * Ho * Wo);
+  int oy = rem / Wo, ox = rem - oy * Wo;
+  for (; p - kh < p_end; p += 2) {
+    float a = 0.f, v = 0.f;
+    if (p < p_end) {
+      if (mv) a = dY[p * Cout + mn];
+      const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
+      if (nv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = X[(((long)b * H + iy) * W + ix) * Cin + ci];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
+    ox += 2;
+    while (ox >= Wo) { ox -= Wo; if (++oy == Ho) { oy = 0; ++b; } }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* o = part + (long)blockIdx.x * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // D[row = (r&3) + 8*(r>>2) + 4*kh][col = mn]
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      o[row * 32 + mn] = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dW,
+                                                                int Cout, int N) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 1024) return;
+  const int row = idx >> 5, col = idx & 31;
+  float s = 0.f;
+  for (int bk = 0; bk < nblk; ++bk) s += part[(long)bk * 1024 + idx];
+  if (row < Cout && col < N) dW[row * N + col] = s;
+}
+
 // dW[Cout][3][3][Cin] = sum over output pixels of dY (x) gathered X.  Split-K over pixels through `workspace`.
 extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin,
                                       int Cout, int stride, float* workspace, long ws_bytes, void* stream) {
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  if (9 * Cin <= 32 && Cout <= 32 && workspace != nullptr) {  // the stem's first conv: dedicated single-tile reduction
+    const long total = (long)B * Ho * Wo;
+    int nblk = (int)std::min<long>(512, std::max<long>(1, total / 512));
+    long ppw = (cdiv(total, (long)nblk * 4) + 1) / 2 * 2;  // even, so the two pixels of an MFMA step stay in one wave's range
+    nblk = cdiv(total, ppw * 4);
+    if ((long)nblk * 1024 * (long)sizeof(float) <= ws_bytes) {
+      hipStream_t st = (hipStream_t)stream;
+      hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, X, dY, workspace, B, H, W, Cin, Cout, Ho, Wo, stride,
+                         ppw);
+      TRIS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(4), dim3(256), 0, st, workspace, nblk, dW, Cout, 9 * Cin);
+      TRIS_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   GemmParams p = {};
   p.A = dY; p.B = X; p.C = dW;
   p.M = Cout; p.N = 9 * Cin; p.K = B * Ho * Wo;
