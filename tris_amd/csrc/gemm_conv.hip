@@ -708,16 +708,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   int b = (int)(p / ((long)Ho * Wo));
   int rem = (int)(p - (long)b * Ho * Wo);
   int oy = rem / Wo, ox = rem - oy * Wo;
-  for (; p - kh < p_end; p += 2) {
-    float a = 0.f, v = 0.f;
-    if (p < p_end) {
-      if (mv) a = dY[p * Cout + mn];
-      const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
-      if (nv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = X[(((long)b * H + iy) * W + ix) * Cin + ci];
+  for (; p - kh < p_end; p += 16) {  // 8 MFMA steps (16 pixels) per trip: all 16 loads are in flight before the first MFMA
+    float a[8], v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long pu = p + 2 * u;
+      a[u] = 0.f;
+      v[u] = 0.f;
+      if (pu < p_end) {
+        if (mv) a[u] = dY[pu * Cout + mn];
+        const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
+        if (nv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[u] = X[(((long)b * H + iy) * W + ix) * Cin + ci];
+      }
+      ox += 2;
+      while (ox >= Wo) { ox -= Wo; if (++oy == Ho) { oy = 0; ++b; } }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
-    ox += 2;
-    while (ox >= Wo) { ox -= Wo; if (++oy == Ho) { oy = 0; ++b; } }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], v[u], acc, 0, 0, 0);
   }
   if (wave > 0) {
 #pragma unroll
@@ -734,14 +741,24 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
+// grid 32 blocks: block j sums the partials of outputs [32 j, 32 j + 32) -- 32 outputs x 8 slices of the partial list,
+// fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dW,
                                                                 int Cout, int N) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 1024) return;
-  const int row = idx >> 5, col = idx & 31;
+  __shared__ float sh[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + o;
   float s = 0.f;
-  for (int bk = 0; bk < nblk; ++bk) s += part[(long)bk * 1024 + idx];
-  if (row < Cout && col < N) dW[row * N + col] = s;
+  for (int bk = sl; bk < nblk; bk += 8) s += part[(long)bk * 1024 + idx];
+  sh[sl][o] = s;
+  __syncthreads();
+  if (sl == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sh[q][o];
+    const int row = idx >> 5, col = idx & 31;
+    if (row < Cout && col < N) dW[row * N + col] = t;
+  }
 }
 
 // dW[Cout][3][3][Cin] = sum over output pixels of dY (x) gathered X.  Split-K over pixels through `workspace`.
@@ -751,14 +768,14 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   if (9 * Cin <= 32 && Cout <= 32 && workspace != nullptr) {  // the stem's first conv: dedicated single-tile reduction
     const long total = (long)B * Ho * Wo;
     int nblk = (int)std::min<long>(512, std::max<long>(1, total / 512));
-    long ppw = (cdiv(total, (long)nblk * 4) + 1) / 2 * 2;  // even, so the two pixels of an MFMA step stay in one wave's range
+    long ppw = (cdiv(total, (long)nblk * 4) + 15) / 16 * 16;  // multiple of 16: whole 8-step trips, pixel pairs stay in one range
     nblk = cdiv(total, ppw * 4);
     if ((long)nblk * 1024 * (long)sizeof(float) <= ws_bytes) {
       hipStream_t st = (hipStream_t)stream;
       hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, X, dY, workspace, B, H, W, Cin, Cout, Ho, Wo, stride,
                          ppw);
       TRIS_LAUNCH_CHECK();
-      hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(4), dim3(256), 0, st, workspace, nblk, dW, Cout, 9 * Cin);
+      hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(32), dim3(256), 0, st, workspace, nblk, dW, Cout, 9 * Cin);
       TRIS_LAUNCH_CHECK();
       return 0;
     }
