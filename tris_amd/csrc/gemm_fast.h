@@ -22,6 +22,21 @@
 // the LDS fragment read (the LDS image stays fp32 and is shared with the f32 path).
 #include "x3_split.h"
 
+constexpr bool KM_TR = true;  // k-major operands via the LDS transpose read (false: "row per thread" scalar staging)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// 8 consecutive k (k0 .. k0+7) of column m = m16 + (lane & 15) from a k-major bf16 plane (row stride `ks` bytes)
+__device__ __forceinline__ bf16x8 tr_frag8(const char* plane, int ks, int k0, int m16, int lane) {
+  const int i16 = lane & 15;
+  const char* a = plane + (k0 + (i16 >> 2)) * ks + (m16 + 4 * (i16 & 3)) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * ks));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // NW = waves per workgroup: 4 (2x2 wave grid) or 8 (2x4: smaller wave tiles, twice the resident waves per CU -- used by
 // the x3 mode on 128x128 tiles, where the bf16 MFMA time per tile is short and the barrier / staging phases need hiding)
 template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4>
@@ -49,11 +64,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   // x3 staging of the m-/n-contiguous operands ("row per thread"): thread -> one row (m or n) and KPT consecutive k,
   // loaded with scalar loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), split once, and written as
   // 16-byte bf16 runs into the same [plane][row][k] image the k-contiguous operands use
-  constexpr bool A_KM = (PREC >= 1) && !A_RM, B_KM = (PREC >= 1) && !B_RM;
+  // KM_TR (default): the m-/n-contiguous operands are instead staged like everything else -- 16-byte loads along the
+  // contiguous dimension, split, 8-byte LDS stores into k-major planes [plane][k][m] -- and the MFMA fragments (8 consecutive
+  // k per lane) are gathered by the LDS transpose read ds_read_b64_tr_b16: per 16-lane group, lane i points at the 8-byte
+  // piece [k0 + i/4][m0 + 4(i%4) ..+3] and receives [k0..k0+3][m0 + i] (semantics established with tools/probes/
+  // tr_read_probe.hip).  Plane row stride = 2*BM + 64 bytes: the four k rows of a group and the two groups of a 32-lane
+  // half fall on disjoint banks.
+  constexpr bool A_TR = KM_TR && (PREC >= 1) && !A_RM, B_TR = KM_TR && (PREC >= 1) && !B_RM;
+  constexpr bool A_KM = (PREC >= 1) && !A_RM && !A_TR, B_KM = (PREC >= 1) && !B_RM && !B_TR;
+  constexpr int A_KS = 2 * BM + 64, B_KS = 2 * BN + 64;  // bytes per k row of a k-major plane
   constexpr int A_KG = NTHR / BM, A_KPT = 32 / A_KG, B_KG = NTHR / BN, B_KPT = 32 / B_KG;
   constexpr int PLB = 80;  // bytes per row of one bf16 plane
-  constexpr int A_SZ = A_PL ? BM * 20 * NPLN : (A_RM ? BM * LDK : FBK * (BM + 4));
-  constexpr int B_SZ = B_PL ? BN * 20 * NPLN : (B_RM ? BN * LDK : FBK * (BN + 4));
+  constexpr int A_SZ = A_TR ? NPLN * 8 * A_KS : A_PL ? BM * 20 * NPLN : (A_RM ? BM * LDK : FBK * (BM + 4));
+  constexpr int B_SZ = B_TR ? NPLN * 8 * B_KS : B_PL ? BN * 20 * NPLN : (B_RM ? BN * LDK : FBK * (BN + 4));
   __shared__ __attribute__((aligned(16))) float As[A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
 
@@ -112,6 +135,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
 
   float4 ra[PA], rb[PB];
+  int bw_b[PB], bw_oy[PB], bw_ox[PB];  // B_KN_IM2COL: running (image, row, column) of this thread's pixel rows
   constexpr int PBP = B_PRE ? (BN * 4 + NTHR - 1) / NTHR : 1;  // 16-byte pieces (8 bf16) per thread per plane per tile
   float4 rbp[3 * PBP];  // (a flat float4 array: the 2-D uint4 form was not promoted to registers)
   const unsigned short* bp_src[PBP];
@@ -201,24 +225,43 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         rb[q] = ld4(Bp + ((long)co * 9 + (8 - tapp)) * p.wCin + b_nc);
       }
     } else {  // B_KN_IM2COL: k = output pixel, column = (tap, ci) of the gathered input
-      const int hw = p.gHo * p.gWo;
+      // the pixel coordinates of this thread's PB rows are carried from tile to tile (tiles are requested in order, 32
+      // pixels apart): two integer divisions per row once, then additions
+      if (k0 == kbeg) {
+        const int hw = p.gHo * p.gWo;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int kk = k0 + tid / BF4 + q * BRPP;
+          bw_b[q] = kk / hw;
+          const int r = kk - bw_b[q] * hw;
+          bw_oy[q] = r / p.gWo;
+          bw_ox[q] = r - bw_oy[q] * p.gWo;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
-        const int kk = k0 + tid / BF4 + q * BRPP;
-        const int b = kk / hw;
-        const int r = kk - b * hw;
-        const int oy = r / p.gWo, ox = r - oy * p.gWo;
-        const int iy = oy * p.gStride - 1 + bj_ky, ix = ox * p.gStride - 1 + bj_kx;
+        const int iy = bw_oy[q] * p.gStride - 1 + bj_ky, ix = bw_ox[q] * p.gStride - 1 + bj_kx;
         const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
-        const long off = inb ? ((long)(b * p.gH + iy) * p.gW + ix) * p.gC + bj_ci : 0;
+        const long off = inb ? ((long)(bw_b[q] * p.gH + iy) * p.gW + ix) * p.gC + bj_ci : 0;
         float4 v = ld4(Bp + off);
         rb[q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        bw_ox[q] += FBK;  // next tile
+        while (bw_ox[q] >= p.gWo) { bw_ox[q] -= p.gWo; if (++bw_oy[q] == p.gHo) { bw_oy[q] = 0; ++bw_b[q]; } }
       }
     }
   };
 
   auto store_lds = [&]() {
-    if (A_KM) {
+    if (A_TR) {
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const Split4 sp = split4(ra[q]);
+        char* d = reinterpret_cast<char*>(As) + (tid / AF4 + q * ARPP) * A_KS + (tid % AF4) * 8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + 32 * A_KS) = sp.mid;
+        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 64 * A_KS) = sp.lo;
+      }
+    } else if (A_KM) {
 #pragma unroll
       for (int h = 0; h < A_KPT / 8; ++h) {
         const Split8 sp = split8(make_float4(rka[8 * h], rka[8 * h + 1], rka[8 * h + 2], rka[8 * h + 3]),
@@ -255,6 +298,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
           for (int pl = 0; pl < NPLN; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
         }
+      }
+    } else if (B_TR) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const Split4 sp = split4(rb[q]);
+        char* d = reinterpret_cast<char*>(Bs) + (tid / BF4 + q * BRPP) * B_KS + (tid % BF4) * 8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + 32 * B_KS) = sp.mid;
+        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 64 * B_KS) = sp.lo;
       }
     } else if (B_KM) {
 #pragma unroll
@@ -356,7 +408,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int row = wm * WM + i * 32 + li;
-          if (A_PL) {
+          if (A_TR) {
+            const char* pl0 = reinterpret_cast<const char*>(As);
+            const int m16 = wm * WM + i * 32 + ((lane >> 4) & 1) * 16;
+            sa[i].hi = tr_frag8(pl0, A_KS, g + 8 * kh, m16, lane);
+            sa[i].mid = tr_frag8(pl0 + 32 * A_KS, A_KS, g + 8 * kh, m16, lane);
+            if (NPLN == 3) sa[i].lo = tr_frag8(pl0 + 64 * A_KS, A_KS, g + 8 * kh, m16, lane);
+          } else if (A_PL) {
             const char* s0 = reinterpret_cast<const char*>(As) + row * PLB + g * 2 + kh * 16;
             sa[i].hi = *reinterpret_cast<const bf16x8*>(s0);
             sa[i].mid = *reinterpret_cast<const bf16x8*>(s0 + BM * PLB);
@@ -370,7 +428,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int col = wn * WN + j * 32 + li;
-          if (B_PL) {
+          if (B_TR) {
+            const char* pl0 = reinterpret_cast<const char*>(Bs);
+            const int n16 = wn * WN + j * 32 + ((lane >> 4) & 1) * 16;
+            sb[j].hi = tr_frag8(pl0, B_KS, g + 8 * kh, n16, lane);
+            sb[j].mid = tr_frag8(pl0 + 32 * B_KS, B_KS, g + 8 * kh, n16, lane);
+            if (NPLN == 3) sb[j].lo = tr_frag8(pl0 + 64 * B_KS, B_KS, g + 8 * kh, n16, lane);
+          } else if (B_PL) {
             const char* s0 = reinterpret_cast<const char*>(Bs) + col * PLB + g * 2 + kh * 16;
             sb[j].hi = *reinterpret_cast<const bf16x8*>(s0);
             sb[j].mid = *reinterpret_cast<const bf16x8*>(s0 + BN * PLB);
