@@ -220,9 +220,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     } else if (BKIND == B_KN_DGRAD) {  // k = tap'*Cout + co ; B[k][ci] = W[co][8 - tap'][ci]
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
-        const int kk = k0 + tid / BF4 + q * BRPP;
-        const int tapp = kk / p.wCout, co = kk - tapp * p.wCout;
-        rb[q] = ld4(Bp + ((long)co * 9 + (8 - tapp)) * p.wCin + b_nc);
+        if (k0 == kbeg) {  // (tap', co) of this thread's rows, carried from tile to tile like the im2col coordinates below
+          const int kk = k0 + tid / BF4 + q * BRPP;
+          bw_b[q] = kk / p.wCout;
+          bw_oy[q] = kk - bw_b[q] * p.wCout;
+        }
+        rb[q] = ld4(Bp + ((long)bw_oy[q] * 9 + (8 - bw_b[q])) * p.wCin + b_nc);
+        bw_oy[q] += FBK;
+        while (bw_oy[q] >= p.wCout) { bw_oy[q] -= p.wCout; ++bw_b[q]; }
       }
     } else {  // B_KN_IM2COL: k = output pixel, column = (tap, ci) of the gathered input
       // the pixel coordinates of this thread's PB rows are carried from tile to tile (tiles are requested in order, 32
