@@ -15,6 +15,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 os.environ.setdefault("TRIS_AUTOTUNE", "0")
 
 
+def pytest_sessionstart(session):
+    """Build infrastructure, not a fallback: if the in-tree library has not been built on this machine yet and hipcc is
+    here, build it once (what `__graft_entry__.build()` does) so that the suite tests the product instead of failing on
+    a missing artefact.  The product itself never builds or falls back at run time (tris_amd/_lib.py raises)."""
+    import subprocess
+    lib = os.path.join(ROOT, "tris_amd", "libtris_hip.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(lib) and os.path.exists(hipcc):
+        subprocess.call(["bash", os.path.join(ROOT, "tris_amd", "csrc", "build.sh")])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
