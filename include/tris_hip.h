@@ -118,7 +118,7 @@ int tris_layernorm_fwd_f32(const float* X, const float* gamma, const float* beta
                            long rows, int W, float eps, void* stream);
 long tris_layernorm_bwd_workspace_bytes(long rows, int W);
 int tris_layernorm_bwd_f32(const float* dY, const float* X, const float* gamma, const float* mean, const float* rstd,
-                           float* dX, float* dgamma, float* dbeta, long rows, int W, float* workspace, void* stream);
+                           float* dX, float* dgamma, float* dbeta, long rows, int W, float* workspace, const float* extra /* optional: added to dX */, void* stream);
 
 /* ---- pooling / elementwise / layout -------------------------------------------------------------------------------- */
 int tris_avgpool2_fwd_f32(const float* X, float* Y, int B, int H, int W, int C, void* stream); /* model.py:25,37,231 */

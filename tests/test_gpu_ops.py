@@ -180,6 +180,40 @@ def test_avgpool_layernorm_gelu(ops):
     close(gx.grad, x.grad)
 
 
+def test_residual_gradient_box_through_layernorm(ops):
+    """y = Linear(LN(x)) + x : the Linear's backward leaves the residual gradient in a GradBox and the LayerNorm
+    backward kernel adds it while writing dX -- same gradients as torch, and the box is emptied."""
+    for W in (512, 100):
+        x, g, b, w, wb = leaf(37, W), leaf(W), leaf(W), leaf(W, W, scale=W ** -0.5), leaf(W)
+        y = F.linear(F.layer_norm(x, (W,), g, b, 1e-5), w, wb) + x
+        (y * y).sum().backward()
+        gx, gg, gb, gw, gwb = (gpu_leaf(t) for t in (x, g, b, w, wb))
+        box = ops.GradBox()
+        gy = ops.linear(ops.layer_norm(gx, gg, gb, 1e-5, box), gw, gwb, resid=gx, grad_box_res=box)
+        (gy * gy).sum().backward()
+        assert box.consumed and box.value is None
+        close(gy, y, 5e-4)
+        for a, r, n in ((gx, x, "dx"), (gg, g, "dgamma"), (gb, b, "dbeta"), (gw, w, "dw"), (gwb, wb, "db")):
+            close(a.grad, r.grad, 5e-4, n)
+
+
+def test_transformer_block_gradients_do_not_depend_on_the_gradient_box(ops, monkeypatch):
+    from tris_amd.CLIP.clip.model import ResidualAttentionBlock
+    torch.manual_seed(3)
+    blk = ResidualAttentionBlock(128, 2, attn_mask=True).cuda()   # head width 64, as every CLIP tower
+    x0 = torch.randn(3, 20, 128, device="cuda")
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TRIS_GRAD_BOX", flag)
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = blk(blk(x))
+        (y * y).mean().backward()
+        grads.append([x.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+    for a, b in zip(*grads):
+        close(a, b, 1e-5)
+
+
 @pytest.mark.parametrize("impl", ["mfma", "valu"])
 @pytest.mark.parametrize("N,L,heads,causal", [(3, 20, 8, True), (2, 50, 12, False), (1, 64, 2, True), (2, 7, 1, False),
                                              (2, 65, 2, True), (1, 401, 3, False), (2, 130, 2, True), (1, 1, 1, True),

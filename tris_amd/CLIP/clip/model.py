@@ -135,8 +135,8 @@ class Linear(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
 
-    def forward(self, x, resid=None, act=0):
-        return ops.linear(x, self.weight, self.bias, resid, act)
+    def forward(self, x, resid=None, act=0, grad_box_res=None):
+        return ops.linear(x, self.weight, self.bias, resid, act, grad_box_res=grad_box_res)
 
 
 class AttentionPool2d(nn.Module):
@@ -218,8 +218,8 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(w))
         self.bias = nn.Parameter(torch.zeros(w))
 
-    def forward(self, x):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+    def forward(self, x, grad_box=None):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, grad_box)
 
 
 class QuickGELU(nn.Module):
@@ -253,16 +253,22 @@ class ResidualAttentionBlock(nn.Module):
         self.causal = attn_mask is not None
 
     def forward(self, x):  # x [N, L, W] batch-first (the reference runs sequence-first; same math)
-        h = self.ln_1(x)
+        # x feeds a LayerNorm and, through the residual add fused into the closing Linear, the block output.  The Linear's
+        # backward runs first (the LayerNorm's depends on it), leaves its residual gradient in a GradBox, and the
+        # LayerNorm backward kernel adds it while writing dX: no separate accumulation pass, no copy.
+        use_box = torch.is_grad_enabled() and x.requires_grad and os.environ.get("TRIS_GRAD_BOX", "1") != "0"
+        b1 = ops.GradBox() if use_box else None
+        b2 = ops.GradBox() if use_box else None
+        h = self.ln_1(x, b1)
         qkv = ops.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
         a = ops.mha(qkv, self.attn.num_heads, self.causal)
-        x = self.attn.out_proj(a, resid=x)
-        h = self.ln_2(x)
+        x = self.attn.out_proj(a, resid=x, grad_box_res=b1)
+        h = self.ln_2(x, b2)
         if torch.is_grad_enabled():
             f = self.mlp.gelu(self.mlp.c_fc(h))
         else:
             f = self.mlp.c_fc(h, act=2)  # QuickGELU fused into the GEMM epilogue (inference / frozen aux text)
-        return self.mlp.c_proj(f, resid=x)
+        return self.mlp.c_proj(f, resid=x, grad_box_res=b2)
 
 
 class Transformer(nn.Module):

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, float* __restrict__ dX,
                                                             float* __restrict__ part, long rows, int W,
-                                                            long rows_per_block) {
+                                                            long rows_per_block, const float* __restrict__ extra) {
   __shared__ float4 lg[4][256];
   __shared__ float4 lb[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -449,6 +449,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.y = rstd * (dh[q].y - c1 - xh[q].y * c2);
           o.z = rstd * (dh[q].z - c1 - xh[q].z * c2);
           o.w = rstd * (dh[q].w - c1 - xh[q].w * c2);
+          if (extra) {  // gradient of the residual branch that by-passes this LayerNorm (ops.GradBox)
+            const float4 e = ld4(extra + row * W + i * 4);
+            o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+          }
           st4(dX + row * W + i * 4, o);
         }
       }
@@ -737,7 +741,7 @@ extern "C" long tris_layernorm_bwd_workspace_bytes(long rows, int W) {
 
 extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const float* gamma, const float* mean,
                                       const float* rstd, float* dX, float* dgamma, float* dbeta, long rows, int W,
-                                      float* workspace, void* stream) {
+                                      float* workspace, const float* extra, void* stream) {
   if (W % 4 || W > 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   long rpb = (rows + 127) / 128;
@@ -745,7 +749,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
   int nb = (int)((rows + rpb - 1) / rpb);
   float* part = dgamma ? workspace : nullptr;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dY, X, gamma, mean, rstd, dX, part, rows, W,
-                     rpb);
+                     rpb, extra);
   TRIS_LAUNCH_CHECK();
   if (dgamma) {
     hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(fin_grid(W, nb)), dim3(256), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);

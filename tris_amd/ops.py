@@ -370,9 +370,9 @@ class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None):
+    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
         _chk(x, w, b, resid)
-        ctx.grad_box, ctx.grad_box_out = grad_box, grad_box_out
+        ctx.grad_box, ctx.grad_box_out, ctx.grad_box_res = grad_box, grad_box_out, grad_box_res
         x = x.contiguous()
         K = x.shape[-1]
         N = w.numel() // K
@@ -423,6 +423,8 @@ class LinearFn(torch.autograd.Function):
         M, N, K = ctx.dims
         dy = dy.contiguous()
         d_res = dy if ctx.has_r and ctx.needs_input_grad[3] else None
+        if d_res is not None and ctx.grad_box_res is not None and ctx.grad_box_res.deposit(d_res):
+            d_res = None   # picked up by the block's LayerNorm backward (read-only there: no copy needed)
         if d_res is not None and _wgrad_enabled() and ctx.needs_input_grad[1]:
             # dy is about to be read by the weight-gradient stream; autograd may accumulate IN PLACE into a gradient
             # tensor it is handed back (InputBuffer steals sole-owner tensors), so the residual branch gets its own copy
@@ -457,11 +459,11 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
-        return dx, dw, db, d_res, None, None, None, None
+        return dx, dw, db, d_res, None, None, None, None, None
 
 
-def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None):
-    y = LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out)
+def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
+    y = LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res)
     return _attach_stats(y) if stats else y
 
 
@@ -773,8 +775,9 @@ def avgpool2(x, grad_box_out=None):
 # ----------------------------------------------------------------------------------------------- transformer pieces
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, b, eps):
+    def forward(ctx, x, g, b, eps, grad_box=None):
         _chk(x, g, b)
+        ctx.grad_box = grad_box
         x = x.contiguous()
         W = x.shape[-1]
         rows = x.numel() // W
@@ -792,23 +795,30 @@ class LayerNormFn(torch.autograd.Function):
         rows, W = ctx.dims
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        box, extra = ctx.grad_box, None
+        if box is not None:   # the block's residual gradient (left by the Linear that added x back): summed in this kernel
+            box.consumed = True
+            if box.value is not None:
+                extra, box.value = box.value.contiguous(), None
+                if dx is None:
+                    raise RuntimeError("a residual gradient was handed to a LayerNorm whose input needs no gradient")
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         ws = workspace(query("tris_layernorm_bwd_workspace_bytes", rows, W))
         sg, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
         if need_p and sg is not None and sb is not None and sg.is_contiguous() and sb.is_contiguous():
             call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(sg), P(sb), rows, W, P(ws),
-                 _stream())
-            return dx, None, None, None
+                 P(extra), _stream())
+            return dx, None, None, None, None
         dgb = torch.empty(2, W, device=x.device, dtype=torch.float32) if need_p else None
         call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(dgb), P(dgb, W),
-             rows, W, P(ws), _stream())
+             rows, W, P(ws), P(extra), _stream())
         dg = _emit(ctx.params[0], lambda o: o.copy_(dgb[0]), ctx.needs_input_grad[1])
         db = _emit(ctx.params[1], lambda o: o.copy_(dgb[1]), ctx.needs_input_grad[2])
-        return dx, dg, db, None
+        return dx, dg, db, None, None
 
 
-def layer_norm(x, g, b, eps=1e-5):
-    return LayerNormFn.apply(x, g, b, eps)
+def layer_norm(x, g, b, eps=1e-5, grad_box=None):
+    return LayerNormFn.apply(x, g, b, eps, grad_box)
 
 
 class MhaFn(torch.autograd.Function):
