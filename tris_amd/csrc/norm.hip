@@ -112,25 +112,38 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   }
 }
 
-// Partial-sum finalizers.  Block = 16 channels x 16 slices of the nb partial rows, reduced through LDS, so the
-// fixed-order (deterministic) sum over up to 512 partial blocks is 16-way parallel per channel.
+// Partial-sum finalizers.  Block = 4 channels x (blockDim/4) slices of the nb partial rows, reduced through LDS in a
+// fixed order (deterministic).  The partial rows lie 2*C doubles apart and were written by other XCDs, so every load is
+// a long-latency miss: what matters is how many are in flight -- C/4 blocks (16..512), and each thread issues its loads
+// in independent batches of 8 before the dependent fp64 adds.  nb <= 512 (col_partial plans): 64 slices, <= 8 loads per
+// thread; conv-epilogue statistics (one row per 128-row GEMM tile, up to ~10^4 rows): 1024-thread blocks, 256 slices.
+constexpr int FIN_CH = 4;
 template <typename T>
 __device__ __forceinline__ void reduce_parts(const T* __restrict__ part, int nb, int C, bool two, double& s, double& ss,
                                              int& c, bool& lead) {
-  // CH channels x (256/CH) row slices per block; many partial rows (fused conv-epilogue statistics: one row per
-  // 128-row GEMM tile, up to ~10^4) -> 4 channels x 64 slices, otherwise 16 x 16.  Grid = ceil(C / CH) (see fin_grid).
-  __shared__ double sh0[256];
-  __shared__ double sh1[256];
-  const int CH = nb > 512 ? 4 : 16, SL = 256 / CH;
-  const int cl = threadIdx.x % CH, j = threadIdx.x / CH;
-  c = blockIdx.x * CH + cl;
+  __shared__ double sh0[1024];
+  __shared__ double sh1[1024];
+  const int SL = blockDim.x / FIN_CH;
+  const int cl = threadIdx.x % FIN_CH, j = threadIdx.x / FIN_CH;
+  c = blockIdx.x * FIN_CH + cl;
   s = 0.0;
   ss = 0.0;
-  if (c < C)
-    for (int b = j; b < nb; b += SL) {
-      s += (double)part[(long)b * 2 * C + c];
-      if (two) ss += (double)part[(long)b * 2 * C + C + c];
+  if (c < C) {
+    constexpr int U = 8;
+    const T* p0 = part + c;
+    for (int b0 = j; b0 < nb; b0 += SL * U) {
+      T v0[U], v1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b = b0 + u * SL;
+        const bool ok = b < nb;
+        v0[u] = ok ? p0[(long)b * 2 * C] : (T)0;
+        v1[u] = (ok && two) ? p0[(long)b * 2 * C + C] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { s += (double)v0[u]; ss += (double)v1[u]; }
     }
+  }
   sh0[threadIdx.x] = s;
   sh1[threadIdx.x] = ss;
   __syncthreads();
@@ -138,13 +151,14 @@ __device__ __forceinline__ void reduce_parts(const T* __restrict__ part, int nb,
   if (lead) {
     s = 0.0;
     ss = 0.0;
-    for (int q = 0; q < SL; ++q) { s += sh0[q * CH + cl]; ss += sh1[q * CH + cl]; }
+    for (int q = 0; q < SL; ++q) { s += sh0[q * FIN_CH + cl]; ss += sh1[q * FIN_CH + cl]; }
   }
 }
-inline int fin_grid(int C, int nb) { return cdiv(C, nb > 512 ? 4 : 16); }
+inline int fin_grid(int C, int nb) { (void)nb; return cdiv(C, FIN_CH); }
+inline int fin_block(int nb) { return nb > 2048 ? 1024 : 256; }
 
 // BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
                                                           float eps, float momentum, float* __restrict__ stats,
                                                           float* running_mean, float* running_var) {
   double s, ss;
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 
 // Sum partials [nb][2][C] -> out0[C] (and out1[C] if given).
 template <typename T>
-__global__ __launch_bounds__(256) void part_finalize_kernel(const T* __restrict__ part, int nb, int C,
+__global__ __launch_bounds__(1024) void part_finalize_kernel(const T* __restrict__ part, int nb, int C,
                                                             float* __restrict__ out0, float* __restrict__ out1) {
   double s, ss;
   int c;
@@ -627,7 +641,7 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
   hipLaunchKernelGGL(col_partial_kernel<0>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, C,
                      (long)C, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, M, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace, p.nb, M, C,
                      eps, momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -636,7 +650,7 @@ extern "C" int tris_bn_stats_f32(const float* X, long M, int C, float eps, float
 // finish BN statistics from fp64 partials produced by a fused conv epilogue (tris_*_bnstat_f32)
 extern "C" int tris_bn_finalize_f32(const double* part, int rows, long M, int C, float eps, float momentum, float* stats,
                                     float* running_mean, float* running_var, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, rows)), dim3(256), 0, (hipStream_t)stream, part, rows, M, C, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, rows)), dim3(fin_block(rows)), 0, (hipStream_t)stream, part, rows, M, C, eps,
                      momentum, stats, running_mean, running_var);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -672,7 +686,7 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, gamma_mask ? nullptr : Y, mean, invstd, M, C,
                      (long)C, p.rpb, (double*)workspace, gamma_mask, beta_mask);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, C,
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace, p.nb, C,
                      sum_dz, sum_dzx);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -700,7 +714,7 @@ extern "C" int tris_colsum_f32(const float* X, long M, int N, long ld, float* ou
   hipLaunchKernelGGL(col_partial_kernel<2>, dim3(p.nb), dim3(256), 0, st, X, nullptr, nullptr, nullptr, nullptr, M, N,
                      ld, p.rpb, (double*)workspace);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(N, p.nb)), dim3(256), 0, st, (const double*)workspace, p.nb, N,
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(N, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace, p.nb, N,
                      out, (float*)nullptr);
   TRIS_LAUNCH_CHECK();
   return 0;
@@ -752,7 +766,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
                      rpb, extra);
   TRIS_LAUNCH_CHECK();
   if (dgamma) {
-    hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(fin_grid(W, nb)), dim3(256), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);
+    hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(fin_grid(W, nb)), dim3(fin_block(nb)), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);
     TRIS_LAUNCH_CHECK();
   }
   return 0;
