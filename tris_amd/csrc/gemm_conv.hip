@@ -43,6 +43,7 @@ struct GemmParams {
   float alpha;
   int vecA, vecB;  // 16-byte vector loads legal for the operand
   int fastA, fastB;  // operand satisfies the preconditions of gemm_fast_kernel
+  int vecC;          // 16-byte epilogue legal: C / resid / bias aligned, N and the leading dimensions multiples of 4 (set by run_cfg)
   double* stat_part;  // optional fused BN statistics partials [tiles_m][2][N] (fast kernel, no split-K)
   int kchunk, splitk;
   int tiles_n;
@@ -492,6 +493,12 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   if (splitk > 1) splitk = cdiv(p.K, p.kchunk), p.splitk = splitk;
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(batch * splitk));
   float* Cfinal = p.C;
+  static const bool vec_epi_ok = !(getenv("TRIS_VEC_EPILOGUE") && getenv("TRIS_VEC_EPILOGUE")[0] == '0');  // developer A/B knob
+  if (splitk > 1)
+    p.vecC = vec_epi_ok && (p.N % 4 == 0) && al16(ws);
+  else
+    p.vecC = vec_epi_ok && (p.N % 4 == 0) && al16(p.C) && (p.ldc % 4 == 0) && (p.sC % 4 == 0) &&
+             (!p.resid || (al16(p.resid) && p.ldr % 4 == 0 && p.sR % 4 == 0)) && (p.bias_mode != 1 || al16(p.bias));
 #define TRIS_FAST(BM_, BN_, EPI_, PREC_)                                                                              \
   do {                                                                                                                 \
     if (BM_ == 128 && BN_ == 128 && nw == 8)                                                                            \
@@ -618,6 +625,14 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
+    if (const char* lg = getenv("TRIS_TUNE_LOG")) {  // developer knob: one line per tuned shape (idle-device time of the winner)
+      if (FILE* f = fopen(lg, "a")) {
+        fprintf(f, "ak=%d bkind=%d M=%d N=%d K=%d batch=%d mode=%d -> %dx%d sk=%d nw=%d  %.1f us  %.1f TFLOP/s\n", AK, BKIND,
+                p.M, p.N, p.K, batch, g_gemm_mode, best.bm, best.bn, best.splitk, best.nw, best_ms * 1e3f,
+                2.0 * p.M * p.N * p.K * batch / (best_ms * 1e-3) * 1e-12);
+        fclose(f);
+      }
+    }
   }
   return run_cfg<AK, BKIND>(p, batch, ws, st, best);  // leave the outputs of the chosen configuration
 }

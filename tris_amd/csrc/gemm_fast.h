@@ -478,6 +478,62 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   float st_s[FN], st_q[FN];  // fused BatchNorm statistics: per-column sum / sum of squares of this block's rows
 #pragma unroll
   for (int j = 0; j < FN; ++j) st_s[j] = st_q[j] = 0.f;
+  // Vector epilogue: in the accumulator layout a lane owns single floats of 16 different rows, so direct stores are 16
+  // scalar instructions per 32x32 block, each touching two 128-byte row pieces (and the residual comes in the same way).
+  // For the short-K products (1x1 convolutions of layer1/2: K = 64..256 against a [M, 256..512] output) that is most of the
+  // kernel.  Each wave instead turns its block around in the idle staging LDS (32 x 36 floats, wave-private: program order
+  // + a wave fence) and handles rows: 8 lanes x 16 bytes per row, 8 rows per instruction -- 4 loads/stores per block.
+  constexpr int ELD = 36;
+  constexpr bool EPI_LDS = (NWN * 32 * ELD <= A_SZ) && (NWN * 32 * ELD <= B_SZ);
+  float4 vs_s[FN], vs_q[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) vs_s[j] = vs_q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool vec_epi = EPI_LDS && p.vecC;  // uniform
+  if (vec_epi) {
+    float* stg = (wm == 0 ? As : Bs) + wn * 32 * ELD;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * kh) * ELD + li] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int col = n0 + wn * WN + j * 32 + ec;
+        float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_STD && p.bias_mode == 1 && col < p.N) bc = ld4(p.bias + col);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = m0 + wm * WM + i * 32 + er + 8 * t;
+          float4 v = *reinterpret_cast<const float4*>(stg + (er + 8 * t) * ELD + ec);
+          if (row < p.M && col < p.N) {  // N % 4 == 0: a vector never straddles the edge
+            if (EPI == EPI_SLAB) {
+              *reinterpret_cast<float4*>(p.C + ((long)blockIdx.z * p.M + row) * p.N + col) = v;
+            } else {
+              v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+              if (p.bias_mode == 1) { v.x += bc.x; v.y += bc.y; v.z += bc.z; v.w += bc.w; }
+              else if (p.bias_mode == 2) { const float bb = p.bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+              if (p.act == 1) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              } else if (p.act == 2) {
+                v.x = v.x / (1.0f + expf(-1.702f * v.x)); v.y = v.y / (1.0f + expf(-1.702f * v.y));
+                v.z = v.z / (1.0f + expf(-1.702f * v.z)); v.w = v.w / (1.0f + expf(-1.702f * v.w));
+              }
+              if (p.resid) {
+                const float4 rr = ld4(p.resid + (long)zb * p.sR + (long)row * p.ldr + col);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+              }
+              *reinterpret_cast<float4*>(p.C + (long)zb * p.sC + (long)row * p.ldc + col) = v;
+              vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
+              vs_q[j].x += v.x * v.x; vs_q[j].y += v.y * v.y; vs_q[j].z += v.z * v.z; vs_q[j].w += v.w * v.w;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+  } else {
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -504,10 +560,30 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         }
       }
     }
+  }
   if (EPI == EPI_STD && p.stat_part != nullptr) {
-    // rows of one column live in the 2 lane halves (kh) and the 2 waves along M: shuffle, then LDS, then one fp64
-    // partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
+    // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the 2 waves along M:
+    // shuffle, then LDS, then one fp64 partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
     float* red = As;  // the k loop ended on a barrier: the staging buffer is free
+    if (vec_epi) {
+      __syncthreads();  // the other waves' epilogue blocks live in As / Bs
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float4 a = vs_s[j], b = vs_q[j];
+#pragma unroll
+        for (int sh = 8; sh < 64; sh <<= 1) {
+          a.x += __shfl_xor(a.x, sh, 64); a.y += __shfl_xor(a.y, sh, 64);
+          a.z += __shfl_xor(a.z, sh, 64); a.w += __shfl_xor(a.w, sh, 64);
+          b.x += __shfl_xor(b.x, sh, 64); b.y += __shfl_xor(b.y, sh, 64);
+          b.z += __shfl_xor(b.z, sh, 64); b.w += __shfl_xor(b.w, sh, 64);
+        }
+        if (lane < 8) {
+          const int cl = wn * WN + j * 32 + lane * 4;
+          float* o = red + (wm * BN + cl) * 2;
+          o[0] = a.x; o[1] = b.x; o[2] = a.y; o[3] = b.y; o[4] = a.z; o[5] = b.z; o[6] = a.w; o[7] = b.w;
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       float a = st_s[j] + __shfl_xor(st_s[j], 32, 64);
@@ -517,6 +593,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         red[(wm * BN + cl) * 2 + 0] = a;
         red[(wm * BN + cl) * 2 + 1] = b;
       }
+    }
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
