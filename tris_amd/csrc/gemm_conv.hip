@@ -435,7 +435,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
   int bm = 64, bn = 64, splitk = 1;
   if (p.stat_part != nullptr) {  // fused BN statistics: fixed 128-row tiles (the caller sizes the partial buffer), no split-K
     bm = 128;
-    bn = p.N <= 64 ? 64 : 128;
+    bn = p.N <= 32 ? 32 : p.N <= 64 ? 64 : 128;  // (run_cfg turns 128x32 into 64x64 when the fast kernel does not apply)
   } else if (can_split && p.K >= 4096) {
     // long-K reductions (wgrad over pixels): 2 co-resident blocks per CU keep the MFMA pipe busy across the
     // barrier / staging phases, and ~512 blocks smooth the wave quantisation -> split K until there are ~512 blocks
@@ -447,16 +447,18 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
     if ((long)splitk * per > ws_bytes) splitk = (int)(ws_bytes / per);
     if (splitk < 2) splitk = 1;
   } else {
-    static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    static const double pen[3] = {1.0, 1.08, 1.2};
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+    static const double pen[4] = {1.0, 1.08, 1.2, 1.15};
+    const bool fastk = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
     double best = 1e30;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
       const int cbm = cand[c][0], cbn = cand[c][1];
-      if (c < 2 && p.M < 96) continue;           // 128-row tiles on a tiny M waste the MFMA
+      if (c != 2 && p.M < 96) continue;          // 128-row tiles on a tiny M waste the MFMA
       if (c == 0 && p.N <= 64) continue;
+      if (c == 3 && !(p.N <= 32 && fastk)) continue;  // 32-wide outputs (stem convolutions): half of a 64-wide tile would be padding
       const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
       // MFMA cycles of one 32x32 fragment pair per 32-deep step: 16 f32 MFMAs x 64, or 12 bf16 MFMAs x 32 (x3 mode)
-      const double per_k32 = (cbm / 64) * (cbn / 64) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 2 ? 192.0 + 200.0 : 1024.0) * pen[c];
+      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 2 ? 192.0 + 200.0 : 1024.0) * pen[c];
       const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
       for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
         if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
@@ -468,12 +470,13 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
       }
     }
   }
-  {  // developer knob: TRIS_FORCE_TILE=128x128|128x64|64x64 overrides the tile choice (tools/x3_probe.py)
+  {  // developer knob: TRIS_FORCE_TILE=128x128|128x64|64x64|128x32 overrides the tile choice (tools/x3_probe.py)
     const char* e = getenv("TRIS_FORCE_TILE");  // read per call: tests switch it at run time
-    const int forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : 0);
+    const int forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : !strcmp(e, "128x32") ? 4 : 0);
     if (forced == 1 && p.N > 64) { bm = 128; bn = 128; }
     if (forced == 2) { bm = 128; bn = 64; }
     if (forced == 3) { bm = 64; bn = 64; }
+    if (forced == 4 && p.N <= 32) { bm = 128; bn = 32; }
   }
   Cfg c = {bm, bn, splitk, g_x3_waves};
   return c;
@@ -484,9 +487,10 @@ template <int AK, int BKIND>
 int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   int bm = cfg.bm, bn = cfg.bn, splitk = cfg.splitk;
   const int nw = cfg.nw;
+  const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
+  if (bn == 32 && !fast) bm = bn = 64;  // the 128x32 tile exists in the fast kernel only
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
-  const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
   const int kalign = fast ? 32 : BK;
   p.splitk = splitk;
   p.kchunk = cdiv(cdiv(p.K, splitk), kalign) * kalign;
@@ -502,10 +506,11 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
 #define TRIS_FAST(BM_, BN_, EPI_, PREC_)                                                                              \
   do {                                                                                                                 \
     if (BM_ == 128 && BN_ == 128 && nw == 8)                                                                            \
-      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_, (BM_ == 128 && BN_ == 128) ? 8 : 4>), grid, \
-                         dim3(512), 0, st, p);                                                                         \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_>), grid, dim3(256), 0, st, p);               \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_, (BM_ == 128 && BN_ == 128 ? 8 : BN_ == 32 ? 2 : 4)>),  \
+                         grid, dim3(512), 0, st, p);                                                       \
+    else  /* 128x32: two waves (2x1); everything else four (2x2) */                                                     \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, PREC_, (BN_ == 32 ? 2 : 4)>), grid,               \
+                         dim3(BN_ == 32 ? 128 : 256), 0, st, p);                                                       \
   } while (0)
 #define TRIS_GO(BM_, BN_)                                                                          \
   do {                                                                                             \
@@ -527,10 +532,25 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
       hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AK, BKIND, EPI_STD>), grid, dim3(256), 0, st, p);  \
     }                                                                                              \
   } while (0)
+#define TRIS_GO_FAST_ONLY(BM_, BN_)                                                                \
+  do {                                                                                             \
+    if (splitk > 1) {                                                                              \
+      p.C = ws;                                                                                    \
+      if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_SLAB, 1);                                      \
+      else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_SLAB, 2);                                 \
+      else TRIS_FAST(BM_, BN_, EPI_SLAB, 0);                                                       \
+    } else {                                                                                       \
+      if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_STD, 1);                                       \
+      else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_STD, 2);                                  \
+      else TRIS_FAST(BM_, BN_, EPI_STD, 0);                                                        \
+    }                                                                                              \
+  } while (0)
   if (bm == 128 && bn == 128) TRIS_GO(128, 128);
   else if (bm == 128 && bn == 64) TRIS_GO(128, 64);
+  else if (bm == 128 && bn == 32) TRIS_GO_FAST_ONLY(128, 32);
   else TRIS_GO(64, 64);
 #undef TRIS_GO
+#undef TRIS_GO_FAST_ONLY
 #undef TRIS_FAST
   TRIS_LAUNCH_CHECK();
   if (splitk > 1) {
@@ -581,7 +601,8 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if (it != g_tuned.end()) return run_cfg<AK, BKIND>(p, batch, ws, st, it->second);
   }
   // candidates
-  static const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+  const bool fastk = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
   static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
   const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
   hipEvent_t e0, e1;
@@ -602,10 +623,11 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     }
     return ms_min;
   };
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < 4; ++t) {
     const int cbm = tiles[t][0], cbn = tiles[t][1];
-    if (t < 2 && p.M < 96) continue;
+    if (t != 2 && p.M < 96) continue;
     if (t == 0 && p.N <= 64) continue;
+    if (t == 3 && !(p.N <= 32 && fastk)) continue;
     const long ntiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
     for (int sk : sks) {
       if (sk > 1 && (!can_split || sk > p.K / 256 || (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes)) break;
