@@ -590,11 +590,12 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   if (BKIND == B_NK_PRE && !(g_gemm_mode >= 1 && p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4 && batch == 1))
     return TRIS_WP_UNSUPPORTED;  // pre-split operands exist only for the fast x3 kernel: the caller falls back to fp32 B
   Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
-  if (p.stat_part != nullptr || !autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
+  if (!autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
+  const bool stat = p.stat_part != nullptr;  // fused BN statistics: 128-row tiles and no split-K are fixed, the tile width is tuned
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
     return run_cfg<AK, BKIND>(p, batch, ws, st, h);
-  const TuneKey key = {AK, BKIND, p.M, p.N, p.K, batch, g_gemm_mode};
+  const TuneKey key = {AK, BKIND + (stat ? 16 : 0), p.M, p.N, p.K, batch, g_gemm_mode};
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
@@ -604,7 +605,7 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
   const bool fastk = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
   static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
-  const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512);
+  const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512) && !stat;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
   hipDeviceSynchronize();  // drain the other streams: candidates are timed on an otherwise idle device
@@ -628,6 +629,7 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if (t != 2 && p.M < 96) continue;
     if (t == 0 && p.N <= 64) continue;
     if (t == 3 && !(p.N <= 32 && fastk)) continue;
+    if (stat && cbm != 128) continue;
     const long ntiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
     for (int sk : sks) {
       if (sk > 1 && (!can_split || sk > p.K / 256 || (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes)) break;
@@ -649,7 +651,7 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     g_tuned[key] = best;
     if (const char* lg = getenv("TRIS_TUNE_LOG")) {  // developer knob: one line per tuned shape (idle-device time of the winner)
       if (FILE* f = fopen(lg, "a")) {
-        fprintf(f, "ak=%d bkind=%d M=%d N=%d K=%d batch=%d mode=%d -> %dx%d sk=%d nw=%d  %.1f us  %.1f TFLOP/s\n", AK, BKIND,
+        fprintf(f, "ak=%d bkind=%d M=%d N=%d K=%d batch=%d mode=%d -> %dx%d sk=%d nw=%d  %.1f us  %.1f TFLOP/s\n", AK, key.bk,
                 p.M, p.N, p.K, batch, g_gemm_mode, best.bm, best.bn, best.splitk, best.nw, best_ms * 1e3f,
                 2.0 * p.M * p.N * p.K * batch / (best_ms * 1e-3) * 1e-12);
         fclose(f);
