@@ -44,7 +44,8 @@ def ops(request):
 
 
 @pytest.mark.parametrize("M,N,K", [(100, 48, 1024), (130, 70, 52), (256, 256, 64), (48, 1024, 2048), (7, 5, 27),
-                                   (3000, 64, 64), (1000, 200, 16)])
+                                   (3000, 64, 64), (1000, 200, 16),
+                                   (200, 70, 64), (129, 33, 96)])   # fast kernel, N % 4 != 0: the scalar epilogue
 def test_linear_fwd_bwd(ops, M, N, K):
     x, w, b, r = leaf(M, K), leaf(N, K, scale=0.1), leaf(N), leaf(M, N)
     y = x @ w.t() + b + r
@@ -57,6 +58,26 @@ def test_linear_fwd_bwd(ops, M, N, K):
     close(gw.grad, w.grad, name="dw")
     close(gb.grad, b.grad, name="db")
     close(gr.grad, r.grad, name="dresid")
+
+
+def test_gemm_epilogue_variants(ops):
+    """bias per row / per column, alpha, batched residual: the vector epilogue (aligned, N % 4 == 0) and the scalar one
+    (C / residual offset by one float) must give the same numbers as torch"""
+    B, M, N, K = 3, 160, 96, 64
+    g = torch.Generator().manual_seed(11)
+    A, Bm = torch.randn(B, M, K, generator=g), torch.randn(B, N, K, generator=g)
+    R, bias_r, bias_c = torch.randn(B, M, N, generator=g), torch.randn(M, generator=g), torch.randn(N, generator=g)
+    dA, dB, dR = A.cuda(), Bm.cuda(), R.cuda()
+    for mode, bias in ((1, bias_c), (2, bias_r)):
+        ref = 0.5 * (A @ Bm.transpose(1, 2)) + (bias[None, None, :] if mode == 1 else bias[None, :, None]) + R
+        for off in (0, 1):                                   # off = 1: C and the residual lose their 16-byte alignment
+            buf = torch.full((B * M * N + 4,), float("nan"), device="cuda")
+            rbuf = torch.zeros(B * M * N + 4, device="cuda")
+            rbuf[off:off + B * M * N] = dR.flatten()
+            C, Rv = buf[off:off + B * M * N], rbuf[off:off + B * M * N]
+            ops.gemm(dA, dB, C, M, N, K, K, K, N, False, True, batch=B, sA=M * K, sB=N * K, sC=M * N, bias=bias.cuda(),
+                     bias_mode=mode, resid=Rv, ldr=N, sR=M * N, alpha=0.5)
+            close(C.view(B, M, N), ref, name=f"bias_mode {mode} offset {off}")
 
 
 def test_linear_relu_and_gelu_epilogues(ops):
