@@ -93,6 +93,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   const float* __restrict__ A = p.A + (long)zb * p.sA;
   const float* __restrict__ Bp = p.B + (long)zb * p.sB;
 
+  // Row handled by this thread's 8-lane set in the row-major kinds.  The split pieces go to LDS with ds_write_b64, which is
+  // serviced in groups of 16 CONTIGUOUS lanes against a 32-bank (128-byte) modulus: two 8-lane sets = two rows of 64 bytes.
+  // With the 80-byte plane rows, rows r and r+1 overlap on four banks (2-way: every store group took two LDS cycles --
+  // SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS 0.84 against 0.01 for the transpose-read kinds); rows r and r+4 are exactly
+  // 16 banks apart.  So within every 8 rows the lane sets visit rows 0,4,1,5,2,6,3,7: same layout, same global
+  // coalescing (one 128-byte row piece per 8 lanes), conflict-free stores.
+  const int trow = ((tid >> 3) & ~7) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3);
   // ---- loader state ---------------------------------------------------------------------------------------------
   // row-major kinds: thread -> (row = tid>>3 + 32*q, kofs = (tid&7)*4);  k-major kinds: (k = tid/F4 + q*RPP, col4)
   long a_off[PA];  // ROWK: row offset; IM2COL: unused
@@ -100,14 +107,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   if (AK == A_ROWK) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      int m = min(m0 + (tid >> 3) + q * RPASS, p.M - 1);
+      int m = min(m0 + trow + q * RPASS, p.M - 1);
       a_off[q] = (long)m * p.lda + (tid & 7) * 4;
     }
   } else if (AK == A_IM2COL) {
     const int hw = p.gHo * p.gWo;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      int m = min(m0 + (tid >> 3) + q * RPASS, p.M - 1);
+      int m = min(m0 + trow + q * RPASS, p.M - 1);
       a_b[q] = m / hw;
       int r = m - a_b[q] * hw;
       int oy = r / p.gWo, ox = r - oy * p.gWo;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   if (BKIND == B_NK) {
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      int n = min(n0 + (tid >> 3) + q * RPASS, p.N - 1);
+      int n = min(n0 + trow + q * RPASS, p.N - 1);
       b_off[q] = (long)n * p.ldb + (tid & 7) * 4;
     }
   }
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
       for (int q = 0; q < PA; ++q) {
         const Split4 sp = split4(ra[q]);
-        char* d = reinterpret_cast<char*>(As) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
+        char* d = reinterpret_cast<char*>(As) + (trow + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
         if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     } else if (A_RM) {
 #pragma unroll
       for (int q = 0; q < PA; ++q)
-        *reinterpret_cast<float4*>(&As[((tid >> 3) + q * RPASS) * LDK + (tid & 7) * 4]) = ra[q];
+        *reinterpret_cast<float4*>(&As[(trow + q * RPASS) * LDK + (tid & 7) * 4]) = ra[q];
     } else {
 #pragma unroll
       for (int q = 0; q < PA; ++q)
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #else
         const Split4 sp = split4(rb[q]);
 #endif
-        char* d = reinterpret_cast<char*>(Bs) + ((tid >> 3) + q * RPASS) * PLB + (tid & 7) * 8;
+        char* d = reinterpret_cast<char*>(Bs) + (trow + q * RPASS) * PLB + (tid & 7) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
         if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     } else if (B_RM) {
 #pragma unroll
       for (int q = 0; q < PB; ++q)
-        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + q * RPASS) * LDK + (tid & 7) * 4]) = rb[q];
+        *reinterpret_cast<float4*>(&Bs[(trow + q * RPASS) * LDK + (tid & 7) * 4]) = rb[q];
     } else {
 #pragma unroll
       for (int q = 0; q < PB; ++q)
