@@ -1,15 +1,20 @@
 // Fast path of the MFMA GEMM / implicit-GEMM core (included by gemm_conv.hip).
 //
-// Same tiling as the generic kernel (BM x BN block, 4 waves 2x2, 32x32 f32 MFMA fragments) but:
+// BM x BN block (128x128 with 8 waves 2x4, 128x64 / 64x64 with 4 waves 2x2, 128x32 with 2 waves 2x1), 32x32 MFMA fragments:
 //   * BK = 32 and *branch-free* tile loaders: rows/columns past the edge are clamped (their results are never
 //     stored) and out-of-image im2col taps are loaded from a valid address and zeroed with a select, so the K loop has
 //     no divergent control flow and the accumulators stay pinned in registers;
-//   * k-contiguous operands (row-major A, B^T, im2col) keep a row-major LDS image [rows][32+4]: 16-byte global loads
-//     go to LDS as ds_write_b128, and a fragment read is ONE ds_read_b128 per lane = 4 k-values feeding 4 MFMAs.
-//     Row stride 36 floats puts the 16 lanes of every ds_read_b128 service group on 16 distinct 16-byte slots
-//     (9*i mod 16 is a permutation) -> conflict-free.  The logical k order inside an MFMA is permuted
+//   * PREC 0 (f32-input MFMA): k-contiguous operands (row-major A, B^T, im2col) keep a row-major LDS image [rows][32+4]:
+//     16-byte global loads go to LDS as ds_write_b128, and a fragment read is ONE ds_read_b128 per lane = 4 k-values
+//     feeding 4 MFMAs.  Row stride 36 floats puts the 16 lanes of every ds_read_b128 service group on 16 distinct
+//     16-byte slots (9*i mod 16 is a permutation) -> conflict-free.  The logical k order inside an MFMA is permuted
 //     (lane-half kh, MFMA j  <->  k = 8g + 4kh + j); both operands use the same permutation, the sum is unchanged;
-//   * m-contiguous operands (A^T for wgrad, B for dgrad / NN) keep the k-major image and read 4 scalars.
+//     m-contiguous operands (A^T for wgrad, B for dgrad / NN) keep the k-major image and read 4 scalars;
+//   * PREC 1 / 2 (split-bf16 x3 / x2, below): operands are split when the tile is stored, the LDS image is bf16 planes --
+//     row-major [plane][row][32+8] for the k-contiguous kinds, k-major [plane][k][m] read with ds_read_b64_tr_b16 for the
+//     m-contiguous ones;
+//   * epilogue: bias / activation / residual / BN statistics, stored as 16-byte rows after an in-LDS turn of each wave's
+//     accumulator block (scalar fallback for unaligned or N % 4 != 0 outputs).
 // Preconditions (checked on the host, otherwise the generic kernel runs): K % 32 == 0 per k-slice, 16-byte aligned
 // operands, M % 4 == 0 / N % 4 == 0 for the m-/n-contiguous kinds, gathered channels % 32 == 0 for im2col.
 #pragma once
