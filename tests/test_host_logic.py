@@ -150,3 +150,16 @@ def test_batchnorm_step_counter_is_flushed_when_observed():
     m._nbt_pending = 2
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
     assert int(m.num_batches_tracked) == 3 and m._nbt_pending == 0
+
+
+def test_gradient_box_protocol():
+    """ops.GradBox hands ONE gradient from a later layer's backward to an earlier layer's kernel epilogue: the first deposit
+    is taken over, a second one (or one arriving after the consumer has run) goes back to autograd."""
+    from tris_amd.ops import GradBox
+    box = GradBox()
+    g1, g2 = torch.ones(3), torch.zeros(3)
+    assert box.value is None and not box.consumed
+    assert box.deposit(g1) and box.value is g1
+    assert not box.deposit(g2) and box.value is g1          # occupied: the second gradient stays with autograd
+    box.value, box.consumed = None, True                     # what the consuming backward does
+    assert not box.deposit(g2) and box.value is None         # too late: the consumer has already run
