@@ -25,8 +25,9 @@ for line in open(sys.argv[1]):
     seen.add(key)
     flop = 2.0 * M * N * K * batch
     ideal = flop / (ref * 1e12) * 1e6
-    gathered = ak == 2 or bk % 16 in (2, 3)                      # implicit GEMM: K counts every tap, the tensor is read once
-    byt = 4.0 * batch * (M * N + (M * K + N * K) / (9.0 if gathered else 1.0))
+    a_el = M * K / (9.0 if ak == 2 else 1.0)                     # implicit GEMM: K counts every tap, the gathered tensor is read once
+    b_el = N * K / (9.0 if bk % 16 == 3 else 1.0)
+    byt = 4.0 * batch * (M * N + a_el + b_el)
     rows.append((us - ideal, ak, bk, M, N, K, batch, f"{bm}x{bn}", sk, us, tf, byt / 5e6))
 rows.sort(reverse=True)
 print(f"{len(rows)} shapes, one call each: {sum(r[9] for r in rows) / 1e3:.2f} ms; above {ref:.0f} TFLOP/s: "
