@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill): no CLIP checkpoint needed
 import sys
 import time
 import warnings
@@ -87,7 +88,7 @@ def main():
     from tris_amd.CLIP import clip
     from tris_amd.model.model_stage1 import TRIS
     from tris_amd.optim import FusedAdamW
-    from tris_amd.parallel import GradReducer, convert_sync_batchnorm, stage1_segments
+    from tris_amd.parallel import attach_reducer, convert_sync_batchnorm
     from tris_amd.train_stage1 import freeze_aux, train_step
     from tris_amd.utils.synth import seed_fill, synthetic_batch
 
@@ -109,9 +110,7 @@ def main():
     reducer = None
     if world > 1 or force:
         convert_sync_batchnorm(model)
-        reducer = GradReducer([ar.g for ar in opt.arenas], force=force)
-        reducer.set_segments(stage1_segments(model, opt))   # all-reduce segments launched from inside backward
-        model.backbone.visual.grad_reducer = reducer
+        reducer = attach_reducer(model, opt, force=force)   # all-reduce segments launched from inside backward
     b = synthetic_batch(a.batch, 320, QL, 3, seed=7, rank=rank)
     img, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
 

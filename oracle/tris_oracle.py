@@ -219,16 +219,10 @@ def pixel_attention(sd, p, vis, lan):
     return F.relu(F.conv2d(Vo * Gi, sd[p + ".Wo.weight"], sd[p + ".Wo.bias"]))
 
 
-def tris_forward(sd, img, word_id, train, focal_p=3.0, focal_c=0.01, attn_multi=0.1,
-                 with_attnpool=False, return_score=False, vit_trunk=False):
-    """TRIS.forward -- model/model_stage1.py:54-119 (focal_loss :122-123, Upsample model/utils.py:5-10)."""
-    B = img.shape[0]
-    size = img.shape[2:]
-    _, hidden = encode_text(sd, "backbone.", word_id)
-    if vit_trunk:
-        c4 = encode_image_vit_spatial(sd, "backbone.", img)[1]
-    else:
-        c4 = encode_image_rn(sd, "backbone.", img, train, with_attnpool)[3]
+def tris_heads(sd, c4, hidden, size, train, focal_p=3.0, focal_c=0.01, attn_multi=0.1, return_score=False):
+    """TRIS.forward behind the two encoders -- model/model_stage1.py:61-119: projections, L2 norms, bilateral_prompt,
+    score, cls head, response maps.  c4 [B,Cv,h,w], hidden [N,E] with N = B sentences (one per image)."""
+    B = c4.shape[0]
     lan = hidden @ sd["lan_project.weight"].t() + sd["lan_project.bias"]
     vis = F.conv2d(c4, sd["vis_project.weight"], sd["vis_project.bias"])
     h_, w_ = vis.shape[2:]
@@ -263,6 +257,17 @@ def tris_forward(sd, img, word_id, train, focal_p=3.0, focal_c=0.01, attn_multi=
     return F.relu(seg)
 
 
+def tris_forward(sd, img, word_id, train, focal_p=3.0, focal_c=0.01, attn_multi=0.1,
+                 with_attnpool=False, return_score=False, vit_trunk=False):
+    """TRIS.forward -- model/model_stage1.py:54-119 (focal_loss :122-123, Upsample model/utils.py:5-10)."""
+    _, hidden = encode_text(sd, "backbone.", word_id)
+    if vit_trunk:
+        c4 = encode_image_vit_spatial(sd, "backbone.", img)[1]
+    else:
+        c4 = encode_image_rn(sd, "backbone.", img, train, with_attnpool)[3]
+    return tris_heads(sd, c4, hidden, img.shape[2:], train, focal_p, focal_c, attn_multi, return_score)
+
+
 # --------------------------------------------------------------------------------------
 # loss block + step (train_stage1.py)
 # --------------------------------------------------------------------------------------
@@ -282,15 +287,10 @@ def max_loss(x):
     return -(torch.log(x.clamp(0.0001, 0.9999))).mean()
 
 
-def stage1_losses(sd, aux, batch, w=(1.0, 5.0, 2.0), faithful=False):
-    """One Stage-1 forward + loss block -- train_stage1.py:317-364.
-
-    faithful=True mirrors the reference's redundant work (attnpool, second aux image forward,
-    per-image negative-text loop); faithful=False computes the same numbers once ("lean",
-    SURVEY.md §6: identical loss).  Returns dict(loss, l1, l4, l5, cls, sig)."""
-    img, ids = batch["img"], batch["word_ids"]
+def stage1_loss_block(aux, img, ids, neg, cls, sig, w=(1.0, 5.0, 2.0), faithful=False):
+    """The loss block behind TRIS.forward -- train_stage1.py:327-364: fg construction, CLIP-guided fg loss (l1),
+    negative-sample loss (l5), cls loss (l4), weighted total."""
     B = img.shape[0]
-    cls, cls_fg, relu_map, sig, _ = tris_forward(sd, img, ids, True, with_attnpool=faithful)
     cam = F.interpolate(sig, (224, 224), mode="bilinear", align_corners=True)
     im224 = F.interpolate(img, (224, 224), mode="bilinear", align_corners=True)
     fg = cam * im224
@@ -303,7 +303,6 @@ def stage1_losses(sd, aux, batch, w=(1.0, 5.0, 2.0), faithful=False):
         l1 = max_loss(((f_i / f_i.norm(dim=-1, keepdim=True)) *
                        (f_t / f_t.norm(dim=-1, keepdim=True))).sum(-1))
     l5 = torch.zeros(())
-    neg = batch.get("neg_word_ids")
     if neg is not None:
         fn = f_i / f_i.norm(dim=-1, keepdim=True)
         if faithful:  # train_stage1.py:346-353, one tiny text forward per image
@@ -319,8 +318,44 @@ def stage1_losses(sd, aux, batch, w=(1.0, 5.0, 2.0), faithful=False):
             l5 = (-(torch.log(1 - (fn[:, None] * t).sum(-1)))).mean(1).mean()
     l4 = F.multilabel_soft_margin_loss(cls, torch.eye(B))
     loss = w[0] * l1 + w[1] * l4 + w[2] * l5
+    return loss, l1, l4, l5
+
+
+def stage1_losses(sd, aux, batch, w=(1.0, 5.0, 2.0), faithful=False):
+    """One Stage-1 forward + loss block -- train_stage1.py:317-364.
+
+    faithful=True mirrors the reference's redundant work (attnpool, second aux image forward,
+    per-image negative-text loop); faithful=False computes the same numbers once ("lean",
+    SURVEY.md §6: identical loss).  Returns dict(loss, l1, l4, l5, cls, sig)."""
+    img, ids = batch["img"], batch["word_ids"]
+    cls, cls_fg, relu_map, sig, _ = tris_forward(sd, img, ids, True, with_attnpool=faithful)
+    loss, l1, l4, l5 = stage1_loss_block(aux, img, ids, batch.get("neg_word_ids"), cls, sig, w, faithful)
     return {"loss": loss, "l1": l1, "l4": l4, "l5": l5, "cls": cls, "cls_fg": cls_fg,
             "sig": sig, "relu": relu_map}
+
+
+def stage1_losses_ddp(sd, aux, batch, world, w=(1.0, 5.0, 2.0)):
+    """N-rank correctness oracle of the data-parallel step (reference: DistributedDataParallel +
+    SyncBatchNorm, train_stage1.py:69-70): ONE process on the concatenated shards.  The only cross-rank couplings of the
+    reference's step are (1) SyncBatchNorm -- batch statistics over all world*B images, which is what train-mode BN over
+    the concatenated batch computes (running stats included) -- and (2) the gradient MEAN over ranks, which is the
+    gradient of the mean of the per-rank losses.  Everything behind the two encoders is rank-local: each rank contrasts
+    its B images with its own B sentences only (block-diagonal cls labels), model/model_stage1.py:66,107.
+    batch: the shards concatenated in rank order.  Returns dict(loss = mean over ranks, per_rank = [world][4] tensors,
+    cls / sig = per-rank lists)."""
+    img, ids, neg = batch["img"], batch["word_ids"], batch.get("neg_word_ids")
+    n = img.shape[0] // world
+    _, hidden = encode_text(sd, "backbone.", ids)
+    c4 = encode_image_rn(sd, "backbone.", img, True)[3]          # BN over world*B images = SyncBatchNorm
+    per, cls_l, sig_l = [], [], []
+    for r in range(world):
+        sl = slice(r * n, (r + 1) * n)
+        cls, _, _, sig, _ = tris_heads(sd, c4[sl], hidden[sl], img.shape[2:], True)
+        per.append(stage1_loss_block(aux, img[sl], ids[sl], None if neg is None else neg[sl], cls, sig, w))
+        cls_l.append(cls)
+        sig_l.append(sig)
+    loss = sum(p[0] for p in per) / world
+    return {"loss": loss, "per_rank": per, "cls": cls_l, "sig": sig_l}
 
 
 def backbone_keys(sd):
@@ -384,7 +419,7 @@ def train_step(sd, aux, batch, lr=5e-5, lr_multi=0.1, wd=0.01, state=None, faith
         for t in aux.values():
             t.requires_grad_(False)
             t.grad = None
-    return {k: float(out[k]) for k in ("loss", "l1", "l4", "l5")}, grads
+    return {k: float(out[k].detach()) for k in ("loss", "l1", "l4", "l5")}, grads
 
 
 # --------------------------------------------------------------------------------------

@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # summation order from run to run; tests that sit on the fp32 noise floor (ReLU-kink flips) need a fixed order.  The
 # autotuned configuration is exercised explicitly by tests/test_gpu_ops.py::test_gemm_autotune_*.
 os.environ.setdefault("TRIS_AUTOTUNE", "0")
+# the suite builds every architecture without a weights file and fills it with the seed-fill protocol
+os.environ.setdefault("TRIS_RANDOM_INIT", "1")
 
 
 def pytest_sessionstart(session):

@@ -1,0 +1,177 @@
+"""Data-parallel Stage-1 step of the REAL model with world_size = 2 (reference: DistributedDataParallel +
+SyncBatchNorm, /root/reference/train_stage1.py:69-70, 435-437).
+
+Two processes share cuda:0 (the GPU box has one device and RCCL refuses two ranks on one device, so the wire is gloo with
+the payload staged through the host -- tris_amd.comm; reducer ordering, segment plan, SyncBatchNorm forward / backward
+math, the count = M * world scaling and the 1/world gradient scaling are the production code).  Each rank trains on its
+shard of 2 images; the N-rank oracle is ONE CPU process on the concatenated 4 images with BatchNorm over all 4
+(= SyncBN), heads and losses per shard (block-diagonal cls labels) and the mean of the per-rank losses
+(oracle.tris_oracle.stage1_losses_ddp).  Checked:
+  * per-rank losses within 1e-3 of the oracle's per-shard losses;
+  * the reduced gradient arenas: cosine >= 0.999 with the oracle's gradient of the mean loss;
+  * no segment was all-reduced before its last gradient was written (NaN-poisoned arenas, GradReducer(check=True));
+  * BatchNorm running statistics = statistics over the 4 images;
+  * parameters are bit-identical on both ranks after the AdamW step.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PER_RANK = 2
+WORLD = 2
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRIS_AUTOTUNE="0", TRIS_RANDOM_INIT="1")
+    import warnings
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tris_amd.args import get_parser
+        from tris_amd.CLIP import clip
+        from tris_amd.model.model_stage1 import TRIS
+        from tris_amd.optim import FusedAdamW
+        from tris_amd.parallel import DataParallel, attach_reducer, convert_sync_batchnorm
+        from tris_amd.train_stage1 import freeze_aux, train_step
+        from tris_amd.utils.synth import seed_fill, synthetic_batch
+        args = get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20",
+                                        "--negative_samples", "3", "--batch_size", str(PER_RANK)])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = TRIS(args).cuda().train()
+            aux, _ = clip.load("ViT-B-32", device="cuda", txt_length=20)
+        # rank 1 starts from DIFFERENT weights: the wrap-time broadcast must equalise them (DDP semantics)
+        seed_fill(net.state_dict(), 1234 if rank == 0 else 99)
+        seed_fill(aux.state_dict(), 4321)
+        freeze_aux(aux)
+        convert_sync_batchnorm(net)
+        model = DataParallel(net)
+        bb, new = net.trainable_parameters()
+        opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                         weight_decay=args.weight_decay)
+        red = attach_reducer(model, opt, check=True)
+        assert red.active and red.world == world
+        full = synthetic_batch(world * PER_RANK, 320, 20, 3, seed=7)
+        sl = slice(rank * PER_RANK, (rank + 1) * PER_RANK)
+        losses = train_step(model, aux, opt, full["img"][sl].cuda(), full["word_ids"][sl].cuda(),
+                            full["neg_word_ids"][sl].cuda(), args, reducer=red)
+        torch.cuda.synchronize()
+        out = {"losses": losses.cpu(), "launch_log": list(red.launch_log),
+               "params": [a.p.detach().cpu() for a in opt.arenas]}
+        if rank == 0:
+            names = {id(p): n for n, p in net.named_parameters()}
+            out["grads"] = {names[id(p)]: p.grad.detach().cpu().clone() for a in opt.arenas for p in a.params}
+            out["running"] = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running_" in k}
+        torch.save(out, os.path.join(tmp, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import tris_oracle as O
+    from tris_amd.utils.shapes import aux_state_dict_spec, empty_state_dict, tris_state_dict_spec
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    ctx = mp.get_context("spawn")
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    # the oracle runs on the host cores while the ranks run on the GPU
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = seed_fill(empty_state_dict(tris_state_dict_spec()), 1234)
+    aux = seed_fill(empty_state_dict(aux_state_dict_spec()), 4321)
+    batch = synthetic_batch(WORLD * PER_RANK, 320, 20, 3, seed=7)
+    bb, new = O.trainable_split(sd)
+    leaves = bb + new
+    for k in leaves:
+        sd[k].requires_grad_(True)
+    ref = O.stage1_losses_ddp(sd, aux, batch, WORLD)
+    ref["loss"].backward()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+
+    # (1) per-rank losses vs the oracle's per-shard losses
+    for r, got in enumerate((r0["losses"], r1["losses"])):
+        want = torch.stack([t.detach() for t in ref["per_rank"][r]])
+        assert float((got - want).abs().max()) < 1e-3, (r, got.tolist(), want.tolist())
+    # (2) every segment was released, the trunk stages from inside backward in completion order, the text encoder last
+    for log in (r0["launch_log"], r1["launch_log"]):
+        assert sorted(log) == sorted(["heads", "embed", "text", "layer4", "layer3", "layer2", "layer1", "stem"])
+        assert [k for k in log if k in ("heads", "layer4", "layer3", "layer2", "layer1")] == \
+            ["heads", "layer4", "layer3", "layer2", "layer1"]
+    # (3) reduced gradients = gradient of the mean loss on the concatenated batch
+    dot = na = nb = 0.0
+    worst = []
+    for k in leaves:
+        if sd[k].grad is None:
+            continue
+        a, b = r0["grads"][k].double().reshape(-1), sd[k].grad.double().reshape(-1)
+        dot += float(a @ b)
+        na += float(a @ a)
+        nb += float(b @ b)
+        if float(b.norm()) > 0:
+            worst.append((float((a @ b) / (a.norm() * b.norm() + 1e-300)), k))
+    cos = dot / ((na ** 0.5) * (nb ** 0.5))
+    assert cos >= 0.999, (cos, sorted(worst)[:5])
+    assert 0.97 < (na / nb) ** 0.5 < 1.03, (na, nb)            # the 1/world scaling (a missing mean would read 2.0)
+    text = [c for c, k in worst if k.startswith("backbone.transformer.")]
+    assert min(text) > 0.99, sorted(worst)[:5]                  # the round-1 defect left these un-reduced
+    # (4) SyncBatchNorm running statistics = statistics over all 4 images
+    for k, v in r0["running"].items():
+        tol = 1e-4 * max(1.0, float(sd[k].abs().max()))
+        assert float((v - sd[k].detach()).abs().max()) < tol, k
+    # (5) replicas stay identical
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+
+
+def test_optimizer_checkpoint_is_torch_adamw_layout():
+    """FusedAdamW.state_dict() is torch.optim.AdamW's layout (the reference saves / resumes it, utils/util.py:50-95):
+    a torch AdamW on the same parameters loads it and continues identically, and the fused optimiser loads a torch one."""
+    from tris_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(33, 7, device="cuda")), torch.nn.Parameter(torch.randn(5, device="cuda")),
+          torch.nn.Parameter(torch.randn(4, 6, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fused = FusedAdamW([{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:]}], lr=3e-2, weight_decay=0.01)
+    ref = torch.optim.AdamW([{"params": qs[:2], "lr": 1e-2}, {"params": qs[2:]}], lr=3e-2, weight_decay=0.01)
+    gs = [torch.randn_like(p) for p in ps]
+    for _ in range(3):
+        for p, q, g in zip(ps, qs, gs):
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        fused.step()
+        ref.step()
+    sd = fused.state_dict()
+    want = ref.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sorted(sd["state"]) == sorted(want["state"])
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in want["param_groups"]]
+    for i in want["state"]:
+        assert float(sd["state"][i]["step"]) == float(want["state"][i]["step"]) == 3.0
+        assert torch.allclose(sd["state"][i]["exp_avg"], want["state"][i]["exp_avg"], atol=1e-6)
+        assert torch.allclose(sd["state"][i]["exp_avg_sq"], want["state"][i]["exp_avg_sq"], atol=1e-6)
+    # torch loads ours; ours loads torch's; both continue to the same parameters
+    ref2 = torch.optim.AdamW([{"params": qs[:2], "lr": 1e-2}, {"params": qs[2:]}], lr=3e-2, weight_decay=0.01)
+    ref2.load_state_dict(sd)
+    fused2 = FusedAdamW([{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:]}], lr=3e-2, weight_decay=0.01)
+    fused2.load_state_dict(want)
+    for p, q, g in zip(ps, qs, gs):
+        p.grad.copy_(g)
+        q.grad = g.clone()
+    fused2.step()
+    ref2.step()
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, atol=1e-5), float((p - q).abs().max())

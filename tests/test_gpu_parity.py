@@ -594,7 +594,7 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
     import os
     import torch.distributed as dist
     from tris_amd.optim import FusedAdamW
-    from tris_amd.parallel import GradReducer, stage1_segments
+    from tris_amd.parallel import attach_reducer
     from tris_amd.CLIP.clip.model import BatchNorm2d
     from tris_amd.train_stage1 import train_step
     if dist.is_initialized():
@@ -617,9 +617,7 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
                              weight_decay=args.weight_decay)
             reducer = None
             if sync:
-                reducer = GradReducer([a.g for a in opt.arenas], force=True)
-                reducer.set_segments(stage1_segments(model, opt))
-                model.backbone.visual.grad_reducer = reducer
+                reducer = attach_reducer(model, opt, force=True, check=True)   # check: no segment before its producers
             losses = train_step(model, aux, opt, batch["img"].cuda(), batch["word_ids"].cuda(),
                                 batch["neg_word_ids"].cuda(), args, reducer=reducer).tolist()
             ref = g["losses"]
@@ -636,6 +634,7 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
             if isinstance(m, BatchNorm2d):
                 m.process_group = None
         model.backbone.visual.grad_reducer = None
+        model.backbone.grad_reducer = None
         dist.destroy_process_group()
         refill(model)
 

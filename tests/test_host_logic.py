@@ -108,10 +108,11 @@ def test_checkpoint_roundtrip(tmp_path):
 
 
 def test_gradient_segments_cover_the_arenas_in_backward_order():
-    """GradReducer.plan on the real parameter list (arena layout emulated on CPU): every arena slot belongs to exactly
-    one segment and the trunk stages map to contiguous ranges."""
+    """GradReducer.plan with the product's rule set on the real parameter list (arena layout emulated on CPU): every
+    arena slot belongs to exactly one segment, the trunk stages map to contiguous ranges, and the text encoder is NOT
+    in the segment that is released behind layer4 (tests/test_ddp_order.py runs the graph)."""
     from types import SimpleNamespace
-    from tris_amd.parallel import GradReducer
+    from tris_amd.parallel import STAGE1_RULES, GradReducer
     from tris_amd.utils.shapes import _build_tris
     m = _build_tris()
     bb, new = m.trainable_parameters()
@@ -123,13 +124,7 @@ def test_gradient_segments_cover_the_arenas_in_backward_order():
             offs.append(n)
             n += (p.numel() + 63) // 64 * 64
         arenas.append(SimpleNamespace(params=ps, offsets=offs, numel=n))
-    rules = {"heads_text": lambda n: not n.startswith("backbone.visual."),
-             "layer4": lambda n: n.startswith("backbone.visual.layer4."),
-             "layer3": lambda n: n.startswith("backbone.visual.layer3."),
-             "layer2": lambda n: n.startswith("backbone.visual.layer2."),
-             "layer1": lambda n: n.startswith("backbone.visual.layer1."),
-             "stem": lambda n: True}
-    seg = GradReducer.plan(arenas, list(m.named_parameters()), rules)
+    seg, par = GradReducer.plan(arenas, list(m.named_parameters()), STAGE1_RULES, with_params=True)
     cover = [0, 0]
     for k, ranges in seg.items():
         for ai, s, e in ranges:
@@ -137,7 +132,41 @@ def test_gradient_segments_cover_the_arenas_in_backward_order():
             cover[ai] += e - s
     assert cover == [arenas[0].numel, arenas[1].numel]
     assert len(seg["layer4"]) == 1 and len(seg["layer1"]) == 1 and len(seg["stem"]) == 1
-    assert seg["heads_text"][-1][0] == 1 and seg["heads_text"][-1][1:] == (0, arenas[1].numel)
+    assert seg["heads"] == [(1, 0, arenas[1].numel)]            # the whole second arena, nothing of the backbone
+    assert all(ai == 0 for ai, *_ in seg["text"]) and 1 <= len(seg["text"]) <= 4   # text_projection | transformer | ln_final
+    for ai, s, e, n in (r for ranges in par.values() for r in ranges):
+        assert 0 <= s < e <= arenas[ai].numel
+
+
+def test_clip_load_refuses_to_train_from_random_weights(monkeypatch, tmp_path):
+    """no weights file and no explicit opt-in -> clip.load raises (the reference downloads or fails, clip.py:43-72)"""
+    import pytest
+    from tris_amd.CLIP import clip
+    monkeypatch.delenv("TRIS_RANDOM_INIT", raising=False)
+    clip.allow_random_init(False)
+    try:
+        with pytest.raises(FileNotFoundError):
+            clip.load("ViT-B/32", device="cpu", download_root=str(tmp_path), txt_length=20)
+        with clip.random_init():
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m, _ = clip.load("ViT-B/32", device="cpu", download_root=str(tmp_path), txt_length=20)
+            assert m.txt_length == 20
+        with pytest.raises(FileNotFoundError):
+            clip.load("ViT-B/32", device="cpu", download_root=str(tmp_path), txt_length=20)
+    finally:
+        clip._RANDOM_INIT_OK = None
+
+
+def test_eval_shard_sampler_does_not_pad():
+    """evaluation shards partition the dataset exactly (DistributedSampler would repeat refs to even them out, and the
+    all-reduced I/U accumulators of tris_amd.validate would count those twice)"""
+    from tris_amd.parallel import ShardSampler
+    ds = list(range(10))
+    shards = [list(ShardSampler(ds, rank=r, world=4)) for r in range(4)]
+    assert sorted(i for s in shards for i in s) == ds
+    assert [len(ShardSampler(ds, rank=r, world=4)) for r in range(4)] == [3, 3, 2, 2]
 
 
 def test_batchnorm_step_counter_is_flushed_when_observed():

@@ -1,4 +1,5 @@
 """Dev tool: which torch-side ops launch device copies / elementwise kernels inside one training step."""
+import os; os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill)
 import sys, warnings, torch
 sys.path.insert(0, ".")
 from torch.profiler import profile, ProfilerActivity

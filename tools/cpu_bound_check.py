@@ -1,5 +1,6 @@
 """Dev tool: is the B=48 step launch-bound?  Host time to ENQUEUE a step vs device time to finish it."""
 import os, sys, time, warnings
+os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill): no CLIP checkpoint needed
 import torch
 sys.path.insert(0, ".")
 from tris_amd.args import get_parser

@@ -1,6 +1,7 @@
 """Dev tool: one Stage-1 step with the distributed code path forced on a single rank (SyncBN collectives + segmented
 all-reduce) must reproduce the plain single-GPU step."""
 import os, sys, warnings
+os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill): no CLIP checkpoint needed
 import torch
 import torch.distributed as dist
 sys.path.insert(0, ".")
@@ -9,7 +10,7 @@ from tris_amd.args import get_parser
 from tris_amd.CLIP import clip
 from tris_amd.model.model_stage1 import TRIS
 from tris_amd.optim import FusedAdamW
-from tris_amd.parallel import GradReducer, convert_sync_batchnorm, stage1_segments
+from tris_amd.parallel import attach_reducer, convert_sync_batchnorm
 from tris_amd.train_stage1 import freeze_aux, stage1_forward_losses
 from tris_amd.utils.synth import seed_fill, synthetic_batch
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
@@ -30,11 +31,12 @@ def run(sync):
     for mod in m.modules():
         if hasattr(mod, "process_group"): mod.process_group = None
     m.backbone.visual.grad_reducer = None
+    m.backbone.grad_reducer = None
     if sync:
         convert_sync_batchnorm(m)
-        red = GradReducer([a.g for a in opt.arenas], force=True); red.set_segments(stage1_segments(m, opt))
-        m.backbone.visual.grad_reducer = red
+        red = attach_reducer(m, opt, force=True, check=True)
     losses, _, _ = stage1_forward_losses(m, aux, img, ids, neg, args)
+    if red is not None: red.begin_step()
     losses[0].backward()
     if red is not None: red.finish()
     ops.wgrad_join(); torch.cuda.synchronize()

@@ -1,4 +1,5 @@
 """Dev tool: Stage-1 inference latency at batch 1 (BASELINE.json configs[1]): eager launches vs one captured hipGraph."""
+import os; os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill)
 import sys, time, warnings
 import torch
 sys.path.insert(0, ".")

@@ -1,6 +1,7 @@
 """Dev tool (GPU box): gradient / activation error of the HIP path vs an fp64 CPU oracle, next to the error of the
 fp32 CPU oracle vs the same fp64 truth.  Tells apart 'fp32 round-off amplified by train-mode BN at tiny batch' from
 real bugs.  Usage: python tools/noise_study.py [B] [seed]"""
+import os; os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill)
 import sys
 import warnings
 

@@ -1,5 +1,6 @@
 """Dev tool: time the phases of one Stage-1 step at batch B (prints progressively)."""
 import os, sys, time, warnings
+os.environ.setdefault("TRIS_RANDOM_INIT", "1")  # synthetic weights (seed-fill): no CLIP checkpoint needed
 import torch
 sys.path.insert(0, ".")
 from tris_amd import ops

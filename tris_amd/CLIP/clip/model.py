@@ -196,7 +196,7 @@ class ModifiedResNet(nn.Module):
         if red is not None:
             x = red.boundary(x, "layer1")          # backward passing this point => every layer1 gradient is written
         for name, layer in (("layer2", self.layer1), ("layer3", self.layer2), ("layer4", self.layer3),
-                            ("heads_text", self.layer4)):
+                            ("heads", self.layer4)):
             for blk in layer:
                 x = blk(x)
             if red is not None:
@@ -395,6 +395,11 @@ class CLIP(nn.Module):
         if ids.shape[1] > self.txt_length:
             raise ValueError(f"token length {ids.shape[1]} exceeds txt_length {self.txt_length}")
         x = ops.embed(ids, self.token_embedding.weight, self.positional_embedding)
+        red = getattr(self, "grad_reducer", None)
+        if red is not None:
+            # data-parallel: once backward passes this point every gradient of the text transformer, ln_final and
+            # text_projection is written (they were all created after it); the embedding tables follow in finish()
+            x = red.boundary(x, "text")
         x = self.transformer(x)
         x = self.ln_final(x)
         hidden = ops.matmul(ops.eot_gather(ids, x), self.text_projection)

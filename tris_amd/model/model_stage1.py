@@ -49,6 +49,12 @@ class TRIS(nn.Module):
         clip_model, _ = clip.load(args.backbone.split("-", 1)[-1] if self.vit_trunk else args.backbone.split("-")[-1],
                                   device=device, jit=False, txt_length=args.max_query_len)
         self.backbone = clip_model.float()
+        if self.vit_trunk:
+            # the dense trunk stops after the last block (forward_spatial): ln_post / proj never receive a gradient, so --
+            # like torch.optim.AdamW, which skips parameters whose grad is None -- they must stay out of the optimiser
+            # arenas (no weight decay on them either)
+            for p in list(self.backbone.visual.ln_post.parameters()) + [self.backbone.visual.proj]:
+                p._tris_no_grad_path = True
         self.vis_project = Conv2d(last_vis_channel, args.hidden_dim, 1, bias=True)
         self.lan_project = Linear(self.textdim, args.hidden_dim)
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))

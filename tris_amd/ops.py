@@ -671,11 +671,11 @@ class BatchNormFn(torch.autograd.Function):
             if group is None:
                 local_stats(rmean, rvar)
             else:
-                import torch.distributed as dist
+                from . import comm
                 local_stats(None, None)
-                world = dist.get_world_size(group)
+                world = comm.world_size(group)
                 allv = torch.empty(world * 3 * C, device=x.device, dtype=torch.float32)
-                dist.all_gather_into_tensor(allv, stats, group=group)   # the stats block travels as is
+                comm.all_gather_into(allv, stats, group=group)   # the stats block travels as is
                 call("tris_bn_sync_combine_f32", P(allv), world, C, M, eps, momentum, P(stats), P(rmean), P(rvar),
                      _stream())
                 count = M * world  # DistributedSampler gives every rank the same per-step batch
@@ -725,8 +725,8 @@ class BatchNormFn(torch.autograd.Function):
             dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
             db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
             if group is not None:
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=group)
+                from . import comm
+                comm.all_reduce(sums, group=group)
         dx = None
         if ctx.needs_input_grad[0] or want_dz:
             dx = torch.empty_like(x)

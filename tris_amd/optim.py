@@ -17,6 +17,10 @@ from . import _lib, ops
 ALIGN = 64  # floats (256 B)
 
 
+def _mark_accumulating(p):
+    p._tris_accumulates = True
+
+
 class Arena:
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad and not getattr(p, "_tris_no_grad_path", False)]
@@ -38,6 +42,11 @@ class Arena:
             p.data = pv
             p.grad = gv
             p._tris_sink = True
+            # Backward kernels OVERWRITE the arena gradient of a parameter they are handed directly.  A parameter that
+            # reaches its kernel through a torch view (e.g. `w.reshape(...)`) or a torch op instead gets its gradient from
+            # autograd's AccumulateGrad, which ADDS into the arena view: remember those so that zero_grad() clears them.
+            p._tris_accumulates = False
+            p.register_post_accumulate_grad_hook(_mark_accumulating)
 
     @staticmethod
     def _view(flat, p, off):
@@ -61,7 +70,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._steps = 0
 
     def zero_grad(self, set_to_none=False):
-        # gradients are overwritten (not accumulated) by the backward kernels each step; keep the sinks attached
+        """Gradients written by the backward kernels are overwritten each step (the sinks stay attached, nothing to
+        clear); the few parameters whose gradient arrives through autograd's AccumulateGrad (seen at run time:
+        `_tris_accumulates`) are zeroed here so that they do not sum over steps."""
+        for a in self.arenas:
+            for p in a.params:
+                if p._tris_accumulates:
+                    p.grad.zero_()
         return None
 
     @torch.no_grad()
@@ -74,15 +89,68 @@ class FusedAdamW(torch.optim.Optimizer):
             _lib.call("tris_adamw_f32", a.p.data_ptr(), a.g.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.numel,
                       float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._steps, st)
 
+    # ---- checkpoint format: torch.optim.AdamW's own layout -----------------------------------------------------------
+    # The reference saves `optimizer.state_dict()` of torch.optim.AdamW under 'optimizer' (utils/util.py:50-64) and loads
+    # it back on --resume (:83-95).  state_dict() therefore emits exactly that layout -- {'state': {param index:
+    # {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [indices]}]} with indices running over the
+    # groups' parameters in order -- and load_state_dict() accepts it (from either code base) by scattering the
+    # per-parameter moments into the arenas.  Parameters outside the arenas (no gradient path) have no state entry, as in
+    # torch, which creates state lazily for parameters that received a gradient.
+    def _index(self):
+        """[(group idx, arena, {id(p): offset}), first param index]"""
+        out, base = [], 0
+        for gi, (g, a) in enumerate(zip(self.param_groups, self.arenas)):
+            out.append((gi, g, a, {id(p): o for p, o in zip(a.params, a.offsets)}, base))
+            base += len(g["params"])
+        return out
+
     def state_dict(self):
-        sd = {"steps": self._steps, "groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-              "exp_avg": [a.m.clone() for a in self.arenas], "exp_avg_sq": [a.v.clone() for a in self.arenas]}
-        return sd
+        state, groups = {}, []
+        for gi, g, a, offs, base in self._index():
+            if self._steps > 0:
+                for j, p in enumerate(g["params"]):
+                    o = offs.get(id(p))
+                    if o is None:
+                        continue
+                    state[base + j] = {"step": torch.tensor(float(self._steps)),
+                                       "exp_avg": Arena._view(a.m, p, o).detach().clone(),
+                                       "exp_avg_sq": Arena._view(a.v, p, o).detach().clone()}
+            pg = {k: v for k, v in g.items() if k != "params"}
+            pg["params"] = list(range(base, base + len(g["params"])))
+            groups.append(pg)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._steps = sd["steps"]
-        for g, s in zip(self.param_groups, sd["groups"]):
-            g.update(s)
-        for a, m, v in zip(self.arenas, sd["exp_avg"], sd["exp_avg_sq"]):
-            a.m.copy_(m)
-            a.v.copy_(v)
+        if "param_groups" not in sd:   # round-1 layout of this code base (flat arenas)
+            self._steps = sd["steps"]
+            for g, s in zip(self.param_groups, sd["groups"]):
+                g.update(s)
+            for a, m, v in zip(self.arenas, sd["exp_avg"], sd["exp_avg_sq"]):
+                a.m.copy_(m)
+                a.v.copy_(v)
+            return
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError(f"optimizer state has {len(sd['param_groups'])} parameter groups, this optimizer "
+                             f"{len(self.param_groups)}")
+        steps = set()
+        for (gi, g, a, offs, base), sg in zip(self._index(), sd["param_groups"]):
+            if len(sg["params"]) != len(g["params"]):
+                raise ValueError(f"parameter group {gi}: {len(sg['params'])} parameters in the checkpoint, "
+                                 f"{len(g['params'])} in the model")
+            g.update({k: v for k, v in sg.items() if k != "params"})
+            a.m.zero_()
+            a.v.zero_()
+            for j, (p, idx) in enumerate(zip(g["params"], sg["params"])):
+                st = sd["state"].get(idx)
+                o = offs.get(id(p))
+                if st is None or o is None:
+                    continue
+                with torch.no_grad():
+                    Arena._view(a.m, p, o).copy_(st["exp_avg"].reshape(p.shape))
+                    Arena._view(a.v, p, o).copy_(st["exp_avg_sq"].reshape(p.shape))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            # one fused launch uses one bias-correction step count; torch keeps it per parameter.  They only differ when
+            # parameters joined training at different times, which the Stage-1 recipe never does.
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not representable by the fused AdamW")
+        self._steps = steps.pop() if steps else 0

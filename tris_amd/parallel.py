@@ -3,14 +3,25 @@ SyncBatchNorm, train_stage1.py:69-70, 435-437).
 
 The only exchange steps of the path are (1) the gradient mean over ranks and (2) SyncBatchNorm statistics.
 (1) runs on the flat gradient arenas of tris_amd.optim in a few large chunks (xGMI rings are per-link bound, so
-big messages; ~400 MB total) on a side stream; (2) lives in ops.BatchNormFn (all_gather of [mean|var|count],
-all_reduce of the two backward sums).  Nothing else crosses ranks: the in-batch contrastive heads are rank-local
-(model_stage1.py:66,107).  Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" for CPU tests of
-the host logic).
+big messages; ~400 MB total) launched from inside backward; (2) lives in ops.BatchNormFn (all_gather of
+[mean|var|count], all_reduce of the two backward sums).  Nothing else crosses ranks: the in-batch contrastive heads
+are rank-local (model_stage1.py:66,107).  Works with any torch.distributed backend through tris_amd.comm ("nccl" =
+RCCL on ROCm; "gloo" for the CPU tests of the host logic and the two-ranks-on-one-GPU parity test).
+
+Which segment may be released WHERE (the invariant the reducer rests on): autograd's engine runs, among the nodes
+that are ready, the one created LAST in forward first.  A `boundary()` placed in the forward graph therefore runs its
+backward only after every node created after it has run -- i.e. after every gradient produced "downstream" of that
+point has been written.  TRIS.forward issues the text encoder BEFORE the RN50 trunk (so that it overlaps the trunk on a
+second stream), which makes the text encoder's backward run AFTER the stem's: its parameters must not ride on a trunk
+boundary.  They have their own boundary on the text path (behind the embedding), and the embedding tables, whose
+gradient is written after that boundary, are released by `finish()`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+from . import comm
 from .CLIP.clip.model import BatchNorm2d
 
 
@@ -23,71 +34,104 @@ def convert_sync_batchnorm(module, process_group=None):
     return module
 
 
+class ReducerOrderError(RuntimeError):
+    pass
+
+
 class GradReducer:
     """Mean-all-reduce of the flat gradient arenas, overlapped with backward.
 
-    The arenas are cut into SEGMENTS in the order backward completes them (heads + text encoder first, then the RN50
-    trunk from layer4 down to the stem).  `boundary(x, k)` is an identity placed in the forward graph where segment k's
-    last gradient has been written once backward passes it; its backward launches the (asynchronous, chunked)
-    all-reduce of that segment on RCCL's stream while the rest of backward keeps computing.  `finish()` before the
-    optimiser step launches whatever is left and waits.  With one rank everything is a no-op (unless force=True,
-    which runs the collectives for code-path testing).
+    The arenas are cut into SEGMENTS in the order backward completes them.  `boundary(x, k)` is an identity placed in
+    the forward graph at a point where segment k's last gradient has been written once backward passes it; its backward
+    launches the (asynchronous, chunked) all-reduce of that segment while the rest of backward keeps computing.
+    `finish()` before the optimiser step launches whatever is left and waits.  With one rank everything is a no-op
+    (unless force=True, which runs the collectives for code-path testing).
+
+    check=True (env TRIS_DDP_CHECK=1; tests): `poison()` fills every parameter's gradient with NaN before backward and
+    every launch first verifies -- with a device sync -- that its segment holds no NaN any more, i.e. that no segment is
+    released before its last producer ran.  Raises ReducerOrderError otherwise.
     """
 
-    def __init__(self, flats, group=None, chunk_mb=64, force=False):
+    def __init__(self, flats, group=None, chunk_mb=64, force=False, check=None):
         self.flats = list(flats)
         self.group = group
         self.chunk = chunk_mb * (1 << 20) // 4
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force
-        self.segments = {}      # key -> list of (flat index, start, end)
+        self.segments = {}      # key -> list of (flat index, start, end)           : what is all-reduced
+        self.param_ranges = {}  # key -> list of (flat index, start, end, name)     : the parameters inside (no padding)
         self.pending = []
         self.done = set()
+        self.launch_log = []    # keys in launch order of the current / last step (tests)
         self.active = self.world > 1 or force
-        # NCCL/RCCL averages in the collective; gloo (CPU tests) has no AVG: sum, then scale in finish()
+        self.check = (os.environ.get("TRIS_DDP_CHECK") == "1") if check is None else check
+        # NCCL/RCCL averages in the collective; gloo has no AVG: sum, then scale in finish()
         self.avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
 
     # ---- segment planning ------------------------------------------------------------------------------------------
     @staticmethod
-    def plan(arenas, named_params, rules):
+    def plan(arenas, named_params, rules, with_params=False):
         """rules: ordered {segment key: predicate(param name)}.  Returns {key: [(arena idx, start, end), ...]} covering
-        every arena slot exactly once (parameters matching no rule fall into the LAST key)."""
+        every arena slot exactly once (parameters matching no rule fall into the LAST key).  with_params=True also
+        returns {key: [(arena idx, start, end, name)]} with the exact extent of each parameter."""
         name_of = {id(p): n for n, p in named_params}
         keys = list(rules)
         seg = {k: [] for k in keys}
+        par = {k: [] for k in keys}
         for ai, ar in enumerate(arenas):
-            ends = ar.offsets[1:] + [ar.numel]
             cur_key, cur_start = None, 0
-            for p, o, e in zip(ar.params, ar.offsets, ends):
+            for p, o in zip(ar.params, ar.offsets):
                 n = name_of.get(id(p), "")
                 k = next((kk for kk in keys if rules[kk](n)), keys[-1])
+                par[k].append((ai, o, o + p.numel(), n))
                 if k != cur_key:
                     if cur_key is not None:
                         seg[cur_key].append((ai, cur_start, o))
                     cur_key, cur_start = k, o
             if cur_key is not None:
                 seg[cur_key].append((ai, cur_start, ar.numel))
-        return seg
+        return (seg, par) if with_params else seg
 
-    def set_segments(self, segments):
+    def set_segments(self, segments, param_ranges=None):
         self.segments = segments
+        self.param_ranges = param_ranges or {}
+
+    # ---- order check (tests / TRIS_DDP_CHECK=1) -----------------------------------------------------------------------
+    def poison(self):
+        """NaN into every parameter's gradient (not the padding): call before backward when check is on"""
+        for ranges in self.param_ranges.values():
+            for ai, s, e, _ in ranges:
+                self.flats[ai][s:e].fill_(float("nan"))
+
+    def _verify(self, key):
+        from . import ops
+        ops.wgrad_join()
+        if self.flats and self.flats[0].is_cuda:
+            torch.cuda.synchronize()
+        bad = [n for ai, s, e, n in self.param_ranges.get(key, []) if bool(torch.isnan(self.flats[ai][s:e]).any())]
+        if bad:
+            raise ReducerOrderError(f"segment {key!r} released before the gradient of {bad[:4]} "
+                                    f"(+{max(len(bad) - 4, 0)} more) was written")
 
     # ---- runtime -----------------------------------------------------------------------------------------------------
     def _launch(self, key):
         if key in self.done or not self.active:
             return
         self.done.add(key)
+        self.launch_log.append(key)
         from . import ops
-        ops.wgrad_join()  # the segment's weight gradients may still be in flight on the weight-gradient stream
+        if self.check and self.param_ranges:
+            self._verify(key)
+        ops.wgrad_join()  # the segment's weight gradients may still be in flight on the weight-gradient / text streams
         for ai, s, e in self.segments.get(key, []):
             f = self.flats[ai]
             for c in range(s, e, self.chunk):
-                self.pending.append(dist.all_reduce(f[c:min(e, c + self.chunk)], op=self.op, group=self.group,
+                self.pending.append(comm.all_reduce(f[c:min(e, c + self.chunk)], op=self.op, group=self.group,
                                                     async_op=True))
 
     def boundary(self, x, key):
-        if not self.active or not torch.is_grad_enabled():
+        if not self.active or not torch.is_grad_enabled() or not x.requires_grad:
             return x
         return _Boundary.apply(x, self, key)
 
@@ -98,9 +142,11 @@ class GradReducer:
                 for k in self.segments:
                     self._launch(k)
             else:  # no plan: whole arenas
+                from . import ops
+                ops.wgrad_join()
                 for f in self.flats:
                     for c in range(0, f.numel(), self.chunk):
-                        self.pending.append(dist.all_reduce(f[c:c + self.chunk], op=self.op, group=self.group,
+                        self.pending.append(comm.all_reduce(f[c:c + self.chunk], op=self.op, group=self.group,
                                                             async_op=True))
             for h in self.pending:
                 h.wait()
@@ -109,6 +155,11 @@ class GradReducer:
                     f.mul_(1.0 / self.world)
         self.pending = []
         self.done = set()
+
+    def begin_step(self):
+        self.launch_log = []
+        if self.check and self.active:
+            self.poison()
 
     reduce = finish  # the non-overlapped entry point keeps working
 
@@ -125,18 +176,38 @@ class _Boundary(torch.autograd.Function):
         return g, None, None
 
 
-def stage1_segments(model, optimizer):
-    """Backward completion order of the Stage-1 graph (tris_amd.model.model_stage1.TRIS.forward): heads and the text
-    encoder finish first (they are created last in forward), then the trunk from layer4 down to the stem."""
-    rules = {
-        "heads_text": lambda n: not n.startswith("backbone.visual."),
-        "layer4": lambda n: n.startswith("backbone.visual.layer4."),
-        "layer3": lambda n: n.startswith("backbone.visual.layer3."),
-        "layer2": lambda n: n.startswith("backbone.visual.layer2."),
-        "layer1": lambda n: n.startswith("backbone.visual.layer1."),
-        "stem": lambda n: True,
-    }
-    return GradReducer.plan(optimizer.arenas, list(model.named_parameters()), rules)
+# where each segment is released (tris_amd.CLIP.clip.model places the boundaries):
+#   "heads"  : vis_project / lan_project / attn_fusion           -- boundary behind layer4 (created before every head node)
+#   "layer4" ... "layer1" : boundary behind the previous stage
+#   "text"   : text transformer, ln_final, text_projection      -- boundary on the text path behind the embedding
+#   "embed"  : token / positional embedding (written after the "text" boundary) and
+#   "stem"   : the three stem convolutions (last to finish in the trunk) -- finish()
+STAGE1_RULES = {
+    "heads": lambda n: not n.startswith("backbone."),
+    "embed": lambda n: n in ("backbone.token_embedding.weight", "backbone.positional_embedding"),
+    "text": lambda n: not n.startswith("backbone.visual."),
+    "layer4": lambda n: n.startswith("backbone.visual.layer4."),
+    "layer3": lambda n: n.startswith("backbone.visual.layer3."),
+    "layer2": lambda n: n.startswith("backbone.visual.layer2."),
+    "layer1": lambda n: n.startswith("backbone.visual.layer1."),
+    "stem": lambda n: True,
+}
+
+
+def stage1_segments(model, optimizer, with_params=False):
+    """Segments of the Stage-1 graph (tris_amd.model.model_stage1.TRIS.forward) in the order backward may release them."""
+    return GradReducer.plan(optimizer.arenas, list(model.named_parameters()), STAGE1_RULES, with_params)
+
+
+def attach_reducer(model, optimizer, group=None, force=False, check=None, chunk_mb=64):
+    """GradReducer over the optimiser's gradient arenas, planned for `model` (a TRIS) and hooked into its forward."""
+    net = model.module if hasattr(model, "module") else model
+    red = GradReducer([a.g for a in optimizer.arenas], group=group, chunk_mb=chunk_mb, force=force, check=check)
+    seg, par = stage1_segments(net, optimizer, with_params=True)
+    red.set_segments(seg, par)
+    net.backbone.visual.grad_reducer = red     # trunk boundaries (ModifiedResNet.forward_cl)
+    net.backbone.grad_reducer = red            # text boundary (CLIP.encode_text)
+    return red
 
 
 class DataParallel(torch.nn.Module):
@@ -149,7 +220,27 @@ class DataParallel(torch.nn.Module):
         self.group = group
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=0, group=group)
+                comm.broadcast(t.data, src=0, group=group)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+
+class ShardSampler:
+    """Evaluation sampler: rank r takes dataset indices r, r + world, ...  Unlike DistributedSampler it does NOT pad to
+    a multiple of the world size, so no ref is counted twice when the five evaluation accumulators are all-reduced
+    (validate.py:237-249 reports rank-local meters; tris_amd.validate returns the global numbers)."""
+
+    def __init__(self, dataset, rank=None, world=None):
+        self.n = len(dataset)
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+
+    def __iter__(self):
+        return iter(range(self.rank, self.n, self.world))
+
+    def __len__(self):
+        return len(range(self.rank, self.n, self.world))
+
+    def set_epoch(self, epoch):
+        pass

@@ -93,6 +93,8 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
     with (WeightPlanes.active() if (wp is not None or wa is not None) else contextlib.nullcontext()):
         losses, _, _ = stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args)
         optimizer.zero_grad()
+        if reducer is not None:
+            reducer.begin_step()
         losses[0].backward()
     if reducer is not None:
         reducer.reduce()
@@ -174,8 +176,15 @@ def build_loader(args, dataset, batch_size, shuffle, distributed):
     DataLoader(num_workers=2, pin_memory=True) over the same dataset."""
     sampler = None
     if distributed:
-        from torch.utils.data.distributed import DistributedSampler
-        sampler = DistributedSampler(dataset, shuffle=shuffle)
+        if getattr(dataset, "eval_mode", False):
+            # no padding: DistributedSampler repeats refs to even out the shards, which would count them twice in the
+            # all-reduced evaluation accumulators (tris_amd.validate)
+            from .parallel import ShardSampler
+            sampler = ShardSampler(dataset)
+        else:
+            # equal shard sizes on every rank (DistributedSampler pads), which SyncBatchNorm's count = M * world relies on
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(dataset, shuffle=shuffle)
     if os.environ.get("TRIS_HBM_LOADER", "1") != "0":
         from .dataset.hbm import HbmLoader, HbmReferCache
         return HbmLoader(HbmReferCache(dataset, args.size), batch_size=batch_size, sampler=sampler,
@@ -192,7 +201,7 @@ def main(args, tokenizer=None):
     from .CLIP import clip
     from .model.model_stage1 import TRIS
     from .optim import FusedAdamW
-    from .parallel import DataParallel, GradReducer, convert_sync_batchnorm, stage1_segments
+    from .parallel import DataParallel, attach_reducer, convert_sync_batchnorm
     from .utils.util import load_checkpoint, load_pretrained_checkpoint, save_checkpoint
     from .validate import validate
     if args.distributed:
@@ -221,9 +230,7 @@ def main(args, tokenizer=None):
     ], lr=args.lr, weight_decay=args.weight_decay)
     reducer = None
     if args.distributed:
-        reducer = GradReducer([a.g for a in optimizer.arenas])
-        reducer.set_segments(stage1_segments(net, optimizer))
-        net.backbone.visual.grad_reducer = reducer
+        reducer = attach_reducer(net, optimizer)   # segmented all-reduce launched from inside backward
 
     def evaluate():
         res = [validate(args, vl, model, local_rank, logger=log) for vl in val_loaders]

@@ -10,7 +10,8 @@ def _build_tris(extra=()):
     from ..model.model_stage1 import TRIS
     args = get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20",
                                     "--negative_samples", "3"] + list(extra))
-    with warnings.catch_warnings():
+    from ..CLIP import clip
+    with warnings.catch_warnings(), clip.random_init():   # architecture only: callers fill the weights (seed_fill)
         warnings.simplefilter("ignore")
         return TRIS(args)
 
