@@ -9,7 +9,11 @@
  *     scratch is passed in (`workspace`, size from the matching *_workspace_bytes helper or documented inline);
  *   - activations are channels-last: an NHWC tensor is the row-major matrix [B*H*W, C];
  *   - conv weights are [Cout][kh][kw][Cin] (= torch.channels_last memory of the reference's [Cout,Cin,kh,kw]);
- *   - `stream` is a hipStream_t (0 = default stream); launches are asynchronous, stateless and re-entrant;
+ *   - `stream` is a hipStream_t (0 = default stream); launches are asynchronous and re-entrant.  The ONLY state the
+ *     library keeps is host-side configuration read at launch time: the arithmetic mode of the dense products (a
+ *     process-wide default, tris_set_gemm_mode, plus a per-thread override, tris_set_gemm_mode_thread), the autotune
+ *     switch with its per-process cache of tuned (tile, split-K) choices (tris_set_autotune).  No entry point keeps
+ *     device state between calls;
  *   - return value: 0 on success, otherwise a hipError_t.
  */
 #ifndef TRIS_HIP_H
@@ -20,7 +24,8 @@ extern "C" {
 #endif
 
 /* ---- dense products -------------------------------------------------------------------------------------------
- * C[b] = act(alpha * opA(A[b]) . opB(B[b]) + bias) + resid[b]        (f32 MFMA, exact f32 accumulate)
+ * C[b] = act(alpha * opA(A[b]) . opB(B[b]) + bias) + resid[b]        fp32 in / fp32 out; evaluated in the arithmetic mode
+ *   in force for the launching thread (tris_set_gemm_mode below; default split-bf16 "x3", fp32-class accuracy)
  *   opA: transA=0 -> A[m*lda+k], 1 -> A[k*lda+m];  opB: transB=0 -> B[k*ldb+n], 1 -> B[n*ldb+k]
  *   bias_mode 1: bias[n], 2: bias[m];  act 0 none, 1 ReLU, 2 QuickGELU x*sigmoid(1.702x)
  *   workspace (optional, batch==1): enables split-K for small output grids; any size, used opportunistically.
@@ -32,12 +37,16 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                   int bias_mode, const float* resid, long ldr, long strideR, int act, float alpha, float* workspace,
                   long workspace_bytes, void* stream);
 
-/* Arithmetic of the dense-product kernels (process-wide): 0 = v_mfma_f32_32x32x2_f32 (f32 in, bit-equal to an fmaf chain);
+/* Arithmetic of the dense-product kernels.  tris_set_gemm_mode sets the process-wide DEFAULT; tris_set_gemm_mode_thread
+ * sets an override for the calling thread only (-1 = none) -- e.g. the autograd thread running the weight-gradient
+ * products in another mode -- so that concurrent launches from other threads are unaffected.  Both are host-side values
+ * read when a product is launched; tris_get_gemm_mode returns the mode in force for the calling thread.  0 = v_mfma_f32_32x32x2_f32 (f32 in, bit-equal to an fmaf chain);
  * 1 = split-bf16 "x3": every fp32 operand is the exact sum of three bf16 pieces, the six significant piece products
  * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -> fp32-class accuracy (measured: error vs fp64 <= the f32-MFMA
  * path's) at up to 2.6x the f32-MFMA peak;  2 = split-bf16 "x2": two pieces, three products (16-bit significands, relative
  * product error <= 2^-15 -- between fp32 and TF32): an opt-in throughput mode.  Default: 1. */
 int tris_set_gemm_mode(int mode);
+int tris_set_gemm_mode_thread(int mode);
 /* Pre-split weight operands (x3 arithmetic).  tris_weight_planes_f32 splits weight matrices once per optimiser step into
  * three bf16 planes P[pl][r*ld + c] (same indexing as the fp32 source) and the transposed planes PT[pl][c*pt_ld + r] the
  * data-gradient products use; `table` is a device int64[entries][10] = {src, src row stride, rows, cols, P, P plane

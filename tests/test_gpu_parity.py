@@ -181,6 +181,62 @@ def test_g5_g6_train_step(model, aux, batch, golden):
         assert getattr(named[k], "_tris_no_grad_path", False), k
 
 
+def test_full_train_step_at_the_headline_batch_48(model, aux):
+    """BASELINE configs[2] at its REAL size: one full Stage-1 train step on 48 x 320px images (+ 3 negatives each) against
+    the CPU oracle's step on the same inputs -- losses, cls_out and the sigmoid map within the north star's 1e-3, the
+    gradient arenas in direction and size.  At batch 48 train-mode BatchNorm noise is far below the batch-2 golden case,
+    so this is the sharper pin of the whole step (VERDICT r1, weak #9 / next #5)."""
+    import os
+    from oracle import tris_oracle as O
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import stage1_forward_losses
+    from tris_amd.utils.synth import synthetic_batch
+    from tris_amd import ops
+    B = 48
+    refill(model)
+    model.train()
+    args = _args(["--batch_size", str(B)])
+    b = synthetic_batch(B, 320, 20, 3, seed=7)
+    sd = cpu_sd(model)
+    auxsd = {k: v.detach().cpu().clone() for k, v in aux.state_dict().items()}
+    # HIP path first (asynchronous), the oracle on the host cores while the GPU works
+    bb, new = model.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                     weight_decay=args.weight_decay)
+    losses, cls, sig = stage1_forward_losses(model, aux, b["img"].cuda(), b["word_ids"].cuda(),
+                                             b["neg_word_ids"].cuda(), args)
+    opt.zero_grad()
+    losses[0].backward()
+    ops.wgrad_join()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    oleaves = [k for k in O.trainable_split(sd)[0] + O.trainable_split(sd)[1]]
+    for k in oleaves:
+        sd[k].requires_grad_(True)
+    ref = O.stage1_losses(sd, auxsd, b, faithful=False)
+    ref["loss"].backward()
+    got = losses.tolist()
+    want = [float(ref[k].detach()) for k in ("loss", "l1", "l4", "l5")]
+    assert all(abs(a - c) < TOL for a, c in zip(got, want)), (got, want)
+    assert err(cls, ref["cls"]) < TOL
+    assert err(sig, ref["sig"]) < TOL
+    named = dict(model.named_parameters())
+    dot = na = nb = 0.0
+    low = []
+    for k in oleaves:
+        if sd[k].grad is None:
+            continue
+        a, c = named[k].grad.detach().double().cpu().reshape(-1), sd[k].grad.double().reshape(-1)
+        dot += float(a @ c)
+        na += float(a @ a)
+        nb += float(c @ c)
+        low.append((float((a @ c) / (a.norm() * c.norm() + 1e-300)), k))
+    cos = dot / (na ** 0.5 * nb ** 0.5)
+    assert cos > 0.9999, (cos, sorted(low)[:5])
+    assert abs((na / nb) ** 0.5 - 1.0) < 1e-3, (na, nb)
+    assert min(c for c, _ in low) > 0.995, sorted(low)[:5]
+    refill(model)
+
+
 def test_g5_losses_with_autotuned_gemm(model, aux, batch, golden):
     """the production configuration (bench.py): per-shape autotuned (tile, split-K) -- same losses as the reference"""
     from tris_amd import ops

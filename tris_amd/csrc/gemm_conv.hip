@@ -419,7 +419,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // arithmetic of the fast kernels: 0 = f32-input MFMA, 1 = split-bf16 x3 (6 bf16 MFMAs per product, fp32-class accuracy),
 // 2 = split-bf16 x2 (3 bf16 MFMAs per product, 16-bit significands: between fp32 and TF32)
-static int g_gemm_mode = 1;
+// Process-wide default + per-thread override, both read on the HOST when a product is launched (a launch is otherwise
+// stateless).  The override exists for callers that run some products in another arithmetic from their own thread (the
+// autograd engine thread running weight-gradient products in x2) without touching what other threads launch.
+static int g_mode_default = 1;
+static thread_local int g_mode_thread = -1;
+#define g_gemm_mode (g_mode_thread >= 0 ? g_mode_thread : g_mode_default)
 static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")) == 4) ? 4 : 8;  // waves per 128x128 x3 block
 
 #include "gemm_fast.h"
@@ -979,7 +984,12 @@ extern "C" int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long
 
 extern "C" int tris_set_gemm_mode(int mode) {
   if (mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
-  g_gemm_mode = mode;
+  g_mode_default = mode;
+  return 0;
+}
+extern "C" int tris_set_gemm_mode_thread(int mode) {
+  if (mode < -1 || mode > 2) return (int)hipErrorInvalidValue;
+  g_mode_thread = mode;
   return 0;
 }
 extern "C" int tris_set_autotune(int on) {

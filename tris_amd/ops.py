@@ -70,6 +70,17 @@ def set_gemm_mode(mode):
 _BWD_MODE = None
 
 
+_TLS = __import__("threading").local()
+
+
+def _set_thread_mode(mode):
+    """per-thread arithmetic override of the dense products (None = none); returns the previous override"""
+    prev = getattr(_TLS, "mode", None)
+    _TLS.mode = mode
+    call("tris_set_gemm_mode_thread", -1 if mode is None else {"f32": 0, "x3": 1, "x2": 2}[mode])
+    return prev
+
+
 def set_backward_gemm_mode(mode):
     """Arithmetic of the dense products launched from backward (data and weight gradients): None = same as forward,
     or 'x2' / 'x3' / 'f32'.  Forward results (response maps, losses -- the parity bar) do not depend on it.  Env:
@@ -98,11 +109,11 @@ def _wgrad_arith(fn):
     prev = get_gemm_mode()
     if prev == _WGRAD_MODE or prev == "f32":
         return fn()
-    set_gemm_mode(_WGRAD_MODE)
+    outer = _set_thread_mode(_WGRAD_MODE)   # per-thread override: launches of other threads keep their arithmetic
     try:
         return fn()
     finally:
-        set_gemm_mode(prev)
+        _set_thread_mode(outer)
 
 
 def _bwd_arith(fn):
@@ -116,11 +127,11 @@ def _bwd_arith(fn):
         prev = get_gemm_mode()
         if prev == _BWD_MODE or prev == "f32":
             return fn(ctx, *grads)
-        set_gemm_mode(_BWD_MODE)   # host-side flag read at launch time: affects exactly the launches issued below
+        outer = _set_thread_mode(_BWD_MODE)   # host-side, this thread only, read at launch time: the launches issued below
         try:
             return fn(ctx, *grads)
         finally:
-            set_gemm_mode(prev)
+            _set_thread_mode(outer)
     return wrapper
 
 
