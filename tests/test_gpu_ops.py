@@ -32,14 +32,19 @@ def gpu_leaf(t):
     return t.detach().clone().cuda().requires_grad_(True)
 
 
-@pytest.fixture(scope="module", params=["x3", "f32"])
+@pytest.fixture(scope="module", params=["x3", "x3-classic", "f32"])
 def ops(request):
-    """Every kernel test runs under both arithmetic modes of the dense-product core: split-bf16 x3 (default) and
-    the f32-input MFMA."""
+    """Every kernel test runs under both arithmetic modes of the dense-product core -- split-bf16 x3 (default) and the
+    f32-input MFMA -- and x3 under both of its loop structures: the pipelined one (default: two 16-deep LDS stages, one
+    barrier per K tile) and the classic one (TRIS_FORCE_PIPE=0)."""
+    import os
     from tris_amd import ops as o
     prev = o.get_gemm_mode()
-    o.set_gemm_mode(request.param)
+    o.set_gemm_mode(request.param.split("-")[0])
+    if request.param == "x3-classic":
+        os.environ["TRIS_FORCE_PIPE"] = "0"
     yield o
+    os.environ.pop("TRIS_FORCE_PIPE", None)
     o.set_gemm_mode(prev)
 
 
@@ -509,7 +514,8 @@ def test_gemm_autotune_every_candidate_and_the_cached_choice(ops, M, N, K, tA, t
     finally:
         ops.set_autotune(False)
     assert float((first - ref).abs().max()) <= 2e-4 * scale and float((cached - ref).abs().max()) <= 2e-4 * scale
-    for tile in ("128x128", "128x64", "64x64", "128x32"):   # (128x32 applies to N <= 32 only: otherwise the cost model's choice)
+    # (128x32 applies to N <= 32 only, 256x128 to the pipelined x3 loop with N > 64: otherwise the cost model's choice)
+    for tile in ("128x128", "128x64", "64x64", "128x32", "256x128"):
         os.environ["TRIS_FORCE_TILE"] = tile
         try:
             out = run()

@@ -10,7 +10,7 @@ import sys
 
 ref = float(sys.argv[2]) if len(sys.argv) > 2 else 160.0
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-pat = re.compile(r"ak=(\d+) bkind=(\d+) M=(\d+) N=(\d+) K=(\d+) batch=(\d+) mode=(\d+) -> (\d+)x(\d+) sk=(\d+) nw=(\d+)\s+"
+pat = re.compile(r"ak=(\d+) bkind=(\d+) M=(\d+) N=(\d+) K=(\d+) batch=(\d+) mode=(\d+) -> (\d+)x(\d+) sk=(\d+) nw=(\d+)(?: pipe=\d+)?\s+"
                  r"([\d.]+) us\s+([\d.]+) TFLOP")
 rows, seen = [], set()
 for line in open(sys.argv[1]):

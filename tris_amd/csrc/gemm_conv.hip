@@ -49,6 +49,7 @@ struct GemmParams {
   int tiles_n;
   // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
   int gH, gW, gC, gHo, gWo, gStride;
+  int gB;           // images in the gathered tensor (B_KN_IM2COL: bounds the running pixel coordinates of surplus prefetches)
   int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
   long bpl;         // B_NK_PRE: elements between the bf16 planes of B
 };
@@ -429,8 +430,31 @@ static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")
 
 #include "gemm_fast.h"
 
+// TRIS_FORCE_PIPE=0|1 (read per call: tests switch it at run time) overrides the loop structure of the x3 products
+static int forced_pipe() {
+  const char* e = getenv("TRIS_FORCE_PIPE");
+  return !e ? -1 : (e[0] == '1' ? 1 : 0);
+}
+static bool pipe_ok(const GemmParams& p) {
+  return g_gemm_mode == 1 && p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
+}
+// static choice of the loop structure (the autotuner times both)
+static int default_pipe(const GemmParams& p, int bm, int bn, int splitk) {
+  if (!pipe_ok(p) || bn == 32) return 0;
+  const int f = forced_pipe();
+  if (f >= 0) return f;
+  // measured (tools/gemm_bench.py, autotuned tiles, classic | pipelined): the 3x3 convolutions from 128 channels up gain
+  // 3-13 % (fwd 40x40x256: 165 -> 175, 20x20x512: 136 -> 154, wgrad 20x20x512: 154 -> 174 TFLOP/s); the short-K 1x1
+  // products and the transformer GEMMs are on par or a few % slower -> static default by kind, the autotuner times both
+  static const int dflt = getenv("TRIS_PIPE") ? (getenv("TRIS_PIPE")[0] == '0' ? 0 : 1) : -1;
+  if (dflt >= 0) return dflt;
+  return p.gC >= 128 ? 1 : 0;
+}
+
 // ---- configuration = (tile, split-K) ----------------------------------------------------------------------------------
-struct Cfg { int bm, bn, splitk, nw; };  // nw: waves per 128x128 block of the split-bf16 kernels (8 = 2x4 wave grid, 4 = 2x2)
+struct Cfg { int bm, bn, splitk, nw, pipe; };  // nw: waves per 128x128 block of the split-bf16 kernels (8 = 2x4 wave grid, 4 = 2x2)
+// pipe = 1: the pipelined loop of gemm_fast.h (x3 only: two 16-deep LDS stages, one barrier per K tile); tiles 256x128 exist
+// in that form only
 
 // Tile / split-K choice by a small cost model (cycles on the MFMA pipe); also the starting point of the autotuner.
 //   per-wave cycles per 32-deep k step = (BM/64)*(BN/64)*c; a block owns a CU's 4 SIMDs; blocks beyond the 256 CUs queue.
@@ -477,13 +501,15 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
   }
   {  // developer knob: TRIS_FORCE_TILE=128x128|128x64|64x64|128x32 overrides the tile choice (tools/x3_probe.py)
     const char* e = getenv("TRIS_FORCE_TILE");  // read per call: tests switch it at run time
-    const int forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : !strcmp(e, "128x32") ? 4 : 0);
+    const int forced = !e ? 0 : (!strcmp(e, "128x128") ? 1 : !strcmp(e, "128x64") ? 2 : !strcmp(e, "64x64") ? 3 : !strcmp(e, "128x32") ? 4
+                                 : !strcmp(e, "256x128") ? 5 : 0);
     if (forced == 1 && p.N > 64) { bm = 128; bn = 128; }
     if (forced == 2) { bm = 128; bn = 64; }
     if (forced == 3) { bm = 64; bn = 64; }
     if (forced == 4 && p.N <= 32) { bm = 128; bn = 32; }
+    if (forced == 5 && p.N > 64 && p.M >= 256 && p.stat_part == nullptr) { bm = 256; bn = 128; }   // (pipelined x3 loop only: run_cfg falls back)
   }
-  Cfg c = {bm, bn, splitk, g_x3_waves};
+  Cfg c = {bm, bn, splitk, g_x3_waves, default_pipe(p, bm, bn, splitk)};
   return c;
 }
 
@@ -494,6 +520,8 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   const int nw = cfg.nw;
   const bool fast = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
   if (bn == 32 && !fast) bm = bn = 64;  // the 128x32 tile exists in the fast kernel only
+  const bool pipe = cfg.pipe && pipe_ok(p) && BKIND != B_NK_PRE && bn != 32;
+  if (bm == 256 && !pipe) bm = 128;     // the 256-row tile exists in the pipelined form only
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
   const int kalign = fast ? 32 : BK;
@@ -550,11 +578,29 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
       else TRIS_FAST(BM_, BN_, EPI_STD, 0);                                                        \
     }                                                                                              \
   } while (0)
+#define TRIS_PIPE_GO(BM_, BN_, NW_, NWM_)                                                                                  \
+  do {                                                                                                                     \
+    if (splitk > 1) {                                                                                                      \
+      p.C = ws;                                                                                                            \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, (BKIND == B_NK_PRE ? B_NK : BKIND), EPI_SLAB, 1, NW_, 16, 2, NWM_>), grid, \
+                         dim3(NW_ * 64), 0, st, p);                                                                        \
+    } else {                                                                                                               \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, (BKIND == B_NK_PRE ? B_NK : BKIND), EPI_STD, 1, NW_, 16, 2, NWM_>), grid,  \
+                         dim3(NW_ * 64), 0, st, p);                                                                        \
+    }                                                                                                                      \
+  } while (0)
+  if (pipe) {
+    if (bm == 256 && bn == 128) TRIS_PIPE_GO(256, 128, 8, 4);
+    else if (bm == 128 && bn == 128) TRIS_PIPE_GO(128, 128, 8, 2);
+    else if (bm == 128 && bn == 64) TRIS_PIPE_GO(128, 64, 4, 2);
+    else TRIS_PIPE_GO(64, 64, 4, 2);
+  } else
   if (bm == 128 && bn == 128) TRIS_GO(128, 128);
   else if (bm == 128 && bn == 64) TRIS_GO(128, 64);
   else if (bm == 128 && bn == 32) TRIS_GO_FAST_ONLY(128, 32);
   else TRIS_GO(64, 64);
 #undef TRIS_GO
+#undef TRIS_PIPE_GO
 #undef TRIS_GO_FAST_ONLY
 #undef TRIS_FAST
   TRIS_LAUNCH_CHECK();
@@ -607,10 +653,11 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     if (it != g_tuned.end()) return run_cfg<AK, BKIND>(p, batch, ws, st, it->second);
   }
   // candidates
-  static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+  static const int tiles[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {256, 128}};
   const bool fastk = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;
   static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
   const bool can_split = (batch == 1 && ws != nullptr && p.K >= 512) && !stat;
+  const bool can_pipe = pipe_ok(p) && BKIND != B_NK_PRE && forced_pipe() != 0;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
   hipDeviceSynchronize();  // drain the other streams: candidates are timed on an otherwise idle device
@@ -629,21 +676,20 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     }
     return ms_min;
   };
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < 5; ++t) {
     const int cbm = tiles[t][0], cbn = tiles[t][1];
     if (t != 2 && p.M < 96) continue;
-    if (t == 0 && p.N <= 64) continue;
+    if ((t == 0 || t == 4) && p.N <= 64) continue;
     if (t == 3 && !(p.N <= 32 && fastk)) continue;
+    if (t == 4 && (!can_pipe || p.M < 256)) continue;   // the 256-row tile exists in the pipelined form only
     if (stat && cbm != 128) continue;
     const long ntiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
     for (int sk : sks) {
       if (sk > 1 && (!can_split || sk > p.K / 256 || (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes)) break;
       if (sk > 1 && ntiles * sk > 1536) break;  // more than ~6 blocks per CU buys nothing
       if (sk * 8 < h.splitk && ntiles * sk < 256) continue;  // a handful of blocks walking a huge K serially: not worth timing
-      for (int nw = 8; nw >= 4; nw -= 4) {
-        static const bool tune_nw = getenv("TRIS_TUNE_WAVES") && getenv("TRIS_TUNE_WAVES")[0] == '1';  // off: measured no gain (-0.3%)
-        if (nw == 4 && !(tune_nw && g_gemm_mode >= 1 && t == 0 && g_x3_waves == 8)) break;  // the 4-wave variant exists for 128x128 x3/x2 only
-        const Cfg c = {cbm, cbn, sk, nw};
+      for (int pipe = (can_pipe && t != 3) ? 1 : 0; pipe >= (t == 4 || forced_pipe() == 1 ? (can_pipe && t != 3 ? 1 : 0) : 0); --pipe) {
+        const Cfg c = {cbm, cbn, sk, g_x3_waves, pipe};
         const float ms = time_cfg(c);
         if (ms < best_ms) { best_ms = ms; best = c; }
       }
@@ -656,8 +702,8 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
     g_tuned[key] = best;
     if (const char* lg = getenv("TRIS_TUNE_LOG")) {  // developer knob: one line per tuned shape (idle-device time of the winner)
       if (FILE* f = fopen(lg, "a")) {
-        fprintf(f, "ak=%d bkind=%d M=%d N=%d K=%d batch=%d mode=%d -> %dx%d sk=%d nw=%d  %.1f us  %.1f TFLOP/s\n", AK, key.bk,
-                p.M, p.N, p.K, batch, g_gemm_mode, best.bm, best.bn, best.splitk, best.nw, best_ms * 1e3f,
+        fprintf(f, "ak=%d bkind=%d M=%d N=%d K=%d batch=%d mode=%d -> %dx%d sk=%d nw=%d pipe=%d  %.1f us  %.1f TFLOP/s\n", AK, key.bk,
+                p.M, p.N, p.K, batch, g_gemm_mode, best.bm, best.bn, best.splitk, best.nw, best.pipe, best_ms * 1e3f,
                 2.0 * p.M * p.N * p.K * batch / (best_ms * 1e-3) * 1e-12);
         fclose(f);
       }
@@ -700,7 +746,7 @@ extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, i
   p.A = X; p.B = Wt; p.C = Y;
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
-  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride; p.gB = B;
   p.vecA = al16(X) && (Cin % 16 == 0);
   p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
   p.fastA = al16(X) && (Cin % 32 == 0);
@@ -715,7 +761,7 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   p.A = dY; p.B = Wt; p.C = dX;
   p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
   p.ldc = Cin; p.alpha = 1.f;
-  p.gH = H; p.gW = W; p.gC = Cout; p.gHo = H; p.gWo = W; p.gStride = 1;
+  p.gH = H; p.gW = W; p.gC = Cout; p.gHo = H; p.gWo = W; p.gStride = 1; p.gB = B;
   p.wCin = Cin; p.wCout = Cout;
   p.vecA = al16(dY) && (Cout % 16 == 0);
   p.vecB = al16(Wt) && (Cin % 4 == 0);
@@ -828,7 +874,7 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   p.A = dY; p.B = X; p.C = dW;
   p.M = Cout; p.N = 9 * Cin; p.K = B * Ho * Wo;
   p.lda = Cout; p.ldc = 9L * Cin; p.alpha = 1.f;
-  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride; p.gB = B;
   p.vecA = al16(dY) && (Cout % 4 == 0);
   p.vecB = al16(X) && (Cin % 4 == 0);
   p.fastA = p.vecA;
@@ -864,7 +910,7 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   p.A = X; p.B = Wt; p.C = Y;
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
-  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride; p.gB = B;
   p.vecA = al16(X) && (Cin % 16 == 0);
   p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
   p.fastA = al16(X) && (Cin % 32 == 0);
@@ -970,7 +1016,7 @@ extern "C" int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long
   p.A = X; p.B = reinterpret_cast<const float*>(Wplanes); p.bpl = bpl; p.C = Y;
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
-  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = Ho; p.gWo = Wo; p.gStride = stride; p.gB = B;
   p.vecA = al16(X) && (Cin % 16 == 0);
   p.vecB = al16(Wplanes) && ((9 * Cin) % 8 == 0) && (bpl % 8 == 0);
   p.fastA = al16(X) && (Cin % 32 == 0);

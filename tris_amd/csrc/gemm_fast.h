@@ -1,18 +1,24 @@
 // Fast path of the MFMA GEMM / implicit-GEMM core (included by gemm_conv.hip).
 //
-// BM x BN block (128x128 with 8 waves 2x4, 128x64 / 64x64 with 4 waves 2x2, 128x32 with 2 waves 2x1), 32x32 MFMA fragments:
-//   * BK = 32 and *branch-free* tile loaders: rows/columns past the edge are clamped (their results are never
-//     stored) and out-of-image im2col taps are loaded from a valid address and zeroed with a select, so the K loop has
-//     no divergent control flow and the accumulators stay pinned in registers;
-//   * PREC 0 (f32-input MFMA): k-contiguous operands (row-major A, B^T, im2col) keep a row-major LDS image [rows][32+4]:
-//     16-byte global loads go to LDS as ds_write_b128, and a fragment read is ONE ds_read_b128 per lane = 4 k-values
-//     feeding 4 MFMAs.  Row stride 36 floats puts the 16 lanes of every ds_read_b128 service group on 16 distinct
+// BM x BN block, NW waves in an NWM x (NW/NWM) grid, 32x32 MFMA fragments, FBK-deep K tiles:
+//   * *branch-free* tile loaders: rows/columns past the edge are clamped (their results are never stored) and out-of-image
+//     im2col taps are loaded from a valid address and zeroed with a select, so the K loop has no divergent control flow
+//     and the accumulators stay pinned in registers;
+//   * PREC 0 (f32-input MFMA, FBK = 32): k-contiguous operands (row-major A, B^T, im2col) keep a row-major LDS image
+//     [rows][32+4]: 16-byte global loads go to LDS as ds_write_b128, and a fragment read is ONE ds_read_b128 per lane =
+//     4 k-values feeding 4 MFMAs.  Row stride 36 floats puts the 16 lanes of every ds_read_b128 service group on 16 distinct
 //     16-byte slots (9*i mod 16 is a permutation) -> conflict-free.  The logical k order inside an MFMA is permuted
 //     (lane-half kh, MFMA j  <->  k = 8g + 4kh + j); both operands use the same permutation, the sum is unchanged;
 //     m-contiguous operands (A^T for wgrad, B for dgrad / NN) keep the k-major image and read 4 scalars;
 //   * PREC 1 / 2 (split-bf16 x3 / x2, below): operands are split when the tile is stored, the LDS image is bf16 planes --
-//     row-major [plane][row][32+8] for the k-contiguous kinds, k-major [plane][k][m] read with ds_read_b64_tr_b16 for the
+//     row-major [plane][row][FBK + 8] for the k-contiguous kinds, k-major [plane][k][m] read with ds_read_b64_tr_b16 for the
 //     m-contiguous ones;
+//   * two loop structures:
+//       NSTG = 1 ("classic"): one LDS buffer, register-staged prefetch, two barriers per K tile (compute | store);
+//       NSTG = 2 ("pipelined", PREC >= 1): two LDS stages held in SEPARATE __shared__ objects (so the compiler may interleave
+//         the split + LDS stores of tile k+1 with the fragment reads + MFMAs of tile k), ONE barrier per K tile, global
+//         loads two tiles ahead in two register sets, branch-free steady state (a load inside a conditional block makes
+//         the compiler's wait-count pass wait for the loads it has just issued).  FBK = 16 keeps two such blocks per CU.
 //   * epilogue: bias / activation / residual / BN statistics, stored as 16-byte rows after an in-LDS turn of each wave's
 //     accumulator block (scalar fallback for unaligned or N % 4 != 0 outputs).
 // Preconditions (checked on the host, otherwise the generic kernel runs): K % 32 == 0 per k-slice, 16-byte aligned
@@ -23,11 +29,8 @@
 // An fp32 value is EXACTLY the sum of three bf16 pieces (round-to-nearest residual splitting: 8 + 8 + 8 significand
 // bits).  a*b = sum of the 9 piece products; the 6 with combined weight >= 2^-24 are kept, each is exact in fp32
 // (8 x 8 bits) and is accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Result: fp32-class accuracy at 6 bf16 MFMAs per
-// 16-deep step (6 x 32 cycles) instead of 8 f32 MFMAs (8 x 64 cycles).  Pieces are produced in registers right after
-// the LDS fragment read (the LDS image stays fp32 and is shared with the f32 path).
+// 16-deep step (6 x 32 cycles) instead of 8 f32 MFMAs (8 x 64 cycles).
 #include "x3_split.h"
-
-constexpr bool KM_TR = true;  // k-major operands via the LDS transpose read (false: "row per thread" scalar staging)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -42,48 +45,61 @@ __device__ __forceinline__ bf16x8 tr_frag8(const char* plane, int ks, int k0, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// NW = waves per workgroup: 4 (2x2 wave grid) or 8 (2x4: smaller wave tiles, twice the resident waves per CU -- used by
-// the x3 mode on 128x128 tiles, where the bf16 MFMA time per tile is short and the barrier / staging phases need hiding)
-template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(GemmParams p) {
-  constexpr int NTHR = NW * 64, RPASS = NTHR / 8, NWN = NW / 2;
-  constexpr int FBK = 32;
+// LDS bytes of one operand stage (host + device): see the layout notes in the kernel
+constexpr int gf_stage_floats(int BMN, int FBK, int PREC, bool row_major) {
+  const int NPLN = PREC == 2 ? 2 : 3;
+  return PREC >= 1 ? (row_major ? BMN * (2 * FBK + 16) * NPLN / 4 : NPLN * FBK * (2 * BMN + 64) / 4)
+                   : (row_major ? BMN * (FBK + 4) : FBK * (BMN + 4));
+}
+constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm) {
+  if (NSTG == 1) return NW == 8 ? 4 : 2;   // (the classic kernels: two co-resident blocks per CU, as tuned in round 1)
+  const int lds = 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
+  const int blocks = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int w = blocks * NW / 4;
+  return w < 1 ? 1 : w;
+}
+
+// NW = waves per workgroup; NWM x (NW / NWM) wave grid (classic kernels: 2 x NW/2)
+template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4, int FBK = 32, int NSTG = 1, int NWM = 2>
+__global__ __launch_bounds__(NW * 64, gf_min_waves_per_simd(BM, BN, PREC, NW, FBK, NSTG, AK != A_COLK,
+                                                             BKIND == B_NK || BKIND == B_NK_PRE))
+void gemm_fast_kernel(GemmParams p) {
+  constexpr int NTHR = NW * 64, NWN = NW / NWM;
+  constexpr int KL = FBK / 4;          // 16-byte pieces per row of a row-major tile
+  constexpr int RPASS = NTHR / KL;     // rows of a row-major tile covered per pass
   constexpr int LDK = FBK + 4;
   constexpr bool A_RM = (AK != A_COLK);
   // B_NK_PRE: the B operand arrives already split -- three bf16 planes [plane][N][K] (weights, split once per step by
-  // tris_weight_planes_f32): 16-byte loads go straight to the LDS planes, no VALU work (x3 only).  Measured ON PAR with the
-  // in-kernel split at this kernel's operating point: three half-line (64 B) streams per row cost in address/tag
-  // work what the split saves in VALU, and the 8-wave kernel has no registers left to fetch full-line 64-k windows.
+  // tris_weight_planes_f32): 16-byte loads go straight to the LDS planes, no VALU work (x3 only, classic loop only).
   constexpr bool B_PRE = (BKIND == B_NK_PRE);
   constexpr bool B_RM = (BKIND == B_NK) || B_PRE;
-  constexpr int WM = BM / 2, WN = BN / NWN;
+  static_assert(PREC >= 1 || (FBK == 32 && NSTG == 1), "the f32-MFMA path exists as the classic 32-deep loop only");
+  static_assert(!B_PRE || (FBK == 32 && NSTG == 1), "pre-split B planes: classic loop only");
+  static_assert(NW % NWM == 0 && BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0, "wave grid does not tile the block");
+  constexpr int WM = BM / NWM, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
-  constexpr int PA = BM / RPASS, PB = BN / RPASS;  // float4 per thread per tile
-  // x3 mode: every operand is split into its three bf16 pieces ONCE, when the tile is stored: the LDS image is three
-  // bf16 planes [plane][row][32 + 8 pad] (row stride 80 B = 5 sixteen-byte slots -> conflict-free ds_read_b128), i.e.
-  // 60 floats' worth per row.
-  // PREC 1 = x3 (three bf16 pieces, six products: fp32-class); PREC 2 = x2 (two pieces, three products hi.hi + hi.mid + mid.hi:
-  // 16 significand bits per operand, relative product error <= 2^-15 -- between fp32 and TF32; planes shrink to 4 B/element)
+  constexpr int PA = BM * FBK / (4 * NTHR), PB = BN * FBK / (4 * NTHR);  // float4 per thread per tile
+  static_assert(PA >= 1 && PB >= 1 && PA * 4 * NTHR == BM * FBK && PB * 4 * NTHR == BN * FBK, "tile / thread count mismatch");
+  // x3 / x2: every operand is split into its bf16 pieces ONCE, when the tile is stored.  Row-major kinds: three planes
+  // [plane][row][FBK + 8 pad] (row stride PLB = 2 FBK + 16 bytes: 80 -> 5, 48 -> 3 sixteen-byte slots, both odd, so the 16
+  // lanes of a ds_read_b128 service group fall on 16 distinct slots).  PREC 2 = x2: two pieces, three products
+  // hi.hi + hi.mid + mid.hi (16 significand bits per operand, relative product error <= 2^-15: between fp32 and TF32).
   constexpr bool A_PL = (PREC >= 1), B_PL = (PREC >= 1);
   constexpr int NPLN = PREC == 2 ? 2 : 3;  // bf16 planes per operand
-  // x3 staging of the m-/n-contiguous operands ("row per thread"): thread -> one row (m or n) and KPT consecutive k,
-  // loaded with scalar loads (a wave covers 64 consecutive rows = 256 contiguous bytes per k), split once, and written as
-  // 16-byte bf16 runs into the same [plane][row][k] image the k-contiguous operands use
-  // KM_TR (default): the m-/n-contiguous operands are instead staged like everything else -- 16-byte loads along the
-  // contiguous dimension, split, 8-byte LDS stores into k-major planes [plane][k][m] -- and the MFMA fragments (8 consecutive
-  // k per lane) are gathered by the LDS transpose read ds_read_b64_tr_b16: per 16-lane group, lane i points at the 8-byte
-  // piece [k0 + i/4][m0 + 4(i%4) ..+3] and receives [k0..k0+3][m0 + i] (semantics established with tools/probes/
-  // tr_read_probe.hip).  Plane row stride = 2*BM + 64 bytes: the four k rows of a group and the two groups of a 32-lane
-  // half fall on disjoint banks.
-  constexpr bool A_TR = KM_TR && (PREC >= 1) && !A_RM, B_TR = KM_TR && (PREC >= 1) && !B_RM;
-  constexpr bool A_KM = (PREC >= 1) && !A_RM && !A_TR, B_KM = (PREC >= 1) && !B_RM && !B_TR;
+  // m-/n-contiguous operands: 16-byte loads along the contiguous dimension, split, 8-byte LDS stores into k-major planes
+  // [plane][k][m], and the MFMA fragments (8 consecutive k per lane) are gathered by the LDS transpose read
+  // ds_read_b64_tr_b16: per 16-lane group, lane i points at the 8-byte piece [k0 + i/4][m0 + 4(i%4) ..+3] and receives
+  // [k0..k0+3][m0 + i] (semantics established with tools/probes/tr_read_probe.hip).  Plane row stride = 2*BM + 64 bytes:
+  // the four k rows of a group and the two groups of a 32-lane half fall on disjoint banks.
+  constexpr bool A_TR = (PREC >= 1) && !A_RM, B_TR = (PREC >= 1) && !B_RM;
   constexpr int A_KS = 2 * BM + 64, B_KS = 2 * BN + 64;  // bytes per k row of a k-major plane
-  constexpr int A_KG = NTHR / BM, A_KPT = 32 / A_KG, B_KG = NTHR / BN, B_KPT = 32 / B_KG;
-  constexpr int PLB = 80;  // bytes per row of one bf16 plane
-  constexpr int A_SZ = A_TR ? NPLN * 8 * A_KS : A_PL ? BM * 20 * NPLN : (A_RM ? BM * LDK : FBK * (BM + 4));
-  constexpr int B_SZ = B_TR ? NPLN * 8 * B_KS : B_PL ? BN * 20 * NPLN : (B_RM ? BN * LDK : FBK * (BN + 4));
+  constexpr int PLB = 2 * FBK + 16;                      // bytes per row of one row-major bf16 plane
+  constexpr int A_SZ = gf_stage_floats(BM, FBK, PREC, A_RM);
+  constexpr int B_SZ = gf_stage_floats(BN, FBK, PREC, B_RM);
   __shared__ __attribute__((aligned(16))) float As[A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
+  __shared__ __attribute__((aligned(16))) float As1[NSTG == 2 ? A_SZ : 4];   // second stage (pipelined loop): separate objects
+  __shared__ __attribute__((aligned(16))) float Bs1[NSTG == 2 ? B_SZ : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -98,22 +114,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   const float* __restrict__ A = p.A + (long)zb * p.sA;
   const float* __restrict__ Bp = p.B + (long)zb * p.sB;
 
-  // Row handled by this thread's 8-lane set in the row-major kinds.  The split pieces go to LDS with ds_write_b64, which is
-  // serviced in groups of 16 CONTIGUOUS lanes against a 32-bank (128-byte) modulus: two 8-lane sets = two rows of 64 bytes.
-  // With the 80-byte plane rows, rows r and r+1 overlap on four banks (2-way: every store group took two LDS cycles --
-  // SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS 0.84 against 0.01 for the transpose-read kinds); rows r and r+4 are exactly
-  // 16 banks apart.  So within every 8 rows the lane sets visit rows 0,4,1,5,2,6,3,7: same layout, same global
-  // coalescing (one 128-byte row piece per 8 lanes), conflict-free stores.
-  const int trow = ((tid >> 3) & ~7) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3);
+  // Row handled by this thread's KL-lane set in the row-major kinds.  The split pieces go to LDS with ds_write_b64, which is
+  // serviced in groups of 16 CONTIGUOUS lanes against a 32-bank (128-byte) modulus.
+  //   FBK 32: two 8-lane sets = two rows of 64 bytes per group; with 80-byte plane rows, rows r and r+1 overlap on four banks
+  //     (2-way), rows r and r+4 are exactly 16 banks apart -> within every 8 rows the sets visit rows 0,4,1,5,2,6,3,7;
+  //   FBK 16: four 4-lane sets = four rows of 32 bytes per group; with 48-byte plane rows, rows {0,2,4,6} (and {1,3,5,7}) start
+  //     at byte offsets {0,96,64,32} (+48) mod 128 -> four disjoint 32-byte windows -> a group takes the even or the odd rows.
+  // Same layout, same global coalescing (one contiguous row piece per lane set), conflict-free stores.
+  const int trow = KL == 8 ? (((tid >> 3) & ~7) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3))
+                           : (((tid >> 5) << 3) | (2 * ((tid >> 2) & 3) + ((tid >> 4) & 1)));
+  const int kq4 = (tid % KL) * 4;   // first k of this thread's 16-byte piece (row-major kinds)
   // ---- loader state ---------------------------------------------------------------------------------------------
-  // row-major kinds: thread -> (row = tid>>3 + 32*q, kofs = (tid&7)*4);  k-major kinds: (k = tid/F4 + q*RPP, col4)
   long a_off[PA];  // ROWK: row offset; IM2COL: unused
   int a_b[PA], a_iy0[PA], a_ix0[PA];
   if (AK == A_ROWK) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       int m = min(m0 + trow + q * RPASS, p.M - 1);
-      a_off[q] = (long)m * p.lda + (tid & 7) * 4;
+      a_off[q] = (long)m * p.lda + kq4;
     }
   } else if (AK == A_IM2COL) {
     const int hw = p.gHo * p.gWo;
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
       int n = min(n0 + trow + q * RPASS, p.N - 1);
-      b_off[q] = (long)n * p.ldb + (tid & 7) * 4;
+      b_off[q] = (long)n * p.ldb + kq4;
     }
   }
   constexpr int BF4 = BN / 4, BRPP = NTHR / BF4;
@@ -146,8 +164,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   }
   const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
 
-  float4 ra[PA], rb[PB];
-  int bw_b[PB], bw_oy[PB], bw_ox[PB];  // B_KN_IM2COL: running (image, row, column) of this thread's pixel rows
+  int bw_b[PB], bw_oy[PB], bw_ox[PB];  // B_KN_IM2COL / B_KN_DGRAD: running coordinates of this thread's k rows
   constexpr int PBP = B_PRE ? (BN * 4 + NTHR - 1) / NTHR : 1;  // 16-byte pieces (8 bf16) per thread per plane per tile
   float4 rbp[3 * PBP];  // (a flat float4 array: the 2-D uint4 form was not promoted to registers)
   const unsigned short* bp_src[PBP];
@@ -158,20 +175,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
       bp_src[q] = reinterpret_cast<const unsigned short*>(p.B) + (long)row * p.ldb + (tid & 3) * 8;
     }
   }
-  float rka[A_KM ? A_KPT : 1], rkb[B_KM ? B_KPT : 1];
-  const int a_rm = min(m0 + tid % BM, p.M - 1), a_kg = tid / BM;  // x3 row-per-thread coordinates
-  const int b_rn = min(n0 + tid % BN, p.N - 1), b_kg = tid / BN;
-  int bx_tap = 0, bx_ci = 0;
-  if (BKIND == B_KN_IM2COL) { bx_tap = b_rn / p.gC; bx_ci = b_rn - bx_tap * p.gC; }
-  const int bx_ky = bx_tap / 3, bx_kx = bx_tap - (bx_tap / 3) * 3;
 
-  auto load_A = [&](int k0) {
+  // Tiles must be requested in order, FBK apart, starting at kbeg (the im2col / dgrad coordinates are carried from tile to tile)
+  auto load_A = [&](float4 (&ra)[PA], int k0) {
     if (AK == A_ROWK) {
 #pragma unroll
       for (int q = 0; q < PA; ++q) ra[q] = ld4(A + a_off[q] + k0);
     } else if (AK == A_IM2COL) {
-      const int tap = k0 / p.gC;  // whole 32-wide k tile lies inside one tap (gC % 32 == 0)
-      const int ci = k0 - tap * p.gC + (tid & 7) * 4;
+      const int tap = k0 / p.gC;  // a whole FBK-wide k tile lies inside one tap (gC % 32 == 0)
+      const int ci = k0 - tap * p.gC + kq4;
       const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
       for (int q = 0; q < PA; ++q) {
@@ -181,17 +193,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         float4 v = ld4(A + off);
         ra[q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    } else if (A_KM) {  // A_COLK, x3: KPT consecutive k of row a_rm
-      const float* src = A + (long)(k0 + a_kg * A_KPT) * p.lda + a_rm;
-#pragma unroll
-      for (int j = 0; j < A_KPT; ++j) rka[j] = src[(long)j * p.lda];
     } else {  // A_COLK: A[k*lda + m]
 #pragma unroll
       for (int q = 0; q < PA; ++q) ra[q] = ld4(A + (long)(k0 + tid / AF4 + q * ARPP) * p.lda + a_mc);
     }
   };
 
-  auto load_B = [&](int k0) {
+  auto load_B = [&](float4 (&rb)[PB], int k0) {
     if (B_PRE) {
 #pragma unroll
       for (int q = 0; q < PBP; ++q)
@@ -200,32 +208,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     } else if (BKIND == B_NK) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
-    } else if (B_KM) {
-      const int kb = k0 + b_kg * B_KPT;
-      if (BKIND == B_KN) {
-        const float* src = Bp + (long)kb * p.ldb + b_rn;
-#pragma unroll
-        for (int j = 0; j < B_KPT; ++j) rkb[j] = src[(long)j * p.ldb];
-      } else if (BKIND == B_KN_DGRAD) {  // k = tap'*Cout + co (the KPT-run stays inside one tap: Cout % 32 == 0)
-        const int tapp = kb / p.wCout, co = kb - tapp * p.wCout;
-        const float* src = Bp + ((long)co * 9 + (8 - tapp)) * p.wCin + b_rn;
-#pragma unroll
-        for (int j = 0; j < B_KPT; ++j) rkb[j] = src[(long)j * 9 * p.wCin];
-      } else {  // B_KN_IM2COL: k = output pixel (KPT consecutive pixels, walked incrementally), column = (tap, ci)
-        const int hw = p.gHo * p.gWo;
-        int b = kb / hw;
-        const int r = kb - b * hw;
-        int oy = r / p.gWo, ox = r - oy * p.gWo;
-#pragma unroll
-        for (int j = 0; j < B_KPT; ++j) {
-          const int iy = oy * p.gStride - 1 + bx_ky, ix = ox * p.gStride - 1 + bx_kx;
-          const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
-          const long off = inb ? ((long)(b * p.gH + iy) * p.gW + ix) * p.gC + bx_ci : 0;
-          const float v = Bp[off];
-          rkb[j] = inb ? v : 0.f;
-          if (++ox == p.gWo) { ox = 0; if (++oy == p.gHo) { oy = 0; ++b; } }
-        }
-      }
     } else if (BKIND == B_KN) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + (long)(k0 + tid / BF4 + q * BRPP) * p.ldb + b_nc);
@@ -237,12 +219,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
           bw_b[q] = kk / p.wCout;
           bw_oy[q] = kk - bw_b[q] * p.wCout;
         }
-        rb[q] = ld4(Bp + ((long)bw_oy[q] * 9 + (8 - bw_b[q])) * p.wCin + b_nc);
+        rb[q] = ld4(Bp + ((long)bw_oy[q] * 9 + (8 - min(bw_b[q], 8))) * p.wCin + b_nc);   // (min: surplus prefetches past the last tap)
         bw_oy[q] += FBK;
         while (bw_oy[q] >= p.wCout) { bw_oy[q] -= p.wCout; ++bw_b[q]; }
       }
     } else {  // B_KN_IM2COL: k = output pixel, column = (tap, ci) of the gathered input
-      // the pixel coordinates of this thread's PB rows are carried from tile to tile (tiles are requested in order, 32
+      // the pixel coordinates of this thread's PB rows are carried from tile to tile (tiles are requested in order, FBK
       // pixels apart): two integer divisions per row once, then additions
       if (k0 == kbeg) {
         const int hw = p.gHo * p.gWo;
@@ -258,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
         const int iy = bw_oy[q] * p.gStride - 1 + bj_ky, ix = bw_ox[q] * p.gStride - 1 + bj_kx;
-        const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
+        const bool inb = (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW && bw_b[q] < p.gB;
         const long off = inb ? ((long)(bw_b[q] * p.gH + iy) * p.gW + ix) * p.gC + bj_ci : 0;
         float4 v = ld4(Bp + off);
         rb[q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,97 +250,61 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     }
   };
 
-  auto store_lds = [&]() {
+  // ---- LDS stores: one 16-byte piece (chunk) of a tile at a time, so that the pipelined loop can spread them -----------
+  auto store_A = [&](float* Ad, const float4& v, int q) {
     if (A_TR) {
-#pragma unroll
-      for (int q = 0; q < PA; ++q) {
-        const Split4 sp = split4(ra[q]);
-        char* d = reinterpret_cast<char*>(As) + (tid / AF4 + q * ARPP) * A_KS + (tid % AF4) * 8;
-        *reinterpret_cast<uint2*>(d) = sp.hi;
-        *reinterpret_cast<uint2*>(d + 32 * A_KS) = sp.mid;
-        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 64 * A_KS) = sp.lo;
-      }
-    } else if (A_KM) {
-#pragma unroll
-      for (int h = 0; h < A_KPT / 8; ++h) {
-        const Split8 sp = split8(make_float4(rka[8 * h], rka[8 * h + 1], rka[8 * h + 2], rka[8 * h + 3]),
-                                 make_float4(rka[8 * h + 4], rka[8 * h + 5], rka[8 * h + 6], rka[8 * h + 7]));
-        char* d = reinterpret_cast<char*>(As) + (tid % BM) * PLB + (a_kg * A_KPT + 8 * h) * 2;
-        *reinterpret_cast<bf16x8*>(d) = sp.hi;
-        *reinterpret_cast<bf16x8*>(d + BM * PLB) = sp.mid;
-        if (NPLN == 3) *reinterpret_cast<bf16x8*>(d + 2 * BM * PLB) = sp.lo;
-      }
+      const Split4 sp = split4(v);
+      char* d = reinterpret_cast<char*>(Ad) + (tid / AF4 + q * ARPP) * A_KS + (tid % AF4) * 8;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + FBK * A_KS) = sp.mid;
+      if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * FBK * A_KS) = sp.lo;
     } else if (A_PL) {
-#pragma unroll
-      for (int q = 0; q < PA; ++q) {
-        const Split4 sp = split4(ra[q]);
-        char* d = reinterpret_cast<char*>(As) + (trow + q * RPASS) * PLB + (tid & 7) * 8;
-        *reinterpret_cast<uint2*>(d) = sp.hi;
-        *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
-        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
-      }
+      const Split4 sp = split4(v);
+      char* d = reinterpret_cast<char*>(Ad) + (trow + q * RPASS) * PLB + (tid % KL) * 8;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
+      if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BM * PLB) = sp.lo;
     } else if (A_RM) {
-#pragma unroll
-      for (int q = 0; q < PA; ++q)
-        *reinterpret_cast<float4*>(&As[(trow + q * RPASS) * LDK + (tid & 7) * 4]) = ra[q];
+      *reinterpret_cast<float4*>(&Ad[(trow + q * RPASS) * LDK + kq4]) = v;
     } else {
-#pragma unroll
-      for (int q = 0; q < PA; ++q)
-        *reinterpret_cast<float4*>(&As[(tid / AF4 + q * ARPP) * (BM + 4) + (tid % AF4) * 4]) = ra[q];
+      *reinterpret_cast<float4*>(&Ad[(tid / AF4 + q * ARPP) * (BM + 4) + (tid % AF4) * 4]) = v;
     }
-    if (B_PRE) {
-#pragma unroll
-      for (int q = 0; q < PBP; ++q) {
-        const int row = (tid >> 2) + q * (NTHR / 4);
-        if (PBP * (NTHR / 4) == BN || row < BN) {
-          char* d = reinterpret_cast<char*>(Bs) + row * PLB + (tid & 3) * 16;
-#pragma unroll
-          for (int pl = 0; pl < NPLN; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
-        }
-      }
-    } else if (B_TR) {
-#pragma unroll
-      for (int q = 0; q < PB; ++q) {
-        const Split4 sp = split4(rb[q]);
-        char* d = reinterpret_cast<char*>(Bs) + (tid / BF4 + q * BRPP) * B_KS + (tid % BF4) * 8;
-        *reinterpret_cast<uint2*>(d) = sp.hi;
-        *reinterpret_cast<uint2*>(d + 32 * B_KS) = sp.mid;
-        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 64 * B_KS) = sp.lo;
-      }
-    } else if (B_KM) {
-#pragma unroll
-      for (int h = 0; h < B_KPT / 8; ++h) {
-        const Split8 sp = split8(make_float4(rkb[8 * h], rkb[8 * h + 1], rkb[8 * h + 2], rkb[8 * h + 3]),
-                                 make_float4(rkb[8 * h + 4], rkb[8 * h + 5], rkb[8 * h + 6], rkb[8 * h + 7]));
-        char* d = reinterpret_cast<char*>(Bs) + (tid % BN) * PLB + (b_kg * B_KPT + 8 * h) * 2;
-        *reinterpret_cast<bf16x8*>(d) = sp.hi;
-        *reinterpret_cast<bf16x8*>(d + BN * PLB) = sp.mid;
-        if (NPLN == 3) *reinterpret_cast<bf16x8*>(d + 2 * BN * PLB) = sp.lo;
-      }
+  };
+  auto store_B = [&](float* Bd, const float4& v, int q) {
+    if (B_TR) {
+      const Split4 sp = split4(v);
+      char* d = reinterpret_cast<char*>(Bd) + (tid / BF4 + q * BRPP) * B_KS + (tid % BF4) * 8;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + FBK * B_KS) = sp.mid;
+      if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * FBK * B_KS) = sp.lo;
     } else if (B_PL) {
-#pragma unroll
-      for (int q = 0; q < PB; ++q) {
 #ifdef TRIS_EXP_NOBSPLIT   // experiment: what a pre-split (weight) operand would save -- raw bits instead of the split
-        Split4 sp;
-        sp.hi = make_uint2(__builtin_bit_cast(unsigned, rb[q].x), __builtin_bit_cast(unsigned, rb[q].y));
-        sp.mid = make_uint2(__builtin_bit_cast(unsigned, rb[q].z), __builtin_bit_cast(unsigned, rb[q].w));
-        sp.lo = sp.hi;
+      Split4 sp;
+      sp.hi = make_uint2(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y));
+      sp.mid = make_uint2(__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
+      sp.lo = sp.hi;
 #else
-        const Split4 sp = split4(rb[q]);
+      const Split4 sp = split4(v);
 #endif
-        char* d = reinterpret_cast<char*>(Bs) + (trow + q * RPASS) * PLB + (tid & 7) * 8;
-        *reinterpret_cast<uint2*>(d) = sp.hi;
-        *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
-        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
-      }
+      char* d = reinterpret_cast<char*>(Bd) + (trow + q * RPASS) * PLB + (tid % KL) * 8;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
+      if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * BN * PLB) = sp.lo;
     } else if (B_RM) {
-#pragma unroll
-      for (int q = 0; q < PB; ++q)
-        *reinterpret_cast<float4*>(&Bs[(trow + q * RPASS) * LDK + (tid & 7) * 4]) = rb[q];
+      *reinterpret_cast<float4*>(&Bd[(trow + q * RPASS) * LDK + kq4]) = v;
     } else {
+      *reinterpret_cast<float4*>(&Bd[(tid / BF4 + q * BRPP) * (BN + 4) + (tid % BF4) * 4]) = v;
+    }
+  };
+  auto store_B_pre = [&](float* Bd) {
 #pragma unroll
-      for (int q = 0; q < PB; ++q)
-        *reinterpret_cast<float4*>(&Bs[(tid / BF4 + q * BRPP) * (BN + 4) + (tid % BF4) * 4]) = rb[q];
+    for (int q = 0; q < PBP; ++q) {
+      const int row = (tid >> 2) + q * (NTHR / 4);
+      if (PBP * (NTHR / 4) == BN || row < BN) {
+        char* d = reinterpret_cast<char*>(Bd) + row * PLB + (tid & 3) * 16;
+#pragma unroll
+        for (int pl = 0; pl < NPLN; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
+      }
     }
   };
 
@@ -371,122 +317,204 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int li = lane & 31, kh = lane >> 5;
-  load_A(kbeg);
-  load_B(kbeg);
-  store_lds();
-  __syncthreads();
-  for (int k0 = kbeg; k0 < kend; k0 += FBK) {
-    const bool more = (k0 + FBK) < kend;  // uniform
-#ifndef TRIS_EXP_NOLOAD
-    if (more) {
-      load_A(k0 + FBK);
-      load_B(k0 + FBK);
-    }
-#endif
-    if constexpr (PREC == 0) {
-#pragma unroll
-    for (int g = 0; g < FBK; g += 8) {
-      float4 a[FM], b[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = wm * WM + i * 32 + li;
-        if (A_RM) {
-          a[i] = *reinterpret_cast<const float4*>(&As[row * LDK + g + kh * 4]);
-        } else {
-          const float* s = &As[(g + kh * 4) * (BM + 4) + row];
-          a[i] = make_float4(s[0], s[BM + 4], s[2 * (BM + 4)], s[3 * (BM + 4)]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = wn * WN + j * 32 + li;
-        if (B_RM) {
-          b[j] = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + kh * 4]);
-        } else {
-          const float* s = &Bs[(g + kh * 4) * (BN + 4) + col];
-          b[j] = make_float4(s[0], s[BN + 4], s[2 * (BN + 4)], s[3 * (BN + 4)]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+
+  // fragments of k group g (16 k values: lane (li, kh) owns MFMA k-slots 8*kh + j  <->  k = 16 g + 8*kh + j, for A and B alike)
+  auto frag_A = [&](const float* Ac, int g, int i) {
+    Split8 s;
+    const int row = wm * WM + i * 32 + li;
+    if (A_TR) {
+      const char* pl0 = reinterpret_cast<const char*>(Ac);
+      const int m16 = wm * WM + i * 32 + ((lane >> 4) & 1) * 16;
+      s.hi = tr_frag8(pl0, A_KS, g * 16 + 8 * kh, m16, lane);
+      s.mid = tr_frag8(pl0 + FBK * A_KS, A_KS, g * 16 + 8 * kh, m16, lane);
+      if (NPLN == 3) s.lo = tr_frag8(pl0 + 2 * FBK * A_KS, A_KS, g * 16 + 8 * kh, m16, lane);
     } else {
+      const char* s0 = reinterpret_cast<const char*>(Ac) + row * PLB + g * 32 + kh * 16;
+      s.hi = *reinterpret_cast<const bf16x8*>(s0);
+      s.mid = *reinterpret_cast<const bf16x8*>(s0 + BM * PLB);
+      if (NPLN == 3) s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BM * PLB);
+    }
+    return s;
+  };
+  auto frag_B = [&](const float* Bc, int g, int j) {
+    Split8 s;
+    const int col = wn * WN + j * 32 + li;
+    if (B_TR) {
+      const char* pl0 = reinterpret_cast<const char*>(Bc);
+      const int n16 = wn * WN + j * 32 + ((lane >> 4) & 1) * 16;
+      s.hi = tr_frag8(pl0, B_KS, g * 16 + 8 * kh, n16, lane);
+      s.mid = tr_frag8(pl0 + FBK * B_KS, B_KS, g * 16 + 8 * kh, n16, lane);
+      if (NPLN == 3) s.lo = tr_frag8(pl0 + 2 * FBK * B_KS, B_KS, g * 16 + 8 * kh, n16, lane);
+    } else {
+      const char* s0 = reinterpret_cast<const char*>(Bc) + col * PLB + g * 32 + kh * 16;
+      s.hi = *reinterpret_cast<const bf16x8*>(s0);
+      s.mid = *reinterpret_cast<const bf16x8*>(s0 + BN * PLB);
+      if (NPLN == 3) s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * PLB);
+    }
+    return s;
+  };
+  auto mfma_x = [&](const Split8& a, const Split8& b, f32x16& c) {  // smallest terms first
+    if (NPLN == 3) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+  };
+
+  if constexpr (NSTG == 2) {
+    // ---- pipelined loop: one barrier per K tile -----------------------------------------------------------------------------
+    constexpr int G = FBK / 16, NCH = PA + PB, NPR = FM * FN * G;
+    float4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];  // two register sets: tiles of even / odd index
+    // one K step: MFMAs of the current stage, with the split + store of the next tile's chunks spread between the products
+    auto step = [&](const float* Ac, const float* Bc, float* An, float* Bn, const float4 (&ra)[PA], const float4 (&rb)[PB],
+                    bool do_store) {
+      int done = 0;
 #pragma unroll
-      for (int g = 0; g < FBK; g += 16) {
-        // lane (li, kh) owns MFMA k-slots 8*kh + j  <->  k = g + 8*kh + j, for A and B alike
+      for (int g = 0; g < G; ++g) {
         Split8 sa[FM], sb[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int row = wm * WM + i * 32 + li;
-          if (A_TR) {
-            const char* pl0 = reinterpret_cast<const char*>(As);
-            const int m16 = wm * WM + i * 32 + ((lane >> 4) & 1) * 16;
-            sa[i].hi = tr_frag8(pl0, A_KS, g + 8 * kh, m16, lane);
-            sa[i].mid = tr_frag8(pl0 + 32 * A_KS, A_KS, g + 8 * kh, m16, lane);
-            if (NPLN == 3) sa[i].lo = tr_frag8(pl0 + 64 * A_KS, A_KS, g + 8 * kh, m16, lane);
-          } else if (A_PL) {
-            const char* s0 = reinterpret_cast<const char*>(As) + row * PLB + g * 2 + kh * 16;
-            sa[i].hi = *reinterpret_cast<const bf16x8*>(s0);
-            sa[i].mid = *reinterpret_cast<const bf16x8*>(s0 + BM * PLB);
-            if (NPLN == 3) sa[i].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BM * PLB);
-          } else {
-            const float* s0 = &As[(g + kh * 8) * (BM + 4) + row];
-            sa[i] = split8(make_float4(s0[0], s0[BM + 4], s0[2 * (BM + 4)], s0[3 * (BM + 4)]),
-                           make_float4(s0[4 * (BM + 4)], s0[5 * (BM + 4)], s0[6 * (BM + 4)], s0[7 * (BM + 4)]));
-          }
-        }
+        for (int i = 0; i < FM; ++i) sa[i] = frag_A(Ac, g, i);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int col = wn * WN + j * 32 + li;
-          if (B_TR) {
-            const char* pl0 = reinterpret_cast<const char*>(Bs);
-            const int n16 = wn * WN + j * 32 + ((lane >> 4) & 1) * 16;
-            sb[j].hi = tr_frag8(pl0, B_KS, g + 8 * kh, n16, lane);
-            sb[j].mid = tr_frag8(pl0 + 32 * B_KS, B_KS, g + 8 * kh, n16, lane);
-            if (NPLN == 3) sb[j].lo = tr_frag8(pl0 + 64 * B_KS, B_KS, g + 8 * kh, n16, lane);
-          } else if (B_PL) {
-            const char* s0 = reinterpret_cast<const char*>(Bs) + col * PLB + g * 2 + kh * 16;
-            sb[j].hi = *reinterpret_cast<const bf16x8*>(s0);
-            sb[j].mid = *reinterpret_cast<const bf16x8*>(s0 + BN * PLB);
-            if (NPLN == 3) sb[j].lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * PLB);
-          } else {
-            const float* s0 = &Bs[(g + kh * 8) * (BN + 4) + col];
-            sb[j] = split8(make_float4(s0[0], s0[BN + 4], s0[2 * (BN + 4)], s0[3 * (BN + 4)]),
-                           make_float4(s0[4 * (BN + 4)], s0[5 * (BN + 4)], s0[6 * (BN + 4)], s0[7 * (BN + 4)]));
-          }
-        }
+        for (int j = 0; j < FN; ++j) sb[j] = frag_B(Bc, g, j);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {  // smallest terms first
-            if (NPLN == 3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].lo, sb[j].hi, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].lo, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].mid, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < FN; ++j) {
+            mfma_x(sa[i], sb[j], acc[i][j]);
+            const int t = (g * FM + i) * FN + j + 1;  // products issued so far
+            const int want = (t * NCH) / NPR;
+            if (do_store) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c)
+                if (c >= done && c < want) {
+                  if (c < PA) store_A(An, ra[c < PA ? c : 0], c);
+                  else store_B(Bn, rb[c >= PA ? c - PA : 0], c - PA);
+                }
             }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].mid, sb[j].hi, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].mid, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].hi, sb[j].hi, acc[i][j], 0, 0, 0);
+            done = want;
           }
       }
-    }
+    };
+    // Branch-free steady state: every step issues its prefetch and its stores unconditionally; tile positions are clamped to
+    // the last tile (loaders that carry coordinates simply run past the end: their values are stored into a stage that is
+    // never read, and every gather address is formed from clamped / in-range indices).
+    const int nk = (kend - kbeg) / FBK;
+    const int klast = kbeg + (nk - 1) * FBK;
+    load_A(ra0, kbeg);
+    load_B(rb0, kbeg);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) store_A(As, ra0[q], q);
+#pragma unroll
+    for (int q = 0; q < PB; ++q) store_B(Bs, rb0[q], q);
+    load_A(ra1, min(kbeg + FBK, klast));
+    load_B(rb1, min(kbeg + FBK, klast));
     __syncthreads();
-#ifndef TRIS_EXP_NOSTORE
-    if (more) {
-      store_lds();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      // even step: current = stage 0 (tile kt); tile kt+1 (register set 1) -> stage 1; prefetch tile kt+2 into set 0
+      load_A(ra0, min(kbeg + (kt + 2) * FBK, klast));
+      load_B(rb0, min(kbeg + (kt + 2) * FBK, klast));
+      __builtin_amdgcn_sched_barrier(0);
+      step(As, Bs, As1, Bs1, ra1, rb1, true);
+      __syncthreads();
+      // odd step: current = stage 1 (tile kt+1); tile kt+2 (register set 0) -> stage 0; prefetch tile kt+3 into set 1
+      load_A(ra1, min(kbeg + (kt + 3) * FBK, klast));
+      load_B(rb1, min(kbeg + (kt + 3) * FBK, klast));
+      __builtin_amdgcn_sched_barrier(0);
+      step(As1, Bs1, As, Bs, ra0, rb0, true);
       __syncthreads();
     }
+    if (kt < nk) {  // odd tile count: the last tile sits in stage 0
+      step(As, Bs, As1, Bs1, ra1, rb1, false);
+      __syncthreads();
+    }
+  } else {
+    // ---- classic loop: one LDS buffer, two barriers per K tile ----------------------------------------------------------------
+    float4 ra[PA], rb[PB];
+    auto store_lds = [&]() {
+#pragma unroll
+      for (int q = 0; q < PA; ++q) store_A(As, ra[q], q);
+      if (B_PRE) store_B_pre(Bs);
+      else {
+#pragma unroll
+        for (int q = 0; q < PB; ++q) store_B(Bs, rb[q], q);
+      }
+    };
+    load_A(ra, kbeg);
+    load_B(rb, kbeg);
+    store_lds();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += FBK) {
+      const bool more = (k0 + FBK) < kend;  // uniform
+#ifndef TRIS_EXP_NOLOAD
+      if (more) {
+        load_A(ra, k0 + FBK);
+        load_B(rb, k0 + FBK);
+      }
 #endif
+      if constexpr (PREC == 0) {
+#pragma unroll
+        for (int g = 0; g < FBK; g += 8) {
+          float4 a[FM], b[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const int row = wm * WM + i * 32 + li;
+            if (A_RM) {
+              a[i] = *reinterpret_cast<const float4*>(&As[row * LDK + g + kh * 4]);
+            } else {
+              const float* s = &As[(g + kh * 4) * (BM + 4) + row];
+              a[i] = make_float4(s[0], s[BM + 4], s[2 * (BM + 4)], s[3 * (BM + 4)]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int col = wn * WN + j * 32 + li;
+            if (B_RM) {
+              b[j] = *reinterpret_cast<const float4*>(&Bs[col * LDK + g + kh * 4]);
+            } else {
+              const float* s = &Bs[(g + kh * 4) * (BN + 4) + col];
+              b[j] = make_float4(s[0], s[BN + 4], s[2 * (BN + 4)], s[3 * (BN + 4)]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < FBK / 16; ++g) {
+          Split8 sa[FM], sb[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) sa[i] = frag_A(As, g, i);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) sb[j] = frag_B(Bs, g, j);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mfma_x(sa[i], sb[j], acc[i][j]);
+        }
+      }
+      __syncthreads();
+#ifndef TRIS_EXP_NOSTORE
+      if (more) {
+        store_lds();
+        __syncthreads();
+      }
+#endif
+    }
   }
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ---------------------
+  // (both loops end on a barrier: the staging buffers are free)
   float st_s[FN], st_q[FN];  // fused BatchNorm statistics: per-column sum / sum of squares of this block's rows
 #pragma unroll
   for (int j = 0; j < FN; ++j) st_s[j] = st_q[j] = 0.f;
@@ -496,13 +524,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
   // kernel.  Each wave instead turns its block around in the idle staging LDS (32 x 36 floats, wave-private: program order
   // + a wave fence) and handles rows: 8 lanes x 16 bytes per row, 8 rows per instruction -- 4 loads/stores per block.
   constexpr int ELD = 36;
-  constexpr bool EPI_LDS = (NWN * 32 * ELD <= A_SZ) && (NWN * 32 * ELD <= B_SZ);
+  constexpr int EW_A = A_SZ / (32 * ELD), EW_B = B_SZ / (32 * ELD);   // waves whose 32 x 36 turn-around block fits an array
+  constexpr bool EPI_LDS = (EW_A + EW_B) * NSTG >= NW;
   float4 vs_s[FN], vs_q[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) vs_s[j] = vs_q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool vec_epi = EPI_LDS && p.vecC;  // uniform
   if (vec_epi) {
-    float* stg = (wm == 0 ? As : Bs) + wn * 32 * ELD;
+    float* stg;
+    {
+      int w = wave;
+      if (w < EW_A) stg = As + w * 32 * ELD;
+      else if ((w -= EW_A) < EW_B) stg = Bs + w * 32 * ELD;
+      else if ((w -= EW_B) < EW_A) stg = As1 + w * 32 * ELD;
+      else stg = Bs1 + (w - EW_A) * 32 * ELD;
+    }
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -574,11 +610,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     }
   }
   if (EPI == EPI_STD && p.stat_part != nullptr) {
-    // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the 2 waves along M:
+    // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the NWM waves along M:
     // shuffle, then LDS, then one fp64 partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
-    float* red = As;  // the k loop ended on a barrier: the staging buffer is free
+    static_assert(NWM * BN * 2 <= A_SZ, "statistics scratch does not fit the staging buffer");
+    float* red = As;
     if (vec_epi) {
-      __syncthreads();  // the other waves' epilogue blocks live in As / Bs
+      __syncthreads();  // the other waves' epilogue blocks live in the staging buffers
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         float4 a = vs_s[j], b = vs_q[j];
@@ -611,8 +648,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     if (tid < BN && n0 + tid < p.N) {
       const int tm = tile / p.tiles_n;
       double* o = p.stat_part + (long)tm * 2 * p.N;
-      o[n0 + tid] = (double)red[tid * 2] + (double)red[(BN + tid) * 2];
-      o[p.N + n0 + tid] = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWM; ++w) { s += (double)red[(w * BN + tid) * 2]; q += (double)red[(w * BN + tid) * 2 + 1]; }
+      o[n0 + tid] = s;
+      o[p.N + n0 + tid] = q;
     }
   }
 }
