@@ -266,9 +266,15 @@ def main():
         line = json.dumps(out)
     if world > 1 or force:
         dist.barrier()
+        __import__('tris_amd.comm', fromlist=['x']).RcclDirect.reset()
         dist.destroy_process_group()
     if rank == 0:
         sys.stderr.flush()
+        try:   # RCCL prints a version banner through C stdio (buffered when stdout is a pipe): push it out BEFORE the JSON
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(line, flush=True)  # the ONE JSON line, last thing this process writes
 
 

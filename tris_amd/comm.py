@@ -10,6 +10,9 @@ SyncBatchNorm statistics.  Both go through the helpers below so that one place d
     the code under test -- reducer ordering, SyncBN math, scaling by the world size -- identical to production while
     only the wire differs.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -58,3 +61,118 @@ def broadcast(t, src=0, group=None):
         t.copy_(h)
         return
     dist.broadcast(t, src=src, group=group)
+
+
+# ---------------------------------------------------------------------------------------------------- SyncBN fast path
+class RcclDirect:
+    """RCCL called directly on the COMPUTE stream for the per-layer SyncBatchNorm exchanges (reference:
+    nn.SyncBatchNorm.convert_sync_batchnorm, train_stage1.py:69 -- 55 all-gathers of [mean|invstd|var] in forward and 55
+    all-reduces of the two backward sums per step, each a few KB).
+
+    OPT-IN (TRIS_SYNCBN_COMM=rccl), because it measured SLOWER than torch.distributed: with a one-rank group
+    (TRIS_FORCE_DIST=1, B = 48, same box, A/B/A/B) the step takes 52.0 ms without collectives, 55.5 ms through c10d and
+    58.6-59.4 ms through this class.  The cost of these 110 tiny exchanges is not c10d's Work objects or stream hops but
+    RCCL's own enqueue path (~55 us of host work per call), which a direct call pays just the same.  The way to take them
+    off the step is to not call RCCL at all for them: tris_amd.comm.Mailbox (IPC-mapped peer buffers + flags).
+
+    The same RCCL library that torch loaded (torch/lib/librccl.so -- no second copy in the process) is bound with ctypes
+    and its own communicator is created once per process group (unique id from rank 0, distributed through
+    torch.distributed); each exchange is one in-stream launch.  If the library or the communicator cannot be set up,
+    `get()` returns None and the callers use torch.distributed."""
+
+    _by_group = {}
+    NCCL_FLOAT32, NCCL_SUM = 7, 0
+
+    class _UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_ubyte * 128)]   # (c_ubyte: a c_char array reads back NUL-truncated)
+
+    def __init__(self, group):
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = ctypes.CDLL(path)
+        for name, args in (("ncclGetUniqueId", [ctypes.POINTER(self._UniqueId)]),
+                           ("ncclCommInitRank", [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]),
+                           ("ncclAllGather", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                              ctypes.c_void_p]),
+                           ("ncclAllReduce", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_void_p]),
+                           ("ncclCommDestroy", [ctypes.c_void_p])):
+            fn = getattr(lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = args
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+        self.lib = lib
+        self.world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        uid = self._UniqueId()
+        if rank == 0:
+            self._chk(lib.ncclGetUniqueId(ctypes.byref(uid)))
+        box = [ctypes.string_at(ctypes.byref(uid), 128) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        comm = ctypes.c_void_p()
+        self._chk(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, rank))   # binds the current HIP device
+        self.comm = comm
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"RCCL: {self.lib.ncclGetErrorString(rc).decode()} ({rc})")
+
+    def all_gather_into(self, out, inp):
+        self._chk(self.lib.ncclAllGather(inp.data_ptr(), out.data_ptr(), inp.numel(), self.NCCL_FLOAT32, self.comm,
+                                         torch.cuda.current_stream().cuda_stream))
+
+    def all_reduce_sum(self, t):
+        self._chk(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self.NCCL_FLOAT32, self.NCCL_SUM, self.comm,
+                                         torch.cuda.current_stream().cuda_stream))
+
+    @classmethod
+    def get(cls, group=None):
+        """the direct communicator of `group`, or None (then: torch.distributed).  Collective: every rank of the group
+        must call it at the same point the first time (BatchNormFn does: first SyncBN forward of the first step)."""
+        key = id(group) if group is not None else 0
+        if key in cls._by_group:
+            return cls._by_group[key]
+        made = None
+        if (backend(group) == "nccl" and os.environ.get("TRIS_SYNCBN_COMM", "c10d") == "rccl"
+                and not torch.cuda.is_current_stream_capturing()):
+            try:
+                made = cls(group)
+            except Exception as e:   # library missing / init refused: keep training on the c10d path, say so once
+                import warnings
+                warnings.warn(f"direct RCCL communicator for SyncBatchNorm unavailable ({e!r}); using torch.distributed")
+                made = None
+            # every rank must take the same path: agree (one tiny c10d collective, once)
+            ok = torch.tensor([1 if made is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                made = None
+        cls._by_group[key] = made
+        return made
+
+    @classmethod
+    def reset(cls):
+        """drop the cached communicators (call before destroying the process group: tests)"""
+        for c in cls._by_group.values():
+            if c is not None:
+                try:
+                    c.lib.ncclCommDestroy(c.comm)
+                except Exception:
+                    pass
+        cls._by_group = {}
+
+
+def syncbn_all_gather_into(out, inp, group=None):
+    c = RcclDirect.get(group) if inp.is_cuda else None
+    if c is not None:
+        c.all_gather_into(out, inp)
+    else:
+        all_gather_into(out, inp, group)
+
+
+def syncbn_all_reduce_sum(t, group=None):
+    c = RcclDirect.get(group) if t.is_cuda else None
+    if c is not None:
+        c.all_reduce_sum(t)
+    else:
+        all_reduce(t, group=group)

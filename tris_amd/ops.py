@@ -686,7 +686,7 @@ class BatchNormFn(torch.autograd.Function):
                 local_stats(None, None)
                 world = comm.world_size(group)
                 allv = torch.empty(world * 3 * C, device=x.device, dtype=torch.float32)
-                comm.all_gather_into(allv, stats, group=group)   # the stats block travels as is
+                comm.syncbn_all_gather_into(allv, stats, group=group)   # the stats block travels as is (one in-stream RCCL launch)
                 call("tris_bn_sync_combine_f32", P(allv), world, C, M, eps, momentum, P(stats), P(rmean), P(rvar),
                      _stream())
                 count = M * world  # DistributedSampler gives every rank the same per-step batch
@@ -737,7 +737,7 @@ class BatchNormFn(torch.autograd.Function):
             db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
             if group is not None:
                 from . import comm
-                comm.all_reduce(sums, group=group)
+                comm.syncbn_all_reduce_sum(sums, group=group)
         dx = None
         if ctx.needs_input_grad[0] or want_dz:
             dx = torch.empty_like(x)
