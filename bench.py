@@ -119,8 +119,10 @@ def main():
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: (1 - x / max_iter) ** 0.9)
     reducer = None
     if world > 1 or force:
-        convert_sync_batchnorm(model)
-        reducer = attach_reducer(model, opt, force=force)   # all-reduce segments launched from inside backward
+        if os.environ.get("TRIS_DBG_NO_SYNCBN") != "1":       # (developer A/B knobs: which half of the exchange costs what)
+            convert_sync_batchnorm(model)
+        if os.environ.get("TRIS_DBG_NO_REDUCER") != "1":
+            reducer = attach_reducer(model, opt, force=force)   # all-reduce segments launched from inside backward
     b = synthetic_batch(a.batch, 320, QL, 3, seed=7, rank=rank)
     img, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
 
@@ -266,7 +268,7 @@ def main():
         line = json.dumps(out)
     if world > 1 or force:
         dist.barrier()
-        __import__('tris_amd.comm', fromlist=['x']).RcclDirect.reset()
+        __import__('tris_amd.comm', fromlist=['x']).shutdown()
         dist.destroy_process_group()
     if rank == 0:
         sys.stderr.flush()

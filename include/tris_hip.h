@@ -13,7 +13,7 @@
  *     library keeps is host-side configuration read at launch time: the arithmetic mode of the dense products (a
  *     process-wide default, tris_set_gemm_mode, plus a per-thread override, tris_set_gemm_mode_thread), the autotune
  *     switch with its per-process cache of tuned (tile, split-K) choices (tris_set_autotune).  No entry point keeps
- *     device state between calls;
+ *     device state between calls (the SyncBN mailboxes of tris_mbox_* are caller-owned buffers);
  *   - return value: 0 on success, otherwise a hipError_t.
  */
 #ifndef TRIS_HIP_H
@@ -254,6 +254,34 @@ int tris_u8_gather_normalize_f32(const unsigned char* cache, const long* index, 
 /* out[r] = table[index[r]]  for rows of row_bytes (multiple of 4) bytes: token ids of the sampled sentences
  * (ReferDataset.py:172-229) */
 int tris_gather_rows(const void* table, const long* index, long rows, long row_bytes, void* out, void* stream);
+
+/* ---- SyncBatchNorm statistics exchange over xGMI peer memory (csrc/comm.hip) --------------------------------------
+ * Replaces the per-layer collectives of nn.SyncBatchNorm (reference: train_stage1.py:69 convert_sync_batchnorm; torch's
+ * SyncBatchNorm all_gathers [mean|invstd|count] in forward and all_reduces [sum_dy|sum_dy_xmu] in backward) for ranks on
+ * ONE node.  Every rank owns a mailbox in uncached device memory (tris_mbox_alloc; capacity `cap_floats` per sender block,
+ * a multiple of 4) and maps its peers' mailboxes through HIP IPC (tris_mbox_ipc_handle -> 64-byte handle, exchanged by the
+ * host; tris_mbox_ipc_open).  tris_mbox_exchange_f32 is one single-workgroup launch on `stream`: store the block
+ * [src0[n0] | src1[n1]] (n = n0 + n1; src1 may be NULL with n1 = 0) into every
+ * peer's mailbox, publish per-sender flags (system-scope release), wait for the `world` flags of the own mailbox (bounded
+ * spin: after spin_limit polls *err is set to seq and the wait is abandoned), then mode 0: out[world][n] = the gathered
+ * blocks in rank order; mode 1: out[n] = their sum in rank order (bit-identical on every rank).  `boxes` is a DEVICE array of
+ * the `world` mailbox pointers as mapped in this process (own mailbox at index `rank`).  `seq` must be 1, 2, 3, ... in the
+ * same order on every rank (flags are zero-initialised).  World size <= TRIS_MBOX_MAX_WORLD. */
+#define TRIS_MBOX_MAX_WORLD 16
+long tris_mbox_bytes(int cap_floats);
+int tris_mbox_alloc(void** ptr, int cap_floats);
+int tris_mbox_free(void* ptr);
+int tris_mbox_ipc_handle(void* ptr, void* handle64);
+int tris_mbox_ipc_open(const void* handle64, void** ptr);
+int tris_mbox_ipc_close(void* ptr);
+int tris_mbox_exchange_f32(const float* src0, int n0, const float* src1, int n1, float* out, void* const* boxes, int world,
+                           int rank, int seq, int cap_floats, int mode, long spin_limit, int* err, void* stream);
+/* SyncBatchNorm forward in ONE launch: exchange the [mean | invstd | biased var] block (3 C floats, what tris_bn_finalize_f32 /
+ * tris_bn_stats_f32 write) and combine the `world` blocks into the global statistics stats[3C] + running statistics -- the
+ * arithmetic of tris_bn_sync_combine_f32.  Every rank contributes count_per_rank rows. */
+int tris_mbox_bn_combine_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum, float* stats,
+                             float* running_mean, float* running_var, void* const* boxes, int world, int rank, int seq,
+                             int cap_floats, long spin_limit, int* err, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,9 +70,14 @@ def _worker(rank, world, port, tmp):
             names = {id(p): n for n, p in net.named_parameters()}
             out["grads"] = {names[id(p)]: p.grad.detach().cpu().clone() for a in opt.arenas for p in a.params}
             out["running"] = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running_" in k}
+        from tris_amd import comm
+        out["syncbn_transport"] = "mailbox" if any(m is not None for m in comm.Mailbox._by_group.values()) else "c10d"
+        comm.check_errors()
         torch.save(out, os.path.join(tmp, f"rank{rank}.pt"))
         dist.barrier()
     finally:
+        from tris_amd import comm
+        comm.shutdown()
         dist.destroy_process_group()
 
 
@@ -103,6 +108,8 @@ def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path):
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
 
+    # the SyncBatchNorm statistics travelled through the IPC mailboxes (the production transport), not through gloo
+    assert r0["syncbn_transport"] == r1["syncbn_transport"] == os.environ.get("TRIS_EXPECT_SYNCBN", "mailbox")
     # (1) per-rank losses vs the oracle's per-shard losses
     for r, got in enumerate((r0["losses"], r1["losses"])):
         want = torch.stack([t.detach() for t in ref["per_rank"][r]])

@@ -691,7 +691,7 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
                 m.process_group = None
         model.backbone.visual.grad_reducer = None
         model.backbone.grad_reducer = None
-        __import__('tris_amd.comm', fromlist=['x']).RcclDirect.reset()
+        __import__('tris_amd.comm', fromlist=['x']).shutdown()
         dist.destroy_process_group()
         refill(model)
 

@@ -61,5 +61,5 @@ import statistics
 print("params", len(worst), "median rel diff", statistics.median(w[0] for w in worst), "n>1e-3:", sum(w[0] > 1e-3 for w in worst), "n>1e-5:", sum(w[0] > 1e-5 for w in worst))
 for w in worst[:25]: print(f"  {w[0]:.3e} {w[1]}")
 print("text/head params:", [(f"{w[0]:.1e}", w[1]) for w in worst if not w[1].startswith("backbone.visual")][:6])
-__import__('tris_amd.comm', fromlist=['x']).RcclDirect.reset()
+__import__('tris_amd.comm', fromlist=['x']).shutdown()
 dist.destroy_process_group()

@@ -162,7 +162,141 @@ class RcclDirect:
         cls._by_group = {}
 
 
+class Mailbox:
+    """SyncBatchNorm exchanges through IPC-mapped peer mailboxes (csrc/comm.hip; include/tris_hip.h `tris_mbox_*`): one
+    single-workgroup launch on the compute stream per exchange -- stores over xGMI into every peer's mailbox, per-sender
+    flags, bounded spin on the own mailbox -- instead of an RCCL collective.  Default transport of the SyncBN statistics
+    whenever every rank of the group can map every other rank's mailbox (one node); otherwise torch.distributed.
+
+    Set-up is collective (first SyncBN forward of the first step): allocate, exchange the 64-byte IPC handles through
+    torch.distributed, open the peers' handles, agree that everyone succeeded."""
+
+    _by_group = {}
+    CAP = 3 * 4096           # floats per sender block: [mean|invstd|var] of the widest BatchNorm (2048 channels) with headroom
+    SPIN_LIMIT = int(os.environ.get("TRIS_MBOX_SPIN", "20000000"))  # polls (~ seconds) before an exchange gives up and raises the error flag
+
+    def __init__(self, group):
+        from . import _lib
+        self.lib = _lib.load()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if self.world > _lib.CONSTS["TRIS_MBOX_MAX_WORLD"]:
+            raise RuntimeError(f"world size {self.world} exceeds TRIS_MBOX_MAX_WORLD")
+        own = ctypes.c_void_p()
+        self._chk(self.lib.tris_mbox_alloc(ctypes.byref(own), self.CAP), "tris_mbox_alloc")
+        self.own = own
+        handle = ctypes.create_string_buffer(64)
+        self._chk(self.lib.tris_mbox_ipc_handle(own, handle), "tris_mbox_ipc_handle")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=group)
+        ptrs, self.opened = [], []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs.append(own.value)
+                continue
+            p = ctypes.c_void_p()
+            self._chk(self.lib.tris_mbox_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(p)), "tris_mbox_ipc_open")
+            self.opened.append(p)
+            ptrs.append(p.value)
+        self.boxes = torch.tensor(ptrs, dtype=torch.int64, device="cuda")
+        self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.seq = 0
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with hipError_t {rc}")
+
+    def exchange(self, src, out, mode, src1=None):
+        """block = [src | src1]; mode 0: out[world][n] gathered, mode 1: out[n] = sum over ranks"""
+        self.seq += 1
+        self._chk(self.lib.tris_mbox_exchange_f32(src.data_ptr(), src.numel(), None if src1 is None else src1.data_ptr(),
+                                                  0 if src1 is None else src1.numel(), out.data_ptr(), self.boxes.data_ptr(),
+                                                  self.world, self.rank, self.seq, self.CAP, mode, self.SPIN_LIMIT,
+                                                  self.err.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                  "tris_mbox_exchange_f32")
+
+    def bn_combine(self, local_stats, C, count_per_rank, eps, momentum, stats, running_mean, running_var):
+        """SyncBN forward exchange + combine in one launch (include/tris_hip.h: tris_mbox_bn_combine_f32)"""
+        self.seq += 1
+        self._chk(self.lib.tris_mbox_bn_combine_f32(local_stats.data_ptr(), C, count_per_rank, eps, momentum, stats.data_ptr(),
+                                                    None if running_mean is None else running_mean.data_ptr(),
+                                                    None if running_var is None else running_var.data_ptr(),
+                                                    self.boxes.data_ptr(), self.world, self.rank, self.seq, self.CAP,
+                                                    self.SPIN_LIMIT, self.err.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "tris_mbox_bn_combine_f32")
+
+    def check(self):
+        """host-side check of the time-out flag (synchronises): raise if an exchange was abandoned"""
+        e = int(self.err.item())
+        if e:
+            raise RuntimeError(f"SyncBatchNorm mailbox exchange #{e} timed out on rank {self.rank}: a peer never posted its "
+                               f"block (crashed rank, or ranks running different numbers of BatchNorm layers)")
+
+    def close(self):
+        for p in self.opened:
+            self.lib.tris_mbox_ipc_close(p)
+        self.lib.tris_mbox_free(self.own)
+        self.opened = []
+
+    @classmethod
+    def get(cls, group=None):
+        key = id(group) if group is not None else 0
+        if key in cls._by_group:
+            return cls._by_group[key]
+        made = None
+        if os.environ.get("TRIS_SYNCBN_COMM", "mailbox") == "mailbox" and not torch.cuda.is_current_stream_capturing():
+            try:
+                made = cls(group)
+            except Exception as e:
+                import warnings
+                warnings.warn(f"SyncBatchNorm mailboxes unavailable ({e!r}); using torch.distributed collectives")
+                made = None
+            ok = torch.tensor([1.0 if made is not None else 0.0], device="cuda")
+            all_reduce(ok, op=dist.ReduceOp.MIN, group=group)    # every rank must take the same path
+            if float(ok.item()) == 0.0:
+                if made is not None:
+                    made.close()
+                made = None
+        cls._by_group[key] = made
+        return made
+
+    @classmethod
+    def reset(cls):
+        for m in cls._by_group.values():
+            if m is not None:
+                torch.cuda.synchronize()
+                m.close()
+        cls._by_group = {}
+
+
+def check_errors():
+    """raise if any SyncBatchNorm mailbox exchange timed out (host sync: call where the loop syncs anyway)"""
+    for m in Mailbox._by_group.values():
+        if m is not None:
+            m.check()
+
+
+def shutdown():
+    """release the SyncBN transports (call before dist.destroy_process_group)"""
+    Mailbox.reset()
+    RcclDirect.reset()
+
+
+def syncbn_mailbox(group, numel):
+    """the mailbox transport of `group` if it can carry a block of `numel` floats, else None"""
+    if numel > Mailbox.CAP or not torch.cuda.is_available():
+        return None
+    return Mailbox.get(group)
+
+
 def syncbn_all_gather_into(out, inp, group=None):
+    if inp.is_cuda and inp.numel() <= Mailbox.CAP:
+        m = Mailbox.get(group)
+        if m is not None:
+            m.exchange(inp, out, 0)
+            return
     c = RcclDirect.get(group) if inp.is_cuda else None
     if c is not None:
         c.all_gather_into(out, inp)
@@ -171,6 +305,11 @@ def syncbn_all_gather_into(out, inp, group=None):
 
 
 def syncbn_all_reduce_sum(t, group=None):
+    if t.is_cuda and t.numel() <= Mailbox.CAP:
+        m = Mailbox.get(group)
+        if m is not None:
+            m.exchange(t, t, 1)
+            return
     c = RcclDirect.get(group) if t.is_cuda else None
     if c is not None:
         c.all_reduce_sum(t)

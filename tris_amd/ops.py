@@ -212,12 +212,14 @@ def side_stream(name):
     return _SIDE_STREAMS[key]
 
 
-def wgrad_join():
-    """Make the current stream wait for every auxiliary stream that may still be producing gradients (the weight-gradient
-    stream and the named side streams): call before anything consumes the gradient arenas (optimiser, all-reduce)."""
+def wgrad_join(into=None):
+    """Make a stream (default: the current one) wait for every auxiliary stream that may still be producing gradients (the
+    weight-gradient stream and the named side streams): call before anything consumes the gradient arenas (optimiser,
+    all-reduce).  `into`: the stream that should wait -- the data-parallel reducer passes its own stream so that the COMPUTE
+    stream is not stalled in the middle of backward."""
     if not _WG and not _SIDE_STREAMS:
         return  # nothing was ever issued on an auxiliary stream (also: host-only / CPU test contexts)
-    cur = torch.cuda.current_stream()
+    cur = torch.cuda.current_stream() if into is None else into
     dev = torch.cuda.current_device()
     if dev in _WG and _WG[dev] != cur:
         cur.wait_stream(_WG[dev])
@@ -672,23 +674,30 @@ class BatchNormFn(torch.autograd.Function):
         if training:
             stats = torch.empty(3 * C, device=x.device, dtype=torch.float32)
 
-            def local_stats(rm, rv):
+            def local_stats(rm, rv, dst=None):
+                dst = stats if dst is None else dst
                 if part is not None:  # partial sums came out of the producing conv's epilogue
-                    call("tris_bn_finalize_f32", part[0].data_ptr(), part[1], M, C, eps, momentum, P(stats), P(rm),
+                    call("tris_bn_finalize_f32", part[0].data_ptr(), part[1], M, C, eps, momentum, P(dst), P(rm),
                          P(rv), _stream())
                 else:
                     ws = workspace(query("tris_col_workspace_bytes", M, C))
-                    call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(stats), P(rm), P(rv), P(ws), _stream())
+                    call("tris_bn_stats_f32", P(x), M, C, eps, momentum, P(dst), P(rm), P(rv), P(ws), _stream())
             if group is None:
                 local_stats(rmean, rvar)
             else:
                 from . import comm
-                local_stats(None, None)
                 world = comm.world_size(group)
-                allv = torch.empty(world * 3 * C, device=x.device, dtype=torch.float32)
-                comm.syncbn_all_gather_into(allv, stats, group=group)   # the stats block travels as is (one in-stream RCCL launch)
-                call("tris_bn_sync_combine_f32", P(allv), world, C, M, eps, momentum, P(stats), P(rmean), P(rvar),
-                     _stream())
+                mb = comm.syncbn_mailbox(group, 3 * C)
+                if mb is not None:   # one launch: peer-mailbox exchange + combine (+ running statistics)
+                    loc = torch.empty(3 * C, device=x.device, dtype=torch.float32)
+                    local_stats(None, None, dst=loc)
+                    mb.bn_combine(loc, C, M, eps, momentum, stats, rmean, rvar)
+                else:
+                    local_stats(None, None)
+                    allv = torch.empty(world * 3 * C, device=x.device, dtype=torch.float32)
+                    comm.syncbn_all_gather_into(allv, stats, group=group)   # the stats block travels as is
+                    call("tris_bn_sync_combine_f32", P(allv), world, C, M, eps, momentum, P(stats), P(rmean), P(rvar),
+                         _stream())
                 count = M * world  # DistributedSampler gives every rank the same per-step batch
             mean, invstd = stats[:C], stats[C:2 * C]
         else:
@@ -720,9 +729,14 @@ class BatchNormFn(torch.autograd.Function):
         # kernels and the apply kernel emits dz for the residual branch in the same pass
         ws = workspace(query("tris_col_workspace_bytes", M, C))
         sg, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
-        direct = (group is None and sg is not None and sb is not None and ctx.needs_input_grad[1]
-                  and ctx.needs_input_grad[2] and sg.is_contiguous() and sb.is_contiguous())
-        if direct:   # the two reductions ARE dbeta / dgamma: write them straight into the gradient arena
+        in_arena = (sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+                    and sg.is_contiguous() and sb.is_contiguous())
+        mb = None
+        if group is not None and in_arena:
+            from . import comm
+            mb = comm.syncbn_mailbox(group, 2 * C)
+        direct = in_arena and (group is None or mb is not None)
+        if direct:   # the two LOCAL reductions ARE dbeta / dgamma: write them straight into the gradient arena
             p_dz, p_dzx = P(sb), P(sg)
             dg = db = None
         else:
@@ -732,7 +746,13 @@ class BatchNormFn(torch.autograd.Function):
         mask_x = relu and not has_res and y is None
         call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
              P(gamma) if mask_x else None, P(beta) if mask_x else None, _stream())
-        if not direct:
+        if mb is not None:
+            # SyncBatchNorm: the arena keeps this rank's dbeta / dgamma (the data-parallel reducer averages them like every
+            # other gradient); the sums over ALL ranks that dX needs come from one peer-mailbox launch reading the arena
+            sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            mb.exchange(sb, sums, 1, src1=sg)
+            p_dz, p_dzx = P(sums), P(sums, C)
+        elif not direct:
             dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
             db = _emit(ctx.params[1], lambda o: o.copy_(sums[:C]), ctx.needs_input_grad[2])
             if group is not None:

@@ -123,12 +123,25 @@ class GradReducer:
         from . import ops
         if self.check and self.param_ranges:
             self._verify(key)
-        ops.wgrad_join()  # the segment's weight gradients may still be in flight on the weight-gradient / text streams
-        for ai, s, e in self.segments.get(key, []):
-            f = self.flats[ai]
-            for c in range(s, e, self.chunk):
-                self.pending.append(comm.all_reduce(f[c:min(e, c + self.chunk)], op=self.op, group=self.group,
-                                                    async_op=True))
+        # The collectives are issued from the reducer's OWN stream: it (not the compute stream) waits for the weight-gradient
+        # and text streams that may still be writing this segment, so backward keeps running while the segment drains; the
+        # compute stream meets the collectives again only in finish().
+        on_gpu = bool(self.flats) and self.flats[0].is_cuda
+        if on_gpu:
+            rs = ops.side_stream("reduce")
+            rs.wait_stream(torch.cuda.current_stream())
+            ops.wgrad_join(into=rs)
+            ctx = torch.cuda.stream(rs)
+        else:
+            import contextlib
+            ops.wgrad_join()
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for ai, s, e in self.segments.get(key, []):
+                f = self.flats[ai]
+                for c in range(s, e, self.chunk):
+                    self.pending.append(comm.all_reduce(f[c:min(e, c + self.chunk)], op=self.op, group=self.group,
+                                                        async_op=True))
 
     def boundary(self, x, key):
         if not self.active or not torch.is_grad_enabled() or not x.requires_grad:
@@ -150,6 +163,9 @@ class GradReducer:
                                                             async_op=True))
             for h in self.pending:
                 h.wait()
+            if self.flats and self.flats[0].is_cuda:
+                from . import ops
+                torch.cuda.current_stream().wait_stream(ops.side_stream("reduce"))
             if not self.avg and self.world > 1:
                 for f in self.flats:
                     f.mul_(1.0 / self.world)

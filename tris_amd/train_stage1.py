@@ -127,6 +127,9 @@ def train_one_epoch(train_loader, model, optimizer, epoch, local_rank, args, ite
         last = train_step(model, clip_model, optimizer, img, word_ids, neg, args, lr_scheduler, reducer)
         if idx % args.print_freq == 0 and local_rank == 0:
             v = last.tolist()  # the only host sync, every print_freq steps (the reference syncs every step, :374-387)
+            if args.distributed:
+                from . import comm
+                comm.check_errors()   # a SyncBN mailbox exchange that timed out fails the run here instead of hanging it
             msg = (f"Train:[{epoch:2d}/{args.epoch}][{idx:4d}/{num_steps}] | lr {optimizer.param_groups[0]['lr']:.6f} || "
                    f"loss: {v[0]:.4f} | l1: {v[1]:.4f} | l4: {v[2]:.4f} | l5: {v[3]:.4f} | "
                    f"time/step: {(time.time() - t0) / (idx + 1):.4f}")
