@@ -142,7 +142,10 @@ def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
     assert sorted(names) == sorted(trainable)
     # the text encoder is NOT in the segment released behind layer4 (the round-1 defect)
     assert all(not n.startswith("backbone.") for *_, n in par["heads"])
-    assert any(n.startswith("backbone.transformer.") for *_, n in par["text"])
+    assert any(n.startswith("backbone.transformer.resblocks.0.") for *_, n in par["text"])
+    assert any(n.startswith("backbone.transformer.resblocks.11.") for *_, n in par["text_hi"])
+    assert any(n.startswith("backbone.transformer.resblocks.5.") for *_, n in par["text_mid"])
+    assert "backbone.text_projection" in {n for *_, n in par["text_hi"]}
     assert {n for *_, n in par["embed"]} == {"backbone.token_embedding.weight", "backbone.positional_embedding"}
 
     written = set()
@@ -175,8 +178,9 @@ def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
     order = [k for k in in_backward if k in ("heads", "layer4", "layer3", "layer2", "layer1")]
     assert order == ["heads", "layer4", "layer3", "layer2", "layer1"]
     assert "text" in in_backward and "embed" not in in_backward and "stem" not in in_backward
+    assert [k for k in in_backward if k.startswith("text")] == ["text_hi", "text_mid", "text"]
     if overlap:   # text encoder issued first => its backward (and its release) come after the whole trunk
-        assert in_backward.index("text") > in_backward.index("layer1")
+        assert in_backward.index("text_hi") > in_backward.index("layer1")
     else:         # issued after the trunk => released before the trunk starts
         assert in_backward.index("text") < in_backward.index("layer4")
     assert len(written) >= len(trainable)

@@ -116,7 +116,7 @@ def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path):
         assert float((got - want).abs().max()) < 1e-3, (r, got.tolist(), want.tolist())
     # (2) every segment was released, the trunk stages from inside backward in completion order, the text encoder last
     for log in (r0["launch_log"], r1["launch_log"]):
-        assert sorted(log) == sorted(["heads", "embed", "text", "layer4", "layer3", "layer2", "layer1", "stem"])
+        assert sorted(log) == sorted(["heads", "embed", "text_hi", "text_mid", "text", "layer4", "layer3", "layer2", "layer1", "stem"])
         assert [k for k in log if k in ("heads", "layer4", "layer3", "layer2", "layer1")] == \
             ["heads", "layer4", "layer3", "layer2", "layer1"]
     # (3) reduced gradients = gradient of the mean loss on the concatenated batch

@@ -133,7 +133,7 @@ def test_gradient_segments_cover_the_arenas_in_backward_order():
     assert cover == [arenas[0].numel, arenas[1].numel]
     assert len(seg["layer4"]) == 1 and len(seg["layer1"]) == 1 and len(seg["stem"]) == 1
     assert seg["heads"] == [(1, 0, arenas[1].numel)]            # the whole second arena, nothing of the backbone
-    assert all(ai == 0 for ai, *_ in seg["text"]) and 1 <= len(seg["text"]) <= 4   # text_projection | transformer | ln_final
+    assert all(ai == 0 for k in ("text", "text_mid", "text_hi") for ai, *_ in seg[k]) and 1 <= len(seg["text"]) <= 4   # text_projection | transformer | ln_final
     for ai, s, e, n in (r for ranges in par.values() for r in ranges):
         assert 0 <= s < e <= arenas[ai].numel
 

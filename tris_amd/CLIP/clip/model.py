@@ -400,7 +400,13 @@ class CLIP(nn.Module):
             # data-parallel: once backward passes this point every gradient of the text transformer, ln_final and
             # text_projection is written (they were all created after it); the embedding tables follow in finish()
             x = red.boundary(x, "text")
-        x = self.transformer(x)
+            from ...parallel import TEXT_BOUNDARIES   # sub-segments of the text encoder (see tris_amd.parallel)
+            for i, blk in enumerate(self.transformer.resblocks):
+                x = blk(x)
+                if i in TEXT_BOUNDARIES:
+                    x = red.boundary(x, TEXT_BOUNDARIES[i])
+        else:
+            x = self.transformer(x)
         x = self.ln_final(x)
         hidden = ops.matmul(ops.eot_gather(ids, x), self.text_projection)
         return x, hidden

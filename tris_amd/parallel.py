@@ -195,12 +195,31 @@ class _Boundary(torch.autograd.Function):
 # where each segment is released (tris_amd.CLIP.clip.model places the boundaries):
 #   "heads"  : vis_project / lan_project / attn_fusion           -- boundary behind layer4 (created before every head node)
 #   "layer4" ... "layer1" : boundary behind the previous stage
-#   "text"   : text transformer, ln_final, text_projection      -- boundary on the text path behind the embedding
+#   "text_hi" / "text_mid" / "text" : text transformer blocks 8-11 (+ ln_final, text_projection) / 4-7 / 0-3 -- boundaries
+#              on the text path behind blocks 7 and 3 and behind the embedding.  The text encoder's backward is the LAST part
+#              of backward (it is issued first in forward), so whatever of it is still un-reduced when backward ends is
+#              exposed communication: three sub-segments leave only the last third (+ the embedding) to finish()
 #   "embed"  : token / positional embedding (written after the "text" boundary) and
 #   "stem"   : the three stem convolutions (last to finish in the trunk) -- finish()
+def _text_block(name):
+    """index of the text-transformer block a parameter belongs to; ln_final / text_projection count as behind the last
+    block (99); anything else -1"""
+    pre = "backbone.transformer.resblocks."
+    if name.startswith(pre):
+        return int(name[len(pre):].split(".")[0])
+    if name.startswith("backbone.ln_final.") or name == "backbone.text_projection":
+        return 99
+    return -1
+
+
+TEXT_BOUNDARIES = {7: "text_hi", 3: "text_mid"}   # behind block i: every block > i (created later) has finished its backward
+
+
 STAGE1_RULES = {
     "heads": lambda n: not n.startswith("backbone."),
     "embed": lambda n: n in ("backbone.token_embedding.weight", "backbone.positional_embedding"),
+    "text_hi": lambda n: (not n.startswith("backbone.visual.")) and _text_block(n) >= 8,
+    "text_mid": lambda n: (not n.startswith("backbone.visual.")) and 4 <= _text_block(n) < 8,
     "text": lambda n: not n.startswith("backbone.visual."),
     "layer4": lambda n: n.startswith("backbone.visual.layer4."),
     "layer3": lambda n: n.startswith("backbone.visual.layer3."),
