@@ -179,14 +179,10 @@ int tris_softmax_bwd_f32(const float* dY, const float* Y, float* dX, long rows, 
  *   new_vis[b] = softmax_n(Qv[b].Kt^T*scale).Vt      [B,P,C]
  *   new_lan[b] = softmax_p(Qt.Kv[b]^T*scale).Vv[b]   [B,N,C]
  * probs [B,4,P,N] (scratch + saved for backward): plane 0 = Av, plane 1 = Kv.Qt^T logits, plane 2 = AtT (pixel-major),
- * plane 3 = Qv.Kt^T logits (two-launch x3 path only).
- * workspace (optional; tris_xattn_workspace_bytes(N, C), 16-byte aligned): scratch for the pre-split sentence operands of the
- * fastest x3 path (bf16 piece planes of Kt / Qt / Vt in MFMA fragment order, built once per call); without it the
- * two-launch path that splits them in every workgroup runs. */
-long tris_xattn_workspace_bytes(int N, int C);
+ * plane 3 = Qv.Kt^T logits (x3 path only). */
 int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                        const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
-                       float* workspace, long workspace_bytes, void* stream);
+                       void* stream);
 /* backward of a softmax taken over the P axis of [B,P,N]: dX = scale*Y*(dY - sum_p Y*dY)  (model/attn.py:122) */
 int tris_softmax_col_bwd_f32(const float* dY, const float* Y, float* dX, int B, int P, int N, float scale,
                              void* stream);

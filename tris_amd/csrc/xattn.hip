@@ -16,9 +16,6 @@
 // Launch 2 (outputs): one workgroup per (32-channel tile, image): probabilities (2 x P x N), a Vt tile and a Vv tile
 //   are staged in LDS (Vv/Vt with coalesced 16-byte loads), the pixel softmax is finished, then both products run on
 //   the f32 MFMA.  ~65 KB LDS -> 2 workgroups per CU, 32*B workgroups >> 256 CUs.
-#include <cstdlib>
-#include <cstring>
-
 #include "common.h"
 #include "tris_hip.h"
 #include "x3_split.h"
@@ -423,6 +420,7 @@ constexpr int XLT = 132;   // row stride (floats) of the At plane [n][p]
 
 // grid (C / 128, B); block 256 (wave w owns channels c0 + 32w .. +31: two MFMA column tiles share every probability
 // fragment); dynamic LDS (round16(P) * XLD + 64 * XLT) floats
+template <int ABL = 0>   // ABL: developer ablation bits (tools/probes/xattn_out_probe.hip); 0 in the product
 __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restrict__ Vv, const float* __restrict__ Vt,
                                                            float* __restrict__ probs, float* __restrict__ new_vis,
                                                            float* __restrict__ new_lan, int P, int N, int C) {
@@ -445,7 +443,7 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int p = ks * 32 + kg * 8 + i;
-        vv[ct][ks][i] = (ks < PK && p < P) ? Vv[((long)b * P + p) * C + c + ct * 16] : 0.f;
+        vv[ct][ks][i] = ((ABL & 1) == 0 && ks < PK && p < P) ? Vv[((long)b * P + p) * C + c + ct * 16] : 0.5f;
       }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
@@ -488,7 +486,7 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
     }
   }
   __syncthreads();
-  if (tid < PR) {  // Av: softmax over the sentences of pixel `tid`; k padding (n >= N) and pad rows become exact zeros
+  if ((ABL & 2) == 0 && tid < PR) {  // Av: softmax over the sentences of pixel `tid`; k padding (n >= N) and pad rows become exact zeros
     float* row = Sa + tid * XLD;
     float4 v[16];
 #pragma unroll
@@ -520,7 +518,7 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
       *reinterpret_cast<float4*>(row + q * 4) = v[q];
     }
   }
-  {  // At: softmax over the pixels of sentence n -- 4 threads per sentence, 32 pixels each (p = q4 + 4 i)
+  if ((ABL & 2) == 0) {  // At: softmax over the pixels of sentence n -- 4 threads per sentence, 32 pixels each (p = q4 + 4 i)
     const int n = tid >> 2, q4 = tid & 3;
     float* row = St + n * XLT;
     float e[32];
@@ -576,7 +574,9 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
         for (int rt = 0; rt < 8; ++rt) {
           if (rt < PT) {
             const float* s = Sa + (rt * 16 + r) * XLD + ks * 32 + kg * 8;
-            const Split8 sa = split8(ld4(s), ld4(s + 4));
+            Split8 sa;
+            if (ABL & 8) { const float4 u = ld4(s), w = ld4(s + 4); sa.hi = __builtin_bit_cast(bf16x8, make_uint4(__builtin_bit_cast(unsigned, u.x), __builtin_bit_cast(unsigned, u.y), __builtin_bit_cast(unsigned, u.z), __builtin_bit_cast(unsigned, u.w))); sa.mid = __builtin_bit_cast(bf16x8, make_uint4(__builtin_bit_cast(unsigned, w.x), __builtin_bit_cast(unsigned, w.y), __builtin_bit_cast(unsigned, w.z), __builtin_bit_cast(unsigned, w.w))); sa.lo = sa.hi; }
+            else sa = split8(ld4(s), ld4(s + 4));
             acc[0][rt] = mfma6(sa, sb[0], acc[0][rt]);
             acc[1][rt] = mfma6(sa, sb[1], acc[1][rt]);
           }
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int p = rt * 16 + 4 * kg + t;
-          if (rt < PT && p < P) new_vis[((long)b * P + p) * C + c + ct * 16] = acc[ct][rt][t];
+          if ((ABL & 4) == 0 ? (rt < PT && p < P) : (acc[ct][rt][t] == 12345.f)) new_vis[((long)b * P + p) * C + c + ct * 16] = acc[ct][rt][t];
         }
   }
   // new_lan[b][n][c] = sum_p At[n][p] Vv[b][p][c]
@@ -612,7 +612,9 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
         for (int nt = 0; nt < 4; ++nt) {
           if (nt < NT) {
             const float* s = St + (nt * 16 + r) * XLT + ks * 32 + kg * 8;
-            const Split8 sa = split8(ld4(s), ld4(s + 4));
+            Split8 sa;
+            if (ABL & 8) { const float4 u = ld4(s), w = ld4(s + 4); sa.hi = __builtin_bit_cast(bf16x8, make_uint4(__builtin_bit_cast(unsigned, u.x), __builtin_bit_cast(unsigned, u.y), __builtin_bit_cast(unsigned, u.z), __builtin_bit_cast(unsigned, u.w))); sa.mid = __builtin_bit_cast(bf16x8, make_uint4(__builtin_bit_cast(unsigned, w.x), __builtin_bit_cast(unsigned, w.y), __builtin_bit_cast(unsigned, w.z), __builtin_bit_cast(unsigned, w.w))); sa.lo = sa.hi; }
+            else sa = split8(ld4(s), ld4(s + 4));
             acc[0][nt] = mfma6(sa, sb[0], acc[0][nt]);
             acc[1][nt] = mfma6(sa, sb[1], acc[1][nt]);
           }
@@ -626,388 +628,9 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int n = nt * 16 + 4 * kg + t;
-          if (nt < NT && n < N) new_lan[((long)b * N + n) * C + c + ct * 16] = acc[ct][nt][t];
+          if ((ABL & 4) == 0 ? (nt < NT && n < N) : (acc[ct][nt][t] == 12345.f)) new_lan[((long)b * N + n) * C + c + ct * 16] = acc[ct][nt][t];
         }
   }
-}
-
-// ---- "v2" split-bf16 path: three launches, sentence operands pre-split ONCE ------------------------------------------------
-// What the two kernels above still pay for: (1) the sentence operands (Kt, Qt, Vt -- shared by all images) are re-split to
-// bf16 pieces by every workgroup that touches them (150 row tiles x 4 waves in the scores kernel, 384 workgroups in the
-// outputs kernel): half of the scores kernel's VALU work; (2) 1200 four-wave score workgroups do not tile 1024 SIMDs, and
-// 384 output workgroups run as 1.5 rounds on 256 CUs; (3) both soft-maxes are redone by each of the 8 channel-tile
-// workgroups of an image.  v2:
-//   prep   (xattn_prep_kernel, one tiny launch): Kt / Qt / Vt -> bf16 piece planes stored in MFMA *fragment order*
-//          ([plane][k step][16-column tile][lane][8 bf16]): a B fragment is then ONE coalesced 16-byte load per lane straight
-//          from L2 -- no LDS round trip, no VALU -- for every workgroup of the two kernels below;
-//   scores (xattn_scores2_kernel): 32 pixel rows per workgroup, four (or eight) waves splitting C, pixel rows through the
-//          wave-private LDS turn as before, sentence fragments from the planes; the row soft-max of Qv.Kt^T is finished
-//          here (each row is complete in the workgroup), so plane 0 leaves this kernel as the final Av;
-//   outputs(xattn_out2_kernel): one workgroup of eight waves per (256-channel group, image) = 192 workgroups, ONE round;
-//          only the pixel soft-max (At) is left to do, by 8 threads per sentence; Vt fragments come from the planes.
-// Measured at B = 48, P = 100, N = 48, C = 1024 (rocprofv3 kernel trace, same box): v1 22.5 + 31.6 = 54.1 us; v2 prep 5.2 +
-// scores 17.3 + outputs 28.8 = 51.3 us.  The outputs kernel is latency-bound (one 8-wave workgroup per CU: global -> LDS ->
-// barrier -> exp -> barrier -> a 312-MFMA chain per wave with 1500 VALU of probability splitting -> 80 scalar stores per lane);
-// see DESIGN.md for what the 0.6-of-HBM target would take.
-constexpr int V2_W = 8;  // waves per workgroup of the outputs kernel
-
-// planes: sc[z = 0 (Kt) | 1 (Qt)][plane 3][ks = C/32][nt][lane 64][8 bf16]  and  vt[plane 3][ks2 2][ct = C/16][lane 64][8 bf16]
-__global__ __launch_bounds__(256) void xattn_prep_kernel(const float* __restrict__ Kt, const float* __restrict__ Qt,
-                                                         const float* __restrict__ Vt, bf16x8* __restrict__ sc,
-                                                         bf16x8* __restrict__ vtp, int N, int C, int NT) {
-  const int KST = C / 32, CT = C / 16;
-  const long n_sc = 2L * KST * NT * 64, n_vt = 2L * CT * 64;
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
-  if (id < n_sc) {
-    const int lane = (int)(id & 63);
-    long t = id >> 6;
-    const int nt = (int)(t % NT); t /= NT;
-    const int ks = (int)(t % KST);
-    const int z = (int)(t / KST);
-    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
-    const float* T = z == 0 ? Kt : Qt;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (n < N) { a = ld4(T + (long)n * C + k0); b = ld4(T + (long)n * C + k0 + 4); }
-    const Split8 sp = split8(a, b);
-    const long pst = (long)KST * NT * 64;  // fragments per plane
-    bf16x8* o = sc + (long)z * 3 * pst + ((long)ks * NT + nt) * 64 + lane;
-    o[0] = sp.hi; o[pst] = sp.mid; o[2 * pst] = sp.lo;
-  } else if (id < n_sc + n_vt) {
-    const long j = id - n_sc;
-    const int lane = (int)(j & 63);
-    long t = j >> 6;
-    const int ct = (int)(t % CT);
-    const int ks2 = (int)(t / CT);
-    const int c = ct * 16 + (lane & 15), n0 = ks2 * 32 + (lane >> 4) * 8;
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (n0 + i < N) ? Vt[(long)(n0 + i) * C + c] : 0.f;
-    const Split8 sp = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
-    const long pst = 2L * CT * 64;
-    bf16x8* o = vtp + ((long)ks2 * CT + ct) * 64 + lane;
-    o[0] = sp.hi; o[pst] = sp.mid; o[2 * pst] = sp.lo;
-  }
-}
-
-// grid (ceil(B*P / 32), 2); block 512.  y = 0: Av = softmax_n(Qv.Kt^T * scale) -> plane 0 (final), y = 1: Kv.Qt^T * scale -> plane 1.
-// W waves split C; KSW = 32-channel steps per wave = C / (32 W).
-template <int NT, int KSW, int W>
-__global__ __launch_bounds__(W * 64) void xattn_scores2_kernel(const float* __restrict__ Qv, const float* __restrict__ Kv,
-                                                            const bf16x8* __restrict__ sc, float* __restrict__ probs, long R,
-                                                            int P, int N, int C, float scale) {
-  __shared__ __attribute__((aligned(16))) float At[W][32 * TLD];                      // wave-private row tiles
-  __shared__ __attribute__((aligned(16))) f32x4v red[W - 1][2 * NT][64];              // cross-wave reduction
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, kg = lane >> 4;
-  const int lr = lane >> 3, lc = (lane & 7) * 4;
-  const int m = blockIdx.y;
-  const float* __restrict__ A = m == 0 ? Qv : Kv;
-  const long row0 = (long)blockIdx.x * 32;
-  const int KST = C / 32;
-  const long pst = (long)KST * NT * 64;
-  const bf16x8* __restrict__ bfr = sc + (long)m * 3 * pst + (long)(wave * KSW) * NT * 64 + lane;
-  const float* ap[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) ap[q] = A + min(row0 + q * 8 + lr, R - 1) * C + wave * (KSW * 32) + lc;
-  // pixel rows are requested two steps (2 x 128 B per row) ahead, sentence fragments one step ahead (registers: two
-  // 512-thread workgroups per CU need <= 128 VGPRs)
-  float4 a[2][4];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-    if (s < KSW) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a[s][q] = ld4(ap[q] + s * 32);
-    }
-  bf16x8 bq[NT][3];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bq[j][pl] = bfr[pl * pst + j * 64];
-  f32x4v acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-  float* at = At[wave];
-#pragma unroll
-  for (int s = 0; s < KSW; ++s) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(at + (q * 8 + lr) * TLD + lc) = a[s & 1][q];
-    if (s + 2 < KSW) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a[s & 1][q] = ld4(ap[q] + (s + 2) * 32);
-    }
-    Split8 sb[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { sb[j].hi = bq[j][0]; sb[j].mid = bq[j][1]; sb[j].lo = bq[j][2]; }
-    if (s + 1 < KSW) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bq[j][pl] = bfr[pl * pst + ((long)(s + 1) * NT + j) * 64];
-    }
-    wave_lds_fence();
-    Split8 sa[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      sa[i] = split8(*reinterpret_cast<const float4*>(at + (i * 16 + r) * TLD + kg * 8),
-                     *reinterpret_cast<const float4*>(at + (i * 16 + r) * TLD + kg * 8 + 4));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      acc[0][j] = mfma6(sa[0], sb[j], acc[0][j]);
-      acc[1][j] = mfma6(sa[1], sb[j], acc[1][j]);
-    }
-    wave_lds_fence();
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) red[wave - 1][i * NT + j][lane] = acc[i][j];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        f32x4v v = acc[i][j];
-#pragma unroll
-        for (int w = 0; w < W - 1; ++w) v += red[w][i * NT + j][lane];   // fixed order: deterministic
-        acc[i][j] = v * scale;
-      }
-    if (m == 0) {  // row soft-max over the N sentences: a row's values sit in the 16 lanes of one kg group x NT tiles
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float mx = -INFINITY;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) mx = fmaxf(mx, (j * 16 + r < N) ? acc[i][j][t] : -INFINITY);
-#pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sh, 64));
-          float e[NT], sum = 0.f;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) { e[j] = (j * 16 + r < N) ? __expf(acc[i][j][t] - mx) : 0.f; sum += e[j]; }
-#pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1) sum += __shfl_xor(sum, sh, 64);
-          const float inv = 1.f / sum;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j][t] = e[j] * inv;
-        }
-    }
-    const int plane = m == 0 ? 0 : 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = j * 16 + r;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {  // D[4*kg + t][r]
-          const long row = row0 + i * 16 + 4 * kg + t;
-          if (row < R && n < N) {
-            const long b = row / P;
-            const int p = (int)(row - b * P);
-            probs[((b * NPL + plane) * P + p) * N + n] = acc[i][j][t];
-          }
-        }
-      }
-  }
-}
-
-// grid (C / 256, B); block 512 (wave w owns channels c0 + 32w .. +31); dynamic LDS (round16(P) * XLD + 64 * XLT) floats.
-// plane 0 holds the final Av (xattn_scores2_kernel), plane 1 the scaled Kv.Qt^T logits; plane 2 (AtT) is written here.
-__global__ __launch_bounds__(512) void xattn_out2_kernel(const float* __restrict__ Vv, const bf16x8* __restrict__ vtp,
-                                                         float* __restrict__ probs, float* __restrict__ new_vis,
-                                                         float* __restrict__ new_lan, int P, int N, int C) {
-  extern __shared__ __attribute__((aligned(16))) float xlds[];
-  const int PR = (P + 15) / 16 * 16;
-  float* Sa = xlds;             // Av  [p][n]  (pads exact zeros)
-  float* St = xlds + PR * XLD;  // S2 logits -> At  [n][p]   (softmax over p)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, kg = lane >> 4;
-  const int b = blockIdx.y;
-  const int c = blockIdx.x * 256 + wave * 32 + r;  // first of this lane's two channels (the other is c + 16)
-  const int PT = PR / 16, NT = (N + 15) / 16, NK = (N + 31) / 32, PK = (P + 31) / 32;
-  const int CT = C / 16;
-  const long vpst = 2L * CT * 64;
-
-  // Vv operand fragments straight from global, in MFMA order (8 consecutive pixels per lane): issued first, consumed last
-  float vv[2][4][8];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int p = ks * 32 + kg * 8 + i;
-        vv[ct][ks][i] = (ks < PK && p < P) ? Vv[((long)b * P + p) * C + c + ct * 16] : 0.f;
-      }
-  // Vt fragments: pre-split planes in fragment order (one 16-byte load per plane)
-  bf16x8 vt[2][2][3];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        vt[ct][ks][pl] = vtp[pl * vpst + ((long)ks * CT + (blockIdx.x * 16 + wave * 2 + ct)) * 64 + lane];
-
-  const float* s1 = probs + ((long)b * NPL + 0) * P * N;
-  const float* s2 = probs + ((long)b * NPL + 1) * P * N;
-  // Av -> Sa with exact-zero pads (rows >= P, columns >= N); S2 logits -> St transposed
-  for (int i = tid; i < PR * 64; i += 512) {
-    const int p = i >> 6, n = i & 63;
-    Sa[p * XLD + n] = (p < P && n < N) ? s1[p * N + n] : 0.f;
-  }
-  for (int i = tid; i < P * N; i += 512) {
-    const int p = i / N, n = i - p * N;
-    St[n * XLT + p] = s2[i];
-  }
-  __syncthreads();
-  {  // At: softmax over the pixels of sentence n -- 8 threads per sentence, 16 pixels each (p = q8 + 8 i)
-    const int n = tid >> 3, q8 = tid & 7;
-    float* row = St + n * XLT;
-    float e[16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = q8 + 8 * i;
-      e[i] = (n < N && p < P) ? row[p] : -INFINITY;
-      mx = fmaxf(mx, e[i]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = q8 + 8 * i;
-      e[i] = (n < N && p < P) ? __expf(e[i] - mx) : 0.f;
-      sum += e[i];
-    }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
-    const float inv = n < N ? 1.f / sum : 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) row[q8 + 8 * i] = e[i] * inv;  // pixels >= P and sentences >= N become exact zeros
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {  // AtT for backward: plane 2 [p][n]
-    float* o2 = probs + ((long)b * NPL + 2) * P * N;
-    for (int i = tid; i < P * N; i += 512) {
-      const int p = i / N, n = i - p * N;
-      o2[i] = St[n * XLT + p];
-    }
-  }
-
-  // new_vis[b][p][c] = sum_n Av[p][n] Vt[n][c]
-  {
-    f32x4v acc[2][8];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 8; ++rt) acc[ct][rt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks < NK) {
-        Split8 sb[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) { sb[ct].hi = vt[ct][ks][0]; sb[ct].mid = vt[ct][ks][1]; sb[ct].lo = vt[ct][ks][2]; }
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-          if (rt < PT) {
-            const float* s = Sa + (rt * 16 + r) * XLD + ks * 32 + kg * 8;
-            const Split8 sa = split8(ld4(s), ld4(s + 4));
-            acc[0][rt] = mfma6(sa, sb[0], acc[0][rt]);
-            acc[1][rt] = mfma6(sa, sb[1], acc[1][rt]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int p = rt * 16 + 4 * kg + t;
-          if (rt < PT && p < P) new_vis[((long)b * P + p) * C + c + ct * 16] = acc[ct][rt][t];
-        }
-  }
-  // new_lan[b][n][c] = sum_p At[n][p] Vv[b][p][c]
-  {
-    f32x4v acc[2][4];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < PK) {
-        Split8 sb[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          sb[ct] = split8(make_float4(vv[ct][ks][0], vv[ct][ks][1], vv[ct][ks][2], vv[ct][ks][3]),
-                          make_float4(vv[ct][ks][4], vv[ct][ks][5], vv[ct][ks][6], vv[ct][ks][7]));
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          if (nt < NT) {
-            const float* s = St + (nt * 16 + r) * XLT + ks * 32 + kg * 8;
-            const Split8 sa = split8(ld4(s), ld4(s + 4));
-            acc[0][nt] = mfma6(sa, sb[0], acc[0][nt]);
-            acc[1][nt] = mfma6(sa, sb[1], acc[1][nt]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int n = nt * 16 + 4 * kg + t;
-          if (nt < NT && n < N) new_lan[((long)b * N + n) * C + c + ct * 16] = acc[ct][nt][t];
-        }
-  }
-}
-
-// workspace layout (bytes): score planes 2 x 3 x (C/32) x NT x 1 KiB, then Vt planes 3 x 2 x (C/16) x 1 KiB
-long v2_workspace_bytes(int N, int C) {
-  const long NT = (N + 15) / 16;
-  return (2L * 3 * (C / 32) * NT + 3L * 2 * (C / 16)) * 1024;
-}
-
-template <int NT, int KSW8>
-int launch_fwd_v2(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt, const float* Vt,
-                  float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C, void* ws, hipStream_t st) {
-  const float scale = 1.0f / sqrtf((float)C);
-  const long R = (long)B * P;
-  bf16x8* sc = reinterpret_cast<bf16x8*>(ws);
-  bf16x8* vtp = sc + 2L * 3 * (C / 32) * NT * 64;
-  const long items = 2L * (C / 32) * NT * 64 + 2L * (C / 16) * 64;
-  hipLaunchKernelGGL(xattn_prep_kernel, dim3(cdiv(items, 256)), dim3(256), 0, st, Kt, Qt, Vt, sc, vtp, N, C, NT);
-  TRIS_LAUNCH_CHECK();
-  // waves per score workgroup: 4 measured faster than 8 (17.3 vs 24.2 us at B = 48: the eight-wave form needs 176 registers
-  // -> one workgroup per CU, and its single-wave reduction tail is longer); TRIS_XATTN_W=8 keeps the other for A/B runs
-  static const int sw = getenv("TRIS_XATTN_W") ? atoi(getenv("TRIS_XATTN_W")) : 4;
-  if (sw == 4)
-    hipLaunchKernelGGL((xattn_scores2_kernel<NT, 2 * KSW8, 4>), dim3(cdiv(R, 32), 2), dim3(256), 0, st, Qv, Kv, sc, probs, R, P, N, C, scale);
-  else
-    hipLaunchKernelGGL((xattn_scores2_kernel<NT, KSW8, 8>), dim3(cdiv(R, 32), 2), dim3(512), 0, st, Qv, Kv, sc, probs, R, P, N, C, scale);
-  TRIS_LAUNCH_CHECK();
-  const size_t lds = (size_t)(((P + 15) / 16 * 16) * XLD + 64 * XLT) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)xattn_out2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(xattn_out2_kernel, dim3(C / 256, B), dim3(512), lds, st, Vv, vtp, probs, new_vis, new_lan, P, N, C);
-  TRIS_LAUNCH_CHECK();
-  return 0;
 }
 
 template <int NT, int KS>
@@ -1021,41 +644,24 @@ int launch_fwd_x3(const float* Qv, const float* Kv, const float* Vv, const float
   const size_t lds = (size_t)(((P + 15) / 16 * 16) * XLD + 64 * XLT) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)xattn_out_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)xattn_out_x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        96 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(xattn_out_x3_kernel, dim3(C / 128, B), dim3(256), lds, st, Vv, Vt, probs, new_vis, new_lan, P, N, C);
+  hipLaunchKernelGGL(xattn_out_x3_kernel<0>, dim3(C / 128, B), dim3(256), lds, st, Vv, Vt, probs, new_vis, new_lan, P, N, C);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
 
-extern "C" long tris_xattn_workspace_bytes(int N, int C) { return v2_workspace_bytes(N, C); }
-
 extern "C" int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                                   const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N,
-                                  int C, float* workspace, long workspace_bytes, void* stream) {
+                                  int C, void* stream) {
   if (N < 1 || N > 16 * MAXNF || P < 1 || C % 64 != 0 || out_lds_bytes(P, (N + 15) / 16) > 150 * 1024)
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  static const bool v2_on = !(getenv("TRIS_XATTN") && !strcmp(getenv("TRIS_XATTN"), "v1"));   // developer A/B knob
-  if (v2_on && tris_get_gemm_mode() >= 1 && P <= 128 && (C == 1024 || C == 512 || C == 256) && workspace != nullptr &&
-      workspace_bytes >= v2_workspace_bytes(N, C) && (((uintptr_t)workspace) & 15) == 0) {
-#define TRIS_V2(NT_)                                                                                                          \
-  (C == 1024 ? launch_fwd_v2<NT_, 4>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, workspace, st)               \
-             : C == 512 ? launch_fwd_v2<NT_, 2>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, workspace, st)     \
-                        : launch_fwd_v2<NT_, 1>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, workspace, st))
-    switch ((N + 15) / 16) {
-      case 1: return TRIS_V2(1);
-      case 2: return TRIS_V2(2);
-      case 3: return TRIS_V2(3);
-      default: return TRIS_V2(4);
-    }
-#undef TRIS_V2
-  }
   if (tris_get_gemm_mode() >= 1 && P <= 128 && (C == 1024 || C == 512 || C == 256)) {  // split-bf16: two-launch streaming path
 #define TRIS_X3(NT_)                                                                                                \
   (C == 1024 ? launch_fwd_x3<NT_, 8>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, st)               \

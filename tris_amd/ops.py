@@ -1101,10 +1101,9 @@ class XAttnFn(torch.autograd.Function):
         new_vis = torch.empty(B, Pp, C, device=dev, dtype=torch.float32)
         new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
         probs = torch.empty(B, 4, Pp, N, device=dev, dtype=torch.float32)
-        ws = workspace(query("tris_xattn_workspace_bytes", N, C))
         _timed("xattn_fwd", 8.0 * B * Pp * N * C,
                lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
-                            P(probs), B, Pp, N, C, P(ws), ws.numel() * 4, _stream()))
+                            P(probs), B, Pp, N, C, _stream()))
         ctx.dims = (B, Pp, N, C)
         ctx.save_for_backward(Qv, Kv, Vv, Qt, Kt, Vt, probs)
         return new_vis, new_lan
