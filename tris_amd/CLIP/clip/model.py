@@ -298,10 +298,14 @@ class VisionTransformer(nn.Module):
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self.spacial_dim = 7
+        # their gradients come back through torch ops (slice / interpolate / cat in forward_spatial, VitAssembleFn's returned
+        # dcls / dpos) and are ACCUMULATED by autograd: FusedAdamW.zero_grad clears them each step
+        self.class_embedding._tris_accumulates = True
+        self.positional_embedding._tris_accumulates = True
 
     def forward_patches(self, patches):
         """patches [B, G*G, 3*ps*ps] (rows ordered (c,ky,kx), see ops.fg_patches) -> [B, output_dim]"""
-        emb = ops.linear(patches, self.conv1.weight.reshape(self.conv1.weight.shape[0], -1))
+        emb = ops.linear(patches, self.conv1.weight)   # [W, 3, ps, ps] contiguous = the [W, 3*ps*ps] GEMM operand; sunk gradient
         x = ops.vit_assemble(emb, self.class_embedding, self.positional_embedding)
         x = self.ln_pre(x)
         x = self.transformer(x)
@@ -315,7 +319,7 @@ class VisionTransformer(nn.Module):
         B, C, H, Wd = x.shape
         ps = self.patch_size
         ones = torch.ones(B, 1, H, Wd, device=x.device, dtype=torch.float32)
-        emb = ops.linear(ops.fg_patches(ones, x.float(), ps), self.conv1.weight.reshape(self.conv1.weight.shape[0], -1))
+        emb = ops.linear(ops.fg_patches(ones, x.float(), ps), self.conv1.weight)
         gh, gw = H // ps, Wd // ps
         sd = self.input_resolution // ps
         width = self.positional_embedding.shape[1]

@@ -17,10 +17,6 @@ from . import _lib, ops
 ALIGN = 64  # floats (256 B)
 
 
-def _mark_accumulating(p):
-    p._tris_accumulates = True
-
-
 class Arena:
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad and not getattr(p, "_tris_no_grad_path", False)]
@@ -43,10 +39,11 @@ class Arena:
             p.grad = gv
             p._tris_sink = True
             # Backward kernels OVERWRITE the arena gradient of a parameter they are handed directly.  A parameter that
-            # reaches its kernel through a torch view (e.g. `w.reshape(...)`) or a torch op instead gets its gradient from
-            # autograd's AccumulateGrad, which ADDS into the arena view: remember those so that zero_grad() clears them.
-            p._tris_accumulates = False
-            p.register_post_accumulate_grad_hook(_mark_accumulating)
+            # reaches its kernels through torch ops instead (the ViT trunk's class / positional embedding: slicing,
+            # interpolation, concatenation) gets its gradient from autograd's AccumulateGrad, which ADDS into the arena
+            # view: the model flags those (`_tris_accumulates`) and zero_grad() clears them.  (A post-accumulate hook
+            # cannot discover them at run time: torch calls it for sunk parameters too.)
+            p._tris_accumulates = bool(getattr(p, "_tris_accumulates", False))
 
     @staticmethod
     def _view(flat, p, off):
