@@ -199,7 +199,7 @@ def main():
 
     # PMC-derived HBM traffic of the same kernel family (separate rocprofv3 --pmc passes, committed under profiles/)
     try:
-        pmc_file = "r1x_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
+        pmc_file = "r2_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["gemm_family"]
         roof["traffic"] = int((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / pmc["launches_per_step"])
         roof["traffic_note"] = ("bytes per launch, averaged over the family: (FETCH_SIZE x2 + WRITE_SIZE) per step / launches per "
@@ -207,11 +207,11 @@ def main():
     except Exception:
         pass
     try:   # matrix-pipe utilisation of the family from the SQ counters (separate --pmc pass, committed under profiles/)
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r1x_pmc_mfma_util.json")))
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_mfma_util.json")))
         if mode == "x3":
             roof["mfma_utilisation_pmc"] = sq["families"]["gemm_family"]["mfma_utilisation"]
             roof["mfma_utilisation_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family, "
-                                             "profiles/r1x_pmc_mfma_util.json (rocprofv3 --pmc, kernels serialised, static tile choice)")
+                                             "profiles/r2_pmc_mfma_util.json (rocprofv3 --pmc, kernels serialised, static tile choice)")
     except Exception:
         pass
     roof_x = None
@@ -228,16 +228,16 @@ def main():
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
 
     if roof_x is not None and mode == "x3":
-        try:   # HBM bytes of the two cross-attention launches from the same --pmc passes (profiles/r1x_pmc_hbm_traffic.csv)
+        try:   # HBM bytes of the two cross-attention launches from the same --pmc passes (profiles/r2_pmc_hbm_traffic.csv)
             import csv as _csv
             tr = 0
-            for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", "r1x_pmc_hbm_traffic.csv"))):
+            for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.csv"))):
                 if "xattn_" in r["Kernel"]:
                     tr += int(r["FetchBytesPerStep(x2 corrected)"]) + int(r["WriteBytesPerStep"])
             if tr:
                 roof_x["traffic"] = tr
                 roof_x["traffic_note"] = ("FETCH_SIZE x2 + WRITE_SIZE of xattn_scores_x3_kernel + xattn_out_x3_kernel, one forward "
-                                          "(rocprofv3 --pmc, B=48): 1.27x the algorithmic bytes (logit planes round trip, sentence tiles)")
+                                          f"(rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes (logit planes round trip, sentence tiles)")
         except Exception:
             pass
     if rank == 0:

@@ -616,6 +616,26 @@ def test_tris_vit_b16_forward_matches_oracle_and_trains(aux):
     losses = train_step(m, aux, opt, b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda(), args).tolist()
     assert all(np.isfinite(losses))
     assert float((m.backbone.visual.positional_embedding.detach() - before).abs().max()) > 0   # the trunk is trained
+    # Gradients must not sum over steps: the class / positional embedding get theirs through autograd's
+    # AccumulateGrad (torch ops in forward_spatial), zero_grad() has to clear them; conv1.weight is written by its kernel.
+    # Same inputs, lr = 0  =>  the second step must leave exactly the first step's gradients.
+    # ln_post / proj have no gradient path in the trunk use: outside the arenas (no weight decay on them either).
+    vis = m.backbone.visual
+    in_arena = {id(p) for a in opt.arenas for p in a.params}
+    assert id(vis.proj) not in in_arena and id(vis.ln_post.weight) not in in_arena
+    assert id(vis.class_embedding) in in_arena and id(vis.conv1.weight) in in_arena
+    for g in opt.param_groups:
+        g["lr"] = 0.0
+        g["weight_decay"] = 0.0
+    x, ids, neg = b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda()
+    train_step(m, aux, opt, x, ids, neg, args)
+    g1 = {k: getattr(vis, k).grad.detach().clone() for k in ("class_embedding", "positional_embedding")}
+    g1["conv1"] = vis.conv1.weight.grad.detach().clone()
+    train_step(m, aux, opt, x, ids, neg, args)
+    for k, v in g1.items():
+        now = (vis.conv1.weight if k == "conv1" else getattr(vis, k)).grad
+        assert float(v.abs().max()) > 0
+        assert float((now - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-9, k   # (a doubled gradient would differ by 100 %)
 
 
 # ---- (e) multi-GPU exchange steps on the GPU box ---------------------------------------------------------------------

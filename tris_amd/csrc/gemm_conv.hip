@@ -49,6 +49,7 @@ struct GemmParams {
   int tiles_n;
   // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
   int gH, gW, gC, gHo, gWo, gStride;
+  int xcd_remap;    // fast kernel: place all tiles of one split-K slice on one XCD (see gemm_fast.h)
   int gB;           // images in the gathered tensor (B_KN_IM2COL: bounds the running pixel coordinates of surplus prefetches)
   int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
   long bpl;         // B_NK_PRE: elements between the bf16 planes of B
@@ -529,6 +530,10 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
   p.kchunk = cdiv(cdiv(p.K, splitk), kalign) * kalign;
   if (splitk > 1) splitk = cdiv(p.K, p.kchunk), p.splitk = splitk;
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(batch * splitk));
+  {  // 3x3 weight gradients: the tap tiles of a k slice share their operands -> one XCD per slice (TRIS_XCD_REMAP=0: A/B knob)
+    static const bool remap_ok = !(getenv("TRIS_XCD_REMAP") && getenv("TRIS_XCD_REMAP")[0] == '0');
+    p.xcd_remap = (remap_ok && fast && BKIND == B_KN_IM2COL && batch == 1 && splitk >= 8 && splitk % 8 == 0 && tiles_m * tiles_n > 1) ? 1 : 0;
+  }
   float* Cfinal = p.C;
   static const bool vec_epi_ok = !(getenv("TRIS_VEC_EPILOGUE") && getenv("TRIS_VEC_EPILOGUE")[0] == '0');  // developer A/B knob
   if (splitk > 1)

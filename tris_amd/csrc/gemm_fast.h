@@ -104,11 +104,24 @@ void gemm_fast_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
-  const int tile = blockIdx.x;
+  // Workgroup -> (tile, z) mapping.  The dispatcher places consecutive workgroups on consecutive XCDs (8 private L2s).  For the
+  // 3x3 weight gradient the N tiles of one k slice are the nine TAPS of the same pixel window: they gather the same input rows
+  // (shifted by a pixel / a row) and read the same dY rows -- spread over 8 XCDs every L2 fetches its own copy (measured:
+  // 1.6 GB of fabric traffic per layer1 launch for 157 MB of operands).  With xcd_remap (host: split-K slices % 8 == 0) all
+  // tiles of a slice run on ONE XCD, so that L2 serves eight of the nine reads.  Pure placement: any mapping is correct.
+  int bid_x = blockIdx.x, bid_z = blockIdx.z;
+  if (p.xcd_remap) {
+    const int T = gridDim.x;
+    const int L = bid_x + T * bid_z;          // dispatch order (gridDim.y == 1)
+    const int xcd = L & 7, j = L >> 3;        // j-th workgroup of its XCD
+    bid_z = xcd + 8 * (j / T);                // bijective for gridDim.z % 8 == 0
+    bid_x = j % T;
+  }
+  const int tile = bid_x;
   const int m0 = (tile / p.tiles_n) * BM;
   const int n0 = (tile % p.tiles_n) * BN;
-  const int zb = blockIdx.z / p.splitk;
-  const int zs = blockIdx.z % p.splitk;
+  const int zb = bid_z / p.splitk;
+  const int zs = bid_z % p.splitk;
   const int kbeg = zs * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const float* __restrict__ A = p.A + (long)zb * p.sA;
@@ -557,7 +570,7 @@ void gemm_fast_kernel(GemmParams p) {
           float4 v = *reinterpret_cast<const float4*>(stg + (er + 8 * t) * ELD + ec);
           if (row < p.M && col < p.N) {  // N % 4 == 0: a vector never straddles the edge
             if (EPI == EPI_SLAB) {
-              *reinterpret_cast<float4*>(p.C + ((long)blockIdx.z * p.M + row) * p.N + col) = v;
+              *reinterpret_cast<float4*>(p.C + ((long)bid_z * p.M + row) * p.N + col) = v;
             } else {
               v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
               if (p.bias_mode == 1) { v.x += bc.x; v.y += bc.y; v.z += bc.z; v.w += bc.w; }
@@ -593,7 +606,7 @@ void gemm_fast_kernel(GemmParams p) {
         if (row < p.M && col < p.N) {
           float v = acc[i][j][r];
           if (EPI == EPI_SLAB) {
-            p.C[((long)blockIdx.z * p.M + row) * p.N + col] = v;
+            p.C[((long)bid_z * p.M + row) * p.N + col] = v;
           } else {
             v *= p.alpha;
             if (p.bias_mode == 1) v += p.bias[col];
