@@ -94,6 +94,9 @@ class _FakeStream:
     def wait_stream(self, other):
         pass
 
+    def wait_event(self, ev):
+        pass
+
 
 def _emulated_arenas(m):
     bb, new = m.trainable_parameters()
@@ -108,16 +111,23 @@ def _emulated_arenas(m):
     return arenas
 
 
-@pytest.mark.parametrize("overlap", [True, False], ids=["text-on-side-stream", "serial"])
+class _FakeEvent:
+    def record(self, stream=None):
+        pass
+
+
+@pytest.mark.parametrize("overlap", [True, "mid", False], ids=["text-issued-first", "text-issued-mid-trunk", "serial"])
 def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
     from tris_amd import comm, parallel
     from tris_amd.model import model_stage1
     from tris_amd.utils.shapes import _build_tris
     _install_standins(monkeypatch)
-    monkeypatch.setattr(model_stage1, "_overlap_enabled", lambda: overlap)
+    monkeypatch.setattr(model_stage1, "_overlap_enabled", lambda: bool(overlap))
+    monkeypatch.setenv("TRIS_TEXT_AT", "layer2" if overlap == "mid" else "start")
     monkeypatch.setattr(model_stage1, "_side_stream", lambda dev: _FakeStream())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _FakeStream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: _FakeEvent())
     monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None, raising=False)
     reduced = []
     monkeypatch.setattr(comm, "all_reduce", lambda t, op=None, group=None, async_op=False: (reduced.append(t.numel()), comm._Done())[1])
@@ -179,9 +189,11 @@ def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
     assert order == ["heads", "layer4", "layer3", "layer2", "layer1"]
     assert "text" in in_backward and "embed" not in in_backward and "stem" not in in_backward
     assert [k for k in in_backward if k.startswith("text")] == ["text_hi", "text_mid", "text"]
-    if overlap:   # text encoder issued first => its backward (and its release) come after the whole trunk
+    if overlap == "mid":   # issued behind layer2 => its backward sits between layer3's and layer2's
+        assert in_backward.index("layer4") < in_backward.index("text_hi") and in_backward.index("text") < in_backward.index("layer2")
+    elif overlap:          # issued first => its backward (and its release) come after the whole trunk
         assert in_backward.index("text_hi") > in_backward.index("layer1")
-    else:         # issued after the trunk => released before the trunk starts
+    else:                  # issued after the trunk => released before the trunk starts
         assert in_backward.index("text") < in_backward.index("layer4")
     assert len(written) >= len(trainable)
 
@@ -193,9 +205,11 @@ def test_round1_plan_would_have_been_caught(monkeypatch):
     from tris_amd.utils.shapes import _build_tris
     _install_standins(monkeypatch)
     monkeypatch.setattr(model_stage1, "_overlap_enabled", lambda: True)
+    monkeypatch.setenv("TRIS_TEXT_AT", "start")
     monkeypatch.setattr(model_stage1, "_side_stream", lambda dev: _FakeStream())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _FakeStream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: _FakeEvent())
     monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None, raising=False)
     monkeypatch.setattr(comm, "all_reduce", lambda t, op=None, group=None, async_op=False: comm._Done())
     m = _build_tris().train()

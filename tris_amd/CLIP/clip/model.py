@@ -183,14 +183,18 @@ class ModifiedResNet(nn.Module):
             layers.append(Bottleneck(self._inplanes, planes))
         return nn.Sequential(*layers)
 
-    def forward_cl(self, x):
-        """x [B,3,H,W] (NCHW, as the reference's callers pass it) -> (c1,c2,c3,c4) channels-last [B,h,w,C]."""
+    def forward_cl(self, x, hooks=None):
+        """x [B,3,H,W] (NCHW, as the reference's callers pass it) -> (c1,c2,c3,c4) channels-last [B,h,w,C].
+        hooks: optional {"stem" | "layer1" | "layer2" | "layer3" | "layer4": callable} run right after that stage has been ISSUED -- TRIS uses
+        it to issue the text encoder (side stream) in the middle of the trunk, see model_stage1.TRIS.forward."""
         x = ops.nchw_to_nhwc(x.float())
         tr = self.training
         x = self.bn1(self.conv1(x, stats=tr), relu=True)   # (conv1 has Cin=3: not eligible, separate statistics pass)
         x = self.bn2(self.conv2(x, stats=tr), relu=True)
         x = self.bn3(self.conv3(x, stats=tr), relu=True)
         x = self.avgpool(x)
+        if hooks and "stem" in hooks:
+            hooks["stem"]()
         outs = []
         red = getattr(self, "grad_reducer", None)  # data-parallel: overlap the gradient all-reduce with backward
         if red is not None:
@@ -202,6 +206,9 @@ class ModifiedResNet(nn.Module):
             if red is not None:
                 x = red.boundary(x, name)          # the boundary AFTER a stage releases the segment of the NEXT one
             outs.append(x)
+            stage = {"layer2": "layer1", "layer3": "layer2", "layer4": "layer3", "heads": "layer4"}.get(name)   # the stage just issued
+            if hooks and stage in hooks:
+                hooks[stage]()
         return tuple(outs)
 
     def forward(self, x):

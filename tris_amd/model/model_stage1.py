@@ -27,6 +27,13 @@ def _side_stream(device):
     return ops.side_stream("text")
 
 
+def _text_issue_point():
+    """start | stem | layer1 | layer2 | layer3 | layer4: after which trunk stage the text encoder is issued (TRIS_TEXT_AT)"""
+    import os
+    at = os.environ.get("TRIS_TEXT_AT", "layer4")
+    return at if at in ("start", "stem", "layer1", "layer2", "layer3", "layer4") else "layer4"
+
+
 class TRIS(nn.Module):
     def __init__(self, args=None):
         super().__init__()
@@ -67,14 +74,17 @@ class TRIS(nn.Module):
             new.append(self.attn_fusion)
         return list(self.backbone.parameters()), list(nn.ModuleList(new).parameters())
 
-    def encode_visual(self, x):
+    def encode_visual(self, x, hooks=None):
         """Image-only half of forward (RN50 trunk -> vis_project -> L2 norm).  Returned state can be reused for every
         sentence of the same image (validate.py re-runs the trunk per sentence; the values are identical)."""
         B = x.shape[0]
         if self.vit_trunk:
+            if hooks:
+                for h in hooks.values():
+                    h()
             c4 = self.backbone.visual.forward_spatial(x)[1]             # [B,h,w,768] channels-last
         else:
-            c4 = self.backbone.visual.forward_cl(x)[3]                  # [B,h,w,2048] channels-last
+            c4 = self.backbone.visual.forward_cl(x, hooks)[3]           # [B,h,w,2048] channels-last
         h_, w_ = c4.shape[1:3]
         vis = self.vis_project(c4).reshape(B, h_ * w_, -1)              # [B,P,C]
         return ops.l2norm(vis), h_, w_
@@ -107,12 +117,31 @@ class TRIS(nn.Module):
         # The text encoder (short GEMMs that cannot fill 256 CUs) runs on a second HIP stream, concurrently with the
         # RN50 trunk; autograd replays each branch's backward on the stream its forward ran on, so the overlap holds
         # in both directions.  Joined before the heads.
+        # WHERE in the issue order the text encoder goes decides where its backward goes: autograd replays nodes in reverse
+        # creation order, so a text encoder issued first has its backward issued last -- after the whole trunk backward, as
+        # a tail of small kernels with nothing left to overlap (and its gradients are the last to reach the data-parallel
+        # reducer).  Issued behind layer<k> of the trunk instead (default: behind layer4, i.e. after the whole trunk has been
+        # ISSUED -- the host runs several ms ahead of the GPU, so the text forward still executes under the trunk's tail), its
+        # backward is issued before / in the middle of the trunk backward and executes under the BatchNorm-heavy layer1/2/stem
+        # part.  Measured (B = 48, same box, img/s): start 968-970 | stem 970 | layer1 987 | layer2 996-1000 | layer3 1003;
+        # second box: layer2 1024-1027 | layer3 1025-1027 | layer4 1031.
         main = torch.cuda.current_stream()
         side = _side_stream(x.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            _, hidden = self.backbone.encode_text(word_id)
-        vis = self.encode_visual(x)
+        box = {}
+        ready = torch.cuda.Event()
+        ready.record(main)             # inputs and parameters are complete here: the text encoder depends on nothing later
+
+        def issue_text():
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                box["hidden"] = self.backbone.encode_text(word_id)[1]
+        at = _text_issue_point()
+        if at == "start":
+            issue_text()
+            vis = self.encode_visual(x)
+        else:
+            vis = self.encode_visual(x, hooks={at: issue_text})
+        hidden = box["hidden"]
         main.wait_stream(side)
         hidden.record_stream(main)
         return self.forward_cached(vis, word_id, x.shape[2], hidden=hidden)

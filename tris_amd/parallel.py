@@ -11,10 +11,10 @@ RCCL on ROCm; "gloo" for the CPU tests of the host logic and the two-ranks-on-on
 Which segment may be released WHERE (the invariant the reducer rests on): autograd's engine runs, among the nodes
 that are ready, the one created LAST in forward first.  A `boundary()` placed in the forward graph therefore runs its
 backward only after every node created after it has run -- i.e. after every gradient produced "downstream" of that
-point has been written.  TRIS.forward issues the text encoder BEFORE the RN50 trunk (so that it overlaps the trunk on a
-second stream), which makes the text encoder's backward run AFTER the stem's: its parameters must not ride on a trunk
-boundary.  They have their own boundary on the text path (behind the embedding), and the embedding tables, whose
-gradient is written after that boundary, are released by `finish()`.
+point has been written.  WHERE TRIS.forward issues the text encoder (before the trunk, in the middle of it, behind it:
+TRIS_TEXT_AT, default behind layer4) decides where its backward runs relative to the trunk's, so its parameters must not
+ride on a trunk boundary.  They have their own boundaries on the text path (behind blocks 7 and 3 and behind the
+embedding), and the embedding tables, whose gradient is written after the last of them, are released by `finish()`.
 """
 import os
 
