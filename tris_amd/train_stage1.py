@@ -31,8 +31,7 @@ def MaxLoss(x):
 def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     """train_stage1.py:317-364.  Returns (losses[4] = total,l1,l4,l5 ; cls ; sig_out)."""
     B = img.shape[0]
-    # frozen aux text tower (positives + negatives in one batch, no gradient): issued first, on the side stream, so it
-    # overlaps the RN50 trunk of the model forward
+    # frozen aux text tower (positives + negatives in one batch, no gradient): on the side stream, see below
     from .model.model_stage1 import _overlap_enabled, _side_stream
     f_all = None
     ids_all = word_ids.long()
@@ -40,12 +39,24 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     if neg_word_ids is not None and args.negative_samples > 0:
         K = neg_word_ids.shape[1]
         ids_all = torch.cat([ids_all, neg_word_ids.long().reshape(B * K, -1)], 0)
+    main = side = ready = None
+    early = os.environ.get("TRIS_AUX_TEXT_AT", "after") == "start"   # developer A/B knob (round-1 order: before the trunk)
     if _overlap_enabled():
         main, side = torch.cuda.current_stream(), _side_stream(img.device)
-        side.wait_stream(main)
+        ready = torch.cuda.Event()
+        ready.record(main)           # ids_all is complete here
+        if early:
+            side.wait_event(ready)
+            with torch.cuda.stream(side), torch.no_grad():
+                f_all = clip_model.encode_text(ids_all)[1]
+    cls, _, _, sig_out, _ = model(img, word_ids)
+    if side is not None and not early:
+        # The frozen aux text tower has no backward and its output is needed only by the loss: it is ISSUED here, behind the
+        # TRIS forward (whose own text encoder is needed sooner and shares the side stream), so that the host starts the
+        # trunk at once instead of issuing ~130 small launches first; it executes under the rest of the forward.
+        side.wait_event(ready)
         with torch.cuda.stream(side), torch.no_grad():
             f_all = clip_model.encode_text(ids_all)[1]
-    cls, _, _, sig_out, _ = model(img, word_ids)
     if img.shape[2] != CLIP_INPUT:
         cam = ops.resize_bilinear(sig_out, (CLIP_INPUT, CLIP_INPUT), True)
         with torch.no_grad():
