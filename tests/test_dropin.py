@@ -50,6 +50,16 @@ def test_install_refuses_to_shadow_and_uninstall_restores():
     import types
     import tris_amd.dropin as d
     d.uninstall()
+    # other tests of this session may have imported the live reference under its own names (oracle.ref_shim): park those
+    tops = {n.split(".")[0] for n in d.ALIASES}
+    parked = {n: sys.modules.pop(n) for n in list(sys.modules) if n.split(".")[0] in tops}
+    try:
+        _refuse_and_restore(d, types)
+    finally:
+        sys.modules.update(parked)
+
+
+def _refuse_and_restore(d, types):
     sentinel = types.ModuleType("args")
     sys.modules["args"] = sentinel
     try:

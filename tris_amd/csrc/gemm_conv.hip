@@ -648,15 +648,15 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
   if (!autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
   const bool stat = p.stat_part != nullptr;  // fused BN statistics: 128-row tiles and no split-K are fixed, the tile width is tuned
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
-    return run_cfg<AK, BKIND>(p, batch, ws, st, h);
   const TuneKey key = {AK, BKIND + (stat ? 16 : 0), p.M, p.N, p.K, batch, g_gemm_mode};
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) return run_cfg<AK, BKIND>(p, batch, ws, st, it->second);
   }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // tuning synchronises the device: never under stream capture
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return run_cfg<AK, BKIND>(p, batch, ws, st, h);          // (a shape first met during capture runs the cost model's choice)
   // candidates
   static const int tiles[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {256, 128}};
   const bool fastk = p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4;

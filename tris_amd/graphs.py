@@ -43,3 +43,50 @@ class GraphedStage1Eval:
         self.s_ids.copy_(ids, non_blocking=True)
         self.g_txt.replay()
         return self.out
+
+
+class GraphedFrozenText:
+    """hipGraph replay of a FROZEN text tower (the aux CLIP of the Stage-1 loss, train_stage1.py:167, 346-347): ~130 short
+    kernels per step whose only cost is the host time to issue them -- time during which the compute stream has nothing
+    queued.  Static shapes ([n sentences, L tokens]), no gradient: captured once (after two eager warm-up calls, so that the
+    GEMM autotuner has seen every shape), replayed as ONE launch per step on the caller's side stream.  The output is a static
+    buffer: consume it before the next replay (the step's own stream order guarantees that)."""
+
+    def __init__(self, clip_model, n, L, warmup=2):
+        dev = next(clip_model.parameters()).device
+        self.key = (n, L, clip_model.token_embedding.weight.data_ptr())
+        self.s_ids = torch.zeros(n, L, device=dev, dtype=torch.int64)
+        self.s_ids[:, 0] = 49406
+        self.s_ids[:, 1] = 49407
+        with torch.no_grad():
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                for _ in range(warmup):
+                    clip_model.encode_text(self.s_ids)
+            torch.cuda.current_stream().wait_stream(cap)
+            self.g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g):
+                self.out = clip_model.encode_text(self.s_ids)[1]
+
+    def __call__(self, ids):
+        """replay on the CURRENT stream; returns the static [n, E] output"""
+        self.s_ids.copy_(ids, non_blocking=True)
+        self.g.replay()
+        return self.out
+
+
+def frozen_text(clip_model, ids):
+    """encode_text(ids)[1] of a frozen tower through a cached hipGraph (TRIS_HIPGRAPH=0: eager)"""
+    import os
+    if os.environ.get("TRIS_HIPGRAPH", "1") == "0" or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
+        return clip_model.encode_text(ids)[1]
+    n, L = ids.shape
+    cache = clip_model.__dict__.setdefault("_tris_text_graphs", {})
+    key = (n, L, clip_model.token_embedding.weight.data_ptr())
+    g = cache.get(key)
+    if g is None:
+        if len(cache) >= 4:
+            cache.clear()
+        g = cache[key] = GraphedFrozenText(clip_model, n, L)
+    return g(ids)

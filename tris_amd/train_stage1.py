@@ -32,6 +32,7 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     """train_stage1.py:317-364.  Returns (losses[4] = total,l1,l4,l5 ; cls ; sig_out)."""
     B = img.shape[0]
     # frozen aux text tower (positives + negatives in one batch, no gradient): on the side stream, see below
+    from .graphs import frozen_text
     from .model.model_stage1 import _overlap_enabled, _side_stream
     f_all = None
     ids_all = word_ids.long()
@@ -48,15 +49,16 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
         if early:
             side.wait_event(ready)
             with torch.cuda.stream(side), torch.no_grad():
-                f_all = clip_model.encode_text(ids_all)[1]
+                f_all = frozen_text(clip_model, ids_all)
     cls, _, _, sig_out, _ = model(img, word_ids)
     if side is not None and not early:
         # The frozen aux text tower has no backward and its output is needed only by the loss: it is ISSUED here, behind the
         # TRIS forward (whose own text encoder is needed sooner and shares the side stream), so that the host starts the
         # trunk at once instead of issuing ~130 small launches first; it executes under the rest of the forward.
+        # Replayed from a hipGraph (tris_amd.graphs.frozen_text): one launch instead of ~130.
         side.wait_event(ready)
         with torch.cuda.stream(side), torch.no_grad():
-            f_all = clip_model.encode_text(ids_all)[1]
+            f_all = frozen_text(clip_model, ids_all)
     if img.shape[2] != CLIP_INPUT:
         cam = ops.resize_bilinear(sig_out, (CLIP_INPUT, CLIP_INPUT), True)
         with torch.no_grad():
