@@ -138,6 +138,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = step()
+    host_issue = time.perf_counter() - t0    # the host's share: all K steps issued (it may have waited on a full queue)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -253,6 +254,7 @@ def main():
                           "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": QL,
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
                "untimed_priming_steps": 1, "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
+               "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
                "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
                            "weight_gradients_on_side_stream": os.environ.get("TRIS_WGRAD_STREAM", "1") != "0"},
                "roofline": roof, "roofline_xattn": roof_x}

@@ -144,6 +144,53 @@ def test_conv3x3(ops, B, H, W, Cin, Cout, stride):
         close(gx.grad.permute(0, 3, 1, 2), x.grad, name="dx")
 
 
+@pytest.mark.parametrize("cfg,B,H,W,Cin,Cout", [(1, 2, 32, 32, 32, 128), (1, 1, 16, 48, 128, 160), (2, 2, 32, 16, 48, 64),
+                                                (3, 2, 16, 32, 64, 32), (3, 3, 16, 16, 32, 32), (4, 3, 10, 10, 64, 128),
+                                                (4, 2, 12, 20, 128, 256), (4, 1, 40, 40, 128, 128), (5, 5, 10, 10, 64, 128),
+                                                (5, 2, 20, 20, 32, 192), (5, 1, 40, 40, 128, 128), (6, 2, 8, 32, 32, 128),
+                                                (6, 1, 24, 16, 64, 192)])
+def test_conv3x3_direct_kernels(cfg, B, H, W, Cin, Cout, monkeypatch):
+    """Every configuration of the direct 3x3 convolution (one split of the input window per 16-channel chunk, tris_amd/csrc/
+    gemm_fast.h A_HALO) -- forward, fused BatchNorm statistics and data gradient -- against the fp32 CPU reference and against
+    the implicit GEMM it replaces: 2-D patches (cfg 1-3, 6) and flattened pixel runs in padded coordinates (cfg 4, 5: tiles that
+    cross row and image boundaries, a ragged last tile)."""
+    from tris_amd import ops as o
+    prev = o.get_gemm_mode()
+    o.set_gemm_mode("x3")
+    try:
+        x, w = leaf(B, Cin, H, W), leaf(Cout, Cin, 3, 3, scale=0.1)
+        y = F.conv2d(x, w, padding=1)
+        gy0 = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+        y.backward(gy0)
+        outs = {}
+        for mode in ("0", str(cfg)):
+            monkeypatch.setenv("TRIS_CONV_DIRECT", mode)
+            gx = x.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+            gw = w.detach().clone().contiguous(memory_format=torch.channels_last).cuda().requires_grad_(True)
+            gy = o.conv3x3(gx, gw, 1, stats=True)
+            part = getattr(gy, "_bn_part", None)
+            g, b = torch.ones(Cout).cuda(), torch.zeros(Cout).cuda()
+            rm, rv = torch.zeros(Cout).cuda(), torch.ones(Cout).cuda()
+            with torch.no_grad():
+                o.batch_norm(gy, g, b, rm, rv, None, False, True)
+            gy.backward(gy0.permute(0, 2, 3, 1).contiguous().cuda())
+            outs[mode] = (gy.detach().cpu(), gx.grad.cpu(), rm.cpu(), rv.cpu(), part[1] if part is not None else 0)
+            close(gy.permute(0, 3, 1, 2), y, name=f"y[{mode}]")
+            close(gx.grad.permute(0, 3, 1, 2), x.grad, name=f"dx[{mode}]")
+            close(gw.grad, w.grad, name=f"dw[{mode}]")
+        a, d = outs["0"], outs[str(cfg)]
+        close(d[0], a[0], 2e-6, name="direct vs implicit: y")
+        close(d[1], a[1], 2e-6, name="direct vs implicit: dx")
+        close(d[2], a[2], 1e-5, name="running_mean from the fused statistics")
+        close(d[3], a[3], 1e-5, name="running_var from the fused statistics")
+        if Cin % 32 == 0 and B * H * W >= 128:      # (the statistics epilogue's own preconditions)
+            tiles = (B * (H // 16) * (W // 16) if cfg <= 3 else B * (H // 8) * (W // 16) if cfg == 6 else
+                     -(-B * H * W // (128 if cfg == 4 else 256)))
+            assert d[4] == tiles, (d[4], tiles)     # the direct kernel ran (one partial row per M tile), not a fallback
+    finally:
+        o.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
 @pytest.mark.parametrize("shape", [(2, 10, 10, 64), (3, 40, 40, 32), (2, 5, 5, 2048)])
 def test_batchnorm_train(ops, shape, res, relu):

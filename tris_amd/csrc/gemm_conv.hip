@@ -24,7 +24,7 @@
 
 namespace {
 
-enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2 };
+enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2, A_HALO = 3 };  // A_HALO: direct 3x3 convolution (gemm_fast.h)
 enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3, B_NK_PRE = 4 };  // B_NK_PRE: pre-split bf16 planes (fast x3 kernel only)
 enum { EPI_STD = 0, EPI_SLAB = 1 };
 
@@ -53,6 +53,7 @@ struct GemmParams {
   int gB;           // images in the gathered tensor (B_KN_IM2COL: bounds the running pixel coordinates of surplus prefetches)
   int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
   long bpl;         // B_NK_PRE: elements between the bf16 planes of B
+  int hmode;        // A_HALO: window shape, 1 = BM consecutive pixels in padded coordinates, 2 = (BM/16) x 16 patches
 };
 
 constexpr int BK = 16;
@@ -719,6 +720,144 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
 
 
 
+
+// ---- direct 3x3 convolution: configurations of the A_HALO kernels (gemm_fast.h) and the choice between them and the
+// implicit GEMM ---------------------------------------------------------------------------------------------------------------
+struct HaloCfg { int bm, bn, nw, nwm, hs, hmode; };
+static const HaloCfg kHalo[] = {
+    {0, 0, 0, 0, 0, 0},             // 0: the implicit GEMM (A_IM2COL)
+    {256, 128, 8, 4, 324, 2},       // 1: 16 x 16 patches, wide outputs (W, H % 16 == 0: the 80 x 80 stages)
+    {256, 64, 4, 4, 324, 2},        // 2:                  64 output channels (layer1, stem conv3)
+    {256, 32, 4, 4, 324, 2},        // 3:                  32 output channels (stem conv2, stem data gradients)
+    {128, 128, 4, 2, 324, 1},       // 4: 128 consecutive pixels, padded coordinates (W <= 40)
+    {256, 128, 8, 4, 452, 1},       // 5: 256 consecutive pixels
+    {128, 128, 4, 2, 180, 2},       // 6: 8 x 16 patches (W % 16 == 0, H % 8 == 0)
+};
+constexpr int kHaloN = 7;
+
+static bool halo_shape_ok(const GemmParams& p) {
+  return g_gemm_mode == 1 && p.gStride == 1 && p.gC % 16 == 0 && p.fastB && al16(p.A) && al16(p.B) && p.N % 4 == 0 &&
+         p.gHo == p.gH && p.gWo == p.gW && (long)p.gB * p.gH * p.gW * p.gC < (1L << 31);
+}
+static bool halo_ok(const GemmParams& p, int id) {
+  const HaloCfg& h = kHalo[id];
+  if (h.bn == 128 && p.N <= 64) return false;
+  if (h.bn == 64 && (p.N <= 32 || p.N > 64)) return false;
+  if (h.bn == 32 && p.N > 32) return false;
+  if (p.M < h.bm) return false;
+  if (h.hmode == 2) return p.gW % 16 == 0 && p.gH % (h.bm / 16) == 0;
+  const int pitch = p.gW + 2;   // largest window of a tile: its pixels, the row / image padding they cross, one row either side
+  const long slots = (h.bm - 1) + 2L * cdiv(h.bm - 1, p.gW) + 2L * pitch * cdiv(h.bm - 1, p.gH * p.gW) + 2L * pitch + 3;
+  return slots <= h.hs;
+}
+static int halo_tiles_m(const GemmParams& p, int id) {
+  const HaloCfg& h = kHalo[id];
+  return h.hmode == 2 ? p.gB * (p.gH / (h.bm / 16)) * (p.gW / 16) : cdiv(p.M, h.bm);
+}
+
+template <int BKIND>
+int run_halo(GemmParams p, int id, hipStream_t st) {
+  const HaloCfg& h = kHalo[id];
+  p.hmode = h.hmode;
+  p.tiles_n = cdiv(p.N, h.bn);
+  p.splitk = 1;
+  p.kchunk = p.gC;
+  p.xcd_remap = 0;
+  static const bool vec_epi_ok = !(getenv("TRIS_VEC_EPILOGUE") && getenv("TRIS_VEC_EPILOGUE")[0] == '0');
+  p.vecC = vec_epi_ok && (p.N % 4 == 0) && al16(p.C) && (p.ldc % 4 == 0) && (!p.resid || (al16(p.resid) && p.ldr % 4 == 0));
+  dim3 grid((unsigned)(halo_tiles_m(p, id) * p.tiles_n), 1, 1);
+#define TRIS_HALO_GO(BM_, BN_, NW_, NWM_, HS_)                                                                          \
+  hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, A_HALO, BKIND, EPI_STD, 1, NW_, 16, 2, NWM_, HS_>), grid, dim3(NW_ * 64), 0, st, p)
+  switch (id) {
+    case 1: TRIS_HALO_GO(256, 128, 8, 4, 324); break;
+    case 2: TRIS_HALO_GO(256, 64, 4, 4, 324); break;
+    case 3: TRIS_HALO_GO(256, 32, 4, 4, 324); break;
+    case 4: TRIS_HALO_GO(128, 128, 4, 2, 324); break;
+    case 5: TRIS_HALO_GO(256, 128, 8, 4, 452); break;
+    case 6: TRIS_HALO_GO(128, 128, 4, 2, 180); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef TRIS_HALO_GO
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+// 3x3 convolution, stride 1 (forward and data gradient): direct kernel or implicit GEMM, timed once per shape like the tile
+// choice.  TRIS_CONV_DIRECT=0 keeps the implicit GEMM, =1..6 forces a direct configuration where it applies (tests).
+// *stat_rows (when statistics are fused) = number of partial rows the chosen kernel writes.
+template <int BKIND>
+int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
+  const bool stat = p.stat_part != nullptr;
+  auto im2col = [&]() {
+    if (stat_rows) *stat_rows = stat ? cdiv(p.M, 128) : 0;
+    return launch_cfg<A_IM2COL, BKIND>(p, 1, nullptr, 0, st);
+  };
+  auto direct = [&](int id) {
+    if (stat_rows) *stat_rows = stat ? halo_tiles_m(p, id) : 0;
+    return run_halo<BKIND>(p, id, st);
+  };
+  const char* e = getenv("TRIS_CONV_DIRECT");   // read per call: tests switch it at run time
+  const int forced = e ? atoi(e) : -1;
+  if (forced == 0 || !halo_shape_ok(p)) return im2col();
+  if (forced > 0) return (forced < kHaloN && halo_ok(p, forced)) ? direct(forced) : im2col();
+  int first = 0;
+  for (int id = 1; id < kHaloN && !first; ++id)
+    if (halo_ok(p, id)) first = id;
+  if (!first) return im2col();
+  const TuneKey key = {A_HALO, BKIND + (stat ? 16 : 0), p.M, p.N, p.K, p.gH * 4096 + p.gW, g_gemm_mode};
+  int cached = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);   // (released before the launch: the implicit GEMM looks up its own tile under it)
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) cached = it->second.bm;
+  }
+  if (cached >= 0) return cached ? direct(cached) : im2col();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (!autotune_enabled() || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return direct(first);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return direct(first);
+  int rc = im2col();   // (tunes the implicit GEMM's own tile on first sight)
+  if (rc != 0) return rc;
+  hipDeviceSynchronize();
+  auto timed = [&](int id) -> float {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, st);
+      if ((id ? direct(id) : im2col()) != 0) return 1e30f;
+      hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+      float ms = 1e30f;
+      hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    return best;
+  };
+  int best_id = 0;
+  const float t_im2col = timed(0);
+  float best_ms = t_im2col;
+  for (int id = 1; id < kHaloN; ++id) {
+    if (!halo_ok(p, id)) continue;
+    const float ms = timed(id);
+    if (ms < best_ms) { best_ms = ms; best_id = id; }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = Cfg{best_id, 0, 1, 0, 0};
+    if (const char* lg = getenv("TRIS_TUNE_LOG")) {
+      if (FILE* f = fopen(lg, "a")) {
+        fprintf(f, "conv3x3 bkind=%d M=%d N=%d K=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)\n", key.bk, p.M, p.N,
+                p.K, p.gH, p.gW, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f,
+                2.0 * p.M * p.N * p.K / (best_ms * 1e-3) * 1e-12, t_im2col * 1e3f);
+        fclose(f);
+      }
+    }
+  }
+  return best_id ? direct(best_id) : im2col();   // leave the outputs (and *stat_rows) of the chosen kernel
+}
+
 }  // namespace
 
 extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
@@ -756,7 +895,7 @@ extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, i
   p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
   p.fastA = al16(X) && (Cin % 32 == 0);
   p.fastB = p.vecB;
-  return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+  return conv3_dispatch<B_NK>(p, (hipStream_t)stream, nullptr);
 }
 
 // dX[B,H,W,Cin] = conv3x3_transpose(dY[B,H,W,Cout], Wt), stride 1 only: a 3x3 conv of dY with the taps mirrored.
@@ -773,7 +912,7 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   p.fastA = al16(dY) && (Cout % 32 == 0);
   p.fastB = p.vecB;
   if (Cout % 16 != 0) return (int)hipErrorInvalidValue;  // k tile must not straddle taps for the B loader
-  return launch_cfg<A_IM2COL, B_KN_DGRAD>(p, 1, nullptr, 0, (hipStream_t)stream);
+  return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, nullptr);
 }
 
 // ---- weight gradient of the stem's first convolution (Cin = 3: the 27-wide "N" does not fit the tiled kernels) -----------
@@ -921,8 +1060,7 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   p.fastA = al16(X) && (Cin % 32 == 0);
   p.fastB = p.vecB;
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
-  *stat_rows = p.stat_part ? cdiv(p.M, 128) : 0;
-  return launch_cfg<A_IM2COL, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+  return conv3_dispatch<B_NK>(p, (hipStream_t)stream, stat_rows);
 }
 
 // ---- pre-split weight operands ("weight planes") ---------------------------------------------------------------------------

@@ -51,20 +51,37 @@ constexpr int gf_stage_floats(int BMN, int FBK, int PREC, bool row_major) {
   return PREC >= 1 ? (row_major ? BMN * (2 * FBK + 16) * NPLN / 4 : NPLN * FBK * (2 * BMN + 64) / 4)
                    : (row_major ? BMN * (FBK + 4) : FBK * (BMN + 4));
 }
-constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm) {
+constexpr int gf_halo_floats(int HS) { return HS * 24; }   // HS pixel slots x 3 planes x 16 channels bf16 (no padding)
+constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm, int HS = 0) {
   if (NSTG == 1) return NW == 8 ? 4 : 2;   // (the classic kernels: two co-resident blocks per CU, as tuned in round 1)
-  const int lds = 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
+  const int lds = HS > 0 ? 4 * (gf_halo_floats(HS) + NSTG * gf_stage_floats(BN, FBK, PREC, b_rm))
+                         : 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
   const int blocks = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int w = blocks * NW / 4;
+  if (HS > 0) return w > 2 ? 2 : (w < 1 ? 1 : w);   // (direct 3x3: the window registers need more than 128 VGPRs)
   return w < 1 ? 1 : w;
 }
 
 // NW = waves per workgroup; NWM x (NW / NWM) wave grid (classic kernels: 2 x NW/2)
-template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4, int FBK = 32, int NSTG = 1, int NWM = 2>
+// AK == A_HALO (3x3 convolution, stride 1, x3 arithmetic, FBK 16, NSTG 2, HS > 0): see "direct 3x3" below
+template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4, int FBK = 32, int NSTG = 1, int NWM = 2, int HS = 0>
 __global__ __launch_bounds__(NW * 64, gf_min_waves_per_simd(BM, BN, PREC, NW, FBK, NSTG, AK != A_COLK,
-                                                             BKIND == B_NK || BKIND == B_NK_PRE))
+                                                             BKIND == B_NK || BKIND == B_NK_PRE, HS))
 void gemm_fast_kernel(GemmParams p) {
   constexpr int NTHR = NW * 64, NWN = NW / NWM;
+  // ---- direct 3x3 convolution (A_HALO) ---------------------------------------------------------------------------------------
+  // The implicit GEMM above (A_IM2COL) re-gathers and RE-SPLITS every input value nine times, once per tap, and the split
+  // (5.5 VALU operations per element) + LDS store of the A tile is what bounds the x3 kernels (tools/probes/x3_pipe_probe).
+  // Here the block's input window -- its BM output pixels plus the one-pixel border -- is split ONCE per 16-channel chunk into
+  // an LDS image [plane][channel half][pixel slot][8 ch]; the nine taps of that chunk then read their A fragments from the same
+  // image at a per-tap slot offset ((ty-1) * pitch + (tx-1)): the zero padding of the convolution is part of the image, so
+  // the tap loop has no bounds logic at all.  The K order is (channel chunk, tap, channel); B (weights) is staged per
+  // (chunk, tap) exactly as in the pipelined loop.  Two window shapes (p.hmode):
+  //   2: 2-D patches of (BM/16) x 16 pixels (W % 16 == 0, H % (BM/16) == 0), slot pitch 18: 1.27x input re-read at BM 256;
+  //   1: BM consecutive pixels of the flattened [B, H, W] grid, held in PADDED coordinates (pitch W + 2, one zero row between
+  //      images): any H, W; the window is BM + ~2 W slots, so this is for the narrow late stages (W <= 40).
+  constexpr bool HALO = (AK == A_HALO);
+  static_assert(!HALO || (PREC == 1 && FBK == 16 && NSTG == 2 && HS % 8 == 4), "A_HALO: x3, 16-channel chunks, pipelined B");
   constexpr int KL = FBK / 4;          // 16-byte pieces per row of a row-major tile
   constexpr int RPASS = NTHR / KL;     // rows of a row-major tile covered per pass
   constexpr int LDK = FBK + 4;
@@ -78,8 +95,12 @@ void gemm_fast_kernel(GemmParams p) {
   static_assert(NW % NWM == 0 && BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0, "wave grid does not tile the block");
   constexpr int WM = BM / NWM, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
-  constexpr int PA = BM * FBK / (4 * NTHR), PB = BN * FBK / (4 * NTHR);  // float4 per thread per tile
-  static_assert(PA >= 1 && PB >= 1 && PA * 4 * NTHR == BM * FBK && PB * 4 * NTHR == BN * FBK, "tile / thread count mismatch");
+  // float4 per thread per tile; B_PART: a B tile smaller than one piece per thread (32-wide tiles of the direct convolution):
+  // the first BN * FBK / 4 threads stage it
+  constexpr bool B_PART = (BN * FBK < 4 * NTHR);
+  constexpr int PA = BM * FBK / (4 * NTHR), PB = B_PART ? 1 : BN * FBK / (4 * NTHR);
+  static_assert(PA >= 1 && PA * 4 * NTHR == BM * FBK && (B_PART ? HALO : PB * 4 * NTHR == BN * FBK), "tile / thread count mismatch");
+  const bool b_act = !B_PART || threadIdx.x < BN * FBK / 4;
   // x3 / x2: every operand is split into its bf16 pieces ONCE, when the tile is stored.  Row-major kinds: three planes
   // [plane][row][FBK + 8 pad] (row stride PLB = 2 FBK + 16 bytes: 80 -> 5, 48 -> 3 sixteen-byte slots, both odd, so the 16
   // lanes of a ds_read_b128 service group fall on 16 distinct slots).  PREC 2 = x2: two pieces, three products
@@ -94,11 +115,11 @@ void gemm_fast_kernel(GemmParams p) {
   constexpr bool A_TR = (PREC >= 1) && !A_RM, B_TR = (PREC >= 1) && !B_RM;
   constexpr int A_KS = 2 * BM + 64, B_KS = 2 * BN + 64;  // bytes per k row of a k-major plane
   constexpr int PLB = 2 * FBK + 16;                      // bytes per row of one row-major bf16 plane
-  constexpr int A_SZ = gf_stage_floats(BM, FBK, PREC, A_RM);
+  constexpr int A_SZ = HALO ? gf_halo_floats(HS) : gf_stage_floats(BM, FBK, PREC, A_RM);
   constexpr int B_SZ = gf_stage_floats(BN, FBK, PREC, B_RM);
   __shared__ __attribute__((aligned(16))) float As[A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
-  __shared__ __attribute__((aligned(16))) float As1[NSTG == 2 ? A_SZ : 4];   // second stage (pipelined loop): separate objects
+  __shared__ __attribute__((aligned(16))) float As1[(NSTG == 2 && !HALO) ? A_SZ : 4];   // second stage (pipelined loop): separate objects
   __shared__ __attribute__((aligned(16))) float Bs1[NSTG == 2 ? B_SZ : 4];
 
   const int tid = threadIdx.x;
@@ -188,6 +209,96 @@ void gemm_fast_kernel(GemmParams p) {
       bp_src[q] = reinterpret_cast<const unsigned short*>(p.B) + (long)row * p.ldb + (tid & 3) * 8;
     }
   }
+
+  // ---- direct 3x3: window geometry (see the head of the kernel) -------------------------------------------------------------
+  constexpr int HP = HALO ? (HS * 4 + NTHR - 1) / NTHR : 1;   // 16-byte pieces (4 channels of one slot) per thread per chunk
+  int h_pitch = 0, h_b = 0, h_y0 = 0, h_x0 = 0;
+  int h_rowslot[FM];   // slot of the CENTRE tap of this lane's row in fragment i
+  int h_pix[HP];       // input pixel (b*H + y)*W + x held by this thread's q-th slot, -1 = padding
+  if constexpr (HALO) {
+    const int tm = tile / p.tiles_n;
+    if (p.hmode == 2) {
+      constexpr int TH = BM / 16;
+      const int txn = p.gW / 16, tpi = txn * (p.gH / TH);
+      h_b = tm / tpi;
+      const int r = tm - h_b * tpi;
+      h_y0 = (r / txn) * TH;
+      h_x0 = (r - (r / txn) * txn) * 16;
+      h_pitch = 18;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int rl = wm * WM + i * 32 + (lane & 31);
+        h_rowslot[i] = ((rl >> 4) + 1) * 18 + (rl & 15) + 1;
+      }
+#pragma unroll
+      for (int q = 0; q < HP; ++q) {
+        const int sl = (tid + q * NTHR) >> 2;
+        const int sy = sl / 18, sx = sl - sy * 18;
+        const int iy = h_y0 + sy - 1, ix = h_x0 + sx - 1;
+        const bool ok = sl < HS && (unsigned)iy < (unsigned)p.gH && (unsigned)ix < (unsigned)p.gW;
+        h_pix[q] = ok ? (h_b * p.gH + iy) * p.gW + ix : -1;
+      }
+    } else {
+      h_pitch = p.gW + 2;
+      const int hw = p.gH * p.gW, pp = (p.gH + 2) * h_pitch;
+      auto padded = [&](int m) {
+        const int b = m / hw, r = m - b * hw;
+        const int y = r / p.gW, x = r - y * p.gW;
+        return (b * (p.gH + 2) + y + 1) * h_pitch + x + 1;
+      };
+      const int base = padded(m0) - h_pitch - 1;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) h_rowslot[i] = padded(min(m0 + wm * WM + i * 32 + (lane & 31), p.M - 1)) - base;
+#pragma unroll
+      for (int q = 0; q < HP; ++q) {
+        const int sl = (tid + q * NTHR) >> 2;
+        const int qd = base + sl;
+        const int b = qd / pp, r = qd - b * pp;
+        const int y = r / h_pitch, x = r - y * h_pitch;
+        const bool ok = sl < HS && b < p.gB && y >= 1 && y <= p.gH && x >= 1 && x <= p.gW;
+        h_pix[q] = ok ? (b * p.gH + y - 1) * p.gW + x - 1 : -1;
+      }
+    }
+  }
+  // tile-local row -> row of the output matrix (rows >= p.M are not stored)
+  auto grow = [&](int rl) -> int {
+    if (HALO && p.hmode == 2) return (h_b * p.gH + h_y0 + (rl >> 4)) * p.gW + h_x0 + (rl & 15);
+    return m0 + rl;
+  };
+  auto load_halo = [&](float4 (&hr)[HP], int c0) {
+#pragma unroll
+    for (int q = 0; q < HP; ++q) {
+      const bool ok = h_pix[q] >= 0;
+      const float4 v = ld4(A + (ok ? (long)h_pix[q] * p.gC + c0 + ((tid + q * NTHR) & 3) * 4 : 0));
+      hr[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_halo = [&](float* Ad, const float4 (&hr)[HP]) {
+#pragma unroll
+    for (int q = 0; q < HP; ++q) {
+      const int j = tid + q * NTHR;
+      if (HP * NTHR == HS * 4 || j < HS * 4) {
+        const Split4 sp = split4(hr[q]);
+        // image [plane][channel half kh][slot][8 ch]: a fragment read is 16 lanes x 16 contiguous bytes (conflict-free without
+        // padding); the four 8-byte pieces of a slot go to two 64-byte windows HS*16 bytes apart (HS % 8 == 4: disjoint banks)
+        char* d = reinterpret_cast<char*>(Ad) + (j >> 2) * 16 + ((j >> 1) & 1) * (HS * 16) + (j & 1) * 8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + HS * 32) = sp.mid;
+        *reinterpret_cast<uint2*>(d + 2 * HS * 32) = sp.lo;
+      }
+    }
+  };
+  // B tile of (tap, 16 channels from c0) -- B_NK: weights [n][tap][c]; B_KN_DGRAD: k = (tap, co) reads W[co][8 - tap][n]
+  auto load_Bh = [&](float4 (&rb)[PB], int tap, int c0) {
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      if (BKIND == B_NK) rb[q] = ld4(Bp + b_off[q] + tap * p.gC + c0);
+      else {
+        const int co = min(c0 + tid / BF4 + q * BRPP, p.wCout - 1);
+        rb[q] = ld4(Bp + ((long)co * 9 + (8 - tap)) * p.wCin + b_nc);
+      }
+    }
+  };
 
   // Tiles must be requested in order, FBK apart, starting at kbeg (the im2col / dgrad coordinates are carried from tile to tile)
   auto load_A = [&](float4 (&ra)[PA], int k0) {
@@ -377,6 +488,83 @@ void gemm_fast_kernel(GemmParams p) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
   };
 
+  if constexpr (HALO) {
+    // ---- direct 3x3 loop: per 16-channel chunk ONE window image, nine pipelined (tap) steps over it --------------------------
+    const int cbeg = zs * p.kchunk;                       // channel range of this k slice (kchunk: channels, multiple of 16)
+    const int nch = (min(p.gC, cbeg + p.kchunk) - cbeg) / 16;
+    auto frag_H = [&](int i, int tapoff) {
+      Split8 s;
+      const char* s0 = reinterpret_cast<const char*>(As) + (h_rowslot[i] + tapoff) * 16 + kh * (HS * 16);
+      s.hi = *reinterpret_cast<const bf16x8*>(s0);
+      s.mid = *reinterpret_cast<const bf16x8*>(s0 + HS * 32);
+      s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * HS * 32);
+      return s;
+    };
+    // (chunk, tap) past the end are clamped to the last tile: surplus tiles go to a stage that is never read
+    auto tile_B = [&](float4 (&rb)[PB], int c, int tap) {
+      if (tap >= 9) { tap -= 9; ++c; }
+      if (c >= nch) { c = nch - 1; tap = 8; }
+      load_Bh(rb, tap, cbeg + c * 16);
+    };
+    auto step_h = [&](const float* Bc, float* Bn, const float4 (&rb)[PB], int tap) {
+      const int tapoff = (tap / 3 - 1) * h_pitch + (tap % 3 - 1);
+      Split8 sa[FM], sb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) sa[i] = frag_H(i, tapoff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) sb[j] = frag_B(Bc, 0, j);
+      int done = 0;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          mfma_x(sa[i], sb[j], acc[i][j]);
+          const int want = ((i * FN + j + 1) * PB) / (FM * FN);
+#pragma unroll
+          for (int c = 0; c < PB; ++c)
+            if (c >= done && c < want && b_act) store_B(Bn, rb[c], c);
+          done = want;
+        }
+    };
+    float4 hr[HP], rb0[PB], rb1[PB];
+    // one chunk.  Entry: window image of chunk c in LDS, B tile (c, tap 0) in S0, registers r1 = tile (c, tap 1).
+    // Exit (nine steps later, an odd number): tile (c+1, 0) in S1, registers r0 = tile (c+1, 1), window image of chunk c+1.
+    auto chunk = [&](float* S0, float* S1, float4 (&r0)[PB], float4 (&r1)[PB], int c) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap == 5) {   // the next chunk's window: in flight over the last four steps only (register pressure)
+          load_halo(hr, cbeg + min(c + 1, nch - 1) * 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tap % 2 == 0) {
+          tile_B(r0, c, tap + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          step_h(S0, S1, r1, tap);
+        } else {
+          tile_B(r1, c, tap + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          step_h(S1, S0, r0, tap);
+        }
+        __syncthreads();
+      }
+      store_halo(As, hr);
+      __syncthreads();
+    };
+    load_halo(hr, cbeg);
+    tile_B(rb0, 0, 0);
+    store_halo(As, hr);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (b_act) store_B(Bs, rb0[q], q);
+    tile_B(rb1, 0, 1);
+    __syncthreads();
+    int c = 0;
+    for (; c + 1 < nch; c += 2) {
+      chunk(Bs, Bs1, rb0, rb1, c);
+      chunk(Bs1, Bs, rb1, rb0, c + 1);
+    }
+    if (c < nch) chunk(Bs, Bs1, rb0, rb1, c);
+  } else
   if constexpr (NSTG == 2) {
     // ---- pipelined loop: one barrier per K tile -----------------------------------------------------------------------------
     constexpr int G = FBK / 16, NCH = PA + PB, NPR = FM * FN * G;
@@ -538,7 +726,8 @@ void gemm_fast_kernel(GemmParams p) {
   // + a wave fence) and handles rows: 8 lanes x 16 bytes per row, 8 rows per instruction -- 4 loads/stores per block.
   constexpr int ELD = 36;
   constexpr int EW_A = A_SZ / (32 * ELD), EW_B = B_SZ / (32 * ELD);   // waves whose 32 x 36 turn-around block fits an array
-  constexpr bool EPI_LDS = (EW_A + EW_B) * NSTG >= NW;
+  constexpr int EW_A1 = (NSTG == 2 && !HALO) ? EW_A : 0, EW_B1 = NSTG == 2 ? EW_B : 0;
+  constexpr bool EPI_LDS = EW_A + EW_B + EW_A1 + EW_B1 >= NW;
   float4 vs_s[FN], vs_q[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) vs_s[j] = vs_q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -549,8 +738,8 @@ void gemm_fast_kernel(GemmParams p) {
       int w = wave;
       if (w < EW_A) stg = As + w * 32 * ELD;
       else if ((w -= EW_A) < EW_B) stg = Bs + w * 32 * ELD;
-      else if ((w -= EW_B) < EW_A) stg = As1 + w * 32 * ELD;
-      else stg = Bs1 + (w - EW_A) * 32 * ELD;
+      else if ((w -= EW_B) < EW_A1) stg = As1 + w * 32 * ELD;
+      else stg = Bs1 + (w - EW_A1) * 32 * ELD;
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
@@ -566,7 +755,7 @@ void gemm_fast_kernel(GemmParams p) {
         if (EPI == EPI_STD && p.bias_mode == 1 && col < p.N) bc = ld4(p.bias + col);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int row = m0 + wm * WM + i * 32 + er + 8 * t;
+          const int row = grow(wm * WM + i * 32 + er + 8 * t);
           float4 v = *reinterpret_cast<const float4*>(stg + (er + 8 * t) * ELD + ec);
           if (row < p.M && col < p.N) {  // N % 4 == 0: a vector never straddles the edge
             if (EPI == EPI_SLAB) {
@@ -602,7 +791,7 @@ void gemm_fast_kernel(GemmParams p) {
       const int col = n0 + wn * WN + j * 32 + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = grow(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh);
         if (row < p.M && col < p.N) {
           float v = acc[i][j][r];
           if (EPI == EPI_SLAB) {
