@@ -67,6 +67,9 @@ int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long bpl, float
  * run-to-run rounding). */
 int tris_set_autotune(int on);
 int tris_get_gemm_mode(void);
+/* Diagnostics: launches so far of the direct 3x3 convolution kernels (kind 0: forward / data gradient) and of the direct 3x3
+ * weight-gradient kernel (kind 1) -- the tests use it to prove which kernel ran.  Host-side counters, not thread-safe. */
+long tris_direct_launches(int kind);
 
 /* 3x3 convolution, pad 1, implicit GEMM (no im2col buffer).  CLIP/clip/model.py:21 (Bottleneck.conv2), :212-229 (stem).
  * fwd: stride 1 or 2.  dgrad: stride 1 only (the only strided conv on the path, the stem's conv1, reads the image and

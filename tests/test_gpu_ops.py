@@ -191,6 +191,38 @@ def test_conv3x3_direct_kernels(cfg, B, H, W, Cin, Cout, monkeypatch):
         o.set_gemm_mode(prev)
 
 
+@pytest.mark.parametrize("cfg,B,H,W,Cin,Cout", [(1, 2, 8, 32, 32, 32), (1, 3, 12, 16, 32, 32), (2, 2, 16, 16, 32, 64),
+                                                (3, 2, 6, 32, 64, 64), (3, 1, 4, 16, 128, 192), (3, 5, 10, 48, 64, 128),
+                                                (2, 2, 8, 32, 64, 128), (4, 2, 8, 32, 64, 64), (4, 3, 12, 16, 128, 64)])
+def test_conv3x3_direct_weight_gradient(cfg, B, H, W, Cin, Cout, monkeypatch):
+    """The direct 3x3 weight-gradient kernel (one split of each dY / input window, nine taps read the same LDS image;
+    tris_amd/csrc/gemm_conv.hip wgrad3x3_direct_kernel) against the fp32 CPU reference and the implicit GEMM."""
+    from tris_amd import ops as o
+    prev = o.get_gemm_mode()
+    o.set_gemm_mode("x3")
+    try:
+        x, w = leaf(B, Cin, H, W), leaf(Cout, Cin, 3, 3, scale=0.1)
+        y = F.conv2d(x, w, padding=1)
+        gy0 = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+        y.backward(gy0)
+        got, ran = {}, []
+        from tris_amd._lib import query
+        for mode in ("0", str(cfg)):
+            monkeypatch.setenv("TRIS_WGRAD_DIRECT", mode)
+            gx = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+            gw = w.detach().clone().contiguous(memory_format=torch.channels_last).cuda().requires_grad_(True)
+            n0 = query("tris_direct_launches", 1)
+            o.conv3x3(gx, gw, 1).backward(gy0.permute(0, 2, 3, 1).contiguous().cuda())
+            torch.cuda.synchronize()
+            ran.append(query("tris_direct_launches", 1) - n0)
+            got[mode] = gw.grad.detach().cpu()
+            close(got[mode], w.grad, name=f"dw[{mode}]")
+        close(got[str(cfg)], got["0"], 2e-6, name="direct vs implicit")
+        assert ran == [0, 1], ran   # the direct kernel ran exactly when asked to
+    finally:
+        o.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
 @pytest.mark.parametrize("shape", [(2, 10, 10, 64), (3, 40, 40, 32), (2, 5, 5, 2048)])
 def test_batchnorm_train(ops, shape, res, relu):

@@ -723,6 +723,7 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
 
 // ---- direct 3x3 convolution: configurations of the A_HALO kernels (gemm_fast.h) and the choice between them and the
 // implicit GEMM ---------------------------------------------------------------------------------------------------------------
+static long g_direct_launches[2] = {0, 0};   // diagnostics: launches of the direct convolution / direct weight-gradient kernels
 struct HaloCfg { int bm, bn, nw, nwm, hs, hmode; };
 static const HaloCfg kHalo[] = {
     {0, 0, 0, 0, 0, 0},             // 0: the implicit GEMM (A_IM2COL)
@@ -779,6 +780,7 @@ int run_halo(GemmParams p, int id, hipStream_t st) {
   }
 #undef TRIS_HALO_GO
   TRIS_LAUNCH_CHECK();
+  ++g_direct_launches[0];
   return 0;
 }
 
@@ -856,6 +858,227 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
     }
   }
   return best_id ? direct(best_id) : im2col();   // leave the outputs (and *stat_rows) of the chosen kernel
+}
+
+
+// ---- direct 3x3 weight gradient ---------------------------------------------------------------------------------------------
+// dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p + tap][ci].  As an implicit GEMM (A_COLK x B_KN_IM2COL) every one of
+// the 9 Cin / BN column tiles re-stages -- and re-splits -- the same dY rows and its own shifted copy of the same X rows, and
+// for the wide early stages (160 x 160 x 32, 80 x 80 x 64: one or two row tiles, K = 10^5..10^6 pixels) that staging is the
+// whole kernel.  Here a block owns a (COT x CIT) tile of (co, ci) for ALL nine taps and walks R x 16 pixel windows: the
+// window's dY rows and its (R+2) x 18 input rows are split ONCE into k-major LDS planes; the nine taps read the SAME input
+// image at nine slot offsets (ds_read_b64_tr_b16 fragments, as in the GEMM's k-major kinds).  Accumulators: 9 taps x 32 x 32
+// per wave (144 registers).  WK > 1: waves share a tile and take alternate window rows (narrow tiles: the stem).
+// Blocks (and the WK waves of a block) write partial tiles to slabs [slice][Co][9 Cin], summed by splitk_reduce_kernel.
+template <int COT, int CIT, int WCO, int WCI, int WK, int R, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                 float* __restrict__ slab, int H, int W, int Ci, int Co,
+                                                                 int n_ci_tiles, int units_per_block, int n_units) {
+  static_assert(WCO * WCI * WK == 4 && COT == 32 * WCO && CIT == 32 * WCI && R % WK == 0, "wave layout");
+  constexpr int NPX = R * 16, NSL = (R + 2) * 18;
+  constexpr int KS_A = COT == 32 ? 64 : 2 * COT + 64, KS_X = CIT == 32 ? 64 : 2 * CIT + 64;  // bytes per k row: odd multiples of 64
+  constexpr int PA = NPX * COT / 4 / 256, PX = (NSL * CIT / 4 + 255) / 256;
+  static_assert(PA * 256 * 4 == NPX * COT, "dY window / thread count mismatch");
+  __shared__ __attribute__((aligned(16))) char Ash[3 * NPX * KS_A];
+  __shared__ __attribute__((aligned(16))) char Xsh[3 * NSL * KS_X];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % WK, wci = (wave / WK) % WCI, wco = wave / (WK * WCI);
+  const int kh = lane >> 5;
+  const int co0 = (blockIdx.x / n_ci_tiles) * COT, ci0 = (blockIdx.x % n_ci_tiles) * CIT;
+  const int u_beg = blockIdx.y * units_per_block, u_end = min(n_units, u_beg + units_per_block);
+  const int xsn = W / 16, upi = xsn * (H / R);   // units per image
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 ra[PA], rx[PX];
+  auto load_unit = [&](int u) {
+    const int b = u / upi, r0 = u - b * upi;
+    const int y0 = (r0 / xsn) * R, x0 = (r0 - (r0 / xsn) * xsn) * 16;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int j = tid + q * 256;
+      const int px = j / (COT / 4), c4 = j - px * (COT / 4);
+      ra[q] = ld4(dY + ((long)(b * H + y0 + (px >> 4)) * W + x0 + (px & 15)) * Co + co0 + c4 * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const int j = tid + q * 256;
+      const int sl = j / (CIT / 4), c4 = j - sl * (CIT / 4);
+      const int sy = sl / 18, sx = sl - sy * 18;
+      const int iy = y0 + sy - 1, ix = x0 + sx - 1;
+      const bool ok = sl < NSL && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const float4 v = ld4(X + (ok ? ((long)(b * H + iy) * W + ix) * Ci + ci0 + c4 * 4 : 0));
+      rx[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_unit = [&]() {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int j = tid + q * 256;
+      const int px = j / (COT / 4), c4 = j - px * (COT / 4);
+      const Split4 sp = split4(ra[q]);
+      char* d = Ash + px * KS_A + c4 * 8;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + NPX * KS_A) = sp.mid;
+      *reinterpret_cast<uint2*>(d + 2 * NPX * KS_A) = sp.lo;
+    }
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const int j = tid + q * 256;
+      const int sl = j / (CIT / 4), c4 = j - sl * (CIT / 4);
+      if (PX * 256 * 4 == NSL * CIT || sl < NSL) {
+        const Split4 sp = split4(rx[q]);
+        char* d = Xsh + sl * KS_X + c4 * 8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + NSL * KS_X) = sp.mid;
+        *reinterpret_cast<uint2*>(d + 2 * NSL * KS_X) = sp.lo;
+      }
+    }
+  };
+  const int m16 = wco * 32 + ((lane >> 4) & 1) * 16, n16 = wci * 32 + ((lane >> 4) & 1) * 16;
+  if (u_beg < u_end) load_unit(u_beg);
+  for (int u = u_beg; u < u_end; ++u) {
+    __syncthreads();   // the previous window has been consumed
+    store_unit();
+    __syncthreads();
+    load_unit(min(u + 1, u_end - 1));   // (unconditional: a load under a branch stalls on itself, see gemm_fast.h)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < R / WK; ++g) {
+      const int row = g * WK + wk;   // window row of this wave's k group (16 pixels)
+      Split8 a;
+      a.hi = tr_frag8(Ash, KS_A, row * 16 + 8 * kh, m16, lane);
+      a.mid = tr_frag8(Ash + NPX * KS_A, KS_A, row * 16 + 8 * kh, m16, lane);
+      a.lo = tr_frag8(Ash + 2 * NPX * KS_A, KS_A, row * 16 + 8 * kh, m16, lane);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int k0 = (row + t / 3) * 18 + (t % 3) + 8 * kh;
+        Split8 b;
+        b.hi = tr_frag8(Xsh, KS_X, k0, n16, lane);
+        b.mid = tr_frag8(Xsh + NSL * KS_X, KS_X, k0, n16, lane);
+        b.lo = tr_frag8(Xsh + 2 * NSL * KS_X, KS_X, k0, n16, lane);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if constexpr (WK > 1) {
+    // the WK waves of a (co, ci) quadrant hold partial sums over alternate window rows: add them up tap by tap through LDS
+    // (fixed order wk = 1, 2, ..: deterministic); wave wk = 0 keeps the result
+    static_assert((WK - 1) * WCO * WCI * 16 * 64 * 4 <= (int)sizeof(Xsh), "reduction scratch does not fit");
+    float* red = reinterpret_cast<float*>(Xsh);
+    const int quad = wco * WCI + wci;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      __syncthreads();
+      if (wk > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wk - 1) * (WCO * WCI) + quad) * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int w = 1; w < WK; ++w)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += red[(((w - 1) * (WCO * WCI) + quad) * 16 + r) * 64 + lane];
+      }
+    }
+  }
+  // partial tile of this block -> slab blockIdx.y: rows co, columns (tap, ci)
+  if (wk == 0) {
+    float* o = slab + (long)blockIdx.y * Co * 9 * Ci;
+    const int ci = ci0 + wci * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        o[((long)co * 9 + t) * Ci + ci] = acc[t][r];
+      }
+  }
+}
+
+// out[i] = sum over S slabs of ws[s][i] (i < total, total % 4 == 0).  The direct weight gradient leaves hundreds of slabs of a
+// SMALL matrix (9 K..150 K elements): 64 column vectors x 4 slab groups per block, 4 loads in flight per thread, the groups
+// meet in LDS in fixed order (deterministic).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, int S, long total, float* __restrict__ out) {
+  __shared__ float4 sh[3][64];
+  const int cv = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long idx = ((long)blockIdx.x * 64 + cv) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < total) {
+    int s = g;
+    for (; s + 12 < S; s += 16) {
+      const float4 a = ld4(ws + (long)s * total + idx), b = ld4(ws + (long)(s + 4) * total + idx);
+      const float4 c = ld4(ws + (long)(s + 8) * total + idx), d = ld4(ws + (long)(s + 12) * total + idx);
+      v.x = (((v.x + a.x) + b.x) + c.x) + d.x;
+      v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+      v.z = (((v.z + a.z) + b.z) + c.z) + d.z;
+      v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; s < S; s += 4) {
+      const float4 a = ld4(ws + (long)s * total + idx);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+  }
+  if (g > 0) sh[g - 1][cv] = v;
+  __syncthreads();
+  if (g == 0 && idx < total) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const float4 a = sh[q][cv]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    *reinterpret_cast<float4*>(out + idx) = v;
+  }
+}
+
+struct WgCfg { int cot, cit, wk, r; };
+static const WgCfg kWg[] = {{0, 0, 0, 0}, {32, 32, 4, 4}, {64, 32, 2, 4}, {64, 64, 1, 2}, {64, 64, 1, 4}};
+constexpr int kWgN = 5;
+static bool wg_ok(int id, int H, int W, int Ci, int Co) {
+  const WgCfg& c = kWg[id];
+  return W % 16 == 0 && H % c.r == 0 && Co % c.cot == 0 && Ci % c.cit == 0 && (id >= 2 || (Co == c.cot && Ci == c.cit));
+}
+// slices: enough blocks for ~3 per CU, bounded by the workspace
+static int wg_slices(int id, int B, int H, int W, int Ci, int Co, long ws_bytes) {
+  const WgCfg& c = kWg[id];
+  const int tiles = (Co / c.cot) * (Ci / c.cit);
+  const int units = B * (H / c.r) * (W / 16);
+  long s = std::max(1, 512 / tiles);   // two blocks per CU
+  s = std::min<long>(s, std::max(1, units / 8));
+  const long per = (long)Co * 9 * Ci * (long)sizeof(float);
+  if (s * per > ws_bytes) s = ws_bytes / per;
+  return (int)s;
+}
+static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co, float* ws,
+                            long ws_bytes, hipStream_t st) {
+  const WgCfg& c = kWg[id];
+  const int S = wg_slices(id, B, H, W, Ci, Co, ws_bytes);
+  if (S < 1) return (int)hipErrorInvalidValue;
+  const int units = B * (H / c.r) * (W / 16);
+  const int upb = cdiv(units, S);
+  const int slices = cdiv(units, upb);
+  dim3 grid((unsigned)((Co / c.cot) * (Ci / c.cit)), (unsigned)slices);
+  const int nci = Ci / c.cit;
+  switch (id) {
+    case 1: hipLaunchKernelGGL((wgrad3x3_direct_kernel<32, 32, 1, 1, 4, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
+    case 2: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
+    case 3: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 2>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
+    case 4: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 4, 1>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  TRIS_LAUNCH_CHECK();
+  const long total = (long)Co * 9 * Ci;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(total / 4, 64)), dim3(256), 0, st, ws, slices, total, dW);
+  TRIS_LAUNCH_CHECK();
+  ++g_direct_launches[1];
+  return 0;
 }
 
 }  // namespace
@@ -1023,7 +1246,73 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   p.vecB = al16(X) && (Cin % 4 == 0);
   p.fastA = p.vecA;
   p.fastB = p.vecB;
-  return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  auto gemm = [&]() { return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, st); };
+  // direct kernel (wgrad3x3_direct_kernel) or the implicit GEMM: timed once per shape.  TRIS_WGRAD_DIRECT=0 keeps the GEMM,
+  // =1..4 forces a direct configuration where it applies (tests).
+  const char* e = getenv("TRIS_WGRAD_DIRECT");
+  const int forced = e ? atoi(e) : -1;
+  const bool shape_ok = g_gemm_mode == 1 && stride == 1 && workspace != nullptr && al16(X) && al16(dY) && al16(dW) && al16(workspace) &&
+                        (long)B * H * W * std::max(Cin, Cout) < (1L << 31);
+  auto direct = [&](int id) { return run_wgrad_direct(id, X, dY, dW, B, H, W, Cin, Cout, workspace, ws_bytes, st); };
+  auto usable = [&](int id) { return wg_ok(id, H, W, Cin, Cout) && wg_slices(id, B, H, W, Cin, Cout, ws_bytes) >= 1; };
+  if (forced == 0 || !shape_ok) return gemm();
+  if (forced > 0) return (forced < kWgN && usable(forced)) ? direct(forced) : gemm();
+  int first = 0;
+  for (int id = 1; id < kWgN && !first; ++id)
+    if (usable(id)) first = id;
+  if (!first) return gemm();
+  const TuneKey key = {A_HALO, 64 + B_KN_IM2COL, p.M, p.N, p.K, H * 4096 + W, g_gemm_mode};
+  int cached = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) cached = it->second.bm;
+  }
+  if (cached >= 0) return cached ? direct(cached) : gemm();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (!autotune_enabled() || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return direct(first);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return direct(first);
+  int rc = gemm();   // (tunes the GEMM's own tile / split-K on first sight)
+  if (rc != 0) return rc;
+  (void)hipDeviceSynchronize();
+  auto timed = [&](int id) -> float {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      (void)hipEventRecord(e0, st);
+      if ((id ? direct(id) : gemm()) != 0) return 1e30f;
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+      float ms = 1e30f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    return best;
+  };
+  const float t_gemm = timed(0);
+  float best_ms = t_gemm;
+  int best_id = 0;
+  for (int id = 1; id < kWgN; ++id) {
+    if (!usable(id)) continue;
+    const float ms = timed(id);
+    if (ms < best_ms) { best_ms = ms; best_id = id; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = Cfg{best_id, 0, 1, 0, 0};
+    if (const char* lg = getenv("TRIS_TUNE_LOG")) {
+      if (FILE* f = fopen(lg, "a")) {
+        fprintf(f, "wgrad3x3 Cout=%d Cin=%d pixels=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)\n", Cout, Cin, p.K, H,
+                W, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f, 2.0 * p.M * p.N * p.K / (best_ms * 1e-3) * 1e-12,
+                t_gemm * 1e3f);
+        fclose(f);
+      }
+    }
+  }
+  return best_id ? direct(best_id) : gemm();
 }
 
 // Conv / 1x1-conv (GEMM) forward with the BatchNorm batch statistics of the OUTPUT fused into the epilogue.
@@ -1187,3 +1476,5 @@ extern "C" int tris_set_autotune(int on) {
 }
 
 extern "C" int tris_get_gemm_mode(void) { return g_gemm_mode; }
+
+extern "C" long tris_direct_launches(int kind) { return (kind == 0 || kind == 1) ? g_direct_launches[kind] : -1; }

@@ -1,6 +1,8 @@
 // Normalisation, pooling and elementwise kernels on channels-last activations [M = B*H*W, C] (gfx950).
 // All of these are HBM-bound streaming kernels: 16-byte loads per lane along the channel axis, per-channel
 // reductions done as deterministic two-stage (per-block partials -> fixed-order finalize), no atomics.
+#include <cstdlib>
+
 #include "common.h"
 #include "tris_hip.h"
 
@@ -616,7 +618,8 @@ inline int bn_grid(long n4, int C) {
 struct ColPlan { int nb; long rpb; };
 inline ColPlan col_plan(long M, int C) {
   int CV = C / 4, CVB = CV < 256 ? CV : 256, RS = 256 / CVB;
-  long rpb = (M + 511) / 512;
+  static const int target = getenv("TRIS_COL_BLOCKS") ? atoi(getenv("TRIS_COL_BLOCKS")) : 512;   // developer knob
+  long rpb = (M + target - 1) / target;
   long minr = (long)RS * 8;
   if (rpb < minr) rpb = minr;
   rpb = (rpb + RS - 1) / RS * RS;
