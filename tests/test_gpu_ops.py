@@ -193,7 +193,8 @@ def test_conv3x3_direct_kernels(cfg, B, H, W, Cin, Cout, monkeypatch):
 
 @pytest.mark.parametrize("cfg,B,H,W,Cin,Cout", [(1, 2, 8, 32, 32, 32), (1, 3, 12, 16, 32, 32), (2, 2, 16, 16, 32, 64),
                                                 (3, 2, 6, 32, 64, 64), (3, 1, 4, 16, 128, 192), (3, 5, 10, 48, 64, 128),
-                                                (2, 2, 8, 32, 64, 128), (4, 2, 8, 32, 64, 64), (4, 3, 12, 16, 128, 64)])
+                                                (2, 2, 8, 32, 64, 128), (4, 2, 8, 32, 64, 64), (4, 3, 12, 16, 128, 64),
+                                                (5, 2, 8, 40, 32, 64), (5, 1, 16, 24, 96, 128)])
 def test_conv3x3_direct_weight_gradient(cfg, B, H, W, Cin, Cout, monkeypatch):
     """The direct 3x3 weight-gradient kernel (one split of each dY / input window, nine taps read the same LDS image;
     tris_amd/csrc/gemm_conv.hip wgrad3x3_direct_kernel) against the fp32 CPU reference and the implicit GEMM."""

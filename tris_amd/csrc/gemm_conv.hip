@@ -870,12 +870,13 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
 // image at nine slot offsets (ds_read_b64_tr_b16 fragments, as in the GEMM's k-major kinds).  Accumulators: 9 taps x 32 x 32
 // per wave (144 registers).  WK > 1: waves share a tile and take alternate window rows (narrow tiles: the stem).
 // Blocks (and the WK waves of a block) write partial tiles to slabs [slice][Co][9 Cin], summed by splitk_reduce_kernel.
-template <int COT, int CIT, int WCO, int WCI, int WK, int R, int OCC = 2>
+template <int COT, int CIT, int WCO, int WCI, int WK, int R, int OCC = 2, int XW = 16>
 __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                                  float* __restrict__ slab, int H, int W, int Ci, int Co,
                                                                  int n_ci_tiles, int units_per_block, int n_units) {
-  static_assert(WCO * WCI * WK == 4 && COT == 32 * WCO && CIT == 32 * WCI && R % WK == 0, "wave layout");
-  constexpr int NPX = R * 16, NSL = (R + 2) * 18;
+  // XW = window width in pixels: 16 (a 16-pixel k group = one window row) or 8 (= two window rows: W = 40)
+  constexpr int NPX = R * XW, NSL = (R + 2) * (XW + 2), PITCH = XW + 2, NG = NPX / 16;
+  static_assert(WCO * WCI * WK == 4 && COT == 32 * WCO && CIT == 32 * WCI && NG % WK == 0 && (XW == 16 || XW == 8), "wave layout");
   constexpr int KS_A = COT == 32 ? 64 : 2 * COT + 64, KS_X = CIT == 32 ? 64 : 2 * CIT + 64;  // bytes per k row: odd multiples of 64
   constexpr int PA = NPX * COT / 4 / 256, PX = (NSL * CIT / 4 + 255) / 256;
   static_assert(PA * 256 * 4 == NPX * COT, "dY window / thread count mismatch");
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
   const int kh = lane >> 5;
   const int co0 = (blockIdx.x / n_ci_tiles) * COT, ci0 = (blockIdx.x % n_ci_tiles) * CIT;
   const int u_beg = blockIdx.y * units_per_block, u_end = min(n_units, u_beg + units_per_block);
-  const int xsn = W / 16, upi = xsn * (H / R);   // units per image
+  const int xsn = W / XW, upi = xsn * (H / R);   // units per image
 
   f32x16 acc[9];
 #pragma unroll
@@ -897,18 +898,18 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
   float4 ra[PA], rx[PX];
   auto load_unit = [&](int u) {
     const int b = u / upi, r0 = u - b * upi;
-    const int y0 = (r0 / xsn) * R, x0 = (r0 - (r0 / xsn) * xsn) * 16;
+    const int y0 = (r0 / xsn) * R, x0 = (r0 - (r0 / xsn) * xsn) * XW;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int j = tid + q * 256;
       const int px = j / (COT / 4), c4 = j - px * (COT / 4);
-      ra[q] = ld4(dY + ((long)(b * H + y0 + (px >> 4)) * W + x0 + (px & 15)) * Co + co0 + c4 * 4);
+      ra[q] = ld4(dY + ((long)(b * H + y0 + px / XW) * W + x0 + px % XW) * Co + co0 + c4 * 4);
     }
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
       const int j = tid + q * 256;
       const int sl = j / (CIT / 4), c4 = j - sl * (CIT / 4);
-      const int sy = sl / 18, sx = sl - sy * 18;
+      const int sy = sl / PITCH, sx = sl - sy * PITCH;
       const int iy = y0 + sy - 1, ix = x0 + sx - 1;
       const bool ok = sl < NSL && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const float4 v = ld4(X + (ok ? ((long)(b * H + iy) * W + ix) * Ci + ci0 + c4 * 4 : 0));
@@ -948,15 +949,15 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
     load_unit(min(u + 1, u_end - 1));   // (unconditional: a load under a branch stalls on itself, see gemm_fast.h)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < R / WK; ++g) {
-      const int row = g * WK + wk;   // window row of this wave's k group (16 pixels)
+    for (int g = 0; g < NG / WK; ++g) {
+      const int row = g * WK + wk;   // this wave's k group: 16 pixels = window row `row` (XW 16) or rows 2 row, 2 row + 1 (XW 8)
       Split8 a;
       a.hi = tr_frag8(Ash, KS_A, row * 16 + 8 * kh, m16, lane);
       a.mid = tr_frag8(Ash + NPX * KS_A, KS_A, row * 16 + 8 * kh, m16, lane);
       a.lo = tr_frag8(Ash + 2 * NPX * KS_A, KS_A, row * 16 + 8 * kh, m16, lane);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int k0 = (row + t / 3) * 18 + (t % 3) + 8 * kh;
+        const int k0 = XW == 16 ? (row + t / 3) * 18 + (t % 3) + 8 * kh : (2 * row + kh + t / 3) * 10 + (t % 3);
         Split8 b;
         b.hi = tr_frag8(Xsh, KS_X, k0, n16, lane);
         b.mid = tr_frag8(Xsh + NSL * KS_X, KS_X, k0, n16, lane);
@@ -1039,17 +1040,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 struct WgCfg { int cot, cit, wk, r; };
-static const WgCfg kWg[] = {{0, 0, 0, 0}, {32, 32, 4, 4}, {64, 32, 2, 4}, {64, 64, 1, 2}, {64, 64, 1, 4}};
-constexpr int kWgN = 5;
+static const WgCfg kWg[] = {{0, 0, 0, 0}, {32, 32, 4, 4}, {64, 32, 2, 4}, {64, 64, 1, 2}, {64, 64, 1, 4}, {64, 32, 2, 8}};
+static const int kWgXW[] = {0, 16, 16, 16, 16, 8};
+constexpr int kWgN = 6;
 static bool wg_ok(int id, int H, int W, int Ci, int Co) {
   const WgCfg& c = kWg[id];
-  return W % 16 == 0 && H % c.r == 0 && Co % c.cot == 0 && Ci % c.cit == 0 && (id >= 2 || (Co == c.cot && Ci == c.cit));
+  return W % kWgXW[id] == 0 && H % c.r == 0 && Co % c.cot == 0 && Ci % c.cit == 0 && (id >= 2 || (Co == c.cot && Ci == c.cit));
 }
 // slices: enough blocks for ~3 per CU, bounded by the workspace
 static int wg_slices(int id, int B, int H, int W, int Ci, int Co, long ws_bytes) {
   const WgCfg& c = kWg[id];
   const int tiles = (Co / c.cot) * (Ci / c.cit);
-  const int units = B * (H / c.r) * (W / 16);
+  const int units = B * (H / c.r) * (W / kWgXW[id]);
   long s = std::max(1, 512 / tiles);   // two blocks per CU
   s = std::min<long>(s, std::max(1, units / 8));
   const long per = (long)Co * 9 * Ci * (long)sizeof(float);
@@ -1061,7 +1063,7 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
   const WgCfg& c = kWg[id];
   const int S = wg_slices(id, B, H, W, Ci, Co, ws_bytes);
   if (S < 1) return (int)hipErrorInvalidValue;
-  const int units = B * (H / c.r) * (W / 16);
+  const int units = B * (H / c.r) * (W / kWgXW[id]);
   const int upb = cdiv(units, S);
   const int slices = cdiv(units, upb);
   dim3 grid((unsigned)((Co / c.cot) * (Ci / c.cit)), (unsigned)slices);
@@ -1071,6 +1073,7 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
     case 2: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
     case 3: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 2>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
     case 4: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 4, 1>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
+    case 5: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 8, 2, 8>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
     default: return (int)hipErrorInvalidValue;
   }
   TRIS_LAUNCH_CHECK();
@@ -1249,7 +1252,7 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   hipStream_t st = (hipStream_t)stream;
   auto gemm = [&]() { return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, st); };
   // direct kernel (wgrad3x3_direct_kernel) or the implicit GEMM: timed once per shape.  TRIS_WGRAD_DIRECT=0 keeps the GEMM,
-  // =1..4 forces a direct configuration where it applies (tests).
+  // =1..5 forces a direct configuration where it applies (tests).
   const char* e = getenv("TRIS_WGRAD_DIRECT");
   const int forced = e ? atoi(e) : -1;
   const bool shape_ok = g_gemm_mode == 1 && stride == 1 && workspace != nullptr && al16(X) && al16(dY) && al16(dW) && al16(workspace) &&
