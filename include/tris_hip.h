@@ -71,9 +71,12 @@ int tris_get_gemm_mode(void);
  * weight-gradient kernel (kind 1) -- the tests use it to prove which kernel ran.  Host-side counters, not thread-safe. */
 long tris_direct_launches(int kind);
 
-/* 3x3 convolution, pad 1, implicit GEMM (no im2col buffer).  CLIP/clip/model.py:21 (Bottleneck.conv2), :212-229 (stem).
+/* 3x3 convolution, pad 1, no im2col buffer.  CLIP/clip/model.py:21 (Bottleneck.conv2), :212-229 (stem).
  * fwd: stride 1 or 2.  dgrad: stride 1 only (the only strided conv on the path, the stem's conv1, reads the image and
- * needs no input gradient).  wgrad: split-K over output pixels; workspace >= 2 slabs of Cout*9*Cin floats, more = faster. */
+ * needs no input gradient).  wgrad: split over output pixels; workspace >= 2 slabs of Cout*9*Cin floats, more = faster.
+ * Each entry point picks, per shape (timed once like the GEMM tile choice; static table when autotuning is off), between
+ * the implicit GEMM and a direct kernel that splits every input value once per window instead of once per tap (x3
+ * arithmetic, stride 1, Cin % 16 == 0).  Same result up to fp32 summation order. */
 int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout, int stride,
                          void* stream);
 int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* dX, int B, int H, int W, int Cin, int Cout,
@@ -83,7 +86,8 @@ int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, in
 
 /* Forward conv / 1x1 conv (A[M,K] . B[N,K]^T) with the train-mode BatchNorm statistics of the OUTPUT fused into the
  * epilogue: stat_part <- [rows][2][N] fp64 partial (sum, sum of squares), *stat_rows (HOST int) <- rows, or 0 when the
- * shape is not eligible (then call tris_bn_stats_f32).  stat_part capacity: ceil(M/128)*2*N doubles.  Finish with
+ * shape is not eligible (then call tris_bn_stats_f32).  stat_part capacity: ceil(M/128)*2*N doubles (rows <= ceil(M/128):
+ * one per M tile of the kernel that ran).  Finish with
  * tris_bn_finalize_f32.  (CLIP/clip/model.py:17-29,45-48: conv -> bn pairs of Bottleneck / stem) */
 int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, int M, int N, int K, double* stat_part,
                          int* stat_rows, void* stream);
@@ -108,10 +112,12 @@ int tris_bn_apply_f32(const float* X, const float* mean, const float* invstd, co
 /* backward: dz = dY * (Y > 0) when Y != NULL.  sum_dz = dbeta, sum_dzx = dgamma.  apply: dZ (optional) receives dz,
  * the gradient of the fused residual branch (Bottleneck identity path).  gamma_mask / beta_mask != NULL (BatchNorm + ReLU
  * without a residual input): the ReLU mask is recomputed from X with tris_bn_apply_f32's own expression -- same sign bit
- * for bit -- and Y is not read (one 4-byte stream less in each of the two passes). */
+ * for bit -- and Y is not read (one 4-byte stream less in each of the two passes).  reduce, dz_out != NULL: the masked
+ * gradient dz is also written; tris_bn_bwd_apply_f32 may then be given dY = dz_out, Y = NULL, dZ = NULL (dz is already
+ * the residual branch's gradient): 7 activation-sized streams over the two passes instead of 8. */
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                            long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,
-                           const float* beta_mask, void* stream);
+                           const float* beta_mask, float* dz_out, void* stream);
 int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                           const float* gamma, const float* sum_dz, const float* sum_dzx, float inv_count, float* dX,
                           float* dZ, long M, int C, const float* beta_mask, void* stream);

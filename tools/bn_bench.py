@@ -41,7 +41,7 @@ for hw, C in SHAPES:
     mean, inv = stats[:C], stats[C:2 * C]
     ta = timeit(lambda: call("tris_bn_apply_f32", P(x), P(mean), P(inv), P(g), P(b), None, P(y), M, C, 1, _stream()))
     tr = timeit(lambda: call("tris_bn_bwd_reduce_f32", P(dy), None, P(x), P(mean), P(inv), M, C, P(sums), P(sums, C),
-                             P(ws), P(g), P(b), _stream()))
+                             P(ws), P(g), P(b), None, _stream()))
     tb = timeit(lambda: call("tris_bn_bwd_apply_f32", P(dy), None, P(x), P(mean), P(inv), P(g), P(sums), P(sums, C),
                              1.0 / M, P(dx), None, M, C, P(b), _stream()))
     n = M * C * 4

@@ -23,7 +23,7 @@ with open(sys.argv[2], "w") as fh:
                     round(util(d), 4)])
 fam = collections.defaultdict(lambda: collections.defaultdict(float))
 for k, c, d in out:
-    f = "gemm_family" if "gemm_" in k else "xattn" if "xattn" in k else "mha_mfma" if "mha_mfma" in k else "other"
+    f = "gemm_family" if ("gemm_" in k or "wgrad3x3_direct" in k) else "xattn" if "xattn" in k else "mha_mfma" if "mha_mfma" in k else "other"
     for n, v in d.items():
         fam[f][n] += v
 summ = {"steps_profiled": steps,

@@ -22,7 +22,7 @@ with open(out_csv, "w") as fh:
     cw.writerow(["Kernel", "LaunchesPerStep", "FetchBytesPerStep(x2 corrected)", "WriteBytesPerStep"])
     for r in rows:
         cw.writerow([r[0], round(r[1], 2), int(r[2]), int(r[3])])
-fam = [r for r in rows if "gemm_fast_kernel" in r[0] or "gemm_kernel" in r[0]]
+fam = [r for r in rows if "gemm_fast_kernel" in r[0] or "gemm_kernel" in r[0] or "wgrad3x3_direct" in r[0]]
 summ = {"steps_profiled": steps, "gemm_family": {"launches_per_step": sum(r[1] for r in fam),
         "fetch_bytes_per_step": int(sum(r[2] for r in fam)), "write_bytes_per_step": int(sum(r[3] for r in fam))},
         "all_kernels": {"fetch_bytes_per_step": int(sum(r[2] for r in rows)), "write_bytes_per_step": int(sum(r[3] for r in rows))},

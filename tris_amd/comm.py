@@ -227,6 +227,23 @@ class Mailbox:
                                                     self.SPIN_LIMIT, self.err.data_ptr(),
                                                     torch.cuda.current_stream().cuda_stream), "tris_mbox_bn_combine_f32")
 
+    def self_test(self):
+        """One real exchange before the transport is trusted: every rank posts (rank + 1) * [1, 2, 3, 4] and must read back
+        every peer's block within a short time-out (peer stores over xGMI that never become visible, a peer mapping that
+        silently aliases local memory, ... -> exception -> the caller falls back to torch.distributed on EVERY rank)."""
+        src = torch.arange(1, 5, device="cuda", dtype=torch.float32) * float(self.rank + 1)
+        out = torch.zeros(self.world * 4, device="cuda", dtype=torch.float32)
+        limit, self.SPIN_LIMIT = self.SPIN_LIMIT, min(self.SPIN_LIMIT, 4000000)
+        try:
+            self.exchange(src, out, 0)
+            torch.cuda.synchronize()
+        finally:
+            self.SPIN_LIMIT = limit
+        want = (torch.arange(1, self.world + 1, device="cuda", dtype=torch.float32)[:, None] *
+                torch.arange(1, 5, device="cuda", dtype=torch.float32)[None, :]).reshape(-1)
+        if int(self.err.item()) != 0 or not torch.equal(out, want):
+            raise RuntimeError(f"mailbox self-test failed on rank {self.rank}: err={int(self.err.item())} got={out.tolist()}")
+
     def check(self):
         """host-side check of the time-out flag (synchronises): raise if an exchange was abandoned"""
         e = int(self.err.item())
@@ -249,9 +266,15 @@ class Mailbox:
         if os.environ.get("TRIS_SYNCBN_COMM", "mailbox") == "mailbox" and not torch.cuda.is_current_stream_capturing():
             try:
                 made = cls(group)
+                made.self_test()
             except Exception as e:
                 import warnings
                 warnings.warn(f"SyncBatchNorm mailboxes unavailable ({e!r}); using torch.distributed collectives")
+                if made is not None:
+                    try:
+                        made.close()
+                    except Exception:
+                        pass
                 made = None
             ok = torch.tensor([1.0 if made is not None else 0.0], device="cuda")
             all_reduce(ok, op=dist.ReduceOp.MIN, group=group)    # every rank must take the same path

@@ -802,10 +802,18 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
   const int forced = e ? atoi(e) : -1;
   if (forced == 0 || !halo_shape_ok(p)) return im2col();
   if (forced > 0) return (forced < kHaloN && halo_ok(p, forced)) ? direct(forced) : im2col();
+  bool any = false;
+  for (int id = 1; id < kHaloN; ++id) any = any || halo_ok(p, id);
+  if (!any) return im2col();
+  // static choice (no autotuning, or under stream capture), from the measured table in DESIGN.md: the 2-D patch kernels win
+  // wherever they apply (W, H multiples of 16: the stem and the 80 x 80 stages); the flattened-window kernels pay only for the
+  // data gradients of the 40 x 40 / 20 x 20 stages from 256 channels up
   int first = 0;
-  for (int id = 1; id < kHaloN && !first; ++id)
-    if (halo_ok(p, id)) first = id;
-  if (!first) return im2col();
+  if (p.N <= 32 && halo_ok(p, 3)) first = 3;
+  else if (p.N <= 64 && halo_ok(p, 2)) first = 2;
+  else if (halo_ok(p, 6)) first = 6;
+  else if (halo_ok(p, 1)) first = 1;
+  else if (BKIND == B_KN_DGRAD && p.N >= 256 && p.gW >= 20 && halo_ok(p, 4)) first = 4;
   const TuneKey key = {A_HALO, BKIND + (stat ? 16 : 0), p.M, p.N, p.K, p.gH * 4096 + p.gW, g_gemm_mode};
   int cached = -1;
   {
@@ -816,9 +824,9 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
   if (cached >= 0) return cached ? direct(cached) : im2col();
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (!autotune_enabled() || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
-    return direct(first);
+    return first ? direct(first) : im2col();
   hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return direct(first);
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return first ? direct(first) : im2col();
   int rc = im2col();   // (tunes the implicit GEMM's own tile on first sight)
   if (rc != 0) return rc;
   hipDeviceSynchronize();
@@ -1261,9 +1269,10 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   auto usable = [&](int id) { return wg_ok(id, H, W, Cin, Cout) && wg_slices(id, B, H, W, Cin, Cout, ws_bytes) >= 1; };
   if (forced == 0 || !shape_ok) return gemm();
   if (forced > 0) return (forced < kWgN && usable(forced)) ? direct(forced) : gemm();
-  int first = 0;
-  for (int id = 1; id < kWgN && !first; ++id)
-    if (usable(id)) first = id;
+  int first = 0;   // static choice: the measured winners; the autotuner times every usable configuration
+  if (usable(1)) first = 1;
+  else if (usable(2)) first = 2;
+  else if (usable(5)) first = 5;
   if (!first) return gemm();
   const TuneKey key = {A_HALO, 64 + B_KN_IM2COL, p.M, p.N, p.K, H * 4096 + W, g_gemm_mode};
   int cached = -1;

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
                                                           const float* __restrict__ invstd, long M, int C, long ld,
                                                           long rows_per_block, double* __restrict__ part,
                                                           const float* __restrict__ gamma = nullptr,
-                                                          const float* __restrict__ beta = nullptr) {
+                                                          const float* __restrict__ beta = nullptr,
+                                                          float* __restrict__ dZ = nullptr) {
   __shared__ d4 l0[256];
   __shared__ d4 l1[256];
   const int CV = C >> 2;
@@ -54,7 +55,9 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         be = ld4(beta + c);
         sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
       }
-      auto accum = [&](const float4 x, float4 g, const float4 y) {
+      // MODE 1, dZ != NULL: the masked gradient dz is also WRITTEN (it is the gradient of the fused residual branch): the apply
+      // pass then reads dz and X only -- one activation-sized stream less over the two passes than masking twice from Y
+      auto accum = [&](const float4 x, float4 g, const float4 y, long o) {
         if (MODE == 0) {
           s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
           s1.x += (double)x.x * x.x; s1.y += (double)x.y * x.y; s1.z += (double)x.z * x.z; s1.w += (double)x.w * x.w;
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
             if (!(y.z > 0.f)) g.z = 0.f;
             if (!(y.w > 0.f)) g.w = 0.f;
           }
+          if (dZ) st4(dZ + o, g);
           s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
           s1.x += (double)(g.x * ((x.x - mu.x) * is.x)); s1.y += (double)(g.y * ((x.y - mu.y) * is.y));
           s1.z += (double)(g.z * ((x.z - mu.z) * is.z)); s1.w += (double)(g.w * ((x.w - mu.w) * is.w));
@@ -90,11 +94,11 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           y[u] = (MODE == 1 && Y) ? ld4(Y + o) : z4;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) accum(x[u], g[u], y[u]);
+        for (int u = 0; u < 4; ++u) accum(x[u], g[u], y[u], (r + (long)u * RS) * ld + c);
       }
       for (; r < rend; r += RS) {
         const long o = r * ld + c;
-        accum(ld4(X + o), (MODE == 1) ? ld4(dY + o) : z4, (MODE == 1 && Y) ? ld4(Y + o) : z4);
+        accum(ld4(X + o), (MODE == 1) ? ld4(dY + o) : z4, (MODE == 1 && Y) ? ld4(Y + o) : z4, o);
       }
     }
     __syncthreads();
@@ -681,13 +685,14 @@ extern "C" int tris_bn_apply_f32(const float* X, const float* mean, const float*
 
 extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean,
                                       const float* invstd, long M, int C, float* sum_dz, float* sum_dzx,
-                                      float* workspace, const float* gamma_mask, const float* beta_mask, void* stream) {
+                                      float* workspace, const float* gamma_mask, const float* beta_mask, float* dz_out,
+                                      void* stream) {
   if (C % 4) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   ColPlan p = col_plan(M, C);
   if ((gamma_mask == nullptr) != (beta_mask == nullptr)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, gamma_mask ? nullptr : Y, mean, invstd, M, C,
-                     (long)C, p.rpb, (double*)workspace, gamma_mask, beta_mask);
+                     (long)C, p.rpb, (double*)workspace, gamma_mask, beta_mask, dz_out);
   TRIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace, p.nb, C,
                      sum_dz, sum_dzx);

@@ -66,7 +66,9 @@ class GraphedFrozenText:
                     clip_model.encode_text(self.s_ids)
             torch.cuda.current_stream().wait_stream(cap)
             self.g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g):
+            # thread_local: other threads of the process (the collective backend's watchdog, the autograd engine of a previous
+            # step) may touch the device while this stream is capturing
+            with torch.cuda.graph(self.g, capture_error_mode="thread_local"):
                 self.out = clip_model.encode_text(self.s_ids)[1]
 
     def __call__(self, ids):

@@ -744,8 +744,13 @@ class BatchNormFn(torch.autograd.Function):
             p_dz, p_dzx = P(sums), P(sums, C)
         # BatchNorm + ReLU without a residual: the mask is recomputed from x inside the kernels, y is not read
         mask_x = relu and not has_res and y is None
+        # residual blocks (out = relu(bn(x) + identity)): the reduce pass writes the masked gradient dz -- which IS the identity
+        # branch's gradient -- and the apply pass reads it back instead of masking dy from y a second time
+        dz_first = want_dz and relu and y is not None and os.environ.get("TRIS_BN_DZ_FIRST", "1") != "0"   # (env: developer A/B knob)
+        if dz_first:
+            d_res = torch.empty_like(x)
         call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
-             P(gamma) if mask_x else None, P(beta) if mask_x else None, _stream())
+             P(gamma) if mask_x else None, P(beta) if mask_x else None, P(d_res) if dz_first else None, _stream())
         if mb is not None:
             # SyncBatchNorm: the arena keeps this rank's dbeta / dgamma (the data-parallel reducer averages them like every
             # other gradient); the sums over ALL ranks that dX needs come from one peer-mailbox launch reading the arena
@@ -759,7 +764,12 @@ class BatchNormFn(torch.autograd.Function):
                 from . import comm
                 comm.syncbn_all_reduce_sum(sums, group=group)
         dx = None
-        if ctx.needs_input_grad[0] or want_dz:
+        if dz_first:
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                call("tris_bn_bwd_apply_f32", P(d_res), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
+                     1.0 / float(count), P(dx), None, M, C, None, _stream())
+        elif ctx.needs_input_grad[0] or want_dz:
             dx = torch.empty_like(x)
             if want_dz:
                 d_res = torch.empty_like(x)
