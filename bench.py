@@ -148,6 +148,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_vals = losses.tolist()
+    transport = None
+    if world > 1 or force:
+        from tris_amd import comm
+        comm.check_errors()    # a SyncBatchNorm mailbox exchange that timed out must fail the run, not skew it
+        transport = "mailbox" if any(m is not None for m in comm.Mailbox._by_group.values()) else "torch.distributed"
 
     # ---- live roofline measurement of the dominant kernel family (one extra, untimed, instrumented step) ----
     # (kernels are timed one at a time: the stream overlap of the production step is switched off for this pass so that a
@@ -252,7 +257,7 @@ def main():
                                       ("configs[2]/[3])" if a.backbone == "clip-RN50" else
                                        "configs[4]; the reference defines no such model: parity unpinned, DESIGN.md)"),
                           "per_gpu_batch": a.batch, "global_batch": world * a.batch, "size": 320, "query_len": QL,
-                          "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1},
+                          "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1, "sync_bn_transport": transport},
                "untimed_priming_steps": 1, "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
                "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
                "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
