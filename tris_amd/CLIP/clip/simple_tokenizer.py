@@ -1,7 +1,8 @@
 """CLIP byte-level BPE tokenizer (host side of CLIP/clip/simple_tokenizer.py:62-133 in the reference).
 
-The merge table `bpe_simple_vocab_16e6.txt.gz` is OpenAI CLIP's data file; it is not vendored here.
-It is looked up at  $TRIS_BPE_VOCAB, next to this module, or in a reference checkout's CLIP/clip/.
+The merge table `bpe_simple_vocab_16e6.txt.gz` is OpenAI CLIP's vocabulary DATA file (MIT licence, the same file every CLIP
+distribution carries); it ships next to this module so that `clip.tokenize` / ReferDataset work on a machine without a
+reference checkout.  Lookup order: $TRIS_BPE_VOCAB, next to this module, a reference checkout's CLIP/clip/.
 """
 import gzip
 import html

@@ -1060,7 +1060,8 @@ static int wg_slices(int id, int B, int H, int W, int Ci, int Co, long ws_bytes)
   const WgCfg& c = kWg[id];
   const int tiles = (Co / c.cot) * (Ci / c.cit);
   const int units = B * (H / c.r) * (W / kWgXW[id]);
-  long s = std::max(1, 512 / tiles);   // two blocks per CU
+  static const int target = getenv("TRIS_WG_BLOCKS") ? atoi(getenv("TRIS_WG_BLOCKS")) : 512;   // developer knob; 512 = two blocks per CU
+  long s = std::max(1, target / tiles);
   s = std::min<long>(s, std::max(1, units / 8));
   const long per = (long)Co * 9 * Ci * (long)sizeof(float);
   if (s * per > ws_bytes) s = ws_bytes / per;
