@@ -84,6 +84,20 @@ int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* dX, int B, i
 int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout,
                            int stride, float* workspace, long workspace_bytes, void* stream);
 
+/* BatchNorm + ReLU folded into the consuming 3x3 convolution (CLIP/clip/model.py:45-46 `relu(bn1(conv1(x)))` -> conv2, and the
+ * stem's conv -> bn -> relu -> conv chain :255-258): conv3x3(relu((X - mean) * invstd * gamma + beta)), stride 1, with the
+ * normalised tensor formed inside the direct kernels' window staging (tris_bn_apply_f32's expression) -- it never exists in HBM.
+ * tris_conv3x3_bnin_ok (host query, x3 arithmetic only) says whether direct kernels serve BOTH the forward product and the weight
+ * gradient of the shape; when it returns 0 the caller materialises the BatchNorm output as usual.  fwd: stat_part / stat_rows
+ * as in tris_conv3x3_fwd_bnstat_f32 (NULL: no statistics).  The data gradient is tris_conv3x3_dgrad_f32 (it does not read X). */
+int tris_conv3x3_bnin_ok(int B, int H, int W, int Cin, int Cout);
+int tris_conv3x3_fwd_bnin_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout, double* stat_part,
+                              int* stat_rows, void* stream);
+int tris_conv3x3_wgrad_bnin_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const float* dY, float* dW, int B, int H, int W, int Cin, int Cout, float* workspace,
+                                long workspace_bytes, void* stream);
+
 /* Forward conv / 1x1 conv (A[M,K] . B[N,K]^T) with the train-mode BatchNorm statistics of the OUTPUT fused into the
  * epilogue: stat_part <- [rows][2][N] fp64 partial (sum, sum of squares), *stat_rows (HOST int) <- rows, or 0 when the
  * shape is not eligible (then call tris_bn_stats_f32).  stat_part capacity: ceil(M/128)*2*N doubles (rows <= ceil(M/128):

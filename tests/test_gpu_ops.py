@@ -191,6 +191,55 @@ def test_conv3x3_direct_kernels(cfg, B, H, W, Cin, Cout, monkeypatch):
         o.set_gemm_mode(prev)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 32, 32, 32), (2, 32, 16, 32, 64), (3, 16, 16, 64, 64), (1, 16, 48, 128, 128),
+                                            (2, 10, 10, 64, 64)])
+def test_batchnorm_relu_folded_into_the_direct_convolution(B, H, W, Cin, Cout, monkeypatch):
+    """conv3x3(relu(bn(x))) with the BatchNorm output never written (ops.batch_norm lazy=True -> the direct kernels normalise x
+    while staging their windows, forward and weight gradient) == the same chain with the BatchNorm output materialised; and
+    both against the fp32 CPU reference.  The last shape has no direct kernel: lazy must quietly fall back."""
+    from tris_amd import ops as o
+    from tris_amd._lib import query
+    prev = o.get_gemm_mode()
+    o.set_gemm_mode("x3")
+    try:
+        x, w = leaf(B, Cin, H, W), leaf(Cout, Cin, 3, 3, scale=0.1)
+        g0 = torch.rand(Cin, generator=torch.Generator().manual_seed(1)) + 0.5
+        b0 = torch.randn(Cin, generator=torch.Generator().manual_seed(2)) * 0.3
+        gam, bet = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = F.conv2d(F.relu(F.batch_norm(x, None, None, gam, bet, True, 0.1, 1e-5)), w, padding=1)
+        gy0 = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+        y.backward(gy0)
+        ok = o.conv3x3_bnin_ok((B, H, W, Cin), Cout)
+        assert ok == (H % 8 == 0 and W % 16 == 0)
+        outs = {}
+        for lazy in (False, True):
+            gx = x.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+            gw = w.detach().clone().contiguous(memory_format=torch.channels_last).cuda().requires_grad_(True)
+            gg, gb = g0.clone().cuda().requires_grad_(True), b0.clone().cuda().requires_grad_(True)
+            rm, rv = torch.zeros(Cin).cuda(), torch.ones(Cin).cuda()
+            n0 = (query("tris_direct_launches", 0), query("tris_direct_launches", 1))
+            a = o.batch_norm(gx, gg, gb, rm, rv, None, True, True, lazy=lazy and ok)
+            assert hasattr(a, "_bn_lazy") == (lazy and ok)
+            if lazy and ok:
+                a.detach().fill_(float("nan"))     # the buffer is never read: poison it
+            gy = o.conv3x3(a, gw, 1)
+            gy.backward(gy0.permute(0, 2, 3, 1).contiguous().cuda())
+            o.wgrad_join()
+            torch.cuda.synchronize()
+            if lazy and ok:
+                assert query("tris_direct_launches", 0) - n0[0] >= 1 and query("tris_direct_launches", 1) - n0[1] == 1
+            outs[lazy] = [t.detach().cpu() for t in (gy, gx.grad, gw.grad, gg.grad, gb.grad, rm, rv)]
+            close(gy.permute(0, 3, 1, 2), y, name=f"y[{lazy}]")
+            close(gx.grad.permute(0, 3, 1, 2), x.grad, 5e-4, name=f"dx[{lazy}]")
+            close(gw.grad, w.grad, name=f"dw[{lazy}]")
+            close(gg.grad, gam.grad, 5e-4, name=f"dgamma[{lazy}]")
+            close(gb.grad, bet.grad, 5e-4, name=f"dbeta[{lazy}]")
+        for u, v, name in zip(outs[True], outs[False], ("y", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")):
+            close(u, v, 5e-6, name="folded vs materialised: " + name)
+    finally:
+        o.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("cfg,B,H,W,Cin,Cout", [(1, 2, 8, 32, 32, 32), (1, 3, 12, 16, 32, 32), (2, 2, 16, 16, 32, 64),
                                                 (3, 2, 6, 32, 64, 64), (3, 1, 4, 16, 128, 192), (3, 5, 10, 48, 64, 128),
                                                 (2, 2, 8, 32, 64, 128), (4, 2, 8, 32, 64, 64), (4, 3, 12, 16, 128, 64),

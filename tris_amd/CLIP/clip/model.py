@@ -68,12 +68,12 @@ class BatchNorm2d(nn.Module):
             self.num_batches_tracked += self._nbt_pending
             self._nbt_pending = 0
 
-    def forward(self, x, resid=None, relu=False, grad_box=None):
+    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False):
         if self.training:
             self._nbt_pending += 1
         group = self.process_group if self.training else None
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
-                              self.training, self.momentum, self.eps, group, grad_box)
+                              self.training, self.momentum, self.eps, group, grad_box, lazy)
 
 
 class AvgPool2d(nn.Module):
@@ -113,7 +113,10 @@ class Bottleneck(nn.Module):
         # down-sampling block: the shortcut's input gradient (avg-pool or 1x1 conv backward) rides along the same way
         box = ops.GradBox() if (tr and torch.is_grad_enabled() and x.requires_grad
                                and os.environ.get("TRIS_GRAD_BOX", "1") != "0") else None
-        out = self.bn1(self.conv1(x, stats=tr, grad_box=box), relu=True)
+        out = self.conv1(x, stats=tr, grad_box=box)
+        # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
+        # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
+        out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout))
         out = self.bn2(self.conv2(out, stats=tr), relu=True)
         out = self.avgpool(out)
         out = self.conv3(out, stats=tr)
@@ -189,8 +192,10 @@ class ModifiedResNet(nn.Module):
         it to issue the text encoder (side stream) in the middle of the trunk, see model_stage1.TRIS.forward."""
         x = ops.nchw_to_nhwc(x.float())
         tr = self.training
-        x = self.bn1(self.conv1(x, stats=tr), relu=True)   # (conv1 has Cin=3: not eligible, separate statistics pass)
-        x = self.bn2(self.conv2(x, stats=tr), relu=True)
+        x = self.conv1(x, stats=tr)                        # (conv1 has Cin=3: not eligible, separate statistics pass)
+        x = self.bn1(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout))   # folded into conv2 where possible
+        x = self.conv2(x, stats=tr)
+        x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout))   # ... into conv3
         x = self.bn3(self.conv3(x, stats=tr), relu=True)
         x = self.avgpool(x)
         if hooks and "stem" in hooks:

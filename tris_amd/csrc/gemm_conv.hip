@@ -54,6 +54,8 @@ struct GemmParams {
   int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
   long bpl;         // B_NK_PRE: elements between the bf16 planes of B
   int hmode;        // A_HALO: window shape, 1 = BM consecutive pixels in padded coordinates, 2 = (BM/16) x 16 patches
+  // A_HALO, optional: the gathered tensor is the raw input x of a BatchNorm + ReLU; the kernel forms relu(bn(x)) in its window
+  const float *in_mean, *in_invstd, *in_gamma, *in_beta;
 };
 
 constexpr int BK = 16;
@@ -787,16 +789,32 @@ int run_halo(GemmParams p, int id, hipStream_t st) {
 // 3x3 convolution, stride 1 (forward and data gradient): direct kernel or implicit GEMM, timed once per shape like the tile
 // choice.  TRIS_CONV_DIRECT=0 keeps the implicit GEMM, =1..6 forces a direct configuration where it applies (tests).
 // *stat_rows (when statistics are fused) = number of partial rows the chosen kernel writes.
+// static choice (no autotuning, or under stream capture), from the measured table in DESIGN.md: the 2-D patch kernels win
+// wherever they apply (W, H multiples of 16: the stem and the 80 x 80 stages); the flattened-window kernels pay only for the
+// data gradients of the 40 x 40 / 20 x 20 stages from 256 channels up.  0 = implicit GEMM.
+static int halo_static_choice(const GemmParams& p, bool dgrad) {
+  if (p.N <= 32 && halo_ok(p, 3)) return 3;
+  if (p.N <= 64 && halo_ok(p, 2)) return 2;
+  if (halo_ok(p, 6)) return 6;
+  if (halo_ok(p, 1)) return 1;
+  if (dgrad && p.N >= 256 && p.gW >= 20 && halo_ok(p, 4)) return 4;
+  return 0;
+}
+
+// direct_only: the caller needs a direct kernel (p.in_mean: BatchNorm + ReLU folded into the window staging) and has checked
+// with tris_conv3x3_bnin_ok that one applies: the implicit GEMM is neither timed nor chosen.
 template <int BKIND>
-int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
+int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_only = false) {
   const bool stat = p.stat_part != nullptr;
-  auto im2col = [&]() {
-    if (stat_rows) *stat_rows = stat ? cdiv(p.M, 128) : 0;
-    return launch_cfg<A_IM2COL, BKIND>(p, 1, nullptr, 0, st);
-  };
+  const int first = halo_shape_ok(p) ? halo_static_choice(p, BKIND == B_KN_DGRAD) : 0;
   auto direct = [&](int id) {
     if (stat_rows) *stat_rows = stat ? halo_tiles_m(p, id) : 0;
     return run_halo<BKIND>(p, id, st);
+  };
+  auto im2col = [&]() {
+    if (direct_only) return first ? direct(first) : (int)hipErrorInvalidValue;   // (stands in for "the default" below)
+    if (stat_rows) *stat_rows = stat ? cdiv(p.M, 128) : 0;
+    return launch_cfg<A_IM2COL, BKIND>(p, 1, nullptr, 0, st);
   };
   const char* e = getenv("TRIS_CONV_DIRECT");   // read per call: tests switch it at run time
   const int forced = e ? atoi(e) : -1;
@@ -805,16 +823,7 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
   bool any = false;
   for (int id = 1; id < kHaloN; ++id) any = any || halo_ok(p, id);
   if (!any) return im2col();
-  // static choice (no autotuning, or under stream capture), from the measured table in DESIGN.md: the 2-D patch kernels win
-  // wherever they apply (W, H multiples of 16: the stem and the 80 x 80 stages); the flattened-window kernels pay only for the
-  // data gradients of the 40 x 40 / 20 x 20 stages from 256 channels up
-  int first = 0;
-  if (p.N <= 32 && halo_ok(p, 3)) first = 3;
-  else if (p.N <= 64 && halo_ok(p, 2)) first = 2;
-  else if (halo_ok(p, 6)) first = 6;
-  else if (halo_ok(p, 1)) first = 1;
-  else if (BKIND == B_KN_DGRAD && p.N >= 256 && p.gW >= 20 && halo_ok(p, 4)) first = 4;
-  const TuneKey key = {A_HALO, BKIND + (stat ? 16 : 0), p.M, p.N, p.K, p.gH * 4096 + p.gW, g_gemm_mode};
+  const TuneKey key = {A_HALO, BKIND + (stat ? 16 : 0) + (direct_only ? 32 : 0), p.M, p.N, p.K, p.gH * 4096 + p.gW, g_gemm_mode};
   int cached = -1;
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);   // (released before the launch: the implicit GEMM looks up its own tile under it)
@@ -881,7 +890,9 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows) {
 template <int COT, int CIT, int WCO, int WCI, int WK, int R, int OCC = 2, int XW = 16>
 __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                                  float* __restrict__ slab, int H, int W, int Ci, int Co,
-                                                                 int n_ci_tiles, int units_per_block, int n_units) {
+                                                                 int n_ci_tiles, int units_per_block, int n_units,
+                                                                 const float* __restrict__ in_mean, const float* __restrict__ in_invstd,
+                                                                 const float* __restrict__ in_gamma, const float* __restrict__ in_beta) {
   // XW = window width in pixels: 16 (a 16-pixel k group = one window row) or 8 (= two window rows: W = 40)
   constexpr int NPX = R * XW, NSL = (R + 2) * (XW + 2), PITCH = XW + 2, NG = NPX / 16;
   static_assert(WCO * WCI * WK == 4 && COT == 32 * WCO && CIT == 32 * WCI && NG % WK == 0 && (XW == 16 || XW == 8), "wave layout");
@@ -904,6 +915,17 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   float4 ra[PA], rx[PX];
+  // in_mean != NULL: X is the raw input of a BatchNorm + ReLU and the convolution's input relu(bn(X)) is formed here, once per
+  // window slot (tris_bn_apply_f32's expression); a thread always stages the same four input channels
+  unsigned rx_ok = 0;
+  float4 x_mu = make_float4(0.f, 0.f, 0.f, 0.f), x_sc = x_mu, x_be = x_mu;
+  if (in_mean != nullptr) {
+    const int c = ci0 + (tid % (CIT / 4)) * 4;
+    const float4 is = ld4(in_invstd + c), ga = ld4(in_gamma + c);
+    x_mu = ld4(in_mean + c);
+    x_be = ld4(in_beta + c);
+    x_sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+  }
   auto load_unit = [&](int u) {
     const int b = u / upi, r0 = u - b * upi;
     const int y0 = (r0 / xsn) * R, x0 = (r0 - (r0 / xsn) * xsn) * XW;
@@ -922,6 +944,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
       const bool ok = sl < NSL && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const float4 v = ld4(X + (ok ? ((long)(b * H + iy) * W + ix) * Ci + ci0 + c4 * 4 : 0));
       rx[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx_ok = ok ? (rx_ok | (1u << q)) : (rx_ok & ~(1u << q));
     }
   };
   auto store_unit = [&]() {
@@ -940,7 +963,14 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
       const int j = tid + q * 256;
       const int sl = j / (CIT / 4), c4 = j - sl * (CIT / 4);
       if (PX * 256 * 4 == NSL * CIT || sl < NSL) {
-        const Split4 sp = split4(rx[q]);
+        float4 v = rx[q];
+        if (in_mean != nullptr && ((rx_ok >> q) & 1u)) {
+          v.x = fmaxf((v.x - x_mu.x) * x_sc.x + x_be.x, 0.f);
+          v.y = fmaxf((v.y - x_mu.y) * x_sc.y + x_be.y, 0.f);
+          v.z = fmaxf((v.z - x_mu.z) * x_sc.z + x_be.z, 0.f);
+          v.w = fmaxf((v.w - x_mu.w) * x_sc.w + x_be.w, 0.f);
+        }
+        const Split4 sp = split4(v);
         char* d = Xsh + sl * KS_X + c4 * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + NSL * KS_X) = sp.mid;
@@ -1067,8 +1097,9 @@ static int wg_slices(int id, int B, int H, int W, int Ci, int Co, long ws_bytes)
   if (s * per > ws_bytes) s = ws_bytes / per;
   return (int)s;
 }
+struct BnIn { const float *mean, *invstd, *gamma, *beta; };
 static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co, float* ws,
-                            long ws_bytes, hipStream_t st) {
+                            long ws_bytes, hipStream_t st, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
   const WgCfg& c = kWg[id];
   const int S = wg_slices(id, B, H, W, Ci, Co, ws_bytes);
   if (S < 1) return (int)hipErrorInvalidValue;
@@ -1078,11 +1109,11 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
   dim3 grid((unsigned)((Co / c.cot) * (Ci / c.cit)), (unsigned)slices);
   const int nci = Ci / c.cit;
   switch (id) {
-    case 1: hipLaunchKernelGGL((wgrad3x3_direct_kernel<32, 32, 1, 1, 4, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
-    case 2: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
-    case 3: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 2>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
-    case 4: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 4, 1>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
-    case 5: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 8, 2, 8>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units); break;
+    case 1: hipLaunchKernelGGL((wgrad3x3_direct_kernel<32, 32, 1, 1, 4, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
+    case 2: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
+    case 3: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 2>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
+    case 4: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 4, 1>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
+    case 5: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 8, 2, 8>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
     default: return (int)hipErrorInvalidValue;
   }
   TRIS_LAUNCH_CHECK();
@@ -1363,6 +1394,70 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   p.fastB = p.vecB;
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, stat_rows);
+}
+
+// ---- BatchNorm + ReLU folded into the consuming 3x3 convolution ------------------------------------------------------------
+// conv3x3(relu(bn(X))) without relu(bn(X)) ever existing in HBM: the direct kernels apply the normalisation while they stage
+// their window (forward: gemm_fast.h A_HALO; weight gradient: wgrad3x3_direct_kernel).  Only where a direct kernel serves BOTH
+// products -- tris_conv3x3_bnin_ok says so -- otherwise the caller materialises relu(bn(X)) with tris_bn_apply_f32 as before.
+static bool bnin_enabled() {
+  const char *a = getenv("TRIS_CONV_DIRECT"), *b = getenv("TRIS_WGRAD_DIRECT"), *c = getenv("TRIS_BN_FOLD");
+  return g_gemm_mode == 1 && !(a && atoi(a) == 0) && !(b && atoi(b) == 0) && !(c && c[0] == '0');
+}
+static GemmParams conv3_fwd_params(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout) {
+  GemmParams p = {};
+  p.A = X; p.B = Wt; p.C = Y;
+  p.M = B * H * W; p.N = Cout; p.K = 9 * Cin;
+  p.ldb = 9L * Cin; p.ldc = Cout; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cin; p.gHo = H; p.gWo = W; p.gStride = 1; p.gB = B;
+  p.vecA = al16(X) && (Cin % 16 == 0);
+  p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
+  p.fastA = al16(X) && (Cin % 32 == 0);
+  p.fastB = p.vecB;
+  return p;
+}
+static int wg_static_choice(int B, int H, int W, int Cin, int Cout, long ws_bytes) {
+  for (int id : {1, 2, 5})
+    if (wg_ok(id, H, W, Cin, Cout) && wg_slices(id, B, H, W, Cin, Cout, ws_bytes) >= 1) return id;
+  return 0;
+}
+
+extern "C" int tris_conv3x3_bnin_ok(int B, int H, int W, int Cin, int Cout) {
+  if (!bnin_enabled() || Cin % 16 != 0 || Cout % 4 != 0) return 0;
+  GemmParams p = conv3_fwd_params(reinterpret_cast<const float*>(16), reinterpret_cast<const float*>(16),
+                                  reinterpret_cast<float*>(16), B, H, W, Cin, Cout);   // (shape test only: aligned dummies)
+  return halo_shape_ok(p) && halo_static_choice(p, false) > 0 && wg_static_choice(B, H, W, Cin, Cout, 64L << 20) > 0;
+}
+
+extern "C" int tris_conv3x3_fwd_bnin_f32(const float* X, const float* mean, const float* invstd, const float* gamma,
+                                         const float* beta, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout,
+                                         double* stat_part, int* stat_rows, void* stream) {
+  GemmParams p = conv3_fwd_params(X, Wt, Y, B, H, W, Cin, Cout);
+  if (!bnin_enabled() || !halo_shape_ok(p) || halo_static_choice(p, false) == 0 || !al16(mean) || !al16(invstd) || !al16(gamma) ||
+      !al16(beta))
+    return (int)hipErrorInvalidValue;   // ask tris_conv3x3_bnin_ok first
+  p.in_mean = mean; p.in_invstd = invstd; p.in_gamma = gamma; p.in_beta = beta;
+  p.stat_part = (stat_part != nullptr && p.fastA && p.M >= 128) ? stat_part : nullptr;
+  if (stat_rows) *stat_rows = 0;
+  return conv3_dispatch<B_NK>(p, (hipStream_t)stream, stat_rows, true);
+}
+
+extern "C" int tris_conv3x3_wgrad_bnin_f32(const float* X, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout,
+                                           float* workspace, long ws_bytes, void* stream) {
+  if (!bnin_enabled() || workspace == nullptr || !al16(X) || !al16(dY) || !al16(dW) || !al16(workspace) || !al16(mean) ||
+      !al16(invstd) || !al16(gamma) || !al16(beta))
+    return (int)hipErrorInvalidValue;
+  int id = wg_static_choice(B, H, W, Cin, Cout, ws_bytes);
+  if (id == 0) return (int)hipErrorInvalidValue;
+  {  // the configuration the plain weight gradient timed as fastest for this shape, if it is a direct one
+    const TuneKey key = {A_HALO, 64 + B_KN_IM2COL, Cout, 9 * Cin, B * H * W, H * 4096 + W, g_gemm_mode};
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end() && it->second.bm > 0) id = it->second.bm;
+  }
+  return run_wgrad_direct(id, X, dY, dW, B, H, W, Cin, Cout, workspace, ws_bytes, (hipStream_t)stream,
+                          BnIn{mean, invstd, gamma, beta});
 }
 
 // ---- pre-split weight operands ("weight planes") ---------------------------------------------------------------------------

@@ -265,7 +265,18 @@ void gemm_fast_kernel(GemmParams p) {
     if (HALO && p.hmode == 2) return (h_b * p.gH + h_y0 + (rl >> 4)) * p.gW + h_x0 + (rl & 15);
     return m0 + rl;
   };
+  // p.in_mean != NULL: the gathered tensor is the RAW input of a BatchNorm + ReLU (x, not y = relu((x - mean) * invstd * gamma
+  // + beta)): y is formed here, once per window slot, with tris_bn_apply_f32's own expression -- y never exists in HBM.  A thread
+  // always stages the same 4-channel group of a chunk ((tid + q NTHR) & 3 == tid & 3), so its constants are three float4.
+  float4 h_mu = make_float4(0.f, 0.f, 0.f, 0.f), h_sc = h_mu, h_be = h_mu;
   auto load_halo = [&](float4 (&hr)[HP], int c0) {
+    if (p.in_mean != nullptr) {   // uniform
+      const int c = c0 + (tid & 3) * 4;
+      const float4 is = ld4(p.in_invstd + c), ga = ld4(p.in_gamma + c);
+      h_mu = ld4(p.in_mean + c);
+      h_be = ld4(p.in_beta + c);
+      h_sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+    }
 #pragma unroll
     for (int q = 0; q < HP; ++q) {
       const bool ok = h_pix[q] >= 0;
@@ -278,7 +289,14 @@ void gemm_fast_kernel(GemmParams p) {
     for (int q = 0; q < HP; ++q) {
       const int j = tid + q * NTHR;
       if (HP * NTHR == HS * 4 || j < HS * 4) {
-        const Split4 sp = split4(hr[q]);
+        float4 v = hr[q];
+        if (p.in_mean != nullptr && h_pix[q] >= 0) {   // (padding slots stay zero: the convolution pads y, not x)
+          v.x = fmaxf((v.x - h_mu.x) * h_sc.x + h_be.x, 0.f);
+          v.y = fmaxf((v.y - h_mu.y) * h_sc.y + h_be.y, 0.f);
+          v.z = fmaxf((v.z - h_mu.z) * h_sc.z + h_be.z, 0.f);
+          v.w = fmaxf((v.w - h_mu.w) * h_sc.w + h_be.w, 0.f);
+        }
+        const Split4 sp = split4(v);
         // image [plane][channel half kh][slot][8 ch]: a fragment read is 16 lanes x 16 contiguous bytes (conflict-free without
         // padding); the four 8-byte pieces of a slot go to two 64-byte windows HS*16 bytes apart (HS % 8 == 4: disjoint banks)
         char* d = reinterpret_cast<char*>(Ad) + (j >> 2) * 16 + ((j >> 1) & 1) * (HS * 16) + (j & 1) * 8;

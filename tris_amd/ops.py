@@ -577,12 +577,34 @@ class Conv3x3Fn(torch.autograd.Function):
     """x [B,H,W,Cin] channels-last, w [Cout,Cin,3,3] in channels_last memory, pad 1, stride 1|2."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, stats=False):
+    def forward(ctx, x, w, stride, stats=False, lazy=None):
+        """lazy = (x_raw, mean, invstd, gamma, beta): `x` is the NOT-YET-WRITTEN output buffer of a BatchNorm + ReLU over x_raw
+        (batch_norm(..., lazy=True)); the direct kernels normalise x_raw while they stage it and `x` is never written -- or, when
+        they cannot serve the shape after all, it is written here first and everything proceeds as usual."""
         _chk(x, w)
         x = x.contiguous()
         ctx.params = (w,)
         w = cl_weight(w)
         B, H, W, Cin = x.shape
+        ctx.lazy = None
+        if lazy is not None:
+            xr, mean, invstd, gamma, beta = lazy
+            if stride == 1 and _planes(ctx.params[0]) is None and conv3x3_bnin_ok(x.shape, w.shape[0]):
+                Cout = w.shape[0]
+                y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
+                fl = 2.0 * B * H * W * Cout * 9 * Cin
+                if stats:
+                    _launch_with_stats(y, B * H * W, Cout, lambda part, rows: _timed(
+                        "conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnin_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta),
+                                                        P(w), P(y), B, H, W, Cin, Cout, part.data_ptr(), rows, _stream())))
+                else:
+                    _timed("conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnin_f32", P(xr), P(mean), P(invstd), P(gamma),
+                                                           P(beta), P(w), P(y), B, H, W, Cin, Cout, None, None, _stream()))
+                ctx.stride = stride
+                ctx.lazy = True
+                ctx.save_for_backward(xr, w, mean, invstd, gamma, beta)
+                return y
+            call("tris_bn_apply_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta), None, P(x), B * H * W, Cin, 1, _stream())
         Cout = w.shape[0]
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
@@ -616,7 +638,10 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     @_bwd_arith
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        if ctx.lazy:
+            x, w, mean, invstd, gamma, beta = ctx.saved_tensors   # x = the BatchNorm's raw input
+        else:
+            x, w = ctx.saved_tensors
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         dy = dy.contiguous()
@@ -635,22 +660,38 @@ class Conv3x3Fn(torch.autograd.Function):
 
         def wgrad(o):
             ws = workspace(0)
-            _wgrad_arith(lambda: _timed(
-                "conv3x3_wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin,
-                lambda: call("tris_conv3x3_wgrad_f32", P(x), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws),
-                             ws.numel() * 4, _stream())))
+            fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin
+
+            def run():
+                xin = x
+                if ctx.lazy:
+                    if conv3x3_bnin_ok(x.shape, Cout):   # (asked again: the weight gradients may run in another arithmetic)
+                        return _timed("conv3x3_wgrad", fl, lambda: call(
+                            "tris_conv3x3_wgrad_bnin_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(dy), P(o), B, H, W, Cin,
+                            Cout, P(ws), ws.numel() * 4, _stream()))
+                    xin = torch.empty_like(x)   # materialise relu(bn(x)) after all
+                    call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
+                return _timed("conv3x3_wgrad", fl, lambda: call(
+                    "tris_conv3x3_wgrad_f32", P(xin), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))
+            _wgrad_arith(run)
         dw = None
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
             if sk is not None:
-                on_wgrad_stream(lambda: wgrad(sk), dy, x)
+                on_wgrad_stream(lambda: wgrad(sk), dy, x, *((mean, invstd) if ctx.lazy else ()))
             else:
                 dw = _emit(ctx.params[0], wgrad, True)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
+
+
+def conv3x3_bnin_ok(xshape, Cout):
+    """can conv3x3(relu(bn(x))) run with the BatchNorm folded into the direct kernels (forward AND weight gradient)?"""
+    B, H, W, Cin = xshape
+    return os.environ.get("TRIS_WEIGHT_PLANES", "0") != "1" and bool(query("tris_conv3x3_bnin_ok", B, H, W, Cin, Cout))
 
 
 def conv3x3(x, w, stride=1, stats=False):
-    y = Conv3x3Fn.apply(x, w, stride, stats)
+    y = Conv3x3Fn.apply(x, w, stride, stats, getattr(x, "_bn_lazy", None))
     return _attach_stats(y) if stats else y
 
 
@@ -662,7 +703,8 @@ class BatchNormFn(torch.autograd.Function):
     SyncBatchNorm).  training=False: running statistics (forward only)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None, grad_box=None):
+    def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None, grad_box=None,
+                lazy=False):
         _chk(x, gamma, beta, rmean, rvar, resid)
         x = x.contiguous()
         C = x.shape[-1]
@@ -703,8 +745,14 @@ class BatchNormFn(torch.autograd.Function):
         else:
             mean = rmean
             invstd = torch.rsqrt(rvar + eps)
-        call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
-             _stream())
+        # lazy: y stays UNWRITTEN -- its only consumer (a 3x3 convolution with direct kernels) normalises x while staging it
+        lazy = bool(lazy and training and relu and resid is None and os.environ.get("TRIS_BN_MASK_X", "1") != "0")
+        if not lazy:
+            call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
+                 _stream())
+        if lazy:
+            global _LAZY_SRC
+            _LAZY_SRC = (x, mean, invstd, gamma, beta)
         ctx.cfg = (M, C, bool(relu), resid is not None, count, group)
         ctx.grad_box = grad_box
         ctx.params = (gamma, beta)
@@ -777,13 +825,24 @@ class BatchNormFn(torch.autograd.Function):
                  1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
         if ctx.grad_box is not None and d_res is not None and ctx.grad_box.deposit(d_res):
             d_res = None   # handed to the block's first conv
-        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None
+
+
+_LAZY_SRC = None
 
 
 def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-               grad_box=None):
+               grad_box=None, lazy=False):
+    """lazy=True (train-mode BatchNorm + ReLU whose ONLY consumer is ops.conv3x3, and conv3x3_bnin_ok said yes): the returned
+    tensor is an unwritten buffer carrying `_bn_lazy`; pass it to ops.conv3x3 and nowhere else."""
+    global _LAZY_SRC
     part = getattr(x, "_bn_part", None) if training else None
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box)
+    _LAZY_SRC = None
+    y = BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy)
+    if _LAZY_SRC is not None:
+        y._bn_lazy = _LAZY_SRC
+        _LAZY_SRC = None
+    return y
 
 
 class AvgPool2Fn(torch.autograd.Function):
