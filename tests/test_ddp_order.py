@@ -35,7 +35,7 @@ def _install_standins(mp):
         return y if resid is None else y + resid
 
     def batch_norm(x, g, b, rm, rv, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-                   grad_box=None):
+                   grad_box=None, lazy=False):
         y = x * g + b          # (statistics are irrelevant for the order of the graph)
         if resid is not None:
             y = y + resid
@@ -83,7 +83,8 @@ def _install_standins(mp):
         cls = score.mean(1)
         return cls, cls.diagonal().detach(), torch.relu(m), torch.sigmoid(m)
 
-    for name, fn in dict(nchw_to_nhwc=nchw_to_nhwc, conv3x3=conv3x3, linear=linear, batch_norm=batch_norm,
+    for name, fn in dict(nchw_to_nhwc=nchw_to_nhwc, conv3x3=conv3x3, conv3x3_bnin_ok=lambda shape, cout: False, linear=linear,
+                         batch_norm=batch_norm,
                          avgpool2=avgpool2, embed=embed, layer_norm=layer_norm, mha=mha, eot_gather=eot_gather,
                          matmul=matmul, bmm=bmm, l2norm=l2norm, instance_norm=instance_norm, xattn=xattn,
                          score_heads=score_heads, quick_gelu=torch.sigmoid, axpy=lambda a, b, s: s * a + b).items():
