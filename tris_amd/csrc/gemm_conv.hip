@@ -723,6 +723,94 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
 
 
 
+
+// ---- the stem's first convolution (Cin = 3, stride 2): dedicated forward ----------------------------------------------------
+// [B,320,320,3] -> [B,160,160,32]: K = 27 does not fill an MFMA k tile of the tiled kernels (16 TFLOP/s as an implicit GEMM with
+// 128 us for a product whose HBM floor is ~40 us).  Here a wave owns 32 consecutive output pixels x 32 channels per trip: the
+// 27 (padded to 28) weights of its (channel, k half) live in registers for the whole kernel, the input values are gathered
+// straight into the A operand of v_mfma_f32_32x32x2_f32 (exact fp32: 14 MFMAs per tile), the 32 x 32 result is stored as sixteen
+// 128-byte pixel rows.  The BatchNorm statistics of the output come from the same registers (one fp64 partial row per block).
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                         float* __restrict__ Y, double* __restrict__ stat_part, int Bn, int H,
+                                                         int W, int Cin, int Cout, int Ho, int Wo, int stride, int tiles_per_wave) {
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mn = lane & 31, kh = lane >> 5;
+  const int K = 9 * Cin;
+  const long total = (long)Bn * Ho * Wo;
+  float wreg[14];
+  int ky[14], kx[14], kc[14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k = 2 * s + kh;
+    const int tap = k / Cin;
+    wreg[s] = (k < K && mn < Cout) ? Wt[mn * K + k] : 0.f;
+    ky[s] = k < K ? tap / 3 : -100000;   // (an always-out-of-range row: the padded k contributes zero)
+    kx[s] = tap - (tap / 3) * 3;
+    kc[s] = k - tap * Cin;
+  }
+  float s1 = 0.f, s2 = 0.f;
+  const long tile0 = ((long)blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int t = 0; t < tiles_per_wave; ++t) {
+    const long p0 = (tile0 + t) * 32;
+    if (p0 >= total) break;   // (wave-uniform)
+    const long p = min(p0 + mn, total - 1);
+    const int b = (int)(p / ((long)Ho * Wo));
+    const int r = (int)(p - (long)b * Ho * Wo);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+    float a[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+      const int iy = iy0 + ky[s], ix = ix0 + kx[s];
+      const bool inb = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      a[s] = inb ? X[(((long)b * H + iy) * W + ix) * Cin + kc[s]] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {  // D[row = (q&3) + 8*(q>>2) + 4*kh][col = mn]
+      const long pix = p0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+      if (pix < total && mn < Cout) {
+        const float v = acc[q];
+        Y[pix * Cout + mn] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (stat_part != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (kh == 0) { red[wave][0][mn] = s1; red[wave][1][mn] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      if (c < Cout)
+        stat_part[((long)blockIdx.x * 2 + which) * Cout + c] =
+            (double)red[0][which][c] + (double)red[1][which][c] + (double)red[2][which][c] + (double)red[3][which][c];
+    }
+  }
+}
+// rows of the fp64 partial buffer = blocks launched; 0 = shape not served
+static int run_stem_conv1(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout, int stride,
+                          double* stat_part, hipStream_t st) {
+  if (9 * Cin > 28 || Cout > 32 || (stride != 1 && stride != 2)) return 0;
+  static const bool on = !(getenv("TRIS_STEM_CONV1") && getenv("TRIS_STEM_CONV1")[0] == '0');   // developer A/B knob
+  if (!on) return 0;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const long tiles = cdiv((long)B * Ho * Wo, 32L);
+  int nblk = (int)std::min<long>(512, cdiv(tiles, 4L));
+  if (stat_part != nullptr && nblk > cdiv(B * Ho * Wo, 128)) nblk = std::max(1, cdiv(B * Ho * Wo, 128));   // partial-buffer capacity
+  const int tpw = (int)cdiv(tiles, (long)nblk * 4);
+  nblk = (int)cdiv(tiles, (long)tpw * 4);
+  hipLaunchKernelGGL(stem_conv1_kernel, dim3(nblk), dim3(256), 0, st, X, Wt, Y, stat_part, B, H, W, Cin, Cout, Ho, Wo, stride, tpw);
+  return hipGetLastError() == hipSuccess ? nblk : -1;
+}
+
 // ---- direct 3x3 convolution: configurations of the A_HALO kernels (gemm_fast.h) and the choice between them and the
 // implicit GEMM ---------------------------------------------------------------------------------------------------------------
 static long g_direct_launches[2] = {0, 0};   // diagnostics: launches of the direct convolution / direct weight-gradient kernels
@@ -1161,6 +1249,8 @@ extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, i
   p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
   p.fastA = al16(X) && (Cin % 32 == 0);
   p.fastB = p.vecB;
+  if (const int rows = run_stem_conv1(X, Wt, Y, B, H, W, Cin, Cout, stride, nullptr, (hipStream_t)stream))
+    return rows > 0 ? 0 : (int)hipErrorLaunchFailure;
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, nullptr);
 }
 
@@ -1392,6 +1482,10 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   p.vecB = al16(Wt) && ((9 * Cin) % 4 == 0);
   p.fastA = al16(X) && (Cin % 32 == 0);
   p.fastB = p.vecB;
+  if (const int rows = run_stem_conv1(X, Wt, Y, B, H, W, Cin, Cout, stride, p.M >= 128 ? stat_part : nullptr, (hipStream_t)stream)) {
+    *stat_rows = (rows > 0 && p.M >= 128 && stat_part != nullptr) ? rows : 0;
+    return rows > 0 ? 0 : (int)hipErrorLaunchFailure;
+  }
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, stat_rows);
 }
