@@ -668,18 +668,18 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   const bool can_pipe = pipe_ok(p) && BKIND != B_NK_PRE && forced_pipe() != 0;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
-  hipDeviceSynchronize();  // drain the other streams: candidates are timed on an otherwise idle device
+  (void)hipDeviceSynchronize();  // drain the other streams: candidates are timed on an otherwise idle device
   Cfg best = h;
   float best_ms = 1e30f;
   auto time_cfg = [&](Cfg c) -> float {
     float ms_min = 1e30f;
     for (int rep = 0; rep < 2; ++rep) {
-      hipEventRecord(e0, st);
+      (void)hipEventRecord(e0, st);
       if (run_cfg<AK, BKIND>(p, batch, ws, st, c) != 0) return 1e30f;
-      hipEventRecord(e1, st);
+      (void)hipEventRecord(e1, st);
       if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
       float ms = 1e30f;
-      hipEventElapsedTime(&ms, e0, e1);
+      (void)hipEventElapsedTime(&ms, e0, e1);
       ms_min = ms < ms_min ? ms : ms_min;
     }
     return ms_min;
@@ -703,8 +703,8 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
       }
     }
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
@@ -926,16 +926,16 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_on
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return first ? direct(first) : im2col();
   int rc = im2col();   // (tunes the implicit GEMM's own tile on first sight)
   if (rc != 0) return rc;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   auto timed = [&](int id) -> float {
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-      hipEventRecord(e0, st);
+      (void)hipEventRecord(e0, st);
       if ((id ? direct(id) : im2col()) != 0) return 1e30f;
-      hipEventRecord(e1, st);
+      (void)hipEventRecord(e1, st);
       if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
       float ms = 1e30f;
-      hipEventElapsedTime(&ms, e0, e1);
+      (void)hipEventElapsedTime(&ms, e0, e1);
       best = ms < best ? ms : best;
     }
     return best;
@@ -948,8 +948,8 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_on
     const float ms = timed(id);
     if (ms < best_ms) { best_ms = ms; best_id = id; }
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = Cfg{best_id, 0, 1, 0, 0};
