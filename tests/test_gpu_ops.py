@@ -246,7 +246,7 @@ def test_batchnorm_relu_folded_into_the_direct_convolution(B, H, W, Cin, Cout, m
                                                 (5, 2, 8, 40, 32, 64), (5, 1, 16, 24, 96, 128)])
 def test_conv3x3_direct_weight_gradient(cfg, B, H, W, Cin, Cout, monkeypatch):
     """The direct 3x3 weight-gradient kernel (one split of each dY / input window, nine taps read the same LDS image;
-    tris_amd/csrc/gemm_conv.hip wgrad3x3_direct_kernel) against the fp32 CPU reference and the implicit GEMM."""
+    tris_amd/csrc/conv_direct.hip wgrad3x3_direct_kernel) against the fp32 CPU reference and the implicit GEMM."""
     from tris_amd import ops as o
     prev = o.get_gemm_mode()
     o.set_gemm_mode("x3")

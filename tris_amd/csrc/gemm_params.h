@@ -1,0 +1,40 @@
+// Shared by the GEMM / convolution translation units (gemm_conv.hip, conv_direct.hip): operand kinds, the launch parameter
+// block and the 16-byte load.  Included INSIDE each unit's anonymous namespace.
+#pragma once
+
+enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2, A_HALO = 3 };  // A_HALO: direct 3x3 convolution (gemm_fast.h)
+enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3, B_NK_PRE = 4 };  // B_NK_PRE: pre-split bf16 planes (fast x3 kernel only)
+enum { EPI_STD = 0, EPI_SLAB = 1 };
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long sA, sB, sC;  // batch strides (elements)
+  const float* bias;
+  int bias_mode;  // 0 none, 1 per column n, 2 per row m
+  const float* resid;
+  long ldr, sR;
+  int act;  // 0 none, 1 relu, 2 quick-gelu
+  float alpha;
+  int vecA, vecB;  // 16-byte vector loads legal for the operand
+  int fastA, fastB;  // operand satisfies the preconditions of gemm_fast_kernel
+  int vecC;          // 16-byte epilogue legal: C / resid / bias aligned, N and the leading dimensions multiples of 4 (set by run_cfg)
+  double* stat_part;  // optional fused BN statistics partials [tiles_m][2][N] (fast kernel, no split-K)
+  int kchunk, splitk;
+  int tiles_n;
+  // gather geometry (conv): gathered tensor [gB, gH, gW, gC] NHWC, output grid [gB, gHo, gWo], pad 1
+  int gH, gW, gC, gHo, gWo, gStride;
+  int xcd_remap;    // fast kernel: place all tiles of one split-K slice on one XCD (see gemm_fast.h)
+  int gB;           // images in the gathered tensor (B_KN_IM2COL: bounds the running pixel coordinates of surplus prefetches)
+  int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
+  long bpl;         // B_NK_PRE: elements between the bf16 planes of B
+  int hmode;        // A_HALO: window shape, 1 = BM consecutive pixels in padded coordinates, 2 = (BM/16) x 16 patches
+  // A_HALO, optional: the gathered tensor is the raw input x of a BatchNorm + ReLU; the kernel forms relu(bn(x)) in its window
+  const float *in_mean, *in_invstd, *in_gamma, *in_beta;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
