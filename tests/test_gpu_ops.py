@@ -596,19 +596,20 @@ def test_xattn_fused(ops, B, P, N, C):
 
 
 @pytest.mark.parametrize("kind,shape", [("conv3", (2, 20, 20, 32, 64)), ("conv3", (3, 24, 24, 64, 160)), ("conv1", (2, 16, 16, 64, 256)),
-                                        ("conv1", (1, 12, 12, 256, 64))])
+                                        ("conv1", (1, 12, 12, 256, 64)), ("stem", (3, 64, 48, 3, 32))])
 def test_fused_bn_statistics_in_conv_epilogue(ops, kind, shape):
     """conv -> train-mode BN with the statistics taken from the GEMM epilogue == the two-kernel path."""
     B, H, W, Cin, Cout = shape
     x = torch.randn(B, H, W, Cin, generator=torch.Generator().manual_seed(1)).cuda() * 2 + 1
-    k = 3 if kind == "conv3" else 1
+    k = 1 if kind == "conv1" else 3
+    stride = 2 if kind == "stem" else 1     # the stem's first convolution (Cin = 3, stride 2): its own kernel and statistics
     w = (torch.randn(Cout, Cin, k, k, generator=torch.Generator().manual_seed(2)) * 0.1).contiguous(
         memory_format=torch.channels_last).cuda()
     g, b = torch.rand(Cout).cuda() + 0.5, torch.randn(Cout).cuda()
 
     def run(stats):
         rm, rv = torch.zeros(Cout).cuda(), torch.ones(Cout).cuda()
-        y = ops.conv3x3(x, w, 1, stats=stats) if k == 3 else ops.linear(x, w, None, stats=stats)
+        y = ops.conv3x3(x, w, stride, stats=stats) if k == 3 else ops.linear(x, w, None, stats=stats)
         assert hasattr(y, "_bn_part") == stats
         return ops.batch_norm(y, g, b, rm, rv, None, True, True), rm, rv
     with torch.no_grad():

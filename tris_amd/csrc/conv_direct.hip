@@ -24,7 +24,7 @@ namespace {
 __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                          float* __restrict__ Y, double* __restrict__ stat_part, int Bn, int H,
                                                          int W, int Cin, int Cout, int Ho, int Wo, int stride, int tiles_per_wave) {
-  __shared__ float red[4][2][32];
+  __shared__ double red[4][2][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mn = lane & 31, kh = lane >> 5;
   const int K = 9 * Cin;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict
     kx[s] = tap - (tap / 3) * 3;
     kc[s] = k - tap * Cin;
   }
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;   // (fp64 like the separate statistics pass: the kernel is gather-bound, the adds are free)
   const long tile0 = ((long)blockIdx.x * 4 + wave) * tiles_per_wave;
   for (int t = 0; t < tiles_per_wave; ++t) {
     const long p0 = (tile0 + t) * 32;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict
       if (pix < total && mn < Cout) {
         const float v = acc[q];
         Y[pix * Cout + mn] = v;
-        s1 += v;
-        s2 += v * v;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
       }
     }
   }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict
       const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
       if (c < Cout)
         stat_part[((long)blockIdx.x * 2 + which) * Cout + c] =
-            (double)red[0][which][c] + (double)red[1][which][c] + (double)red[2][which][c] + (double)red[3][which][c];
+            red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     }
   }
 }
