@@ -92,6 +92,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    _dummies = []
+    for _ in range(int(os.environ.get("TRIS_DBG_DUMMY_STREAMS", "0"))):   # (developer knob: shift the stream -> hardware-queue mapping)
+        st_ = torch.cuda.Stream()
+        with torch.cuda.stream(st_):
+            torch.zeros(1, device="cuda").add_(1)
+        _dummies.append(st_)
+    torch.cuda.synchronize()
 
     from tris_amd import ops
     from tris_amd.args import get_parser

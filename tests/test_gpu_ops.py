@@ -750,3 +750,38 @@ def test_x2_throughput_mode_is_tf32_class_accurate():
     assert errs["x3"][0] < 2e-6 and errs["x3"][1] < 2e-6          # fp32 class
     assert errs["x2"][0] < 1e-4 and errs["x2"][1] < 1e-4          # ~2^-15 per product, averaged down over K
     assert errs["x2"][0] > errs["x3"][0]                          # (and really is the coarser mode)
+
+
+def test_side_streams_are_probed_onto_their_own_hardware_queues():
+    """HIP maps streams onto 4 hardware queues round-robin in creation order; streams created by somebody else (a collective
+    backend) can put a side stream on the compute stream's queue, where it no longer overlaps anything.  ops._calibrated_streams
+    probes candidates with a device-side sleep: whatever was created before, the streams it hands out run concurrently with
+    the compute stream and with each other."""
+    from tris_amd import ops as o
+    decoys = [torch.cuda.Stream() for _ in range(3)]           # shift the round-robin: the 4th new stream wraps onto queue 0
+    for d in decoys:
+        with torch.cuda.stream(d):
+            torch.zeros(1, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    o._CAL.clear()
+    picked = o._calibrated_streams(torch.cuda.current_device())
+    assert len(picked) >= 2, picked
+    x = torch.zeros(64, device="cuda")
+
+    def overlap(a, b):
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(a):
+            e0.record()
+            torch.cuda._sleep(3000000)
+            e1.record()
+        with torch.cuda.stream(b):
+            x.add_(1.0)
+            e2.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e2) < 0.5 * e0.elapsed_time(e1)
+    main = torch.cuda.current_stream()
+    for i, a in enumerate(picked):
+        assert overlap(main, a), f"picked stream {i} shares the compute stream's hardware queue"
+        for b in picked[i + 1:]:
+            assert overlap(a, b)

@@ -179,10 +179,64 @@ def _wgrad_enabled():
     return os.environ.get("TRIS_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing()
 
 
+# ---- side streams on their own hardware queues ------------------------------------------------------------------------------
+# The HIP runtime maps streams onto a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) round-robin in creation
+# order, and two streams on one queue run one after the other.  Which queue a new stream gets depends on how many streams the
+# process created before -- a collective backend that creates three or four of its own is enough to put the text or the
+# weight-gradient stream on the COMPUTE stream's queue, and the overlap this path is built on silently disappears (measured:
+# +3.7 ms per step as soon as an RCCL communicator exists, reproduced without RCCL by creating three dummy streams first;
+# DESIGN.md "Streams").  So the side streams are not taken as they come: a handful of candidates is created and PROBED -- a
+# device-side sleep on one stream, a tiny kernel on the other, HIP-event timestamps tell whether they overlapped -- and the
+# first ones that run concurrently with the compute stream and with each other are kept.
+_CAL = {}
+
+
+def _calibrated_streams(dev):
+    """up to three streams of device `dev` that the hardware runs concurrently with the current stream and with each other"""
+    if dev in _CAL:
+        return _CAL[dev]
+    if torch.cuda.is_current_stream_capturing():
+        return []               # (no probing under stream capture; not remembered)
+    picked = []
+    if os.environ.get("TRIS_STREAM_PROBE", "1") != "0" and hasattr(torch.cuda, "_sleep"):
+        main = torch.cuda.current_stream(dev)
+        scratch = torch.zeros(64, device=f"cuda:{dev}")
+
+        def overlap(a, b):
+            torch.cuda.synchronize(dev)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            with torch.cuda.stream(a):
+                e0.record()
+                torch.cuda._sleep(1500000)      # ~0.7 ms on the device
+                e1.record()
+            with torch.cuda.stream(b):
+                scratch.add_(1.0)
+                e2.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e2) < 0.5 * e0.elapsed_time(e1)
+        try:
+            for _ in range(10):
+                c = torch.cuda.Stream(device=dev)
+                if overlap(main, c) and all(overlap(x, c) for x in picked):
+                    picked.append(c)
+                    if len(picked) == 3:
+                        break
+        except Exception:       # the probe is an optimisation: any failure falls back to plain streams
+            picked = []
+    _CAL[dev] = picked
+    return picked
+
+
+def _new_side_stream(dev, slot):
+    """slot 0 = text towers, 1 = weight gradients, 2 = gradient reducer: distinct probed streams where the hardware has them"""
+    pool = _calibrated_streams(dev)
+    return pool[slot] if slot < len(pool) else torch.cuda.Stream(device=dev)
+
+
 def _wgrad_stream():
     dev = torch.cuda.current_device()
     if dev not in _WG:
-        _WG[dev] = torch.cuda.Stream(device=dev)
+        _WG[dev] = _new_side_stream(dev, 1)
     return _WG[dev]
 
 
@@ -208,7 +262,8 @@ def side_stream(name):
     """Named auxiliary HIP stream of the current device (e.g. "text": the text encoders overlap the RN50 trunk)."""
     key = (torch.cuda.current_device(), name)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+        slot = {"text": 0, "reduce": 2}.get(name)
+        _SIDE_STREAMS[key] = _new_side_stream(key[0], slot) if slot is not None else torch.cuda.Stream(device=key[0])
     return _SIDE_STREAMS[key]
 
 
