@@ -92,6 +92,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world > 1 or force:
+        # which stream runs on which hardware queue, with the collective backend's own stream in the picture (ops.place_streams)
+        from tris_amd import ops as _ops
+        cs = _ops.place_streams()
+        if cs is not None:
+            torch.cuda.set_stream(cs)
     _dummies = []
     for _ in range(int(os.environ.get("TRIS_DBG_DUMMY_STREAMS", "0"))):   # (developer knob: shift the stream -> hardware-queue mapping)
         st_ = torch.cuda.Stream()

@@ -207,7 +207,7 @@ def _calibrated_streams(dev):
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             with torch.cuda.stream(a):
                 e0.record()
-                torch.cuda._sleep(1500000)      # ~0.7 ms on the device
+                torch.cuda._sleep(6000000)      # ~2.5 ms on the device
                 e1.record()
             with torch.cuda.stream(b):
                 scratch.add_(1.0)
@@ -215,8 +215,11 @@ def _calibrated_streams(dev):
             torch.cuda.synchronize(dev)
             return e0.elapsed_time(e2) < 0.5 * e0.elapsed_time(e1)
         try:
+            torch.cuda._sleep(1000)
             for _ in range(10):
                 c = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(c):      # first use of a stream creates its queue (milliseconds): not part of the probe
+                    scratch.add_(1.0)
                 if overlap(main, c) and all(overlap(x, c) for x in picked):
                     picked.append(c)
                     if len(picked) == 3:
@@ -225,6 +228,87 @@ def _calibrated_streams(dev):
             picked = []
     _CAL[dev] = picked
     return picked
+
+
+def place_streams(group=None):
+    """Data-parallel start-up (call once on every rank right after init_process_group, before anything else touches the
+    device): sort out which stream runs on which of the four hardware queues WITH the collective backend in the picture.
+    torch's NCCL/RCCL process group runs its kernels on a stream of its own whose queue nobody chooses -- if that is the
+    compute stream's queue, every gradient all-reduce sits in front of the compute kernels until the peers arrive (measured
+    with one rank: a collective issued while the compute stream sleeps completes only after the sleep), and the reducer's
+    overlap is gone without any error.  Probes (device sleep + tiny kernel / tiny all-reduce, HIP-event timestamps) find the
+    queue classes of a few candidate streams and the class of the backend's stream; compute, text and weight-gradient streams
+    are then taken from three classes the backend is NOT on.  Every rank issues the same fixed number of probe collectives.
+    Returns the stream the caller should make current (torch.cuda.set_stream) for all further work, or None to stay."""
+    import torch.distributed as dist
+    dev = torch.cuda.current_device()
+    if os.environ.get("TRIS_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
+        return None
+    null = torch.cuda.current_stream(dev)
+    scratch = torch.zeros(64, device=f"cuda:{dev}")
+    cands = [null]
+    torch.cuda._sleep(1000)
+    for _ in range(7):
+        c = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(c):
+            scratch.add_(1.0)
+        cands.append(c)
+    torch.cuda.synchronize(dev)
+
+    def probe(a, b, op):
+        """does `op`, issued on b, finish while a is still asleep?"""
+        torch.cuda.synchronize(dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(a):
+            e0.record()
+            torch.cuda._sleep(6000000)
+            e1.record()
+        with torch.cuda.stream(b):
+            op()
+            e2.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e2) < 0.5 * e0.elapsed_time(e1)
+    reps, cls = [], []                      # one representative stream per hardware-queue class
+    for c in cands:
+        k = next((i for i, r in enumerate(reps) if r is c or not probe(r, c, lambda: scratch.add_(1.0))), None)
+        if k is None:
+            reps.append(c)
+            k = len(reps) - 1
+        cls.append(k)
+    backend_cls = None
+    if dist.is_initialized() and dist.get_backend(group) == "nccl" and len(reps) >= 2:
+        buf = torch.zeros(256, device=f"cuda:{dev}")
+        for _ in range(2):                  # communicator / stream set-up is not part of the probe
+            dist.all_reduce(buf, group=group)
+        torch.cuda.synchronize(dev)
+        for k in range(4):                  # a FIXED number of collectives on every rank, whatever the probes find locally
+            r = reps[k % len(reps)]
+            issue = reps[(k + 1) % len(reps)]
+
+            def coll():
+                w = dist.all_reduce(buf, group=group, async_op=True)
+                w.wait()
+            dist.barrier(group=group)       # ranks start each probe together: a late peer must not look like a shared queue
+            if not probe(r, issue, coll) and backend_cls is None and k < len(reps):
+                backend_cls = k
+    if os.environ.get("TRIS_STREAM_PROBE_LOG") == "1":
+        print(f"[place_streams] queue classes of the candidates {cls}, collective backend on class {backend_cls}", flush=True)
+    free = [k for k in range(len(reps)) if k != backend_cls]
+    if len(free) < 3:                       # fewer queues than roles: leave everything as the runtime handed it out
+        return None
+    order = ([cls[0]] if cls[0] in free else []) + [k for k in free if k != cls[0]]   # keep the current stream if it may stay
+    compute, text, wgrad = reps[order[0]], reps[order[1]], reps[order[2]]
+    # the reducer's ISSUE stream carries only event records / waits (the backend's own stream runs the kernels), but a wait
+    # parked in a hardware queue blocks whatever is behind it there: it goes on the backend's queue, never the compute one's
+    used = {cls[cands.index(compute)], cls[cands.index(text)], cls[cands.index(wgrad)]}
+    issue = next((c for c, k in zip(cands, cls) if k == backend_cls), None)
+    if issue is None:
+        issue = next((c for c, k in zip(cands, cls) if k not in used), wgrad)
+    _CAL[dev] = [text, wgrad, issue]
+    _WG.pop(dev, None)
+    for key in [k for k in _SIDE_STREAMS if k[0] == dev]:
+        _SIDE_STREAMS.pop(key)
+    return None if compute is null else compute
 
 
 def _new_side_stream(dev, slot):

@@ -225,6 +225,10 @@ def main(args, tokenizer=None):
             dist.init_process_group("nccl")
         local_rank = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
         torch.cuda.set_device(local_rank)
+        if dist.get_backend() == "nccl":
+            cs = ops.place_streams()     # compute / text / weight-gradient streams on hardware queues the collective backend is not on
+            if cs is not None:
+                torch.cuda.set_stream(cs)
     else:
         local_rank = 0
     log = _logger(args, local_rank)
