@@ -665,6 +665,31 @@ def test_sync_bn_combine_kernel_equals_full_batch_statistics():
         assert float((rv.cpu().double() - (0.9 + 0.1 * var * n / (n - 1))).abs().max()) < 1e-4
 
 
+def _check_stream_placement(dist):
+    """ops.place_streams with a live RCCL communicator: a collective issued from the reducer's issue stream while the COMPUTE
+    stream (or the text / weight-gradient stream) is busy must not wait for it -- i.e. the backend's own stream does not share
+    their hardware queue (it would serialise every gradient all-reduce with the compute kernels at N > 1)."""
+    from tris_amd import ops
+    ops._CAL.clear(); ops._WG.clear(); ops._SIDE_STREAMS.clear()
+    cs = ops.place_streams()
+    compute = cs if cs is not None else torch.cuda.current_stream()
+    issue = ops.side_stream("reduce")
+    buf = torch.zeros(256, device="cuda")
+    for name, busy in (("compute", compute), ("text", ops.side_stream("text")), ("wgrad", ops._wgrad_stream())):
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(busy):
+            e0.record()
+            torch.cuda._sleep(6000000)
+            e1.record()
+        with torch.cuda.stream(issue):
+            dist.all_reduce(buf, async_op=True).wait()
+            e2.record()
+        torch.cuda.synchronize()
+        assert e0.elapsed_time(e2) < 0.5 * e0.elapsed_time(e1), (name, e0.elapsed_time(e2), e0.elapsed_time(e1))
+    ops._CAL.clear(); ops._WG.clear(); ops._SIDE_STREAMS.clear()     # (later tests probe again, on the default stream)
+
+
 def test_rccl_code_path_single_rank(model, aux, batch, golden):
     """SyncBatchNorm collectives + the backward-overlapped gradient all-reduce executed over RCCL with a one-rank group
     (the multi-GPU code path, on the one GPU the test box has): same losses as the golden step, same gradients as the
@@ -681,6 +706,7 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
     os.environ.setdefault("MASTER_PORT", "29571")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        _check_stream_placement(dist)
         g = golden("g5_g6_step.npz")
         args = _args()
         grads = {}
