@@ -276,7 +276,7 @@ def place_streams(group=None):
             k = len(reps) - 1
         cls.append(k)
     backend_cls = None
-    if dist.is_initialized() and dist.get_backend(group) == "nccl" and len(reps) >= 2:
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":   # (no condition on what THIS rank found: same collectives everywhere)
         buf = torch.zeros(256, device=f"cuda:{dev}")
         for _ in range(2):                  # communicator / stream set-up is not part of the probe
             dist.all_reduce(buf, group=group)
