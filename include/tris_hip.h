@@ -250,6 +250,10 @@ int tris_stage1_loss_bwd_f32(const float* cls, const float* fi, const float* ft,
 /* torch.optim.AdamW step over a flat arena (train_stage1.py:135-139, 370); step_count is the 1-based t */
 int tris_adamw_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step_count, void* stream);
+/* the same update with the step-dependent scalars in DEVICE memory: hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} (written by
+   the host before the launch) -- the form a captured training step replays (tris_amd/graphs.py GraphedTrainStep) */
+int tris_adamw_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2,
+                       float eps, float weight_decay, void* stream);
 
 /* ---- evaluation post-processing (validate.py:180-190, utils/util.py:9-15) ------------------------------------------- */
 /* relu_map [S,S] of ONE (image, sentence) -> cam [oH,oW] = bilinear(align_corners=True)/(max+1e-5); mask = cam > 1e-9;
@@ -286,7 +290,9 @@ int tris_gather_rows(const void* table, const long* index, long rows, long row_b
  * host; tris_mbox_ipc_open).  tris_mbox_exchange_f32 is one single-workgroup launch on `stream`: store the block
  * [src0[n0] | src1[n1]] (n = n0 + n1; src1 may be NULL with n1 = 0) into every
  * peer's mailbox, publish per-sender flags (system-scope release), wait for the `world` flags of the own mailbox (bounded
- * spin: after spin_limit polls *err is set to seq and the wait is abandoned), then mode 0: out[world][n] = the gathered
+ * spin: after spin_limit polls *err is set to seq, the wait is abandoned and `out` is filled with NaN instead of stale slot
+ * contents -- tris_mbox_bn_combine_f32 likewise writes NaN statistics and leaves the running statistics alone), then mode 0:
+ * out[world][n] = the gathered
  * blocks in rank order; mode 1: out[n] = their sum in rank order (bit-identical on every rank).  `boxes` is a DEVICE array of
  * the `world` mailbox pointers as mapped in this process (own mailbox at index `rank`).  `seq` must be 1, 2, 3, ... in the
  * same order on every rank (flags are zero-initialised).  World size <= TRIS_MBOX_MAX_WORLD. */
@@ -301,7 +307,9 @@ int tris_mbox_exchange_f32(const float* src0, int n0, const float* src1, int n1,
                            int rank, int seq, int cap_floats, int mode, long spin_limit, int* err, void* stream);
 /* SyncBatchNorm forward in ONE launch: exchange the [mean | invstd | biased var] block (3 C floats, what tris_bn_finalize_f32 /
  * tris_bn_stats_f32 write) and combine the `world` blocks into the global statistics stats[3C] + running statistics -- the
- * arithmetic of tris_bn_sync_combine_f32.  Every rank contributes count_per_rank rows. */
+ * arithmetic of tris_bn_sync_combine_f32.  Every rank contributes count_per_rank rows: the SAME number on every rank (the global
+ * count is count_per_rank * world, as with torch's DistributedSampler, which pads the shards to equal length; ranks with
+ * unequal per-step batches are not representable here -- nor in tris_bn_sync_combine_f32 -- and must use equal shards). */
 int tris_mbox_bn_combine_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum, float* stats,
                              float* running_mean, float* running_var, void* const* boxes, int world, int rank, int seq,
                              int cap_floats, long spin_limit, int* err, void* stream);

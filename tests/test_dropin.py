@@ -80,3 +80,41 @@ def _refuse_and_restore(d, types):
     finally:
         d.uninstall()
     assert "model.model_stage1" not in sys.modules
+
+
+def test_reference_syncbn_call_reaches_the_tris_batchnorm():
+    """/root/reference/train_stage1.py:69-72 under the drop-in: `nn.SyncBatchNorm.convert_sync_batchnorm(model)` must not be the
+    silent no-op it is on a module torch does not know -- it sets `process_group` on every tris_amd BatchNorm2d (and converts
+    plain nn.BatchNorm2d children as torch always did), raises without a process group, and uninstall() restores torch's own."""
+    import torch
+    import torch.distributed as dist
+    from torch import nn
+    import tris_amd.dropin as d
+    from tris_amd.CLIP.clip.model import BatchNorm2d
+    orig = nn.SyncBatchNorm.__dict__["convert_sync_batchnorm"]
+    tops = {n.split(".")[0] for n in d.ALIASES}
+    parked = {n: sys.modules.pop(n) for n in list(sys.modules) if n.split(".")[0] in tops and not n.startswith("tris_amd")}
+    d.install()
+    try:
+        model = nn.Sequential(BatchNorm2d(8), nn.Sequential(BatchNorm2d(4), nn.BatchNorm2d(4)))
+        was_init = dist.is_initialized()
+        if not was_init:
+            with pytest.raises(RuntimeError, match="process group"):
+                nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29631")
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            # the reference's call sequence: model = nn.SyncBatchNorm.convert_sync_batchnorm(model); model.module afterwards
+            out = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            ours = [m for m in out.modules() if isinstance(m, BatchNorm2d)]
+            assert len(ours) == 2 and all(m.process_group is dist.group.WORLD for m in ours)
+            assert isinstance(out[1][1], nn.SyncBatchNorm)          # torch's own conversion still happens
+            assert set(out.state_dict()) == set(model.state_dict())  # same keys: checkpoints keep loading
+        finally:
+            if not was_init:
+                dist.destroy_process_group()
+    finally:
+        d.uninstall()
+        sys.modules.update(parked)
+    assert nn.SyncBatchNorm.__dict__["convert_sync_batchnorm"] is orig

@@ -64,104 +64,8 @@ def broadcast(t, src=0, group=None):
 
 
 # ---------------------------------------------------------------------------------------------------- SyncBN fast path
-class RcclDirect:
-    """RCCL called directly on the COMPUTE stream for the per-layer SyncBatchNorm exchanges (reference:
-    nn.SyncBatchNorm.convert_sync_batchnorm, train_stage1.py:69 -- 55 all-gathers of [mean|invstd|var] in forward and 55
-    all-reduces of the two backward sums per step, each a few KB).
-
-    OPT-IN (TRIS_SYNCBN_COMM=rccl), because it measured SLOWER than torch.distributed: with a one-rank group
-    (TRIS_FORCE_DIST=1, B = 48, same box, A/B/A/B) the step takes 52.0 ms without collectives, 55.5 ms through c10d and
-    58.6-59.4 ms through this class.  The cost of these 110 tiny exchanges is not c10d's Work objects or stream hops but
-    RCCL's own enqueue path (~55 us of host work per call), which a direct call pays just the same.  The way to take them
-    off the step is to not call RCCL at all for them: tris_amd.comm.Mailbox (IPC-mapped peer buffers + flags).
-
-    The same RCCL library that torch loaded (torch/lib/librccl.so -- no second copy in the process) is bound with ctypes
-    and its own communicator is created once per process group (unique id from rank 0, distributed through
-    torch.distributed); each exchange is one in-stream launch.  If the library or the communicator cannot be set up,
-    `get()` returns None and the callers use torch.distributed."""
-
-    _by_group = {}
-    NCCL_FLOAT32, NCCL_SUM = 7, 0
-
-    class _UniqueId(ctypes.Structure):
-        _fields_ = [("internal", ctypes.c_ubyte * 128)]   # (c_ubyte: a c_char array reads back NUL-truncated)
-
-    def __init__(self, group):
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        lib = ctypes.CDLL(path)
-        for name, args in (("ncclGetUniqueId", [ctypes.POINTER(self._UniqueId)]),
-                           ("ncclCommInitRank", [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]),
-                           ("ncclAllGather", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
-                                              ctypes.c_void_p]),
-                           ("ncclAllReduce", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                              ctypes.c_void_p, ctypes.c_void_p]),
-                           ("ncclCommDestroy", [ctypes.c_void_p])):
-            fn = getattr(lib, name)
-            fn.restype = ctypes.c_int
-            fn.argtypes = args
-        lib.ncclGetErrorString.restype = ctypes.c_char_p
-        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
-        self.lib = lib
-        self.world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
-        uid = self._UniqueId()
-        if rank == 0:
-            self._chk(lib.ncclGetUniqueId(ctypes.byref(uid)))
-        box = [ctypes.string_at(ctypes.byref(uid), 128) if rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ctypes.memmove(ctypes.byref(uid), box[0], 128)
-        comm = ctypes.c_void_p()
-        self._chk(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, rank))   # binds the current HIP device
-        self.comm = comm
-
-    def _chk(self, rc):
-        if rc != 0:
-            raise RuntimeError(f"RCCL: {self.lib.ncclGetErrorString(rc).decode()} ({rc})")
-
-    def all_gather_into(self, out, inp):
-        self._chk(self.lib.ncclAllGather(inp.data_ptr(), out.data_ptr(), inp.numel(), self.NCCL_FLOAT32, self.comm,
-                                         torch.cuda.current_stream().cuda_stream))
-
-    def all_reduce_sum(self, t):
-        self._chk(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self.NCCL_FLOAT32, self.NCCL_SUM, self.comm,
-                                         torch.cuda.current_stream().cuda_stream))
-
-    @classmethod
-    def get(cls, group=None):
-        """the direct communicator of `group`, or None (then: torch.distributed).  Collective: every rank of the group
-        must call it at the same point the first time (BatchNormFn does: first SyncBN forward of the first step)."""
-        key = id(group) if group is not None else 0
-        if key in cls._by_group:
-            return cls._by_group[key]
-        made = None
-        if (backend(group) == "nccl" and os.environ.get("TRIS_SYNCBN_COMM", "c10d") == "rccl"
-                and not torch.cuda.is_current_stream_capturing()):
-            try:
-                made = cls(group)
-            except Exception as e:   # library missing / init refused: keep training on the c10d path, say so once
-                import warnings
-                warnings.warn(f"direct RCCL communicator for SyncBatchNorm unavailable ({e!r}); using torch.distributed")
-                made = None
-            # every rank must take the same path: agree (one tiny c10d collective, once)
-            ok = torch.tensor([1 if made is not None else 0], device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok.item()) == 0:
-                made = None
-        cls._by_group[key] = made
-        return made
-
-    @classmethod
-    def reset(cls):
-        """drop the cached communicators (call before destroying the process group: tests)"""
-        for c in cls._by_group.values():
-            if c is not None:
-                try:
-                    c.lib.ncclCommDestroy(c.comm)
-                except Exception:
-                    pass
-        cls._by_group = {}
-
-
+# (A direct in-stream ncclAllGather for these exchanges was built and measured in round 2 -- slower than torch.distributed,
+# 58.6 vs 55.5 ms/step at one rank: the cost is RCCL's own enqueue path -- and removed in round 3; `git show 848321e:tris_amd/comm.py`.)
 class Mailbox:
     """SyncBatchNorm exchanges through IPC-mapped peer mailboxes (csrc/comm.hip; include/tris_hip.h `tris_mbox_*`): one
     single-workgroup launch on the compute stream per exchange -- stores over xGMI into every peer's mailbox, per-sender
@@ -173,7 +77,10 @@ class Mailbox:
 
     _by_group = {}
     CAP = 3 * 4096           # floats per sender block: [mean|invstd|var] of the widest BatchNorm (2048 channels) with headroom
-    SPIN_LIMIT = int(os.environ.get("TRIS_MBOX_SPIN", "20000000"))  # polls (~ seconds) before an exchange gives up and raises the error flag
+    # polls before an exchange gives up, raises the error flag and poisons its outputs with NaN.  A poll is an uncached
+    # system-scope load + s_sleep 8 (~1-2.5 us): 4e8 polls is ~10 minutes, the scale of the NCCL watchdog (rank 0 alone writes
+    # the checkpoints -- up to two > 1 GB saves per epoch -- while its peers already sit in the next step's first exchange)
+    SPIN_LIMIT = int(os.environ.get("TRIS_MBOX_SPIN", "400000000"))
 
     def __init__(self, group):
         from . import _lib
@@ -183,17 +90,30 @@ class Mailbox:
         self.rank = dist.get_rank(group)
         if self.world > _lib.CONSTS["TRIS_MBOX_MAX_WORLD"]:
             raise RuntimeError(f"world size {self.world} exceeds TRIS_MBOX_MAX_WORLD")
-        own = ctypes.c_void_p()
-        self._chk(self.lib.tris_mbox_alloc(ctypes.byref(own), self.CAP), "tris_mbox_alloc")
-        self.own = own
-        handle = ctypes.create_string_buffer(64)
-        self._chk(self.lib.tris_mbox_ipc_handle(own, handle), "tris_mbox_ipc_handle")
+        # Set-up must be failure-SYMMETRIC: whatever goes wrong locally (allocation, IPC export), this rank still takes part in
+        # the collective handle exchange -- contributing None -- so that its peers are not left inside all_gather_object
+        # while it has moved on to the agreement all-reduce of get().  The decision is taken afterwards, from what everyone posted.
+        self.own, self.opened = None, []
+        raw, local_err = None, None
+        try:
+            own = ctypes.c_void_p()
+            self._chk(self.lib.tris_mbox_alloc(ctypes.byref(own), self.CAP), "tris_mbox_alloc")
+            self.own = own
+            handle = ctypes.create_string_buffer(64)
+            self._chk(self.lib.tris_mbox_ipc_handle(own, handle), "tris_mbox_ipc_handle")
+            raw = bytes(handle.raw)
+        except Exception as e:   # noqa: BLE001 -- reported below, after the collective
+            local_err = e
         handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle.raw), group=group)
-        ptrs, self.opened = [], []
+        dist.all_gather_object(handles, raw, group=group)
+        if local_err is not None:
+            raise local_err
+        if any(h is None for h in handles):
+            raise RuntimeError(f"rank(s) {[r for r, h in enumerate(handles) if h is None]} could not export a mailbox")
+        ptrs = []
         for r, h in enumerate(handles):
             if r == self.rank:
-                ptrs.append(own.value)
+                ptrs.append(self.own.value)
                 continue
             p = ctypes.c_void_p()
             self._chk(self.lib.tris_mbox_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(p)), "tris_mbox_ipc_open")
@@ -254,7 +174,9 @@ class Mailbox:
     def close(self):
         for p in self.opened:
             self.lib.tris_mbox_ipc_close(p)
-        self.lib.tris_mbox_free(self.own)
+        if self.own is not None:
+            self.lib.tris_mbox_free(self.own)
+            self.own = None
         self.opened = []
 
     @classmethod
@@ -264,17 +186,17 @@ class Mailbox:
             return cls._by_group[key]
         made = None
         if os.environ.get("TRIS_SYNCBN_COMM", "mailbox") == "mailbox" and not torch.cuda.is_current_stream_capturing():
+            made = cls.__new__(cls)
             try:
-                made = cls(group)
+                made.__init__(group)     # (always reaches its collective handle exchange, whatever fails locally)
                 made.self_test()
             except Exception as e:
                 import warnings
                 warnings.warn(f"SyncBatchNorm mailboxes unavailable ({e!r}); using torch.distributed collectives")
-                if made is not None:
-                    try:
-                        made.close()
-                    except Exception:
-                        pass
+                try:
+                    made.close()
+                except Exception:
+                    pass
                 made = None
             ok = torch.tensor([1.0 if made is not None else 0.0], device="cuda")
             all_reduce(ok, op=dist.ReduceOp.MIN, group=group)    # every rank must take the same path
@@ -294,17 +216,25 @@ class Mailbox:
         cls._by_group = {}
 
 
-def check_errors():
-    """raise if any SyncBatchNorm mailbox exchange timed out (host sync: call where the loop syncs anyway)"""
+def check_errors(collective=False):
+    """Raise if any SyncBatchNorm mailbox exchange timed out.  Host sync: call where the loop syncs anyway -- on EVERY rank
+    (a rank that gave up keeps NaN statistics for that layer, its peers may be the next to time out).  collective=True
+    additionally takes the MAX of the flag over the group (one tiny all-reduce), so that every rank raises in the same
+    step; call it at the same point on all ranks."""
     for m in Mailbox._by_group.values():
-        if m is not None:
-            m.check()
+        if m is None:
+            continue
+        if collective and dist.is_initialized():
+            flag = m.err.clone()
+            all_reduce(flag, op=dist.ReduceOp.MAX, group=m.group)
+            if int(flag.item()) != 0 and int(m.err.item()) == 0:
+                raise RuntimeError(f"SyncBatchNorm mailbox exchange #{int(flag.item())} timed out on a peer of rank {m.rank}")
+        m.check()
 
 
 def shutdown():
     """release the SyncBN transports (call before dist.destroy_process_group)"""
     Mailbox.reset()
-    RcclDirect.reset()
 
 
 def syncbn_mailbox(group, numel):
@@ -320,21 +250,13 @@ def syncbn_all_gather_into(out, inp, group=None):
         if m is not None:
             m.exchange(inp, out, 0)
             return
-    c = RcclDirect.get(group) if inp.is_cuda else None
-    if c is not None:
-        c.all_gather_into(out, inp)
-    else:
-        all_gather_into(out, inp, group)
+    all_gather_into(out, inp, group)
 
 
 def syncbn_all_reduce_sum(t, group=None):
     if t.is_cuda and t.numel() <= Mailbox.CAP:
         m = Mailbox.get(group)
         if m is not None:
-            m.exchange(t, t, 1)
+            m.exchange(t, t, 1)   # (in place: the kernel's src / out parameters are not restrict-qualified)
             return
-    c = RcclDirect.get(group) if t.is_cuda else None
-    if c is not None:
-        c.all_reduce_sum(t)
-    else:
-        all_reduce(t, group=group)
+    all_reduce(t, group=group)

@@ -15,8 +15,10 @@
 //   Two parities suffice: a rank can start exchange k+2 (which overwrites parity k) only after it has seen every peer's
 //   flag k+1, and a peer posts flag k+1 only after its own exchange k has completed (stream order).
 //
-// A flag that does not arrive within the spin bound sets *err (checked by the host once per step / logging interval): the step
-// fails loudly instead of hanging the GPU.
+// A flag that does not arrive within the spin bound sets *err (checked by the host on EVERY rank, tris_amd.comm.check_errors)
+// and the kernel does NOT consume the stale slots: its outputs are filled with NaN and the running statistics are left
+// untouched, so the losses of that step are NaN on the rank that gave up -- the step fails loudly instead of hanging the GPU or
+// training on another layer's statistics.
 #include <cstring>
 
 #include "common.h"
@@ -34,10 +36,13 @@ __device__ __forceinline__ float* slot_of(void* box, int parity, int sender, int
 }
 
 // send my block [src0[n0] | src1[n1]] to every mailbox, publish, wait for the world's flags in my mailbox (one workgroup)
-__device__ __forceinline__ void mbox_send_wait(const float* __restrict__ src0, int n0, const float* __restrict__ src1, int n1,
+// returns false (uniformly) when a sender's flag did not arrive within the spin bound
+__device__ __forceinline__ bool mbox_send_wait(const float* src0, int n0, const float* src1, int n1,
                                                void* const* __restrict__ boxes, int world, int rank, unsigned seq, int cap,
                                                long spin_limit, int* __restrict__ err) {
+  __shared__ int s_fail;
   const int tid = threadIdx.x;
+  if (tid == 0) s_fail = 0;
   const int par = seq & 1u;
   for (int w = 0; w < world; ++w) {
     float* dst = slot_of(boxes[w], par, rank, cap);
@@ -60,21 +65,29 @@ __device__ __forceinline__ void mbox_send_wait(const float* __restrict__ src0, i
     long spins = 0;
     while (__hip_atomic_load(&h->flag[par][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > spin_limit) { atomicExch(err, (int)seq); break; }
+      if (++spins > spin_limit) { atomicExch(err, (int)seq); s_fail = 1; break; }
     }
   }
   __syncthreads();
   __threadfence_system();
+  return s_fail == 0;
 }
 
 // mode 0: out[w][n] = gathered blocks, mode 1: out[n] = sum over ranks (fixed order 0..world-1: deterministic and identical
 // on every rank); the block of a rank is [src0[n0] | src1[n1]]
-__global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* __restrict__ src0, int n0, const float* __restrict__ src1,
-                                                            int n1, float* __restrict__ out, void* const* __restrict__ boxes,
+// (src0 / out are NOT restrict: the in-place sum of tris_amd.comm.syncbn_all_reduce_sum passes the same buffer for both;
+// every source element is stored to the mailboxes before the first element of `out` is written)
+__global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* src0, int n0, const float* src1,
+                                                            int n1, float* out, void* const* __restrict__ boxes,
                                                             int world, int rank, unsigned seq, int cap, int mode, long spin_limit,
                                                             int* __restrict__ err) {
-  mbox_send_wait(src0, n0, src1, n1, boxes, world, rank, seq, cap, spin_limit, err);
+  const bool ok = mbox_send_wait(src0, n0, src1, n1, boxes, world, rank, seq, cap, spin_limit, err);
   const int tid = threadIdx.x, par = seq & 1u, n = n0 + n1;
+  if (!ok) {   // a peer never posted: do not read the stale slots
+    const int tot = mode == 0 ? world * n : n;
+    for (int i = tid; i < tot; i += 256) out[i] = __builtin_nanf("");
+    return;
+  }
   if (mode == 0) {
     for (int w = 0; w < world; ++w) {
       const float* s = slot_of(boxes[rank], par, w, cap);
@@ -96,8 +109,12 @@ __global__ __launch_bounds__(256) void mbox_bn_combine_kernel(const float* __res
                                                               float momentum, float* __restrict__ stats, float* running_mean,
                                                               float* running_var, void* const* __restrict__ boxes, int world,
                                                               int rank, unsigned seq, int cap, long spin_limit, int* __restrict__ err) {
-  mbox_send_wait(local, 3 * C, nullptr, 0, boxes, world, rank, seq, cap, spin_limit, err);
+  const bool ok = mbox_send_wait(local, 3 * C, nullptr, 0, boxes, world, rank, seq, cap, spin_limit, err);
   const int par = seq & 1u;
+  if (!ok) {   // a peer never posted: NaN statistics (the step's losses turn NaN), running statistics untouched
+    for (int c = threadIdx.x; c < 3 * C; c += 256) stats[c] = __builtin_nanf("");
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     double mean = 0.0;
     for (int w = 0; w < world; ++w) mean += (double)__builtin_nontemporal_load(slot_of(boxes[rank], par, w, cap) + c);

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void xattn_out_x3_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int p = ks * 32 + kg * 8 + i;
-        vv[ct][ks][i] = ((ABL & 1) == 0 && ks < PK && p < P) ? Vv[((long)b * P + p) * C + c + ct * 16] : 0.5f;
+        vv[ct][ks][i] = (ABL & 1) ? 0.5f : ((ks < PK && p < P) ? Vv[((long)b * P + p) * C + c + ct * 16] : 0.f);
       }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)

@@ -16,6 +16,13 @@ on the MI355X path without editing a single import:
 
 It never shadows silently: if one of the names is already bound to a DIFFERENT module (e.g. the reference's own
 `model` package was imported first) it raises unless `force=True`.  `uninstall()` removes exactly what install() added.
+
+One torch entry point is wrapped as well, because the reference calls it on the model and it would otherwise do NOTHING:
+`nn.SyncBatchNorm.convert_sync_batchnorm(model)` (/root/reference/train_stage1.py:69) only converts `nn.BatchNorm*`
+instances, and the BatchNorm of this path is `tris_amd.CLIP.clip.model.BatchNorm2d` (its own `nn.Module`: the statistics
+exchange lives in ops.BatchNormFn).  Left alone, the reference's script would train data-parallel with UNSYNCHRONISED
+statistics and no warning.  With the drop-in installed the call also sets `process_group` on every tris_amd BatchNorm2d
+(= tris_amd.parallel.convert_sync_batchnorm) -- or raises if no process group exists to synchronise over.
 """
 import importlib
 import sys
@@ -45,6 +52,36 @@ ALIASES = {
 }
 
 _installed = {}
+_torch_patch = {}
+
+
+def _patch_sync_batchnorm():
+    import torch
+    if "convert" in _torch_patch:
+        return
+    orig = torch.nn.SyncBatchNorm.__dict__["convert_sync_batchnorm"]   # the classmethod object itself
+
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        out = orig.__func__(cls, module, process_group)
+        from .CLIP.clip.model import BatchNorm2d
+        if any(isinstance(m, BatchNorm2d) for m in out.modules()):
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("nn.SyncBatchNorm.convert_sync_batchnorm on a tris_amd model needs an initialised process "
+                                   "group (torch.distributed.init_process_group): there is nothing to synchronise the "
+                                   "BatchNorm statistics over")
+            from .parallel import convert_sync_batchnorm as ours
+            ours(out, process_group)
+        return out
+    _torch_patch["convert"] = orig
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm = classmethod(convert_sync_batchnorm)
+
+
+def _unpatch_sync_batchnorm():
+    import torch
+    orig = _torch_patch.pop("convert", None)
+    if orig is not None:
+        torch.nn.SyncBatchNorm.convert_sync_batchnorm = orig
 
 
 def install(force=False):
@@ -59,10 +96,12 @@ def install(force=False):
         if sys.modules.get(name) is not m:
             _installed[name] = sys.modules.get(name)
             sys.modules[name] = m
+    _patch_sync_batchnorm()
     return mods
 
 
 def uninstall():
+    _unpatch_sync_batchnorm()
     for name, prev in list(_installed.items()):
         if prev is None:
             sys.modules.pop(name, None)

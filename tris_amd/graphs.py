@@ -72,10 +72,86 @@ class GraphedFrozenText:
                 self.out = clip_model.encode_text(self.s_ids)[1]
 
     def __call__(self, ids):
-        """replay on the CURRENT stream; returns the static [n, E] output"""
+        """replay on the CURRENT stream; returns a COPY of the static [n, E] output (a few hundred KB): the loss keeps it for
+        its backward, and a second forward before that backward (gradient accumulation, an evaluation helper reusing the step's
+        forward) would otherwise overwrite a tensor autograd still holds"""
         self.s_ids.copy_(ids, non_blocking=True)
         self.g.replay()
-        return self.out
+        return self.out.clone()
+
+
+class GraphedTrainStep:
+    """The WHOLE Stage-1 training step (TRIS forward, loss block with the frozen aux CLIP, backward, AdamW) as ONE hipGraph.
+
+    Why: the eager step is ~1 500 ctypes launches issued from Python / the autograd engine -- 38 ms of host work against a
+    43 ms GPU step (BENCH_r02: host_issue_ms_per_step) -- so the next kernel gains would run into the launch path.  Replayed,
+    the host's share of a step is one input copy, twelve bytes of optimiser scalars and one graph launch.
+
+    How: torch's stream capture around the very code the eager step runs (train_stage1._step_body): every node is one of this
+    repo's kernels launched through the C ABI.  The text and weight-gradient side streams fork from / join the capturing stream
+    through events, so the graph keeps the three-branch overlap of the eager step.  What a graph freezes and the step changes:
+      * inputs          -> static buffers, copied into before each replay;
+      * lr, Adam bias corrections -> a device tensor refreshed by the host per replay (FusedAdamW.push_hyper);
+      * BatchNorm step counters   -> host-side, bumped per replay.
+    Priming (first-encounter GEMM autotuning times kernels with HIP events, workspaces and allocator pools grow: none of that
+    may happen under capture) is two eager forward + backward passes WITHOUT an optimiser step, with the BatchNorm running
+    statistics saved and restored around them -- so the captured step starts from exactly the state the caller handed over and
+    step k of a replayed run equals step k of an eager run.
+
+    Not captured (the eager step runs instead): data-parallel runs (the SyncBatchNorm mailboxes carry a host-side parity
+    and the reducer issues collectives from autograd hooks), profiling passes, batches of another shape."""
+
+    def __init__(self, model, clip_model, optimizer, args, example, lr_scheduler=None, priming=2):
+        from . import ops
+        from .CLIP.clip.model import BatchNorm2d
+        from .train_stage1 import _step_body
+        img, ids, neg = example
+        self.model, self.clip_model, self.optimizer, self.args, self.sched = model, clip_model, optimizer, args, lr_scheduler
+        self.s_img = img.detach().clone()
+        self.s_ids = ids.detach().clone()
+        self.s_neg = None if neg is None else neg.detach().clone()
+        net = model.module if hasattr(model, "module") else model
+        self.bns = [m for m in net.modules() if isinstance(m, BatchNorm2d)]
+        optimizer.enable_device_hyper()
+        # ---- priming: eager forward + backward, no optimiser step, BatchNorm running statistics put back afterwards
+        keep = [(m.running_mean.clone(), m.running_var.clone(), m._nbt_pending) for m in self.bns]
+        for _ in range(priming):
+            _step_body(model, clip_model, optimizer, self.s_img, self.s_ids, self.s_neg, args, None, optimizer_step=False)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for m, (rm, rv, nbt) in zip(self.bns, keep):
+                m.running_mean.copy_(rm)
+                m.running_var.copy_(rv)
+                m._nbt_pending = nbt
+        del keep
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()   # the priming passes' activation pool is not needed again (the graph has its own)
+        nbt = [m._nbt_pending for m in self.bns]
+        self.g = torch.cuda.CUDAGraph()
+        ops._CAPTURE_STREAMS = True
+        try:
+            with torch.cuda.graph(self.g, capture_error_mode="thread_local"):
+                self.losses = _step_body(model, clip_model, optimizer, self.s_img, self.s_ids, self.s_neg, args, None,
+                                         device_hyper=True)
+        finally:
+            ops._CAPTURE_STREAMS = False
+        for m, n in zip(self.bns, nbt):   # (capture launched nothing: the forward's host-side count is taken back)
+            m._nbt_pending = n
+
+    def __call__(self, img, ids, neg):
+        self.s_img.copy_(img, non_blocking=True)
+        self.s_ids.copy_(ids, non_blocking=True)
+        if self.s_neg is not None:
+            self.s_neg.copy_(neg, non_blocking=True)
+        opt = self.optimizer
+        opt._steps += 1
+        opt.push_hyper()
+        self.g.replay()
+        for m in self.bns:
+            m._nbt_pending += 1
+        if self.sched is not None:
+            self.sched.step()
+        return self.losses
 
 
 def frozen_text(clip_model, ids):

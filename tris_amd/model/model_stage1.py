@@ -20,7 +20,7 @@ _SIDE = {}
 
 def _overlap_enabled():
     import os
-    return os.environ.get("TRIS_TEXT_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+    return os.environ.get("TRIS_TEXT_STREAM", "1") != "0" and ops.streams_allowed()
 
 
 def _side_stream(device):

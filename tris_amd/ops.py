@@ -174,9 +174,20 @@ def cl_weight(w):
 _WG = {}
 
 
+# Side streams under stream capture: a capture that forks (event record on the capturing stream, wait on the side stream) and
+# joins again before it ends records the side streams' launches as parallel branches of the graph.  The small inference graphs
+# (tris_amd.graphs.GraphedStage1Eval) stay single-stream; the captured training step switches this on around its capture.
+_CAPTURE_STREAMS = False
+
+
+def streams_allowed():
+    """may work be forked onto a side stream here?  (not under a stream capture, unless the capture asked for it)"""
+    return _CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()
+
+
 def _wgrad_enabled():
     import os
-    return os.environ.get("TRIS_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+    return os.environ.get("TRIS_WGRAD_STREAM", "1") != "0" and streams_allowed()
 
 
 # ---- side streams on their own hardware queues ------------------------------------------------------------------------------
@@ -457,25 +468,15 @@ def nchw_to_nhwc(x):
 
 # ----------------------------------------------------------------------------------------------- fused BN statistics
 # A conv forward can emit the BatchNorm batch statistics of its output from the GEMM epilogue (tris_*_bnstat_f32).
-# The fp64 partials travel from the conv Function to the BatchNorm Function as an attribute of the output tensor.
-_LAST_STATS = None
-
-
+# The fp64 partials travel from the conv Function to the BatchNorm Function as an attribute of the output tensor
+# (`y._bn_part`, set inside the Function's forward: the object returned by apply() is that same tensor).
 def _launch_with_stats(y, M, N, launch):
     import ctypes
-    global _LAST_STATS
     part = torch.empty(((M + 127) // 128) * 2 * N, device=y.device, dtype=torch.float64)
     rows = ctypes.c_int(0)
     launch(part, ctypes.byref(rows))
-    _LAST_STATS = (part, rows.value) if rows.value > 0 else None
-
-
-def _attach_stats(y):
-    global _LAST_STATS
-    if _LAST_STATS is not None:
-        y._bn_part = _LAST_STATS
-        _LAST_STATS = None
-    return y
+    if rows.value > 0:
+        y._bn_part = (part, rows.value)
 
 
 def _wp_call(name, *args):
@@ -615,8 +616,7 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
-    y = LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res)
-    return _attach_stats(y) if stats else y
+    return LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res)
 
 
 class MatmulFn(torch.autograd.Function):
@@ -830,8 +830,7 @@ def conv3x3_bnin_ok(xshape, Cout):
 
 
 def conv3x3(x, w, stride=1, stats=False):
-    y = Conv3x3Fn.apply(x, w, stride, stats, getattr(x, "_bn_lazy", None))
-    return _attach_stats(y) if stats else y
+    return Conv3x3Fn.apply(x, w, stride, stats, getattr(x, "_bn_lazy", None))
 
 
 # ----------------------------------------------------------------------------------------------- BatchNorm
@@ -889,9 +888,8 @@ class BatchNormFn(torch.autograd.Function):
         if not lazy:
             call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
                  _stream())
-        if lazy:
-            global _LAZY_SRC
-            _LAZY_SRC = (x, mean, invstd, gamma, beta)
+        if lazy:   # the hand-off to ops.conv3x3 rides on the (unwritten) output tensor itself
+            y._bn_lazy = (x, mean, invstd, gamma, beta)
         ctx.cfg = (M, C, bool(relu), resid is not None, count, group)
         ctx.grad_box = grad_box
         ctx.params = (gamma, beta)
@@ -967,21 +965,12 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None
 
 
-_LAZY_SRC = None
-
-
 def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
                grad_box=None, lazy=False):
     """lazy=True (train-mode BatchNorm + ReLU whose ONLY consumer is ops.conv3x3, and conv3x3_bnin_ok said yes): the returned
     tensor is an unwritten buffer carrying `_bn_lazy`; pass it to ops.conv3x3 and nowhere else."""
-    global _LAZY_SRC
     part = getattr(x, "_bn_part", None) if training else None
-    _LAZY_SRC = None
-    y = BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy)
-    if _LAZY_SRC is not None:
-        y._bn_lazy = _LAZY_SRC
-        _LAZY_SRC = None
-    return y
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy)
 
 
 class AvgPool2Fn(torch.autograd.Function):

@@ -65,6 +65,44 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise ops.NoGpuError("FusedAdamW needs the model on the GPU before construction")
             self.arenas.append(Arena(g["params"]))
         self._steps = 0
+        self._hyper = None      # device copy of the step-dependent scalars (enable_device_hyper)
+
+    # ---- step-dependent scalars in device memory (captured training step, tris_amd.graphs.GraphedTrainStep) ----------
+    # A hipGraph replays its launches with the kernel arguments frozen at capture time, so lr and the two bias corrections
+    # cannot be host scalars there: they live in a small device tensor that the host refreshes before every replay through
+    # a ring of pinned staging rows (the host may run many steps ahead of the device; a row is reused only after the copy
+    # that read it has completed).
+    RING = 64
+
+    def enable_device_hyper(self):
+        if self._hyper is None:
+            dev = self.arenas[0].p.device
+            n = len(self.param_groups)
+            self._hyper = torch.zeros(n, 4, device=dev, dtype=torch.float32)
+            self._ring = torch.zeros(self.RING, n, 4, dtype=torch.float32).pin_memory()
+            self._ring_ev = [None] * self.RING
+            self._ring_i = 0
+        return self._hyper
+
+    def push_hyper(self, step_count=None):
+        """{lr, 1 - beta1^t, sqrt(1 - beta2^t)} of every group for the 1-based step t -> device (async, current stream)"""
+        import math
+        t = self._steps if step_count is None else step_count
+        slot = self._ring_i % self.RING
+        self._ring_i += 1
+        ev = self._ring_ev[slot]
+        if ev is not None:
+            ev.synchronize()
+        row = self._ring[slot]
+        for gi, g in enumerate(self.param_groups):
+            b1, b2 = g["betas"]
+            row[gi, 0] = float(g["lr"])
+            row[gi, 1] = 1.0 - b1 ** t
+            row[gi, 2] = math.sqrt(1.0 - b2 ** t)
+        self._hyper.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_ev[slot] = ev
 
     def zero_grad(self, set_to_none=False):
         """Gradients written by the backward kernels are overwritten each step (the sinks stay attached, nothing to
@@ -77,10 +115,19 @@ class FusedAdamW(torch.optim.Optimizer):
         return None
 
     @torch.no_grad()
-    def step(self, closure=None):
-        self._steps += 1
+    def step(self, closure=None, device_hyper=False):
+        """device_hyper=True: the launches read lr / bias corrections from the device tensor of enable_device_hyper() and the
+        step counter is NOT advanced here (the caller -- a captured step's replay loop -- advances it and calls push_hyper)."""
         ops.wgrad_join()  # weight gradients are produced on their own stream
         st = torch.cuda.current_stream().cuda_stream
+        if device_hyper:
+            hy = self.enable_device_hyper()
+            for gi, (g, a) in enumerate(zip(self.param_groups, self.arenas)):
+                b1, b2 = g["betas"]
+                _lib.call("tris_adamw_dev_f32", a.p.data_ptr(), a.g.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.numel,
+                          hy[gi].data_ptr(), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), st)
+            return
+        self._steps += 1
         for g, a in zip(self.param_groups, self.arenas):
             b1, b2 = g["betas"]
             _lib.call("tris_adamw_f32", a.p.data_ptr(), a.g.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.numel,

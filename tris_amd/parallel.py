@@ -84,7 +84,12 @@ class GradReducer:
             for p, o in zip(ar.params, ar.offsets):
                 n = name_of.get(id(p), "")
                 k = next((kk for kk in keys if rules[kk](n)), keys[-1])
-                par[k].append((ai, o, o + p.numel(), n))
+                # (exact extents feed the NaN-poison order check.  A parameter whose gradient arrives through autograd's
+                # AccumulateGrad -- `_tris_accumulates`: the ViT trunk's class / positional embedding -- ADDS into its arena
+                # slot, which zero_grad() cleared: poisoning it would undo the zeroing and always trip the check, so it is
+                # left out of the check, not of the segment)
+                if not getattr(p, "_tris_accumulates", False):
+                    par[k].append((ai, o, o + p.numel(), n))
                 if k != cur_key:
                     if cur_key is not None:
                         seg[cur_key].append((ai, cur_start, o))

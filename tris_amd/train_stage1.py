@@ -93,8 +93,10 @@ def _weight_planes(module, frozen):
     return wp
 
 
-def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, lr_scheduler=None, reducer=None):
-    """One optimisation step; returns the device tensor losses[4] (no host sync)."""
+def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, reducer, device_hyper=False,
+               optimizer_step=True):
+    """forward -> losses -> backward -> [all-reduce] -> AdamW: the part of a step that is kernel launches only (what
+    tris_amd.graphs.GraphedTrainStep captures).  device_hyper: the optimiser reads lr / bias corrections from device memory."""
     import contextlib
     from .planes import WeightPlanes
     wp = _weight_planes(model, frozen=False)
@@ -111,7 +113,53 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
         losses[0].backward()
     if reducer is not None:
         reducer.reduce()
-    optimizer.step()
+    if optimizer_step:
+        optimizer.step(device_hyper=device_hyper)
+    else:
+        ops.wgrad_join()
+    return losses
+
+
+def _env_key():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("TRIS_")))
+
+
+def _graphable(model, optimizer, img, reducer):
+    """may this step be replayed from a hipGraph?  Opt-in (TRIS_STEP_GRAPH=1): see train_step"""
+    if os.environ.get("TRIS_STEP_GRAPH", "0") != "1" or reducer is not None or ops._PROF is not None:
+        return False
+    if not img.is_cuda or not hasattr(optimizer, "enable_device_hyper") or torch.cuda.is_current_stream_capturing():
+        return False
+    from .CLIP.clip.model import BatchNorm2d
+    net = model.module if hasattr(model, "module") else model
+    if not net.training or any(m.process_group is not None for m in net.modules() if isinstance(m, BatchNorm2d)):
+        return False
+    return os.environ.get("TRIS_WEIGHT_PLANES", "0") != "1"
+
+
+def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, lr_scheduler=None, reducer=None):
+    """One optimisation step; returns the device tensor losses[4] (no host sync).
+
+    TRIS_STEP_GRAPH=1: single-process steps are replayed from ONE hipGraph (tris_amd.graphs.GraphedTrainStep), captured at the
+    first call for the batch shape seen there; other shapes (a ragged last batch), data-parallel runs and profiling passes run
+    eagerly.  The returned tensor is then the graph's static output: read it (or clone it) before the next step.  Opt-in, because
+    on ROCm 7.x it trades GPU time for host time (measured, B = 48, one box): a graph with parallel branches is launched node by
+    node (host 37 ms, as eager) and its branches execute one after the other (50.0 ms/step against 45.0 eager on three streams);
+    captured on ONE stream the runtime's packet path makes the launch 0.65 ms of host time per step, but the step is the
+    single-stream step (50.1 ms) -- DESIGN.md section 5, "captured step"."""
+    if _graphable(model, optimizer, img, reducer):
+        net = model.module if hasattr(model, "module") else model
+        key = (tuple(img.shape), tuple(word_ids.shape), None if neg_word_ids is None else tuple(neg_word_ids.shape),
+               img.dtype, word_ids.dtype, id(clip_model), id(optimizer), id(lr_scheduler), ops.get_gemm_mode(),
+               ops._BWD_MODE, ops._WGRAD_MODE, _env_key())
+        slot = net.__dict__.get("_tris_step_graph")
+        if slot is None:
+            from .graphs import GraphedTrainStep
+            g = GraphedTrainStep(model, clip_model, optimizer, args, (img, word_ids, neg_word_ids), lr_scheduler)
+            slot = net.__dict__["_tris_step_graph"] = (key, g)
+        if slot[0] == key:
+            return slot[1](img, word_ids, neg_word_ids)
+    losses = _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, reducer)
     if lr_scheduler is not None:
         lr_scheduler.step()
     return losses
@@ -138,11 +186,13 @@ def train_one_epoch(train_loader, model, optimizer, epoch, local_rank, args, ite
         img = samples["img"].cuda(local_rank, non_blocking=True)
         neg = samples["neg_word_ids"].cuda(local_rank, non_blocking=True) if args.negative_samples > 0 else None
         last = train_step(model, clip_model, optimizer, img, word_ids, neg, args, lr_scheduler, reducer)
+        if idx % args.print_freq == 0 and args.distributed:
+            # EVERY rank looks at its SyncBN mailbox time-out flag (and at the group's: one tiny all-reduce at the same point of
+            # the loop on all ranks): a rank that gave up on an exchange has NaN statistics, and training must stop on all of them
+            from . import comm
+            comm.check_errors(collective=True)
         if idx % args.print_freq == 0 and local_rank == 0:
             v = last.tolist()  # the only host sync, every print_freq steps (the reference syncs every step, :374-387)
-            if args.distributed:
-                from . import comm
-                comm.check_errors()   # a SyncBN mailbox exchange that timed out fails the run here instead of hanging it
             msg = (f"Train:[{epoch:2d}/{args.epoch}][{idx:4d}/{num_steps}] | lr {optimizer.param_groups[0]['lr']:.6f} || "
                    f"loss: {v[0]:.4f} | l1: {v[1]:.4f} | l4: {v[2]:.4f} | l5: {v[3]:.4f} | "
                    f"time/step: {(time.time() - t0) / (idx + 1):.4f}")
@@ -299,11 +349,19 @@ def main(args, tokenizer=None):
                 os.remove(best["hit_path"])
             best.update(hit_path=save_checkpoint(epoch, net, optimizer, scheduler, log, args,
                                                  f"ckpt_320_epoch_{epoch}_hit.pth"), hit=hit)
+        if args.distributed:
+            # rank 0 alone writes the checkpoints (up to two > 1 GB saves): its peers wait here instead of inside the next epoch's
+            # first SyncBatchNorm exchange, whose spin is bounded (tris_amd.comm.Mailbox.SPIN_LIMIT)
+            dist.barrier()
         log.info(str(best))
     if best["path"] and local_rank == 0:
         load_pretrained_checkpoint(best["path"], net)
     log.info(f"Training time {train_time:.1f}s; training + testing "
              f"{datetime.timedelta(seconds=int(time.time() - start))}")
+    if args.distributed:
+        from . import comm
+        comm.check_errors(collective=True)
+        comm.shutdown()   # unmap the peers' SyncBN mailboxes before the process group goes away
     return best
 
 
