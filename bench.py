@@ -161,6 +161,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_vals = losses.tolist()
+    comm_exposed = reducer.exposed_ms() if reducer is not None else None   # compute-stream wait for collectives, last timed step
     transport = None
     if world > 1 or force:
         from tris_amd import comm
@@ -273,6 +274,8 @@ def main():
                           "negative_samples": 3, "parallelism": f"dp{world}", "sync_bn": world > 1, "sync_bn_transport": transport},
                "untimed_priming_steps": 1, "losses_last_step": [round(v, 5) for v in loss_vals], "ms_single_step_synced": round(one, 3),
                "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
+               "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 3),
+               "sparse_embed_exchange": bool(reducer is not None and reducer.sparse_embed),
                "streams": {"text_encoders_on_side_stream": os.environ.get("TRIS_TEXT_STREAM", "1") != "0",
                            "weight_gradients_on_side_stream": os.environ.get("TRIS_WGRAD_STREAM", "1") != "0"},
                "roofline": roof, "roofline_xattn": roof_x}
@@ -283,6 +286,14 @@ def main():
                 out["input_pipeline"] = pipeline_measure(batch=a.batch)
             except Exception as e:  # reported, never hidden
                 out["input_pipeline"] = {"error": repr(e)}
+        if world == 1 and not a.no_pipeline and a.backbone == "clip-RN50":
+            # evaluation throughput of configs[1] (validate.py's loop): one ref at a time vs batched, identical metrics
+            try:
+                from tools.eval_throughput import measure as eval_measure
+                out["eval"] = eval_measure()
+                out["eval_refs_per_s"] = out["eval"]["eval_refs_per_s"]
+            except Exception as e:  # reported, never hidden
+                out["eval"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline and a.backbone == "clip-RN50":
             out["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in a.cpu_batches.split(",")))
         line = json.dumps(out)

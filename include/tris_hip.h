@@ -183,6 +183,12 @@ int tris_mha_mfma_bwd_f32(const float* qkv, const float* out, const float* dout,
 int tris_embed_fwd_f32(const long* ids, const float* tok, const float* pos, float* out, int N, int L, int W,
                        void* stream);
 int tris_embed_bwd_f32(const long* ids, const float* dout, float* dtok, float* dpos, int N, int L, int W, void* stream);
+/* token-embedding gradient from a row list, deterministic (fixed summation order, no atomics): dtok[ids[t]] = scale * sum of
+ * rows[t'] over the positions t' with ids[t'] == ids[t]; dtok zero-filled by the caller.  The list is this rank's N*L positions
+ * (then tris_embed_bwd_f32 is called with dtok = NULL for the positional part) or, data-parallel, the all-gathered lists of every
+ * rank with scale = 1 / world: <= world * B * L rows of W floats travel instead of the dense [vocab, W] table (101 MB at
+ * 49408 x 512; reference: DistributedDataParallel all-reduces it densely, train_stage1.py:70). */
+int tris_embed_rows_bwd_f32(const long* ids, const float* rows, float* dtok, int R, int W, float scale, void* stream);
 /* x[arange(N), ids.argmax(-1)]  (model.py:562) */
 int tris_eot_gather_fwd_f32(const long* ids, const float* x, float* out, int N, int L, int W, void* stream);
 int tris_eot_gather_bwd_f32(const long* ids, const float* dout, float* dx, int N, int L, int W, void* stream);
@@ -206,6 +212,20 @@ int tris_softmax_bwd_f32(const float* dY, const float* Y, float* dX, long rows, 
 int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                        const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
                        void* stream);
+/* The same forward as ONE persistent launch (csrc/xattn_fused.hip; split-bf16 arithmetic, C = 512 | 1024, 8 <= P <= 104,
+ * N <= 64): eight workgroups per image, the pixel-softmax coupling resolved by an in-kernel exchange of the logit blocks
+ * (agent-scope release / acquire, bounded spins).  The sentence operands are pre-split once per call into bf16 planes in MFMA
+ * fragment order by a small preparation launch on the same stream.  probs: planes 0 (Av) and 2 (AtT) are written, 1 and 3 are
+ * not touched.  ws: scratch of tris_xattn_fused_ws_bytes(B, N, C) bytes (0 = shape not supported); sync: caller-owned device
+ * words (tris_xattn_fused_sync_words(B) of them), ZEROED once at allocation and then only passed back -- word 0 counts the
+ * completed launches (the epoch that tags the exchange flags lives on the device, so a captured launch replays correctly),
+ * word 2 != 0 after a launch means a wait timed out (outputs undefined).  One sync buffer per stream that may run the kernel.
+ * Returns TRIS_WP_UNSUPPORTED (-2) without launching anything when the shape / arithmetic mode is outside its domain. */
+long tris_xattn_fused_ws_bytes(int B, int N, int C);
+long tris_xattn_fused_sync_words(int B);
+int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
+                             const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
+                             float* ws, long ws_bytes, unsigned* sync, void* stream);
 /* backward of a softmax taken over the P axis of [B,P,N]: dX = scale*Y*(dY - sum_p Y*dY)  (model/attn.py:122) */
 int tris_softmax_col_bwd_f32(const float* dY, const float* Y, float* dX, int B, int P, int N, float scale,
                              void* stream);

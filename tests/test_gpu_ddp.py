@@ -72,7 +72,18 @@ def _worker(rank, world, port, tmp):
             out["running"] = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running_" in k}
         from tris_amd import comm
         out["syncbn_transport"] = "mailbox" if any(m is not None for m in comm.Mailbox._by_group.values()) else "c10d"
-        comm.check_errors()
+        # the token-embedding gradient travelled as (ids, rows) lists: rebuild the DENSE data-parallel result (index_add of the
+        # own rows, all-reduce of the 101 MB table, mean) and compare with what the sparse exchange left in the arena
+        ids, rows = red.last_rows
+        dense = torch.zeros_like(net.backbone.token_embedding.weight)
+        dense.index_add_(0, ids, rows)
+        comm.all_reduce(dense)
+        dense /= world
+        got = net.backbone.token_embedding.weight.grad
+        out["sparse_vs_dense"] = (float((got - dense).abs().max()), float(dense.abs().max()))
+        out["sparse_log"] = list(red.sparse_log)
+        out["tok_grad"] = got.detach().cpu().clone()
+        comm.check_errors(collective=True)
         torch.save(out, os.path.join(tmp, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -143,6 +154,12 @@ def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path):
     # (5) replicas stay identical
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
+    # (6) sparse token-embedding exchange == the dense all-reduce it replaces; bit-identical on both ranks; 2 x 40 rows travelled
+    for r in (r0, r1):
+        diff, scale = r["sparse_vs_dense"]
+        assert diff <= 1e-6 * max(scale, 1e-12) + 1e-12, r["sparse_vs_dense"]
+        assert r["sparse_log"] == [(WORLD * PER_RANK * 20, PER_RANK * 20 * (512 * 4 + 8))], r["sparse_log"]
+    assert torch.equal(r0["tok_grad"], r1["tok_grad"])
 
 
 def test_optimizer_checkpoint_is_torch_adamw_layout():

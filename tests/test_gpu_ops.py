@@ -575,6 +575,36 @@ def test_eval_post(ops):
     assert gcam.flatten()[iu[2]].item() == pytest.approx(float(cam.max()), abs=1e-6)
 
 
+@pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 97, 64, 512), (5, 8, 3, 512),
+                                     (7, 104, 33, 1024)])
+def test_xattn_single_launch_kernel_matches_the_two_launch_pair(ops, monkeypatch, B, P, N, C):
+    """csrc/xattn_fused.hip (one persistent launch, eight workgroups per image, in-kernel all-reduce of the partial logits over
+    agent-scope release / acquire) against an fp64 reference and against the default two-launch pair, including the saved
+    probabilities the backward pass reads; five calls in a row exercise the device-side epoch; no wait may have timed out."""
+    g = torch.Generator().manual_seed(B * 1000 + P + N)
+    Qv, Kv, Vv = (torch.randn(B, P, C, generator=g).cuda() * 1.5 for _ in range(3))
+    Qt, Kt, Vt = (torch.randn(N, C, generator=g).cuda() * 1.5 for _ in range(3))
+    sc = 1.0 / math.sqrt(C)
+    Av = torch.softmax(Qv.cpu().double() @ Kt.cpu().double().t() * sc, dim=2)
+    At = torch.softmax(Qt.cpu().double() @ Kv.cpu().double().transpose(1, 2) * sc, dim=2)
+    rv, rl = Av @ Vt.cpu().double(), At @ Vv.cpu().double()
+    outs = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("TRIS_XATTN_FUSED", fused)
+        before = ops.query("tris_xattn_fused_ws_bytes", B, N, C)
+        assert before > 0
+        for _ in range(5):
+            q = [t.clone().requires_grad_(True) for t in (Qv, Kv, Vv, Qt, Kt, Vt)]
+            nv, nl = ops.xattn(*q)
+        (nv.sum() + nl.sum()).backward()
+        outs[fused] = (nv.detach(), nl.detach(), [t.grad for t in q])
+        close(nv.detach().cpu(), rv.float(), 2e-5, name=f"new_vis fused={fused}")
+        close(nl.detach().cpu(), rl.float(), 2e-5, name=f"new_lan fused={fused}")
+    assert not ops.xattn_timed_out()
+    for a, b in zip(outs["0"][2], outs["1"][2]):   # the backward reads Av / AtT saved by whichever forward ran
+        close(a, b, 2e-4, name="gradient through the saved probabilities")
+
+
 @pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64)])
 def test_xattn_fused(ops, B, P, N, C):
     Qv, Kv, Vv = leaf(B, P, C, seed=1), leaf(B, P, C, seed=2), leaf(B, P, C, seed=3)

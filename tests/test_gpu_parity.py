@@ -354,14 +354,23 @@ def test_validate_and_prms_against_oracle(model, aux):
         loader.append(({"img": img, "word_ids": ids.t().reshape(1, 1, 20, 3), "word_masks": torch.ones(1, 1, 20, 3)},
                        {"target": tgt, "boxes": box, "img_path": torch.tensor([r]), "sentences": []}))
         refs.append((img, ids, tgt[0].bool(), box))
-    oIoU, mIoU, hit = validate(args, loader, model, 0)            # hipGraph replay path (default)
     import os
-    os.environ["TRIS_HIPGRAPH"] = "0"
-    try:
-        e_oIoU, e_mIoU, e_hit = validate(args, loader, model, 0)   # eager launches: identical numbers
-    finally:
-        os.environ.pop("TRIS_HIPGRAPH")
-    assert (e_oIoU, float(e_mIoU), e_hit) == (oIoU, float(mIoU), hit)
+
+    def run(group, graph):
+        os.environ["TRIS_EVAL_GROUP"], os.environ["TRIS_HIPGRAPH"] = group, graph
+        try:
+            o, m, h = validate(args, loader, model, 0)
+            return o, float(m), h
+        finally:
+            os.environ.pop("TRIS_EVAL_GROUP")
+            os.environ.pop("TRIS_HIPGRAPH")
+    oIoU, mIoU, hit = run("1", "1")                     # one ref at a time, hipGraph replay of the two halves
+    assert run("1", "0") == (oIoU, mIoU, hit)           # eager launches: identical numbers
+    # batched evaluation (the default): refs grouped into one trunk call / one text-encoder call / paired heads -- the SAME
+    # numbers bit for bit (ops.batch_invariant: no split-K, one convolution family), whatever the group size
+    assert run("2", "1") == (oIoU, mIoU, hit)
+    assert run("16", "1") == (oIoU, mIoU, hit)
+    assert tuple(float(v) for v in validate(args, loader, model, 0)) == (oIoU, mIoU, hit)
     sd = cpu_sd(model)
     Is = Us = 0
     ious, hits = [], []

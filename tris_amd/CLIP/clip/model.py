@@ -410,8 +410,8 @@ class CLIP(nn.Module):
         ids = text.long()
         if ids.shape[1] > self.txt_length:
             raise ValueError(f"token length {ids.shape[1]} exceeds txt_length {self.txt_length}")
-        x = ops.embed(ids, self.token_embedding.weight, self.positional_embedding)
         red = getattr(self, "grad_reducer", None)
+        x = ops.embed(ids, self.token_embedding.weight, self.positional_embedding, reducer=red)
         if red is not None:
             # data-parallel: once backward passes this point every gradient of the text transformer, ln_final and
             # text_projection is written (they were all created after it); the embedding tables follow in finish()

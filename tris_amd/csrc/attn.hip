@@ -157,16 +157,45 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __re
                                  float* __restrict__ dpos, int N, int L, int W) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long NLW = (long)N * L * W;
-  if (i < NLW) {
+  if (dtok != nullptr && i < NLW) {   // (dtok == NULL: the token part is done by embed_rows_bwd_kernel)
     long t = i / W;
     int c = (int)(i - t * W);
     atomicAdd(dtok + ids[t] * W + c, dout[i]);
   }
-  if (i < (long)L * W) {
+  if (dpos != nullptr && i < (long)L * W) {
     int l = (int)(i / W), c = (int)(i - (long)l * W);
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += dout[((long)n * L + l) * W + c];
     dpos[(long)l * W + c] = s;
+  }
+}
+
+// Token-embedding gradient from a ROW LIST, deterministic (no atomics): dtok[ids[t]] = scale * sum over the list positions t'
+// with ids[t'] == ids[t], added in list order.  One workgroup per list position t; only the FIRST occurrence of an id does the
+// work (it scans the rest of the list for repeats -- SOT / EOT / padding ids repeat in every sentence).  The row list may be
+// this rank's own R = N*L positions or the concatenation of every rank's (sparse data-parallel exchange: identical input in
+// identical order on every rank -> bit-identical token-embedding gradients on every rank).  dtok must be zero-filled.
+__global__ __launch_bounds__(128) void embed_rows_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ rows,
+                                                             float* __restrict__ dtok, int R, int W, float scale) {
+  __shared__ int s_first;
+  const int t = blockIdx.x;
+  const long id = ids[t];
+  if (threadIdx.x == 0) s_first = 1;
+  __syncthreads();
+  for (int u = threadIdx.x; u < t; u += blockDim.x)
+    if (ids[u] == id) s_first = 0;      // (benign race: every writer stores 0)
+  __syncthreads();
+  if (!s_first) return;
+  for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
+    float4 a = *reinterpret_cast<const float4*>(rows + (long)t * W + c);
+    for (int u = t + 1; u < R; ++u) {
+      if (ids[u] == id) {
+        const float4 v = *reinterpret_cast<const float4*>(rows + (long)u * W + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+    *reinterpret_cast<float4*>(dtok + id * W + c) = a;
   }
 }
 
@@ -239,6 +268,14 @@ extern "C" int tris_embed_bwd_f32(const long* ids, const float* dout, float* dto
   long n = (long)N * L * W;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, dout, dtok, dpos, N,
                      L, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_embed_rows_bwd_f32(const long* ids, const float* rows, float* dtok, int R, int W, float scale,
+                                       void* stream) {
+  if (R < 1 || W % 4 != 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(R), dim3(128), 0, (hipStream_t)stream, ids, rows, dtok, R, W, scale);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

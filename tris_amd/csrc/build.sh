@@ -9,7 +9,7 @@ OBJ="$HERE/_obj"
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE"
 pids=()
-for f in gemm_conv conv_direct norm attn attn_mfma heads optim eval xattn data comm; do
+for f in gemm_conv conv_direct norm attn attn_mfma heads optim eval xattn xattn_fused data comm; do
   [ -f "$HERE/$f.hip" ] || continue
   stale=0
   for dep in "$HERE/$f.hip" "$HERE"/*.h "$ROOT/include/tris_hip.h"; do

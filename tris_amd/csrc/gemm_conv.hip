@@ -612,7 +612,7 @@ static bool autotune_enabled() {
 
 template <int AK, int BKIND>
 int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t st) {
-  if (BKIND == B_NK_PRE && !(g_gemm_mode >= 1 && p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4 && batch == 1))
+  if (BKIND == B_NK_PRE && !(g_gemm_mode == 1 && p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4 && batch == 1))
     return TRIS_WP_UNSUPPORTED;  // pre-split operands exist only for the fast x3 kernel: the caller falls back to fp32 B
   Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
   if (!autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);

@@ -51,6 +51,7 @@ constexpr int gf_stage_floats(int BMN, int FBK, int PREC, bool row_major) {
   return PREC >= 1 ? (row_major ? BMN * (2 * FBK + 16) * NPLN / 4 : NPLN * FBK * (2 * BMN + 64) / 4)
                    : (row_major ? BMN * (FBK + 4) : FBK * (BMN + 4));
 }
+constexpr int gf_pre_floats(int BN) { return BN * 48; }    // pre-split B stage: BN rows x 64 B x 3 planes, UNPADDED (LDS-DMA image)
 constexpr int gf_halo_floats(int HS) { return HS * 24; }   // HS pixel slots x 3 planes x 16 channels bf16 (no padding)
 constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm, int HS = 0) {
   if (NSTG == 1) return NW == 8 ? 4 : 2;   // (the classic kernels: two co-resident blocks per CU, as tuned in round 1)
@@ -91,7 +92,7 @@ void gemm_fast_kernel(GemmParams p) {
   constexpr bool B_PRE = (BKIND == B_NK_PRE);
   constexpr bool B_RM = (BKIND == B_NK) || B_PRE;
   static_assert(PREC >= 1 || (FBK == 32 && NSTG == 1), "the f32-MFMA path exists as the classic 32-deep loop only");
-  static_assert(!B_PRE || (FBK == 32 && NSTG == 1), "pre-split B planes: classic loop only");
+  static_assert(!B_PRE || (FBK == 32 && NSTG == 1), "pre-split B planes: 32-deep tiles, one A buffer");   // (launched in x3 arithmetic only)
   static_assert(NW % NWM == 0 && BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0, "wave grid does not tile the block");
   constexpr int WM = BM / NWM, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
@@ -116,11 +117,17 @@ void gemm_fast_kernel(GemmParams p) {
   constexpr int A_KS = 2 * BM + 64, B_KS = 2 * BN + 64;  // bytes per k row of a k-major plane
   constexpr int PLB = 2 * FBK + 16;                      // bytes per row of one row-major bf16 plane
   constexpr int A_SZ = HALO ? gf_halo_floats(HS) : gf_stage_floats(BM, FBK, PREC, A_RM);
-  constexpr int B_SZ = gf_stage_floats(BN, FBK, PREC, B_RM);
-  __shared__ __attribute__((aligned(16))) float As[A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
+  constexpr int B_SZ = B_PRE ? gf_pre_floats(BN) : gf_stage_floats(BN, FBK, PREC, B_RM);
+  // B_PRE: ONE LDS object [A stage | B stage 0 | B stage 1] -- the B stages are filled by LDS-DMA (global_load_lds), and with a
+  // second __shared__ object in the kernel the compiler drains the DMA queue (vmcnt(0)) in front of every fragment read
+  // (cdna_hip_programming.md, "three .s-level traps")
+  constexpr int AS_ALL = B_PRE ? A_SZ + 2 * B_SZ : A_SZ;
+  __shared__ __attribute__((aligned(16))) float As[AS_ALL];
+  __shared__ __attribute__((aligned(16))) float Bs_[B_PRE ? 4 : B_SZ];
   __shared__ __attribute__((aligned(16))) float As1[(NSTG == 2 && !HALO) ? A_SZ : 4];   // second stage (pipelined loop): separate objects
-  __shared__ __attribute__((aligned(16))) float Bs1[NSTG == 2 ? B_SZ : 4];
+  __shared__ __attribute__((aligned(16))) float Bs1_[NSTG == 2 ? B_SZ : 4];
+  float* const Bs = B_PRE ? As + A_SZ : Bs_;
+  float* const Bs1 = B_PRE ? As + A_SZ + B_SZ : Bs1_;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -199,16 +206,31 @@ void gemm_fast_kernel(GemmParams p) {
   const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
 
   int bw_b[PB], bw_oy[PB], bw_ox[PB];  // B_KN_IM2COL / B_KN_DGRAD: running coordinates of this thread's k rows
-  constexpr int PBP = B_PRE ? (BN * 4 + NTHR - 1) / NTHR : 1;  // 16-byte pieces (8 bf16) per thread per plane per tile
-  float4 rbp[3 * PBP];  // (a flat float4 array: the 2-D uint4 form was not promoted to registers)
-  const unsigned short* bp_src[PBP];
+  // B_PRE: the B tile (BN rows x 32 k x 3 planes) goes global -> LDS by DMA, 16 bytes per lane, one wave-instruction = 16 rows
+  // x 64 B = 1 KiB of the (lane-linear, unpadded) stage image.  ds_read_b128 fragment reads of an unpadded 64-byte-row image
+  // would be 4-way bank conflicts (rows 4 apart share their 16-byte slots), so the four 16-byte pieces of row r are stored
+  // rotated by (r >> 2) & 3 -- applied on the SOURCE address here and in frag_B (rule: same involution on both sides).
+  constexpr int PRE_WL = B_PRE ? (3 * BN / 16) / NW : 1;   // wave-instructions per wave per tile
+  static_assert(!B_PRE || PRE_WL * NW * 16 == 3 * BN, "pre-split B: tile rows / wave count mismatch");
+  const unsigned short* pre_src[PRE_WL];
+  int pre_dst[PRE_WL];   // byte offset of this wave-instruction's 1 KiB piece inside a B stage
   if (B_PRE) {
 #pragma unroll
-    for (int q = 0; q < PBP; ++q) {
-      const int row = min(n0 + (tid >> 2) + q * (NTHR / 4), p.N - 1);
-      bp_src[q] = reinterpret_cast<const unsigned short*>(p.B) + (long)row * p.ldb + (tid & 3) * 8;
+    for (int t = 0; t < PRE_WL; ++t) {
+      const int q = wave * PRE_WL + t;              // (wave is wave-uniform: the LDS base below is too)
+      const int pl = q / (BN / 16), rb = q % (BN / 16);
+      const int r = rb * 16 + (lane >> 2);
+      const int jl = (lane & 3) ^ ((r >> 2) & 3);
+      pre_src[t] = reinterpret_cast<const unsigned short*>(p.B) + (long)pl * p.bpl + (long)min(n0 + r, p.N - 1) * p.ldb + jl * 8;
+      pre_dst[t] = pl * BN * 64 + rb * 1024;
     }
   }
+  auto dma_B = [&](float* Bd, int k0) {
+#pragma unroll
+    for (int t = 0; t < PRE_WL; ++t)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_src[t] + k0),
+                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(Bd) + pre_dst[t]), 16, 0, 0);
+  };
 
   // ---- direct 3x3: window geometry (see the head of the kernel) -------------------------------------------------------------
   constexpr int HP = HALO ? (HS * 4 + NTHR - 1) / NTHR : 1;   // 16-byte pieces (4 channels of one slot) per thread per chunk
@@ -342,12 +364,7 @@ void gemm_fast_kernel(GemmParams p) {
   };
 
   auto load_B = [&](float4 (&rb)[PB], int k0) {
-    if (B_PRE) {
-#pragma unroll
-      for (int q = 0; q < PBP; ++q)
-#pragma unroll
-        for (int pl = 0; pl < NPLN; ++pl) rbp[pl * PBP + q] = ld4(reinterpret_cast<const float*>(bp_src[q] + pl * p.bpl + k0));
-    } else if (BKIND == B_NK) {
+    if (BKIND == B_NK) {
 #pragma unroll
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
     } else if (BKIND == B_KN) {
@@ -438,18 +455,6 @@ void gemm_fast_kernel(GemmParams p) {
       *reinterpret_cast<float4*>(&Bd[(tid / BF4 + q * BRPP) * (BN + 4) + (tid % BF4) * 4]) = v;
     }
   };
-  auto store_B_pre = [&](float* Bd) {
-#pragma unroll
-    for (int q = 0; q < PBP; ++q) {
-      const int row = (tid >> 2) + q * (NTHR / 4);
-      if (PBP * (NTHR / 4) == BN || row < BN) {
-        char* d = reinterpret_cast<char*>(Bd) + row * PLB + (tid & 3) * 16;
-#pragma unroll
-        for (int pl = 0; pl < NPLN; ++pl) *reinterpret_cast<float4*>(d + pl * BN * PLB) = rbp[pl * PBP + q];
-      }
-    }
-  };
-
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -487,6 +492,11 @@ void gemm_fast_kernel(GemmParams p) {
       s.hi = tr_frag8(pl0, B_KS, g * 16 + 8 * kh, n16, lane);
       s.mid = tr_frag8(pl0 + FBK * B_KS, B_KS, g * 16 + 8 * kh, n16, lane);
       if (NPLN == 3) s.lo = tr_frag8(pl0 + 2 * FBK * B_KS, B_KS, g * 16 + 8 * kh, n16, lane);
+    } else if (B_PRE) {
+      const char* s0 = reinterpret_cast<const char*>(Bc) + col * 64 + (((g * 2 + kh) ^ ((col >> 2) & 3)) * 16);
+      s.hi = *reinterpret_cast<const bf16x8*>(s0);
+      s.mid = *reinterpret_cast<const bf16x8*>(s0 + BN * 64);
+      s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * 64);
     } else {
       const char* s0 = reinterpret_cast<const char*>(Bc) + col * PLB + g * 32 + kh * 16;
       s.hi = *reinterpret_cast<const bf16x8*>(s0);
@@ -650,17 +660,56 @@ void gemm_fast_kernel(GemmParams p) {
       step(As, Bs, As1, Bs1, ra1, rb1, false);
       __syncthreads();
     }
+  } else if constexpr (B_PRE) {
+    // ---- pre-split B: A as in the classic loop (registers -> split -> one LDS buffer), B by LDS-DMA into two stages ---------------
+    // per K tile: request A(k+1) into registers and DMA B(k+1) into the idle stage, MFMAs on A | B(k), barrier, split + store
+    // A(k+1), barrier (the DMA has had the whole compute phase to land; the barrier's vmcnt(0) covers it).
+    float4 ra[PA];
+    auto compute = [&](const float* Bc) {
+#pragma unroll
+      for (int g = 0; g < FBK / 16; ++g) {
+        Split8 sa[FM], sb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) sa[i] = frag_A(As, g, i);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) sb[j] = frag_B(Bc, g, j);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) mfma_x(sa[i], sb[j], acc[i][j]);
+      }
+    };
+    auto step = [&](const float* Bc, float* Bn, int k0) {
+      const bool more = (k0 + FBK) < kend;  // uniform
+      if (more) {
+        load_A(ra, k0 + FBK);
+        dma_B(Bn, k0 + FBK);
+      }
+      compute(Bc);
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) store_A(As, ra[q], q);
+        __syncthreads();
+      }
+    };
+    load_A(ra, kbeg);
+    dma_B(Bs, kbeg);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) store_A(As, ra[q], q);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * FBK) {
+      step(Bs, Bs1, k0);
+      if (k0 + FBK < kend) step(Bs1, Bs, k0 + FBK);
+    }
   } else {
     // ---- classic loop: one LDS buffer, two barriers per K tile ----------------------------------------------------------------
     float4 ra[PA], rb[PB];
     auto store_lds = [&]() {
 #pragma unroll
       for (int q = 0; q < PA; ++q) store_A(As, ra[q], q);
-      if (B_PRE) store_B_pre(Bs);
-      else {
 #pragma unroll
-        for (int q = 0; q < PB; ++q) store_B(Bs, rb[q], q);
-      }
+      for (int q = 0; q < PB; ++q) store_B(Bs, rb[q], q);
     };
     load_A(ra, kbeg);
     load_B(rb, kbeg);
@@ -743,7 +792,8 @@ void gemm_fast_kernel(GemmParams p) {
   // kernel.  Each wave instead turns its block around in the idle staging LDS (32 x 36 floats, wave-private: program order
   // + a wave fence) and handles rows: 8 lanes x 16 bytes per row, 8 rows per instruction -- 4 loads/stores per block.
   constexpr int ELD = 36;
-  constexpr int EW_A = A_SZ / (32 * ELD), EW_B = B_SZ / (32 * ELD);   // waves whose 32 x 36 turn-around block fits an array
+  // waves whose 32 x 36 turn-around block fits an array (B_PRE: everything lives in As)
+  constexpr int EW_A = AS_ALL / (32 * ELD), EW_B = B_PRE ? 0 : B_SZ / (32 * ELD);
   constexpr int EW_A1 = (NSTG == 2 && !HALO) ? EW_A : 0, EW_B1 = NSTG == 2 ? EW_B : 0;
   constexpr bool EPI_LDS = EW_A + EW_B + EW_A1 + EW_B1 >= NW;
   float4 vs_s[FN], vs_q[FN];
@@ -755,9 +805,9 @@ void gemm_fast_kernel(GemmParams p) {
     {
       int w = wave;
       if (w < EW_A) stg = As + w * 32 * ELD;
-      else if ((w -= EW_A) < EW_B) stg = Bs + w * 32 * ELD;
+      else if ((w -= EW_A) < EW_B) stg = Bs_ + w * 32 * ELD;
       else if ((w -= EW_B) < EW_A1) stg = As1 + w * 32 * ELD;
-      else stg = Bs1 + (w - EW_A1) * 32 * ELD;
+      else stg = Bs1_ + (w - EW_A1) * 32 * ELD;
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
@@ -832,7 +882,7 @@ void gemm_fast_kernel(GemmParams p) {
   if (EPI == EPI_STD && p.stat_part != nullptr) {
     // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the NWM waves along M:
     // shuffle, then LDS, then one fp64 partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
-    static_assert(NWM * BN * 2 <= A_SZ, "statistics scratch does not fit the staging buffer");
+    static_assert(NWM * BN * 2 <= AS_ALL, "statistics scratch does not fit the staging buffer");
     float* red = As;
     if (vec_epi) {
       __syncthreads();  // the other waves' epilogue blocks live in the staging buffers

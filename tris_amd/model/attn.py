@@ -68,6 +68,23 @@ class bilateral_prompt(nn.Module):
         new_lan = self.t_output[0](new_lan)
         return new_vis, new_lan
 
+    def forward_pairs(self, vis, lan, owner):
+        """Evaluation of (image, sentence) PAIRS in one pass (tris_amd.validate): vis [G,P,C] image features, lan [S,C]
+        sentences, owner[k] = image of sentence k.  Every pair is attended exactly as the reference's per-sentence call does
+        (a sentence SET of one: validate.py:173-179 runs the model per sentence), so the soft-max over sentences sees one
+        sentence -- the projections and the output branches are batched over images / pairs, the cross attention itself is
+        launched per pair on views of the batched projections.  -> (new_vis [S,P,C], new_lan [S,1,C])"""
+        Qv, Kv, Vv = (_vbranch(getattr(self, f"v_proj{i}"), vis, True) for i in (1, 2, 3))
+        Qt, Kt, Vt = (getattr(self, f"t_proj{i}")[0](lan, act=1) for i in (1, 2, 3))
+        nv, nl = [], []
+        for k, i in enumerate(owner):
+            a, b = ops.xattn(Qv[i:i + 1], Kv[i:i + 1], Vv[i:i + 1], Qt[k:k + 1], Kt[k:k + 1], Vt[k:k + 1])
+            nv.append(a)
+            nl.append(b)
+        new_vis = _vbranch(self.v_output, torch.cat(nv, 0), False)
+        new_lan = self.t_output[0](torch.cat(nl, 0))
+        return new_vis, new_lan
+
     def forward(self, vis, lan):
         B, C, H, W = vis.shape
         lan_t = lan.transpose(1, 2)  # [B,N,C]

@@ -111,6 +111,32 @@ class TRIS(nn.Module):
             return cls_out, cls_fg, relu_map, sig_map, logit_scale
         return ops.score_heads(score, h_, w_, out_size, False)
 
+    @torch.no_grad()
+    def forward_pairs(self, vis_state, word_id, owner, out_size):
+        """Evaluation: response maps of S (image, sentence) pairs in one pass.  vis_state = encode_visual of G images,
+        word_id [S, L], owner[k] = index of sentence k's image.  Each pair is computed as the reference computes it -- the
+        model called with ONE sentence (validate.py:173-179) -- so under ops.batch_invariant() map k equals
+        forward_cached(encode_visual(img[owner[k]]), word_id[k:k+1]) bit for bit.  -> relu maps [S,1,H,W]"""
+        assert not self.training
+        norm_vis, h_, w_ = vis_state
+        S = word_id.shape[0]
+        idx = torch.as_tensor(list(owner), device=norm_vis.device, dtype=torch.long)
+        _, hidden = self.backbone.encode_text(word_id)                 # [S,E]
+        norm_lan = ops.l2norm(self.lan_project(hidden))                 # [S,C]
+        vis_p = norm_vis.index_select(0, idx)                           # [S,P,C]  (a copy of each pair's image features)
+        if self.args.attn_multi > 0:
+            new_vis, new_lan = self.attn_fusion.forward_pairs(norm_vis, norm_lan, list(owner))
+            vis_p = ops.axpy(new_vis, vis_p, 0.1)
+            lan_p = ops.axpy(new_lan, norm_lan.unsqueeze(1).contiguous(), 0.1)      # [S,1,C]
+        else:
+            lan_p = norm_lan.unsqueeze(1).contiguous()
+        score = ops.bmm(vis_p, lan_p, tB=True) * self.logit_scale.exp()            # [S,P,1]
+        # the map kernels read score[i,:,i] (Stage-1's diagonal): lay the S single-sentence columns out on a diagonal
+        full = torch.zeros(S, score.shape[1], S, device=score.device, dtype=torch.float32)
+        ar = torch.arange(S, device=score.device)
+        full[ar, :, ar] = score[:, :, 0]
+        return ops.score_heads(full, h_, w_, out_size, False)
+
     def forward(self, x, word_id):
         if not _overlap_enabled():
             return self.forward_cached(self.encode_visual(x), word_id, x.shape[2])

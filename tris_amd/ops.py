@@ -431,10 +431,38 @@ def _timed(kind, flops, fn, tag=None):
 
 
 # ----------------------------------------------------------------------------------------------- raw launches
+# Batch-invariant arithmetic (evaluation): with it on, the result of every output ROW of a dense product is independent of how
+# many other rows share the launch.  What can differ between launches of different M is (a) split-K (a different partition of
+# the K sum) and (b) the direct vs implicit 3x3 convolution (different K order); tile shapes and the classic / pipelined loops
+# walk K in the same order and are bitwise neutral.  `batch_invariant()` switches (a) and (b) off for its scope, so that
+# tris_amd.validate can batch images and sentences and still return exactly the numbers of the one-at-a-time loop.
+_BATCH_INVARIANT = 0
+
+
+class batch_invariant:
+    def __enter__(self):
+        global _BATCH_INVARIANT
+        _BATCH_INVARIANT += 1
+        if _BATCH_INVARIANT == 1:
+            self._prev = os.environ.get("TRIS_CONV_DIRECT")
+            os.environ["TRIS_CONV_DIRECT"] = "0"      # (read per call by the convolution dispatch)
+        return self
+
+    def __exit__(self, *exc):
+        global _BATCH_INVARIANT
+        _BATCH_INVARIANT -= 1
+        if _BATCH_INVARIANT == 0:
+            if self._prev is None:
+                os.environ.pop("TRIS_CONV_DIRECT", None)
+            else:
+                os.environ["TRIS_CONV_DIRECT"] = self._prev
+        return False
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
          ldr=0, sR=0, act=0, alpha=1.0, use_ws=True):
     _chk(A, B, C, bias, resid)
-    ws = workspace(0) if (use_ws and batch == 1) else None
+    ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
@@ -1140,10 +1168,15 @@ def quick_gelu(x):
 
 
 class EmbedFn(torch.autograd.Function):
-    """token_embedding[ids] + positional_embedding[:L]"""
+    """token_embedding(ids) + positional_embedding[:L]  (CLIP/clip/model.py:553-554).
+
+    Backward: the positional gradient is a column sum; the token gradient is built from the ROW LIST (ids, d_out rows) by a
+    deterministic kernel (tris_embed_rows_bwd_f32).  Data-parallel (`reducer` given and it takes the table): the list is handed
+    to the reducer, which all-gathers the <= B*L rows of every rank and builds the SAME mean gradient on every rank -- 2 MB per
+    rank on the wire instead of the dense 101 MB table."""
 
     @staticmethod
-    def forward(ctx, ids, tok, pos):
+    def forward(ctx, ids, tok, pos, reducer=None):
         _chk(ids, tok, pos)
         ids = ids.contiguous()
         N, L = ids.shape
@@ -1151,6 +1184,7 @@ class EmbedFn(torch.autograd.Function):
         out = torch.empty(N, L, W, device=tok.device, dtype=torch.float32)
         call("tris_embed_fwd_f32", P(ids), P(tok), P(pos), P(out), N, L, W, _stream())
         ctx.params = (tok, pos)
+        ctx.reducer = reducer
         ctx.save_for_backward(ids, tok, pos)
         return out
 
@@ -1165,12 +1199,19 @@ class EmbedFn(torch.autograd.Function):
         dpos = st[1] if st[1] is not None else torch.empty_like(pos)
         dtok.zero_()
         dpos.zero_()
-        call("tris_embed_bwd_f32", P(ids), P(dout), P(dtok), P(dpos), N, L, W, _stream())
-        return None, (None if st[0] is not None else dtok), (None if st[1] is not None else dpos)
+        call("tris_embed_bwd_f32", P(ids), P(dout), None, P(dpos), N, L, W, _stream())     # positional part
+        red = ctx.reducer
+        if red is not None and st[0] is not None and W % 4 == 0 and red.take_embedding_rows(ctx.params[0], ids.view(-1), dout.view(N * L, W), dtok):
+            pass     # the reducer gathers every rank's rows and scatters them (scale 1 / world) into dtok
+        elif W % 4 == 0:
+            call("tris_embed_rows_bwd_f32", P(ids), P(dout), P(dtok), N * L, W, 1.0, _stream())
+        else:
+            call("tris_embed_bwd_f32", P(ids), P(dout), P(dtok), None, N, L, W, _stream())
+        return None, (None if st[0] is not None else dtok), (None if st[1] is not None else dpos), None
 
 
-def embed(ids, tok, pos):
-    return EmbedFn.apply(ids, tok, pos)
+def embed(ids, tok, pos, reducer=None):
+    return EmbedFn.apply(ids, tok, pos, reducer)
 
 
 class EotGatherFn(torch.autograd.Function):
@@ -1284,6 +1325,28 @@ def instance_norm(x, g, b, relu=False, eps=1e-5):
     return InstNormFn.apply(x, g, b, relu, eps)
 
 
+_XATTN_SYNC = {}
+
+
+def _xattn_sync(dev, B):
+    """the fused cross-attention kernel's device-side bookkeeping (launch epoch, finish ticket, time-out flag, publish flags):
+    zeroed once, then owned by the kernel.  One buffer per (device, stream): launches on one stream are ordered."""
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    n = int(query("tris_xattn_fused_sync_words", B))
+    t = _XATTN_SYNC.get(key)
+    if t is None or t.numel() < n:
+        if torch.cuda.is_current_stream_capturing() and t is not None:
+            raise RuntimeError("fused cross attention: batch grew under stream capture (prime with the largest batch first)")
+        t = torch.zeros(max(n, 16 + 8 * 64), device=dev, dtype=torch.int32)
+        _XATTN_SYNC[key] = t
+    return t
+
+
+def xattn_timed_out():
+    """True if a wait inside any fused cross-attention launch gave up (host sync; tests / debugging)"""
+    return any(int(t[2].item()) != 0 for t in _XATTN_SYNC.values())
+
+
 class XAttnFn(torch.autograd.Function):
     """Fused bilateral cross attention (model/attn.py:117-128): forward = tris_xattn_fwd (two launches for the whole
     batch); backward = nine large single GEMMs on the saved probabilities + two softmax-backward kernels."""
@@ -1298,9 +1361,20 @@ class XAttnFn(torch.autograd.Function):
         new_vis = torch.empty(B, Pp, C, device=dev, dtype=torch.float32)
         new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
         probs = torch.empty(B, 4, Pp, N, device=dev, dtype=torch.float32)
-        _timed("xattn_fwd", 8.0 * B * Pp * N * C,
-               lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
-                            P(probs), B, Pp, N, C, _stream()))
+        done = False
+        # ONE persistent launch (csrc/xattn_fused.hip) -- opt-in (TRIS_XATTN_FUSED=1): correct and single-launch, but measured
+        # SLOWER than the two-launch pair at the Stage-1 shape (77 vs 56 us at B = 48; DESIGN.md section 3 has the phase timeline)
+        ws_bytes = query("tris_xattn_fused_ws_bytes", B, N, C) if os.environ.get("TRIS_XATTN_FUSED", "0") == "1" else 0
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
+            sync = _xattn_sync(dev, B)
+            done = _timed("xattn_fwd", 8.0 * B * Pp * N * C, lambda: _wp_call(
+                "tris_xattn_fused_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B, Pp,
+                N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
+        if not done:
+            _timed("xattn_fwd", 8.0 * B * Pp * N * C,
+                   lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
+                                P(probs), B, Pp, N, C, _stream()))
         ctx.dims = (B, Pp, N, C)
         ctx.save_for_backward(Qv, Kv, Vv, Qt, Kt, Vt, probs)
         return new_vis, new_lan

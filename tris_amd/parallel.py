@@ -68,6 +68,13 @@ class GradReducer:
         # NCCL/RCCL averages in the collective; gloo has no AVG: sum, then scale in finish()
         self.avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        # Sparse exchange of the token-embedding gradient (TRIS_DDP_SPARSE_EMBED=0 switches back to the dense all-reduce): the
+        # table is [49408, 512] fp32 = 101 MB, of which a rank touches <= B*L rows per step.  `sparse_exclude` lists the arena
+        # ranges left out of the dense segments; take_embedding_rows() does the exchange.
+        self.sparse_embed = os.environ.get("TRIS_DDP_SPARSE_EMBED", "1") != "0"
+        self.sparse_exclude = {}   # id(param) -> (flat index, start, end)
+        self.sparse_log = []       # (rows gathered, bytes on the wire per rank) of the current / last step (tests, dist_check)
+        self.exposed = None        # (event before, event after) the compute stream's wait in finish(): exposed communication
 
     # ---- segment planning ------------------------------------------------------------------------------------------
     @staticmethod
@@ -142,11 +149,67 @@ class GradReducer:
             ops.wgrad_join()
             ctx = contextlib.nullcontext()
         with ctx:
-            for ai, s, e in self.segments.get(key, []):
+            for ai, s, e in self._dense_ranges(key):
                 f = self.flats[ai]
                 for c in range(s, e, self.chunk):
                     self.pending.append(comm.all_reduce(f[c:min(e, c + self.chunk)], op=self.op, group=self.group,
                                                         async_op=True))
+
+    def _dense_ranges(self, key):
+        """the ranges of segment `key` that are all-reduced densely: everything except the sparsely exchanged tables"""
+        out = []
+        for ai, s, e in self.segments.get(key, []):
+            cuts = sorted((xs, xe) for xa, xs, xe in self.sparse_exclude.values() if xa == ai and xs >= s and xe <= e)
+            cur = s
+            for xs, xe in cuts:
+                if xs > cur:
+                    out.append((ai, cur, xs))
+                cur = max(cur, xe)
+            if cur < e:
+                out.append((ai, cur, e))
+        return out
+
+    def exclude_sparse(self, param, ai, start, end):
+        self.sparse_exclude[id(param)] = (ai, start, end)
+
+    def take_embedding_rows(self, param, ids, rows, dtok):
+        """Called from the embedding's own backward (ops.EmbedFn) with this rank's row list: all-gather (ids, rows) of every
+        rank and build dtok = (1 / world) * scatter-sum of ALL rows with the deterministic kernel -- the same input in the same
+        order on every rank, hence bit-identical gradients.  Returns False when the table is not exchanged sparsely (the
+        caller then builds its local gradient and the dense all-reduce of the segment carries it)."""
+        if not (self.active and self.sparse_embed and id(param) in self.sparse_exclude):
+            return False
+        from . import ops
+        R, W = rows.shape
+        world = max(self.world, 1)
+        # (backends without AVG -- gloo -- scale the whole arenas by 1 / world in finish(): the table must not be scaled twice)
+        scale = 1.0 / world if self.avg else 1.0
+        if self.world > 1:
+            all_ids = torch.empty(world * R, device=ids.device, dtype=ids.dtype)
+            all_rows = torch.empty(world * R, W, device=rows.device, dtype=rows.dtype)
+            on_gpu = rows.is_cuda
+            if on_gpu:   # issued from the reducer's stream like every other collective of the step
+                rs = ops.side_stream("reduce")
+                rs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(rs):
+                    comm.all_gather_into(all_ids, ids.contiguous(), group=self.group)
+                    comm.all_gather_into(all_rows.view(-1), rows.contiguous().view(-1), group=self.group)
+                    ops.call("tris_embed_rows_bwd_f32", ops.P(all_ids), ops.P(all_rows), ops.P(dtok), world * R, W, scale,
+                             rs.cuda_stream)
+                for t in (ids, rows, all_ids, all_rows, dtok):
+                    t.record_stream(rs)
+            else:
+                comm.all_gather_into(all_ids, ids.contiguous(), group=self.group)
+                comm.all_gather_into(all_rows.view(-1), rows.contiguous().view(-1), group=self.group)
+                dtok.index_add_(0, all_ids, all_rows * scale)
+        else:   # one rank (force=True): the same kernel on the own list
+            if rows.is_cuda:
+                ops.call("tris_embed_rows_bwd_f32", ops.P(ids), ops.P(rows), ops.P(dtok), R, W, 1.0, ops._stream())
+            else:
+                dtok.index_add_(0, ids, rows)
+        self.sparse_log.append((world * R, R * (W * 4 + 8)))
+        self.last_rows = (ids, rows)
+        return True
 
     def boundary(self, x, key):
         if not self.active or not torch.is_grad_enabled() or not x.requires_grad:
@@ -166,19 +229,33 @@ class GradReducer:
                     for c in range(0, f.numel(), self.chunk):
                         self.pending.append(comm.all_reduce(f[c:c + self.chunk], op=self.op, group=self.group,
                                                             async_op=True))
+            on_gpu = bool(self.flats) and self.flats[0].is_cuda
+            if on_gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()    # from here the compute stream only waits: what it waits for is exposed communication
             for h in self.pending:
                 h.wait()
-            if self.flats and self.flats[0].is_cuda:
+            if on_gpu:
                 from . import ops
                 torch.cuda.current_stream().wait_stream(ops.side_stream("reduce"))
+                e1.record()
+                self.exposed = (e0, e1)
             if not self.avg and self.world > 1:
                 for f in self.flats:
                     f.mul_(1.0 / self.world)
         self.pending = []
         self.done = set()
 
+    def exposed_ms(self):
+        """milliseconds the compute stream waited for collectives in the last finish() (host sync; None before the first step)"""
+        if self.exposed is None:
+            return None
+        self.exposed[1].synchronize()
+        return self.exposed[0].elapsed_time(self.exposed[1])
+
     def begin_step(self):
         self.launch_log = []
+        self.sparse_log = []
         if self.check and self.active:
             self.poison()
 
@@ -245,6 +322,12 @@ def attach_reducer(model, optimizer, group=None, force=False, check=None, chunk_
     red = GradReducer([a.g for a in optimizer.arenas], group=group, chunk_mb=chunk_mb, force=force, check=check)
     seg, par = stage1_segments(net, optimizer, with_params=True)
     red.set_segments(seg, par)
+    tok = getattr(getattr(net, "backbone", None), "token_embedding", None)
+    if tok is not None and red.sparse_embed:   # the token table travels as rows (take_embedding_rows), not densely
+        for ai, ar in enumerate(optimizer.arenas):
+            for p, o in zip(ar.params, ar.offsets):
+                if p is tok.weight:
+                    red.exclude_sparse(p, ai, o, o + (p.numel() + 63) // 64 * 64)
     net.backbone.visual.grad_reducer = red     # trunk boundaries (ModifiedResNet.forward_cl)
     net.backbone.grad_reducer = red            # text boundary (CLIP.encode_text)
     return red

@@ -58,6 +58,11 @@ def get_scores(clip_model, fg_224_eval, word_id):
 
 @torch.no_grad()
 def validate(args, data_loader, model, local_rank=0, visualize=False, logger=None, save_cam=False):
+    """TRIS_EVAL_GROUP (default 16) refs are evaluated per pass: ONE trunk call on the stacked images, ONE text-encoder call on
+    all of their sentences, the heads per (image, sentence) pair, one host sync per group -- under ops.batch_invariant(), which
+    makes every row of every dense product independent of the rows it shares a launch with, so the returned (oIoU, mIoU, hit)
+    are bit-for-bit those of the one-ref-at-a-time loop (TRIS_EVAL_GROUP=1: the reference's loop structure, trunk and sentence
+    halves replayed from hipGraphs)."""
     num_steps = len(data_loader)
     model.eval()
     net = model.module if hasattr(model, "module") else model
@@ -68,49 +73,97 @@ def validate(args, data_loader, model, local_rank=0, visualize=False, logger=Non
     if save_cam and args.cam_save_dir:
         os.makedirs(args.cam_save_dir, exist_ok=True)
     batch_time, mIOU_meter = AverageMeter(), AverageMeter()
-    I_sum = U_sum = 0
-    n_sent = hit_acc = hitmask_acc = 0
+    st = {"I": 0, "U": 0, "n_sent": 0, "hit": 0}
     cam_out_name = []
     graphs = {}
+    group = max(1, int(os.environ.get("TRIS_EVAL_GROUP", "16")))
     end = time.time()
-    for idx, (samples, targets) in enumerate(data_loader):
-        img_id = int(_host(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
-        word_ids = samples["word_ids"].squeeze(1).cuda(local_rank, non_blocking=True)      # [1, L, S]
-        img = samples["img"].cuda(local_rank, non_blocking=True)                           # [1, 3, H, W]
-        target = targets["target"].cuda(local_rank, non_blocking=True)
-        tgt = (target.reshape(target.shape[-2:]) != 0).to(torch.uint8)
-        bbox = _host(targets["boxes"]).reshape(-1, 4) if "boxes" in targets else np.zeros((0, 4))
-        gr = _graphed(net, img, word_ids.shape[1], graphs)
-        if gr is not None:
-            gr.visual(img)                                                                 # once per image (hipGraph)
-        else:
-            vis = net.encode_visual(img)
-        for j in range(word_ids.size(-1)):
-            n_sent += 1
-            wid = word_ids[:, :, j].contiguous()
-            out = gr.sentence(wid) if gr is not None else net.forward_cached(vis, wid, img.shape[2])  # [1,1,H,W]
-            iu, cam = ops.eval_post(out, tgt)
-            I, U, am = iu.tolist()                                                         # the one host sync
-            I_sum += I
-            U_sum += U
-            mIOU_meter.update(I / U if U > 0 else 0.0, img.size(0))
-            y, x = divmod(am, cam.shape[1])
-            hit = 0
-            for b in bbox:
-                if b[0] <= x <= b[2] and b[1] <= y <= b[3]:
-                    hit = 1
-                    break
-            hit_acc += hit
-            if args.cam_save_dir is not None and save_cam:
-                np.save(os.path.join(args.cam_save_dir, f"{idx}_{j}_{img_id}.npy"), cam.cpu().numpy())
-            if args.name_save_dir is not None and save_cam:
-                cam_out_name.append(f"{idx}_{j}_{img_id}")
-        batch_time.update(time.time() - end)
+
+    def account(idx, j, img_id, bbox, I, U, am, cam, n_img):
+        """one (image, sentence) result -> the meters, in the reference's order (validate.py:180-236)"""
+        st["n_sent"] += 1
+        st["I"] += I
+        st["U"] += U
+        mIOU_meter.update(I / U if U > 0 else 0.0, n_img)
+        y, x = divmod(am, cam.shape[1])
+        for b in bbox:
+            if b[0] <= x <= b[2] and b[1] <= y <= b[3]:
+                st["hit"] += 1
+                break
+        if args.cam_save_dir is not None and save_cam:
+            np.save(os.path.join(args.cam_save_dir, f"{idx}_{j}_{img_id}.npy"), cam.cpu().numpy())
+        if args.name_save_dir is not None and save_cam:
+            cam_out_name.append(f"{idx}_{j}_{img_id}")
+
+    def report(idx):
+        say(f"Test: [{idx:4d}/{num_steps}] | mIOU {100 * mIOU_meter.avg:.3f} | Overall IOU "
+            f"{100 * float(st['I']) / max(float(st['U']), 1.0):.3f} | Hit {st['hit'] / max(st['n_sent'], 1) * 100:.3f} | "
+            f"Time {batch_time.val:.3f} ({batch_time.avg:.3f})")
+
+    def flush(refs):
+        """refs: [(idx, img_id, img [1,3,H,W], word_ids [1,L,S], tgt u8 [oH,oW], bbox)] with one image shape"""
+        nonlocal end
+        if not refs:
+            return
+        imgs = torch.cat([r[2] for r in refs], 0)
+        vis = net.encode_visual(imgs)
+        ids = torch.cat([r[3][0].t() for r in refs], 0).contiguous()                       # [sum S, L]
+        owner = [i for i, r in enumerate(refs) for _ in range(r[3].size(-1))]
+        maps = net.forward_pairs(vis, ids, owner, imgs.shape[2])                           # [sum S, 1, H, W]
+        ius, cams, k = [], [], 0
+        for r in refs:
+            for _ in range(r[3].size(-1)):
+                iu, cam = ops.eval_post(maps[k:k + 1], r[4])
+                ius.append(iu)
+                cams.append(cam)
+                k += 1
+        vals = torch.stack(ius).tolist()                                                   # the one host sync of the group
+        k = 0
+        for idx, img_id, img, word_ids, tgt, bbox in refs:
+            for j in range(word_ids.size(-1)):
+                I, U, am = vals[k]
+                account(idx, j, img_id, bbox, I, U, am, cams[k], img.size(0))
+                k += 1
+            batch_time.update((time.time() - end) / len(refs))
+            if idx % args.print_freq == 0:
+                report(idx)
         end = time.time()
-        if idx % args.print_freq == 0:
-            say(f"Test: [{idx:4d}/{num_steps}] | mIOU {100 * mIOU_meter.avg:.3f} | Overall IOU "
-                f"{100 * float(I_sum) / max(float(U_sum), 1.0):.3f} | Hit {hit_acc / max(n_sent, 1) * 100:.3f} | "
-                f"Time {batch_time.val:.3f} ({batch_time.avg:.3f})")
+
+    with ops.batch_invariant():
+        pending = []
+        for idx, (samples, targets) in enumerate(data_loader):
+            img_id = int(_host(targets["img_path"]).reshape(-1)[0]) if "img_path" in targets else idx
+            word_ids = samples["word_ids"].squeeze(1).cuda(local_rank, non_blocking=True)      # [1, L, S]
+            img = samples["img"].cuda(local_rank, non_blocking=True)                           # [1, 3, H, W]
+            target = targets["target"].cuda(local_rank, non_blocking=True)
+            tgt = (target.reshape(target.shape[-2:]) != 0).to(torch.uint8)
+            bbox = _host(targets["boxes"]).reshape(-1, 4) if "boxes" in targets else np.zeros((0, 4))
+            if group > 1 and img.shape[0] == 1:
+                if pending and (pending[0][2].shape != img.shape or pending[0][3].shape[1] != word_ids.shape[1]):
+                    flush(pending)
+                    pending = []
+                pending.append((idx, img_id, img, word_ids, tgt, bbox))
+                if len(pending) == group:
+                    flush(pending)
+                    pending = []
+                continue
+            gr = _graphed(net, img, word_ids.shape[1], graphs)
+            if gr is not None:
+                gr.visual(img)                                                                 # once per image (hipGraph)
+            else:
+                vis = net.encode_visual(img)
+            for j in range(word_ids.size(-1)):
+                wid = word_ids[:, :, j].contiguous()
+                out = gr.sentence(wid) if gr is not None else net.forward_cached(vis, wid, img.shape[2])  # [1,1,H,W]
+                iu, cam = ops.eval_post(out, tgt)
+                I, U, am = iu.tolist()                                                         # the one host sync
+                account(idx, j, img_id, bbox, I, U, am, cam, img.size(0))
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if idx % args.print_freq == 0:
+                report(idx)
+        flush(pending)
+    I_sum, U_sum, n_sent, hit_acc = st["I"], st["U"], st["n_sent"], st["hit"]
     if args.name_save_dir is not None and save_cam:
         with open(os.path.join(args.name_save_dir, f"{args.dataset}_train_cam_name.json"), "w") as f:
             f.write(json.dumps(cam_out_name))
