@@ -214,7 +214,8 @@ int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const 
                        void* stream);
 /* The same forward as ONE persistent launch (csrc/xattn_fused.hip; split-bf16 arithmetic, C = 512 | 1024, 8 <= P <= 104,
  * N <= 64): eight workgroups per image, the pixel-softmax coupling resolved by an in-kernel exchange of the logit blocks
- * (agent-scope release / acquire, bounded spins).  The sentence operands are pre-split once per call into bf16 planes in MFMA
+ * (write-through stores + per-(image, slot) flags, bounded spins; all B * 8 workgroups must be co-resident, otherwise the call
+ * declines).  The sentence operands are pre-split once per call into bf16 planes in MFMA
  * fragment order by a small preparation launch on the same stream.  probs: planes 0 (Av) and 2 (AtT) are written, 1 and 3 are
  * not touched.  ws: scratch of tris_xattn_fused_ws_bytes(B, N, C) bytes (0 = shape not supported); sync: caller-owned device
  * words (tris_xattn_fused_sync_words(B) of them), ZEROED once at allocation and then only passed back -- word 0 counts the

@@ -35,13 +35,16 @@ for _ in range(20):
     run()
 b.record(); torch.cuda.synchronize()
 print(f"prep + fused: {a.elapsed_time(b) / 20 * 1e3:.1f} us per call")
-off = (wsb - B * 8 * 8 * 8) // 8
-tr = ws[:wsb // 4].view(torch.int64)[off:off + B * 8 * 8].view(B * 8, 8).cpu().double()
-names = ["start", "logits done", "published", "stage-1 flags", "gathered", "new_vis done", "end"]
+off = (wsb - B * 8 * 16 * 8) // 8
+raw = ws[:wsb // 4].view(torch.int64)[off:off + B * 8 * 16].view(B * 8, 16).cpu().double()
+order = [0, 1, 2, 3, 10, 11, 12, 13, 4, 5, 6]     # stamp ids in program order
+tr = raw[:, order]
+names = ["start", "logits done", "published", "stage-1 flags", "reduced", "soft-max done", "published 2", "stage-2 flags", "gathered",
+         "new_vis done", "end"]
 clk = 2.0e9   # s_memtime ticks at the shader clock (~2 GHz under load: 77 us per call = 1.55e5 ticks); per-XCD counters are not aligned -> per-workgroup deltas
-d = (tr[:, 1:7] - tr[:, 0:6]) / clk * 1e6
-for i in range(6):
+d = (tr[:, 1:] - tr[:, :-1]) / clk * 1e6
+for i in range(len(names) - 1):
     col = d[:, i]
     print(f"{names[i]:13s} -> {names[i + 1]:13s}  min {col.min():7.2f}  median {col.median():7.2f}  max {col.max():7.2f} us")
-tot = (tr[:, 6] - tr[:, 0]) / clk * 1e6
+tot = (tr[:, -1] - tr[:, 0]) / clk * 1e6
 print(f"workgroup lifetime  min {tot.min():.2f}  median {tot.median():.2f}  max {tot.max():.2f} us")

@@ -71,9 +71,15 @@ def load():
     return _lib
 
 
+_FN = {}
+
+
 def call(name, *args):
     """Call an `int`-returning entry point; raise on a non-zero hipError_t."""
-    err = getattr(load(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    err = fn(*args)
     if err != 0:
         raise TrisHipError(f"{name} failed with hipError_t {err}")
 

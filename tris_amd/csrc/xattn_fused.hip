@@ -4,27 +4,39 @@
 //   AtT = softmax_p(Kv Qt^T / sqrt(C))   [B,P,N]      new_lan = AtT^T Vv    [B,N,C]
 //
 // Why one launch and how the work is cut.  The pair is an HBM stream (1.84 MB per image at P = 100, N = 48, C = 1024, 21 FLOP/B)
-// and a CU moves ~25 GB/s of it, so an image has to be spread over several CUs in EVERY phase -- but the pixel soft-max of the
-// sentence->pixel direction couples all pixels of an image.  Eight workgroups per image (B * 8 >= 256 CUs at B = 48):
-//   phase A  workgroup s owns pixels [s P/8, (s+1) P/8) (<= 16 rows): both logit blocks of those rows against ALL sentences,
-//            S_t[n][p] = Qt[n].Kv[p] and S_v[n][p] = Kt[n].Qv[p], full reduction over C (the 4 waves split C, partial tiles are
-//            summed through LDS).  The pixel rows stream from HBM straight into MFMA operand registers (16 rows x 128 B per
-//            instruction); the sentence operands arrive PRE-SPLIT into three bf16 planes in MFMA fragment order (one coalesced
-//            16-byte load per lane per fragment, no VALU, no LDS), written once per call by xattn_text_planes_kernel.
-//   hand-off S_t block (N x 16 floats, 3 KB) -> global, agent-scope release, one flag per (image, slot).  It is issued BEFORE the
-//            pixel->sentence half below, whose work hides the peers' latency.
-//   phase B1 row soft-max of S_v (local), new_vis rows of the own pixels = Av . Vt  (Vt^T fragments pre-split likewise).
-//   phase B2 after the 8 flags of the image: gather the 8 S_t blocks (24 KB), pixel soft-max (each workgroup redundantly, 48 x 100
-//            exponentials), then new_lan[:, c-slice of C/8 channels] = At . Vv[:, slice]: the Vv slice is read row-wise
-//            (512 B per pixel), split once, staged k-major in LDS and gathered by the transpose read ds_read_b64_tr_b16.
-// So every byte of Qv, Kv, Vv is read once and new_vis / new_lan are written once: HBM traffic = algorithmic + the saved
-// probabilities (Av, AtT: 2 %) + 1.2 MB of logit hand-off.  The sentence planes (0.96 MB) are re-read by every workgroup from L2.
+// and a CU moves ~25 GB/s of it, so an image has to be spread over several CUs in EVERY phase -- but both soft-maxes need the
+// full reduction over C, and the pixel soft-max couples all pixels of an image.  Eight workgroups per image (B * 8 = 384 at
+// B = 48), ALL of them sliced by CHANNEL (workgroup s owns channels [s C/8, (s+1) C/8)), so that every operand byte is read by
+// exactly one workgroup and the sentence operands it needs are a 1/8 slice as well:
+//   logits    partial D_t[p][n], D_v[p][n] of ALL pixels of the image over the own slice.  Pixel rows are read row-contiguous
+//             (8 rows x 128 B per instruction) and turned into MFMA fragments through wave-private LDS tiles; the sentence
+//             operands arrive PRE-SPLIT into three bf16 planes in MFMA fragment order (one coalesced 16-byte load per lane per
+//             fragment, no VALU, no LDS), written once per call by xattn_text_planes_kernel (a 4 us launch in front).
+//   exchange  reduce-scatter + all-gather instead of "everyone reads everything" (which cost 132 MB of reads, more than the
+//             kernel's algorithmic bytes): stage 1 -- each workgroup publishes its partial blocks (43 KB), then sums, for 1/8 of
+//             the sentence rows of S_t and for one 16-pixel tile of S_v, the eight partials (46 KB), takes the soft-max of those
+//             complete rows and publishes the PROBABILITIES (5 KB); stage 2 -- everyone reads the image's At and Av (50 KB).
+//   outputs   new_vis[:, slice] = Av . Vt[:, slice] (Vt^T fragments pre-split like the other sentence operands) and
+//             new_lan[:, slice] = At . Vv[:, slice]: the Vv slice (requested before the exchange) is split once, staged k-major
+//             in two LDS buffers and gathered by the transpose read ds_read_b64_tr_b16.  In all four products the CHANNELS are
+//             the MFMA rows, so a lane holds four consecutive channels (pixels) of one output row: every store is 16 bytes.
+// HBM traffic = algorithmic (88.7 MB) + saved probabilities (1.8 MB) + exchange (16.5 + 2.4 MB written, 18 + 19 MB read).
 //
-// Inter-workgroup protocol (MI355X_MICROARCH "workgroup dispatch / visibility"): plain payload stores -> every storing wave
-// drains vmcnt -> barrier -> one lane: agent-scope release fence + drained flag store; consumers: relaxed polls of the 8 flags by
-// one wave, ONE agent-scope acquire, barrier, plain loads.  Placement-independent.  The epoch that tags the flags lives in device
-// memory (sync[0]) and is advanced by the last workgroup to finish, so a captured launch replays correctly; spins are bounded
-// (sync[2] != 0 afterwards = a peer never published; the outputs of that launch are then undefined).
+// Inter-workgroup protocol (MI355X_MICROARCH "workgroup dispatch / visibility", recipe R1): payloads are WRITE-THROUGH (sc1)
+// 16-byte stores, every storing wave drains vmcnt, barrier, ONE lane raises the (image, slot) flag with a relaxed agent-scope
+// store; consumers poll the eight flags relaxed from one wave, barrier, and read the payload with sc1 loads (no L1) -- no
+// release / acquire fence anywhere (the first build used plain stores + fences: each release wrote back the XCD's dirty L2,
+// 8 + 29 us of a 75 us launch).  Placement-independent.  The epoch that tags the flags lives in device memory (sync[0]) and is
+// advanced by the last workgroup to finish, so a captured launch replays correctly; spins are bounded (sync[2] != 0 afterwards:
+// a peer never published, the outputs of that launch are undefined).  All B * 8 workgroups must be co-resident: the entry point
+// declines (TRIS_WP_UNSUPPORTED) when B * 8 exceeds CUs x workgroups per CU.
+//
+// Measured at B = 48 (tools/xattn_fused_trace.py, s_memtime stamps, median workgroup, us): logits 9.3 | publish 1.7 | wait 2.4 |
+// reduce 2.3 | soft-max 1.1 | publish 1.9 | wait 0.7 | gather 1.7 | new_vis 3.4 | new_lan 5.2 = 31 us per workgroup, 42 us per
+// call with the preparation launch (two-launch pair: 57 us).  What bounds it: 384 workgroups on 256 CUs put two workgroups on
+// half the CUs, and a CU fetches ~10 B/clk from HBM: the doubly loaded CUs need 2 x 102 KB / 24 GB/s = 8.5 us for the logits
+// phase alone, ~19 us for their 470 KB in total; with 48 images there is no second image per workgroup to overlap the three
+// dependent phases with.  0.60 of 8 TB/s (18.5 us) is not reachable at this batch size; see DESIGN.md section 3.
 #include "common.h"
 #include "tris_hip.h"
 #include "x3_split.h"
@@ -38,14 +50,14 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int XF_SLOTS = 8;       // workgroups per image
 constexpr int XF_PP = 112;        // padded pixel count: 7 MFMA tiles of 16 (P <= 104 leaves a zero row in the planes)
 constexpr int XF_PK = 104;        // pixel rows of a k-major Vv plane; rows >= P are zero, reads beyond are clamped to row XF_PK - 1
-constexpr int XF_KS = 96;         // bytes per pixel row of a k-major Vv plane (32 channels x 2 B + 32: the 4 k rows of a tr read fall on disjoint banks)
+constexpr int XF_KS = 80;         // bytes per pixel row of a k-major Vv plane (32 channels x 2 B + 16): two plane buffers fit the LDS budget
 constexpr int XF_SYNC_FLAGS = 16; // sync[0] epoch, [1] finish ticket, [2] time-out flag, [16 + (stage*B + b)*8 + s] publish flags of the two exchange stages
 constexpr long XF_SPIN = 4000000; // polls before a wait gives up (~seconds)
 
 // developer build (-DTRIS_XF_TRACE, tools/xattn_fused_trace.py): per-workgroup s_memtime stamps at the phase boundaries, written
 // behind the hand-off scratch; compiled out of the product
 #ifdef TRIS_XF_TRACE
-#define XF_STAMP(i) do { if (tid == 0) xf_trace[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XF_STAMP(i) do { if (tid == 0) xf_trace[(long)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define XF_STAMP(i) do { } while (0)
 #endif
@@ -56,16 +68,26 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Exchange payloads travel WRITE-THROUGH (sc1 stores) and are read with sc1 loads (L1 bypass): no release / acquire fence at all.
+// A release fence writes back every dirty line of the XCD's L2 (6.5 us with this kernel's stores in flight, measured: the two
+// fenced hand-offs of the first build cost 8 + 29 us of the 75 us launch); MI355X_MICROARCH "publish-large": 8.2 vs 3.0 us.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_wt(__amdgpu_buffer_rsrc_t rs, long float_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(float_off * 4), 0, 16);
+}
+__device__ __forceinline__ float4 ld4_wt(__amdgpu_buffer_rsrc_t rs, long float_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(float_off * 4), 0, 16));
+}
 __device__ __forceinline__ bf16x8 ldf(const uint4* p) { return __builtin_bit_cast(bf16x8, *p); }
 
-__device__ __forceinline__ f32x4v mfma6(const Split8& a, const Split8& b, f32x4v c) {   // smallest terms first
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.mid, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.hi, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.mid, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
-  return c;
+// N independent accumulation chains issued piece by piece (chain 0, 1, .., N-1, then the next piece): consecutive MFMAs never
+// depend on each other (a dependent v_mfma waits for its predecessor's result: a serial chain of 6 runs at less than half rate); smallest terms first
+template <int NCH>
+__device__ __forceinline__ void mfma6_n(const Split8 (&a)[NCH], const Split8 (&b)[NCH], f32x4v (&c)[NCH]) {
+#define XF_PIECE(PA, PB)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < NCH; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].PA, b[i].PB, c[i], 0, 0, 0);
+  XF_PIECE(lo, hi) XF_PIECE(hi, lo) XF_PIECE(mid, mid) XF_PIECE(mid, hi) XF_PIECE(hi, mid) XF_PIECE(hi, hi)
+#undef XF_PIECE
 }
 
 // ---- sentence operands -> bf16 piece planes in MFMA fragment order ------------------------------------------------------------
@@ -111,31 +133,19 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
   dst[128] = __builtin_bit_cast(uint4, sp.lo);
 }
 
-// 8 consecutive k (rows k0 .. k0+7, clamped to zrow) of column m16 + (lane & 15) from a k-major bf16 plane
-__device__ __forceinline__ bf16x8 tr_frag8c(const char* plane, int k0, int m16, int lane, int zrow) {
-  const int i16 = lane & 15;
-  const int ra = min(k0 + (i16 >> 2), zrow), rb = min(k0 + 4 + (i16 >> 2), zrow);
-  const int col = (m16 + 4 * (i16 & 3)) * 2;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + ra * XF_KS + col));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + rb * XF_KS + col));
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 // grid B * 8, block 256, dynamic LDS xf_lds_bytes(P, NT).  KS = 32-channel steps of a workgroup's channel slice (C = 256 KS).
 template <int NT, int KS>
 __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __restrict__ Qv, const float* __restrict__ Kv,
                                                              const float* __restrict__ Vv, const uint4* __restrict__ QtF,
                                                              const uint4* __restrict__ KtF, const uint4* __restrict__ VtF,
                                                              float* __restrict__ new_vis, float* __restrict__ new_lan,
-                                                             float* __restrict__ probs, float* __restrict__ Sx,
+                                                             float* __restrict__ probs, float* __restrict__ Sx, int sx_bytes,
                                                              unsigned* __restrict__ sync, int B, int P, int N, float scale) {
   constexpr int CS = KS * 32;            // channels owned by a workgroup
   constexpr int C = CS * XF_SLOTS;
   constexpr int KST = C / 32;            // 32-channel steps over all of C
   constexpr int KS2 = (NT + 1) / 2;      // 32-sentence steps of the new_vis product
-  constexpr int SVS = NT <= 3 ? 52 : 64; // row stride (floats) of the Av plane [p][n] in LDS
+  constexpr int SVS = NT <= 3 ? 56 : 64; // row stride (floats) of the Av plane [p][n] in LDS (>= 3 XF_PK XF_KS bytes in all: second plane buffer)
   constexpr int PP = XF_PP;              // padded pixel count (7 tiles of 16)
   constexpr int NPASS = CS / 32;         // 32-channel passes of the new_lan product
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -150,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
   const int b = blockIdx.x / XF_SLOTS, slot = blockIdx.x % XF_SLOTS;
   const int NPT = (P + 15) >> 4;
   if (tid == 0) *s_epoch_p = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const __amdgpu_buffer_rsrc_t sxr = __builtin_amdgcn_make_buffer_rsrc(Sx, 0, sx_bytes, 0x00020000);   // the exchange scratch (Sx | Ax)
 #ifdef TRIS_XF_TRACE
   unsigned long long* xf_trace = reinterpret_cast<unsigned long long*>(Sx + (long)B * XF_SLOTS * 2 * NT * 16 * PP + (long)B * (NT * 16 * PP + PP * 64));
 #endif
@@ -215,11 +226,10 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
       {
         Split8 sk, sq;
         turn(vk[ks], vq[ks], sk, sq);
+        Split8 ca[2 * NT], cb[2 * NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[0][0][j] = mfma6(sk, fq_[j], acc[0][0][j]);
-          acc[0][1][j] = mfma6(sq, fk_[j], acc[0][1][j]);
-        }
+        for (int j = 0; j < NT; ++j) { ca[j] = sk; cb[j] = fq_[j]; ca[NT + j] = sq; cb[NT + j] = fk_[j]; }
+        mfma6_n<2 * NT>(ca, cb, reinterpret_cast<f32x4v(&)[2 * NT]>(acc[0]));   // 2 NT independent chains
       }
       {   // (a wave without a second tile computes on its clamped rows and never publishes the result)
         Split8 sk, sq;
@@ -228,16 +238,15 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
 #pragma unroll
           for (int h = 0; h < 2; ++h) { wk[h] = ld4(Kv + g1[h] + (ks + 1) * 32); wq[h] = ld4(Qv + g1[h] + (ks + 1) * 32); }
         }
+        Split8 ca[2 * NT], cb[2 * NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[1][0][j] = mfma6(sk, fq_[j], acc[1][0][j]);
-          acc[1][1][j] = mfma6(sq, fk_[j], acc[1][1][j]);
-        }
+        for (int j = 0; j < NT; ++j) { ca[j] = sk; cb[j] = fq_[j]; ca[NT + j] = sq; cb[NT + j] = fk_[j]; }
+        mfma6_n<2 * NT>(ca, cb, reinterpret_cast<f32x4v(&)[2 * NT]>(acc[1]));
       }
     }
     XF_STAMP(1);
     // publish the partial blocks: Sx[b][slot][type][n][p]   (D[p = 16 tile + 4 kg + r][n = 16 j + r16]: 4 consecutive p per lane)
-    float* mine = Sx + ((long)b * XF_SLOTS + slot) * (2 * NT * 16 * PP);
+    const long mine = ((long)b * XF_SLOTS + slot) * (2 * NT * 16 * PP);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (t == 0 || two) {
@@ -246,19 +255,16 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
         for (int y = 0; y < 2; ++y)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            *reinterpret_cast<float4*>(mine + (long)(y * NT * 16 + j * 16 + r16) * PP + pc) =
-                make_float4(acc[t][y][j][0], acc[t][y][j][1], acc[t][y][j][2], acc[t][y][j][3]);
+            st4_wt(sxr, mine + (long)(y * NT * 16 + j * 16 + r16) * PP + pc,
+                   make_float4(acc[t][y][j][0], acc[t][y][j][1], acc[t][y][j][2], acc[t][y][j][3]));
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
   __syncthreads();
   const unsigned epoch = *s_epoch_p;
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0)                                       // ... then ONE lane raises the flag (no fence: nothing is left in a cache)
     __hip_atomic_store(&sync[XF_SYNC_FLAGS + b * XF_SLOTS + slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   XF_STAMP(2);
   // ---- everything that does not depend on the exchange is requested now: Vt^T fragments of the own channel tiles (wave w: tiles
   // 2w, 2w+1 of the slice), the Vv slice of the image ----------------------------------------------------------------------------------------
@@ -294,9 +300,8 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
         }
       }
       if (!ok) atomicExch(&sync[2], epoch);
-      if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __syncthreads();
+    __syncthreads();   // (no acquire fence: the payload is read with sc1 loads, which do not look at this CU's L1)
   };
   wait_flags(XF_SYNC_FLAGS);
   XF_STAMP(3);
@@ -304,9 +309,9 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
   constexpr int P4 = PP / 4;
   float* Rt = reinterpret_cast<float*>(lds);            // [RN][PP]   logits -> At rows
   float* Rv = Rt + RN * PP;                             // [16][64]   logits -> Av rows of pixel tile `slot` ([p][n])
-  float* Ax = Sx + (long)B * XF_SLOTS * (2 * NT * 16 * PP) + (long)b * (NT * 16 * PP + PP * 64);   // image b: At [NT*16][PP] | Av [PP][64]
+  const long Ax = (long)B * XF_SLOTS * (2 * NT * 16 * PP) + (long)b * (NT * 16 * PP + PP * 64);   // image b: At [NT*16][PP] | Av [PP][64]
   {
-    const float* base = Sx + (long)b * XF_SLOTS * (2 * NT * 16 * PP);
+    const long base = (long)b * XF_SLOTS * (2 * NT * 16 * PP);
     constexpr int NA = RN * P4, NB = NT * 16 * 4;
     for (int e = tid; e < NA + NB; e += 256) {
       long off;
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
       else { const int n = (e - NA) >> 2; off = (long)(NT * 16 + n) * PP + slot * 16 + ((e - NA) & 3) * 4; }
       float4 v[XF_SLOTS];
 #pragma unroll
-      for (int s2 = 0; s2 < XF_SLOTS; ++s2) v[s2] = ld4(base + (long)s2 * (2 * NT * 16 * PP) + off);
+      for (int s2 = 0; s2 < XF_SLOTS; ++s2) v[s2] = ld4_wt(sxr, base + (long)s2 * (2 * NT * 16 * PP) + off);
       float4 a = v[0];
 #pragma unroll
       for (int s2 = 1; s2 < XF_SLOTS; ++s2) { a.x += v[s2].x; a.y += v[s2].y; a.z += v[s2].z; a.w += v[s2].w; }
@@ -328,47 +333,63 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
     }
   }
   __syncthreads();
-  if (tid < 64) {   // Av rows of the 16 pixels of tile `slot`: soft-max over the sentences, 4 threads per pixel
+  XF_STAMP(10);
+  if (tid < 64) {   // Av rows of the 16 pixels of tile `slot`: soft-max over the sentences, 4 threads per pixel, values in registers
     const int px = tid >> 2, q = tid & 3;
     float* row = Rv + px * 64;
+    float x[16];
     float m = -INFINITY;
-    for (int n = q; n < N; n += 4) m = fmaxf(m, row[n]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { x[u] = (q + 4 * u < N) ? row[q + 4 * u] : -INFINITY; m = fmaxf(m, x[u]); }
     m = fmaxf(m, __shfl_xor(m, 1, 64));
     m = fmaxf(m, __shfl_xor(m, 2, 64));
     float sm = 0.f;
-    for (int n = q; n < N; n += 4) { const float e = __expf(row[n] - m); row[n] = e; sm += e; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { x[u] = (q + 4 * u < N) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
     sm += __shfl_xor(sm, 1, 64);
     sm += __shfl_xor(sm, 2, 64);
     const float inv = 1.f / sm;
-    for (int n = q; n < N; n += 4) row[n] *= inv;
-    for (int n = N + q; n < 64; n += 4) row[n] = 0.f;   // k padding of the MFMA A operand: exact zeros
-  } else if (tid < 64 + 4 * RN) {   // At rows: soft-max over the pixels, 4 threads per sentence; pad columns -> 0
-    const int rr = (tid - 64) >> 2, q = tid & 3;
-    float* row = Rt + rr * PP;
-    float m = -INFINITY;
-    for (int p = q; p < P; p += 4) m = fmaxf(m, row[p]);
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    m = fmaxf(m, __shfl_xor(m, 2, 64));
-    float sm = 0.f;
-    for (int p = q; p < P; p += 4) { const float e = __expf(row[p] - m); row[p] = e; sm += e; }
-    sm += __shfl_xor(sm, 1, 64);
-    sm += __shfl_xor(sm, 2, 64);
-    const float inv = 1.f / sm;
-    for (int p = q; p < P; p += 4) row[p] *= inv;
-    for (int p = P + q; p < PP; p += 4) row[p] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) row[q + 4 * u] = x[u] * inv;   // (columns >= N: exact zeros = k padding of the MFMA operand)
+  } else {   // At rows: soft-max over the pixels, 32 lanes per sentence row (<= 4 pixels per lane, all in registers); pad columns -> 0
+    const int q = lane & 31;
+    for (int rr = (tid - 64) >> 5; rr < RN; rr += 6) {
+      float* row = Rt + rr * PP;
+      float x[4];
+      float m = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { x[u] = (q + 32 * u < P) ? row[q + 32 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float sm = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { x[u] = (q + 32 * u < P) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float inv = 1.f / sm;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q + 32 * u < PP) row[q + 32 * u] = x[u] * inv;   // (columns >= P: exact zeros)
+    }
   }
   __syncthreads();
+  XF_STAMP(11);
   // publish the finished rows (exchange stage 2) and save the probabilities the backward pass reads
   for (int e = tid; e < RN * P4; e += 256) {
     const int rr = e / P4;
-    *reinterpret_cast<float4*>(Ax + (long)(slot * RN + rr) * PP + (e - rr * P4) * 4) = *reinterpret_cast<const float4*>(Rt + e * 4);
+    st4_wt(sxr, Ax + (long)(slot * RN + rr) * PP + (e - rr * P4) * 4, *reinterpret_cast<const float4*>(Rt + e * 4));
   }
   {
     const int px = tid >> 4, c4 = (tid & 15) * 4;   // 16 pixels x 16 float4
     if (slot * 16 + px < PP)
-      *reinterpret_cast<float4*>(Ax + (long)NT * 16 * PP + (long)(slot * 16 + px) * 64 + c4) = *reinterpret_cast<const float4*>(Rv + px * 64 + c4);
+      st4_wt(sxr, Ax + (long)NT * 16 * PP + (long)(slot * 16 + px) * 64 + c4, *reinterpret_cast<const float4*>(Rv + px * 64 + c4));
   }
-  for (int e = tid; e < 16 * N; e += 256) {       // Av plane of the saved probabilities: [P][N]
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(&sync[XF_SYNC_FLAGS + (B + b) * XF_SLOTS + slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (not part of the exchange, so behind the flag: the probabilities the backward pass reads)
+  for (int e = tid; e < 16 * N; e += 256) {       // Av plane: [P][N]
     const int px = e / N, n = e - px * N;
     if (slot * 16 + px < P) probs[(((long)b * 4 + 0) * P + slot * 16 + px) * N + n] = Rv[px * 64 + n];
   }
@@ -376,20 +397,36 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
     const int rr = e / P, pp = e - rr * P;
     if (slot * RN + rr < N) probs[(((long)b * 4 + 2) * P + pp) * N + slot * RN + rr] = Rt[rr * PP + pp];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&sync[XF_SYNC_FLAGS + (B + b) * XF_SLOTS + slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  XF_STAMP(12);
   wait_flags(XF_SYNC_FLAGS + B * XF_SLOTS);
-  // all-gather: At [NT*16][PP] -> StF, Av [PP][64] -> SvL [PP][SVS]
-  for (int e = tid; e < NT * 16 * P4; e += 256)
-    *reinterpret_cast<float4*>(StF + e * 4) = ld4(Ax + e * 4);
-  for (int e = tid; e < PP * (SVS / 4); e += 256) {
-    const int pp = e / (SVS / 4), c4 = (e - pp * (SVS / 4)) * 4;
-    *reinterpret_cast<float4*>(SvL + pp * SVS + c4) = ld4(Ax + (long)NT * 16 * PP + (long)pp * 64 + c4);
+  XF_STAMP(13);
+  // all-gather: At [NT*16][PP] -> StF, Av [PP][64] -> SvL [PP][SVS]   (all loads of a thread in flight before the first LDS store;
+  // the stage-1 rows Rt / Rv alias SvL, but every thread passed the barrier inside wait_flags after its last read of them)
+  {
+    constexpr int NA = NT * 16 * P4, NV = PP * (SVS / 4), UA = (NA + 255) / 256, UV = (NV + 255) / 256;
+    float4 ga[UA], gv[UV];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int e = tid + u * 256;
+      if (e < NA) ga[u] = ld4_wt(sxr, Ax + e * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int e = tid + u * 256;
+      const int pp = e / (SVS / 4), c4 = (e - pp * (SVS / 4)) * 4;
+      if (e < NV) gv[u] = ld4_wt(sxr, Ax + (long)NT * 16 * PP + (long)pp * 64 + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int e = tid + u * 256;
+      if (e < NA) *reinterpret_cast<float4*>(StF + e * 4) = ga[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int e = tid + u * 256;
+      const int pp = e / (SVS / 4), c4 = (e - pp * (SVS / 4)) * 4;
+      if (e < NV) *reinterpret_cast<float4*>(SvL + pp * SVS + c4) = gv[u];
+    }
   }
   __syncthreads();
   XF_STAMP(4);
@@ -404,15 +441,28 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
       sa[ks] = split8(in ? *reinterpret_cast<const float4*>(a) : make_float4(0.f, 0.f, 0.f, 0.f),
                       in ? *reinterpret_cast<const float4*>(a + 4) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
+    {
+      constexpr int NCH = CTW * KS2;   // independent chains: (channel tile, 32-sentence step)
+      Split8 ca[NCH], cb[NCH];
+      f32x4v co[NCH];
 #pragma unroll
-    for (int ct = 0; ct < CTW; ++ct) {
-      f32x4v o = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) o = mfma6(sa[ks], vt[ct][ks], o);
-      float* dst = new_vis + ((long)b * P + pt * 16 + 4 * kg) * C + slot * CS + (wave * CTW + ct) * 16 + r16;
+        for (int ks = 0; ks < KS2; ++ks) {
+          ca[ct * KS2 + ks] = vt[ct][ks];
+          cb[ct * KS2 + ks] = sa[ks];
+          co[ct * KS2 + ks] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+      mfma6_n<NCH>(ca, cb, co);        // channels as rows: D[c = 4 kg + r][p = r16]
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (pt * 16 + 4 * kg + r < P) dst[(long)r * C] = o[r];
+      for (int ct = 0; ct < CTW; ++ct) {
+        f32x4v o = co[ct * KS2];
+#pragma unroll
+        for (int ks = 1; ks < KS2; ++ks) o += co[ct * KS2 + ks];
+        if (pt * 16 + r16 < P)   // 4 consecutive channels of one pixel per lane: one 16-byte store
+          *reinterpret_cast<float4*>(new_vis + ((long)b * P + pt * 16 + r16) * C + slot * CS + (wave * CTW + ct) * 16 + 4 * kg) =
+              make_float4(o[0], o[1], o[2], o[3]);
+      }
     }
   }
   XF_STAMP(5);
@@ -429,44 +479,73 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
     }
   }
   const int nks = (P + 31) / 32;   // <= 4
+  // two plane buffers: the planes region and the (now dead) Av region -- pass h + 1 is split and stored while pass h computes,
+  // one barrier per pass
+  auto stage = [&](char* dstp, const float4 (&v)[VR]) {
+    const int prow = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+    for (int q = 0; q < VR; ++q) {
+      const int p = q * 32 + prow;
+      if (p < XF_PK) {
+        const Split4 sp = split4(p < P ? v[q] : make_float4(0.f, 0.f, 0.f, 0.f));
+        char* d = dstp + p * XF_KS + c8;
+        *reinterpret_cast<uint2*>(d) = sp.hi;
+        *reinterpret_cast<uint2*>(d + XF_PK * XF_KS) = sp.mid;
+        *reinterpret_cast<uint2*>(d + 2 * XF_PK * XF_KS) = sp.lo;
+      }
+    }
+  };
+  // byte offsets of this lane's two transpose reads of 32-pixel step ks inside a plane (rows clamped to the last plane row)
+  int troff[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int k0 = ks * 32 + kg * 8 + (r16 >> 2);
+    troff[ks][0] = min(k0, XF_PK - 1) * XF_KS + 8 * (r16 & 3);
+    troff[ks][1] = min(k0 + 4, XF_PK - 1) * XF_KS + 8 * (r16 & 3);
+  }
+  auto trf = [&](const char* pl, int ks, int ct) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pl + troff[ks][0] + ct * 32));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pl + troff[ks][1] + ct * 32));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  char* const buf0 = planes;
+  char* const buf1 = lds;   // (SvL: every wave is past new_vis once it has passed the barrier below)
+  stage(buf0, vreg[0]);
+  __syncthreads();
 #pragma unroll
   for (int h = 0; h < NPASS; ++h) {
-    if (h > 0) __syncthreads();   // the previous pass is done with the planes
-    {
-      const int prow = tid >> 3, c8 = (tid & 7) * 8;
+    const char* cur = (h & 1) ? buf1 : buf0;
+    if (h + 1 < NPASS) stage((h & 1) ? buf0 : buf1, vreg[h + 1 < NPASS ? h + 1 : 0]);
+    if (wave < NT) {
+      f32x4v co[4] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int q = 0; q < VR; ++q) {
-        const int p = q * 32 + prow;
-        if (p < XF_PK) {
-          const Split4 sp = split4(p < P ? vreg[h][q] : make_float4(0.f, 0.f, 0.f, 0.f));
-          char* d = planes + p * XF_KS + c8;
-          *reinterpret_cast<uint2*>(d) = sp.hi;
-          *reinterpret_cast<uint2*>(d + XF_PK * XF_KS) = sp.mid;
-          *reinterpret_cast<uint2*>(d + 2 * XF_PK * XF_KS) = sp.lo;
+      for (int kp = 0; kp < 2; ++kp) {   // two 32-pixel steps at a time: chains (ct 0 | 1) x (step 2 kp | 2 kp + 1)
+        if (2 * kp < nks) {
+          Split8 ca[4], cb[4];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int ks = 2 * kp + u;   // (a step beyond nks multiplies clamped plane rows by the zero columns of At)
+              ca[ct * 2 + u].hi = trf(cur, ks, ct);
+              ca[ct * 2 + u].mid = trf(cur + XF_PK * XF_KS, ks, ct);
+              ca[ct * 2 + u].lo = trf(cur + 2 * XF_PK * XF_KS, ks, ct);
+              cb[ct * 2 + u] = at[ks];
+            }
+          mfma6_n<4>(ca, cb, co);          // channels as rows: D[c = 4 kg + r][n = r16]
         }
       }
-    }
-    __syncthreads();
-    if (wave < NT) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        f32x4v o = (f32x4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          if (ks < nks) {
-            Split8 sb;
-            sb.hi = tr_frag8c(planes, ks * 32 + kg * 8, ct * 16, lane, XF_PK - 1);
-            sb.mid = tr_frag8c(planes + XF_PK * XF_KS, ks * 32 + kg * 8, ct * 16, lane, XF_PK - 1);
-            sb.lo = tr_frag8c(planes + 2 * XF_PK * XF_KS, ks * 32 + kg * 8, ct * 16, lane, XF_PK - 1);
-            o = mfma6(at[ks], sb, o);
-          }
-        }
-        float* dst = new_lan + ((long)b * N + wave * 16 + 4 * kg) * C + slot * CS + h * 32 + ct * 16 + r16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (wave * 16 + 4 * kg + r < N) dst[(long)r * C] = o[r];
+        const f32x4v o = co[ct * 2] + co[ct * 2 + 1];
+        if (wave * 16 + r16 < N)
+          *reinterpret_cast<float4*>(new_lan + ((long)b * N + wave * 16 + r16) * C + slot * CS + h * 32 + ct * 16 + 4 * kg) =
+              make_float4(o[0], o[1], o[2], o[3]);
       }
     }
+    if (h + 1 < NPASS) __syncthreads();
   }
   XF_STAMP(6);
   // ---- the last workgroup to finish advances the epoch (the next launch on this stream starts after all of them) -----------------------------------
@@ -481,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fused_kernel(const float* __rest
 
 inline long xf_lds_bytes(int P, int NT) {
   (void)P;
-  const int SVS = NT <= 3 ? 52 : 64;
+  const int SVS = NT <= 3 ? 56 : 64;
   return (long)XF_PP * SVS * 4 + (long)NT * 16 * XF_PP * 4 + 3L * XF_PK * XF_KS + 16;
 }
 
@@ -494,7 +573,7 @@ inline XfPlan xf_plan(int B, int N, int C) {
   p.qtf = 0; p.ktf = a; p.vtf = 2 * a; p.sx = 2 * a + v;
   p.total = p.sx + (long)B * XF_SLOTS * 2 * p.NT * 16 * XF_PP * 4 + (long)B * (p.NT * 16 * XF_PP + XF_PP * 64) * 4;
 #ifdef TRIS_XF_TRACE
-  p.total += (long)B * XF_SLOTS * 8 * 8;
+  p.total += (long)B * XF_SLOTS * 16 * 8;
 #endif
   return p;
 }
@@ -520,7 +599,7 @@ int launch_fused(const float* Qv, const float* Kv, const float* Vv, const float*
     attr_done = true;
   }
   hipLaunchKernelGGL((xattn_fused_kernel<NT, KS>), dim3(B * XF_SLOTS), dim3(256), (size_t)lds, st, Qv, Kv, Vv, QtF, KtF, VtF,
-                     new_vis, new_lan, probs, Sx, sync, B, P, N, 1.0f / sqrtf((float)C));
+                     new_vis, new_lan, probs, Sx, (int)(pl.total - pl.sx), sync, B, P, N, 1.0f / sqrtf((float)C));
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -541,6 +620,17 @@ extern "C" int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const 
   if (tris_get_gemm_mode() < 1 || !(C == 512 || C == 1024) || P < XF_SLOTS || P > 104 || N < 1 || N > 64 || B < 1 ||
       ws == nullptr || sync == nullptr || ws_bytes < xf_plan(B, N, C).total || xf_lds_bytes(P, (N + 15) / 16) > 160 * 1024)
     return TRIS_WP_UNSUPPORTED;
+  {   // every workgroup must be resident at once (they wait for each other)
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 1;
+      cus = n;
+    }
+    const long per_cu = (160L * 1024) / xf_lds_bytes(P, (N + 15) / 16);
+    if ((long)B * XF_SLOTS > (long)cus * (per_cu > 2 ? 2 : per_cu)) return TRIS_WP_UNSUPPORTED;
+  }
   hipStream_t st = (hipStream_t)stream;
   char* w = reinterpret_cast<char*>(ws);
 #define TRIS_XF(NT_)                                                                                                            \

@@ -27,7 +27,14 @@ class NoGpuError(RuntimeError):
     pass
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """raw handle of the current HIP stream (the launch path calls this ~1500 times per step: the raw accessor avoids building a
+    torch.cuda.Stream object each time)"""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -462,6 +469,20 @@ class batch_invariant:
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
          ldr=0, sR=0, act=0, alpha=1.0, use_ws=True):
     _chk(A, B, C, bias, resid)
+    if _BATCH_INVARIANT and batch == 1 and not tA and M < 4 and lda == K and ldc == N and (resid is None or ldr == N) and bias_mode != 2:
+        # products of fewer than four rows run a different (generic) kernel than larger ones: in batch-invariant mode they are
+        # padded to four rows so that a sentence evaluated alone goes through the same arithmetic as one evaluated in a batch
+        A4 = A.new_zeros(4, K)
+        A4[:M].copy_(A.reshape(M, K))
+        R4 = None
+        if resid is not None:
+            R4 = resid.new_zeros(4, N)
+            R4[:M].copy_(resid.reshape(M, N))
+        C4 = C.new_empty(4, N)
+        gemm(A4, B, C4, 4, N, K, K, ldb, N, False, tB, bias=bias, bias_mode=bias_mode, resid=R4, ldr=N, act=act, alpha=alpha,
+             use_ws=use_ws)
+        C.reshape(M, N).copy_(C4[:M])
+        return C
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
@@ -1362,9 +1383,9 @@ class XAttnFn(torch.autograd.Function):
         new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
         probs = torch.empty(B, 4, Pp, N, device=dev, dtype=torch.float32)
         done = False
-        # ONE persistent launch (csrc/xattn_fused.hip) -- opt-in (TRIS_XATTN_FUSED=1): correct and single-launch, but measured
-        # SLOWER than the two-launch pair at the Stage-1 shape (77 vs 56 us at B = 48; DESIGN.md section 3 has the phase timeline)
-        ws_bytes = query("tris_xattn_fused_ws_bytes", B, N, C) if os.environ.get("TRIS_XATTN_FUSED", "0") == "1" else 0
+        # ONE persistent launch (csrc/xattn_fused.hip) where its domain covers the shape and all B * 8 workgroups are co-resident
+        # (45 vs 57 us for the two-launch pair at B = 48; TRIS_XATTN_FUSED=0 forces the pair)
+        ws_bytes = query("tris_xattn_fused_ws_bytes", B, N, C) if os.environ.get("TRIS_XATTN_FUSED", "1") != "0" else 0
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
             sync = _xattn_sync(dev, B)
