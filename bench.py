@@ -219,7 +219,7 @@ def main():
 
     # PMC-derived HBM traffic of the same kernel family (separate rocprofv3 --pmc passes, committed under profiles/)
     try:
-        pmc_file = "r2_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
+        pmc_file = "r3_pmc_hbm_traffic.json" if mode == "x3" else "r1c_pmc_hbm_traffic.json"
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["gemm_family"]
         roof["traffic"] = int((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / pmc["launches_per_step"])
         roof["traffic_note"] = ("bytes per launch, averaged over the family: (FETCH_SIZE x2 + WRITE_SIZE) per step / launches per "
@@ -227,37 +227,48 @@ def main():
     except Exception:
         pass
     try:   # matrix-pipe utilisation of the family from the SQ counters (separate --pmc pass, committed under profiles/)
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_mfma_util.json")))
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_mfma_util.json")))
         if mode == "x3":
             roof["mfma_utilisation_pmc"] = sq["families"]["gemm_family"]["mfma_utilisation"]
             roof["mfma_utilisation_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family, "
-                                             "profiles/r2_pmc_mfma_util.json (rocprofv3 --pmc, kernels serialised, static tile choice)")
+                                             "profiles/r3_pmc_mfma_util.json (rocprofv3 --pmc, kernels serialised, static tile choice)")
     except Exception:
         pass
     roof_x = None
     if xa:
         P_, N_, C_ = 100, a.batch, 1024
         xbytes = a.batch * (4 * P_ * C_ + N_ * C_) * 4 + 3 * N_ * C_ * 4
+        fused = [r for r in xa if r[0] == "xattn_fwd_fused"]
+        if fused and len(fused) == len(xa):
+            xname = ("xattn_fused_kernel<NT,KS> (ONE persistent launch: 8 channel-slice workgroups per sample, write-through "
+                     "reduce-scatter/all-gather of the logits between them) + xattn_text_planes_kernel (sentence bf16 planes)")
+        elif mode in ("x3", "x2"):
+            xname = "xattn_scores_x3_kernel + xattn_out_x3_kernel"
+        else:
+            xname = "xattn_scores_kernel + xattn_colsoftmax_kernel + xattn_out_kernel"
         xms = sum(r[2] for r in xa)
         roof_x = {"bound": "hbm", "achieved": round(xbytes / (xms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(xbytes / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                  "kernel": ("xattn_scores_x3_kernel + xattn_out_x3_kernel" if mode in ("x3", "x2") else
-                             "xattn_scores_kernel + xattn_colsoftmax_kernel + xattn_out_kernel") +
-                            " (fused bilateral cross attention, forward, all launches, HIP events around the call)",
+                  "kernel": xname + " (fused bilateral cross attention, forward, all launches, HIP events around the call)",
+                  "single_launch": bool(fused and len(fused) == len(xa)),
+                  "bound_note": ("B x 8 = 384 workgroups on 256 CUs: the doubly-loaded CUs fetch 2 x 1.6 MB at ~24 GB/s per CU "
+                                 "(~19 us floor before the exchange); measured timeline per workgroup 31 us, 42-45 us per call "
+                                 "(csrc/xattn_fused.hip header, DESIGN.md 4.6): 0.60 of 8 TB/s is not reachable at this size"),
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
 
     if roof_x is not None and mode == "x3":
-        try:   # HBM bytes of the two cross-attention launches from the same --pmc passes (profiles/r2_pmc_hbm_traffic.csv)
+        try:   # HBM bytes of the cross-attention launches from the same --pmc passes (profiles/r3_pmc_hbm_traffic.csv)
             import csv as _csv
             tr = 0
-            for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.csv"))):
+            for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.csv"))):
                 if "xattn_" in r["Kernel"]:
                     tr += int(r["FetchBytesPerStep(x2 corrected)"]) + int(r["WriteBytesPerStep"])
             if tr:
                 roof_x["traffic"] = tr
-                roof_x["traffic_note"] = ("FETCH_SIZE x2 + WRITE_SIZE of xattn_scores_x3_kernel + xattn_out_x3_kernel, one forward "
-                                          f"(rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes (logit planes round trip, sentence tiles)")
+                roof_x["traffic_note"] = ("FETCH_SIZE x2 + WRITE_SIZE of xattn_fused_kernel + xattn_text_planes_kernel, one forward "
+                                          f"(rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes (partial-logit exchange "
+                                          "through the workspace, sentence planes)")
         except Exception:
             pass
     if rank == 0:

@@ -40,3 +40,16 @@ for lo, hi in ((0, 2e3), (2e3, 5e3), (5e3, 2e4), (2e4, 1e5), (1e5, 1e12)):
 big = sorted(((ks[i + 1][0] - ks[i][1], ks[i][2][:60], ks[i + 1][2][:60]) for i in range(len(ks) - 1)), reverse=True)[:12]
 for g, a, b in big:
     print(f"   {g/1e3:8.1f} us between {a} -> {b}")
+# per-stream time by kernel (what the critical stream is made of)
+import re
+for s, ks in sorted(by.items(), key=lambda kv: -sum(b - a for a, b, _ in kv[1])):
+    agg = {}
+    for a, b, n in ks:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = n.split("(")[0][:70] if "gemm_fast_kernel" not in n else n.split("(")[0][:90]
+        e = agg.setdefault(n, [0, 0])
+        e[0] += 1
+        e[1] += b - a
+    print(f"stream {s}: kernel time by name (ms/step, launches/step)")
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"   {t/1e6/steady:7.3f} ms  {c/steady:6.1f}  {n}")

@@ -1389,11 +1389,11 @@ class XAttnFn(torch.autograd.Function):
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
             sync = _xattn_sync(dev, B)
-            done = _timed("xattn_fwd", 8.0 * B * Pp * N * C, lambda: _wp_call(
+            done = _timed("xattn_fwd_fused", 8.0 * B * Pp * N * C, lambda: _wp_call(
                 "tris_xattn_fused_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B, Pp,
                 N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
         if not done:
-            _timed("xattn_fwd", 8.0 * B * Pp * N * C,
+            _timed("xattn_fwd_pair", 8.0 * B * Pp * N * C,
                    lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
                                 P(probs), B, Pp, N, C, _stream()))
         ctx.dims = (B, Pp, N, C)
