@@ -305,6 +305,30 @@ def main():
                 out["eval_refs_per_s"] = out["eval"]["eval_refs_per_s"]
             except Exception as e:  # reported, never hidden
                 out["eval"] = {"error": repr(e)}
+        if world == 1 and not a.no_pipeline and reducer is None and os.environ.get("TRIS_STEP_GRAPH", "0") == "0":
+            # the same step replayed from the chain of single-stream hipGraphs (TRIS_STEP_GRAPH=seg, tris_amd.graphs.
+            # SegmentedTrainStep; bit-identical results, tests/test_gpu_step_graph.py), timed like `value`: what the host's
+            # share of a step becomes, and what it costs / gains in step time on THIS box
+            try:
+                os.environ["TRIS_STEP_GRAPH"] = "seg"
+                del losses
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    step()
+                hi = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                dtg = time.perf_counter() - t0
+                out["step_graph_segmented"] = {"ms_per_step": round(dtg / a.steps * 1e3, 3),
+                                               "host_issue_ms_per_step": round(hi / a.steps * 1e3, 3),
+                                               "img_per_s": round(a.batch * a.steps / dtg, 2), "steps": a.steps,
+                                               "note": "opt-in (TRIS_STEP_GRAPH=seg); `value` above is the eager three-stream step"}
+            except Exception as e:  # reported, never hidden
+                out["step_graph_segmented"] = {"error": repr(e)}
+            finally:
+                os.environ["TRIS_STEP_GRAPH"] = "0"
         if world == 1 and not a.no_cpu_baseline and a.backbone == "clip-RN50":
             out["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in a.cpu_batches.split(",")))
         line = json.dumps(out)

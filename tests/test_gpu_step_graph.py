@@ -1,0 +1,94 @@
+"""The training step replayed from hipGraphs (tris_amd.graphs) against the eager step: same state, same batches -> the same
+losses, parameters, optimiser moments, BatchNorm running statistics and LR after several steps, BIT FOR BIT (the captured step
+launches the very kernels of the eager one, in the same arithmetic; only the issue path differs)."""
+import os
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mode, steps=4, B=3):
+    from tris_amd.args import get_parser
+    from tris_amd.CLIP import clip
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import freeze_aux, train_step
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    old = os.environ.get("TRIS_STEP_GRAPH")
+    os.environ["TRIS_STEP_GRAPH"] = mode
+    try:
+        args = get_parser().parse_args(["--size", "320", "--negative_samples", "3", "--max_query_len", "20"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = TRIS(args).cuda().train()
+            aux, _ = clip.load("ViT-B-32", device="cuda", txt_length=20)
+        seed_fill(model.state_dict(), 1234)
+        seed_fill(aux.state_dict(), 4321)
+        freeze_aux(aux)
+        bb, new = model.trainable_parameters()
+        opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
+                         weight_decay=args.weight_decay)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: (1 - x / 1000) ** 0.9)
+        losses = []
+        for s in range(steps):
+            b = synthetic_batch(B, 320, 20, 3, seed=7 + s)
+            out = train_step(model, aux, opt, b["img"].cuda(), b["word_ids"].cuda(), b["neg_word_ids"].cuda(), args, sched)
+            losses.append(out.clone())   # (a replayed step returns its static output buffer)
+        torch.cuda.synchronize()
+        replayed = "_tris_step_graph" in model.__dict__
+        bns = [m for m in model.modules() if hasattr(m, "flush_batches_tracked")]
+        for m in bns:
+            m.flush_batches_tracked()
+        state = {"p": [a.p.clone() for a in opt.arenas], "m": [a.m.clone() for a in opt.arenas],
+                 "v": [a.v.clone() for a in opt.arenas],
+                 "bn": [(m.running_mean.clone(), m.running_var.clone(), int(m.num_batches_tracked)) for m in bns],
+                 "lr": [g["lr"] for g in opt.param_groups], "steps": opt._steps}
+        return torch.stack(losses), state, replayed
+    finally:
+        if old is None:
+            os.environ.pop("TRIS_STEP_GRAPH")
+        else:
+            os.environ["TRIS_STEP_GRAPH"] = old
+
+
+@pytest.fixture(scope="module")
+def eager():
+    losses, state, replayed = _run("0")
+    assert not replayed
+    return losses, state
+
+
+@pytest.mark.parametrize("mode", ["seg", "1"])
+def test_replayed_step_equals_the_eager_step(eager, mode):
+    """seg: the chain of single-stream graphs on three streams (SegmentedTrainStep); 1: the whole step as one graph"""
+    losses, state, replayed = _run(mode)
+    assert replayed, "the step was not replayed from a graph"
+    assert torch.isfinite(losses).all()
+    assert torch.equal(losses, eager[0]), (losses - eager[0]).abs().max()
+    for k in ("p", "m", "v"):
+        for a, b in zip(state[k], eager[1][k]):
+            assert torch.equal(a, b), (k, float((a - b).abs().max()))
+    for (rm, rv, n), (rm0, rv0, n0) in zip(state["bn"], eager[1]["bn"]):
+        assert torch.equal(rm, rm0) and torch.equal(rv, rv0) and n == n0
+    assert state["lr"] == eager[1]["lr"] and state["steps"] == eager[1]["steps"]
+
+
+def test_segmented_step_updates_every_arena_element_once():
+    """the early / late AdamW split of the segmented step is a partition of the arenas (nothing skipped, nothing twice)"""
+    from tris_amd.graphs import SegmentedTrainStep
+
+    class A:
+        def __init__(self, n):
+            self.numel = n
+            self.g = torch.zeros(n, device="cuda")
+
+    class O:
+        arenas = [A(64 * 40), A(64 * 8)]
+    o = O()
+    sinks = [o.arenas[0].g[64 * 3:64 * 3 + 70], o.arenas[0].g[64 * 9:64 * 10]]
+    spans = SegmentedTrainStep._late_spans(o, sinks)
+    assert spans == {0: (64 * 3, 64 * 10)}
+    assert SegmentedTrainStep._late_spans(o, [torch.zeros(4, device="cuda")]) is None

@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 steady = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
 scol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
-marks = [r[0] for r in cur.execute("select end from kernels where name like '%adamw_kernel%' order by start").fetchall()]
+marks = [r[0] for r in cur.execute("select end from kernels where name like '%adamw%kernel%' order by start").fetchall()]
 t0, t1 = marks[-2 * steady - 1], marks[-1]
 rows = cur.execute(f"select {scol}, start, end, name from kernels where start > {t0} and end <= {t1} order by start").fetchall()
 wall = (t1 - t0) / 1e6 / steady

@@ -197,7 +197,7 @@ class ModifiedResNet(nn.Module):
         x = self.conv2(x, stats=tr)
         x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout))   # ... into conv3
         x = self.bn3(self.conv3(x, stats=tr), relu=True)
-        x = self.avgpool(x)
+        x = ops.cut(self.avgpool(x))                       # (segment boundary of a segmented capture; otherwise x itself)
         if hooks and "stem" in hooks:
             hooks["stem"]()
         outs = []
@@ -207,7 +207,7 @@ class ModifiedResNet(nn.Module):
         for name, layer in (("layer2", self.layer1), ("layer3", self.layer2), ("layer4", self.layer3),
                             ("heads", self.layer4)):
             for blk in layer:
-                x = blk(x)
+                x = ops.cut(blk(x))
             if red is not None:
                 x = red.boundary(x, name)          # the boundary AFTER a stage releases the segment of the NEXT one
             outs.append(x)
@@ -291,7 +291,7 @@ class Transformer(nn.Module):
 
     def forward(self, x):
         for blk in self.resblocks:
-            x = blk(x)
+            x = ops.cut(blk(x))        # (segment boundary of a segmented capture of the trunk; otherwise x itself)
         return x
 
 

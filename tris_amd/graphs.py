@@ -7,6 +7,8 @@
 Inputs are copied into static buffers; outputs are static buffers owned by the graphs (consume or clone them before
 the next replay).  Capture uses torch's stream-capture plumbing (torch.cuda.graph); every captured node is one of
 this repo's HIP kernels launched through the C ABI on the capturing stream."""
+import os
+
 import torch
 
 
@@ -113,19 +115,7 @@ class GraphedTrainStep:
         net = model.module if hasattr(model, "module") else model
         self.bns = [m for m in net.modules() if isinstance(m, BatchNorm2d)]
         optimizer.enable_device_hyper()
-        # ---- priming: eager forward + backward, no optimiser step, BatchNorm running statistics put back afterwards
-        keep = [(m.running_mean.clone(), m.running_var.clone(), m._nbt_pending) for m in self.bns]
-        for _ in range(priming):
-            _step_body(model, clip_model, optimizer, self.s_img, self.s_ids, self.s_neg, args, None, optimizer_step=False)
-        torch.cuda.synchronize()
-        with torch.no_grad():
-            for m, (rm, rv, nbt) in zip(self.bns, keep):
-                m.running_mean.copy_(rm)
-                m.running_var.copy_(rv)
-                m._nbt_pending = nbt
-        del keep
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()   # the priming passes' activation pool is not needed again (the graph has its own)
+        _prime(model, clip_model, optimizer, self.bns, (self.s_img, self.s_ids, self.s_neg), args, priming)
         nbt = [m._nbt_pending for m in self.bns]
         self.g = torch.cuda.CUDAGraph()
         ops._CAPTURE_STREAMS = True
@@ -147,6 +137,348 @@ class GraphedTrainStep:
         opt._steps += 1
         opt.push_hyper()
         self.g.replay()
+        for m in self.bns:
+            m._nbt_pending += 1
+        if self.sched is not None:
+            self.sched.step()
+        return self.losses
+
+
+def _prime(model, clip_model, optimizer, bns, batch, args, priming):
+    """eager forward + backward passes WITHOUT an optimiser step, BatchNorm running statistics put back afterwards: first-
+    encounter autotuning, workspaces and allocator pools settle before anything is captured"""
+    from .train_stage1 import _step_body
+    keep = [(m.running_mean.clone(), m.running_var.clone(), m._nbt_pending) for m in bns]
+    for _ in range(priming):
+        _step_body(model, clip_model, optimizer, batch[0], batch[1], batch[2], args, None, optimizer_step=False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for m, (rm, rv, nbt) in zip(bns, keep):
+            m.running_mean.copy_(rm)
+            m.running_var.copy_(rv)
+            m._nbt_pending = nbt
+    del keep
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
+def _capture(graph, stream, pool, fn):
+    """record fn()'s launches on `stream` into `graph` (allocations from `pool`); nothing executes"""
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        graph.capture_begin(pool=pool, capture_error_mode="thread_local")
+        try:
+            out = fn()
+        finally:
+            graph.capture_end()
+    return out
+
+
+class _Chain:
+    """successive graphs on ONE stream, cut at points chosen while capturing: split() ends the graph being recorded and begins
+    the next (the replay loop puts an event record or wait between the two)"""
+
+    def __init__(self, stream, pool):
+        self.stream, self.pool, self.graphs = stream, pool, []
+
+    def run(self, fn):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self._begin()
+            try:
+                out = fn()
+            finally:
+                self.graphs[-1].capture_end()
+        return out
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self.graphs.append(g)
+
+    def split(self):
+        self.graphs[-1].capture_end()
+        self._begin()
+
+
+class SegmentedTrainStep:
+    """The Stage-1 training step as a CHAIN of single-stream hipGraphs on the step's three streams.
+
+    Why not one graph (GraphedTrainStep): the ROCm 7.x runtime launches a graph with parallel branches node by node (host time
+    as eager) and runs the branches one after the other; only a LINEAR graph takes its packet path (0.65 ms of host time for
+    the whole step) -- but a linear step loses the text / weight-gradient overlap (50 vs 45 ms).  So the step is cut where its
+    streams fork and join, every piece is captured on ONE stream, and the pieces are replayed on the three streams with
+    ordinary events between them -- dependencies only ever cross at graph boundaries, where stream order defines them:
+
+        text    : [F_text: TRIS text encoder + frozen aux text tower] ................ [B_text: text encoder backward]
+        compute : [F_trunk] -> wait F_text -> [F_heads + losses] -> [B_heads] -> [B_seg n] -> ... -> [B_seg 0] -> join -> [AdamW]
+        wgrad   :                                                      [W_heads]   [W_seg n]   ...    [W_seg 0]
+
+    The backward is cut at autograd level: ops.cut() (behind the stem and every Bottleneck) hands the next layer a fresh leaf
+    during capture, and the capture runs torch.autograd.backward segment by segment, feeding each the .grad of the leaf above.
+    A segment's weight-gradient launches are not forked from inside its capture (ops.on_wgrad_stream defers them to this
+    object), they become the graph W_seg for the weight-gradient stream, released by an event behind B_seg.  Every tensor a
+    deferred launch reads stays referenced until all captures are done, so no later segment's capture can be handed its memory.
+    The three streams capture into three private pools (graphs that may run concurrently must not share one).
+
+    Same restrictions and the same bookkeeping (static inputs, device-side optimiser scalars, BatchNorm step counters) as
+    GraphedTrainStep; same kernels in the same arithmetic as the eager step, so step k of a replayed run equals step k of an
+    eager run bit for bit."""
+
+    def __init__(self, model, clip_model, optimizer, args, example, lr_scheduler=None, priming=2):
+        from . import ops
+        from .CLIP.clip.model import BatchNorm2d
+        from .train_stage1 import stage1_loss_block
+        img, ids, neg = example
+        self.model, self.clip_model, self.optimizer, self.args, self.sched = model, clip_model, optimizer, args, lr_scheduler
+        self.s_img = img.detach().clone()
+        self.s_ids = ids.detach().clone()
+        self.s_neg = None if neg is None else neg.detach().clone()
+        net = model.module if hasattr(model, "module") else model
+        self.bns = [m for m in net.modules() if isinstance(m, BatchNorm2d)]
+        optimizer.enable_device_hyper()
+        _prime(model, clip_model, optimizer, self.bns, (self.s_img, self.s_ids, self.s_neg), args, priming)
+        nbt = [m._nbt_pending for m in self.bns]
+        self.text, self.wg = ops.side_stream("text"), ops._wgrad_stream()
+        self.cap = torch.cuda.Stream()           # all compute-stream pieces are captured on this one stream
+        pool_c, pool_t, pool_w = (torch.cuda.graph_pool_handle() for _ in range(3))
+        G = torch.cuda.CUDAGraph
+        self.cuts, self.deferred, self.inline, self.cutting, keep = [], [], False, False, []
+        B = self.s_img.shape[0]
+        K = self.s_neg.shape[1] if (self.s_neg is not None and args.negative_samples > 0) else 0
+
+        def wgrad_graphs(split=False):
+            """the deferred weight-gradient launches of the segment just captured, as a graph for their stream (split: every
+            other one goes into a second graph for the text stream, idle by then -- used for the last segments, whose weight
+            gradients nothing is left to hide behind) -> (graph | None, graph | None, [arena views written])"""
+            fns, self.deferred = self.deferred, []
+            keep.append(fns)
+            parts = [fns[0::2], fns[1::2]] if split and len(fns) > 1 else [fns, []]
+            out = []
+            self.inline = True
+            try:
+                for part, stream, pool in zip(parts, (self.wg, self.text), (pool_w, pool_t)):
+                    g = None
+                    if part:
+                        g = G()
+                        _capture(g, stream, pool, lambda: [fn() for fn, _, _ in part])
+                    out.append(g)
+            finally:
+                self.inline = False
+            return out[0], out[1], [sk for _, _, sk in fns]
+
+        ops._SEG = self
+        try:
+            # ---- forward.  Where the two text towers START relative to the trunk is chosen as in the eager step (model_stage1.
+            # TRIS.forward, train_stage1.stage1_forward_losses): the TRIS text encoder behind a trunk stage (TRIS_SEG_TEXT_AT,
+            # default layer2), the frozen aux tower behind the TRIS forward, joined right before the loss -- each of those
+            # points is a cut of the compute stream's forward graph with an event in it.
+            def ids_all_():
+                ids_all = self.s_ids.long()
+                if K > 0:
+                    ids_all = torch.cat([ids_all, self.s_neg.long().reshape(B * K, -1)], 0)
+                return ids_all
+            self.inline = True                   # (the text encoder's weight gradients stay on the text stream)
+            self.g_ftext = G()
+            hidden = _capture(self.g_ftext, self.text, pool_t, lambda: net.backbone.encode_text(self.s_ids)[1])
+            self.inline = False
+            self.g_faux = G()
+            with torch.no_grad():
+                ids_all, f_all = _capture(self.g_faux, self.text, pool_t,
+                                          lambda: (lambda i: (i, clip_model.encode_text(i)[1]))(ids_all_()))
+            at = os.environ.get("TRIS_SEG_TEXT_AT", "layer2")
+            fwd = _Chain(self.cap, pool_c)
+            marks = {}
+
+            def cut_here(name):
+                def f():
+                    marks[name] = len(fwd.graphs)      # graphs[:n] are behind this point
+                    fwd.split()
+                return f
+
+            def forward():
+                hooks = {at: cut_here("text")} if (at in ("stem", "layer1", "layer2", "layer3") and not net.vit_trunk) else None
+                self.cutting = True
+                vis = net.encode_visual(self.s_img, hooks)
+                self.cutting = False
+                cut_here("trunk")()
+                h = hidden.detach().requires_grad_()
+                cls, _, _, sig_out, _ = net.forward_cached(vis, self.s_ids, self.s_img.shape[2], hidden=h)
+                cut_here("heads")()
+
+                def joined():
+                    cut_here("loss")()
+                    return f_all
+                return vis, h, stage1_loss_block(clip_model, self.s_img, cls, sig_out, joined, ids_all, K, args)
+            vis, h, self.losses = fwd.run(forward)
+            trunk_cuts, self.cuts = self.cuts, []
+            self.fwd, self.fwd_marks = fwd.graphs, marks
+
+            # ---- backward, segment by segment (compute stream), each followed by its weight gradients (their stream)
+            def b_heads():
+                optimizer.zero_grad()
+                self.losses[0].backward()
+            g = G()
+            _capture(g, self.cap, pool_c, b_heads)
+            self.back = [(g,) + wgrad_graphs()[:2]]
+            self.inline = True
+            self.g_btext = G()
+            _capture(self.g_btext, self.text, pool_t, lambda: torch.autograd.backward(hidden, h.grad))
+            self.inline = False
+            n_late = min(int(os.environ.get("TRIS_SEG_LATE", "4")), len(trunk_cuts))
+            split = os.environ.get("TRIS_SEG_SPLIT", "1") != "0"
+            late_sinks = []
+            for k, (x, leaf) in enumerate(reversed(trunk_cuts)):
+                late = k >= len(trunk_cuts) - n_late
+                g = G()
+                _capture(g, self.cap, pool_c, lambda: torch.autograd.backward(x, leaf.grad))
+                gw, gt, sinks = wgrad_graphs(split=late and split)
+                self.back.append((g, gw, gt))
+                if late:
+                    late_sinks += sinks
+            self.first_late = len(self.back) - n_late
+            # ---- AdamW.  The update is element-wise, so it can be cut where the gradients become final: everything outside the
+            # arena span the LATE segments' weight-gradient launches write is complete once the early ones are, and is updated
+            # on the compute stream while those last launches still run; the span itself follows the final join.
+            spans = self._late_spans(optimizer, late_sinks) if n_late and os.environ.get("TRIS_SEG_EARLY_OPT", "1") != "0" else None
+            self.g_opt_early = None
+            if spans:
+                early = []
+                for gi, a in enumerate(optimizer.arenas):
+                    lo, hi = spans.get(gi, (0, 0))
+                    early += [(gi, 0, lo), (gi, hi, a.numel)] if hi > lo else [(gi, 0, a.numel)]
+                self.g_opt_early = G()
+                _capture(self.g_opt_early, self.cap, pool_c, lambda: optimizer.step(device_hyper=True, ranges=early))
+                rest = [(gi, lo, hi) for gi, (lo, hi) in spans.items()]
+            else:
+                rest = None
+            self.g_opt = G()
+            _capture(self.g_opt, self.cap, pool_c, lambda: optimizer.step(device_hyper=True, ranges=rest))
+        finally:
+            ops._SEG = None
+            self.cuts, self.deferred = [], []
+        del keep, trunk_cuts, h, hidden, vis, late_sinks, fwd
+        for m, n in zip(self.bns, nbt):          # (capture launched nothing: the forward's host-side count is taken back)
+            m._nbt_pending = n
+        self.ev = [torch.cuda.Event() for _ in range(len(self.back) + 8)]
+        self.trace = False       # developer switch: per-piece HIP-event time stamps of the next replay -> marks()
+        self._marks = None
+
+    @staticmethod
+    def _late_spans(optimizer, sinks):
+        """{group index: (lo, hi)}: per arena, the element range that covers every gradient view in `sinks`; None if a view lies
+        in no arena"""
+        spans = {}
+        for sk in sinks:
+            for gi, a in enumerate(optimizer.arenas):
+                off = (sk.data_ptr() - a.g.data_ptr()) // 4
+                if 0 <= off < a.numel:
+                    lo, hi = spans.get(gi, (off, off))
+                    end = (off + sk.numel() + 63) // 64 * 64
+                    spans[gi] = (min(lo, off // 64 * 64), max(hi, min(end, a.numel)))
+                    break
+            else:
+                return None
+        return spans
+
+    def marks(self):
+        """[(name, ms since the start of the step)] of the last replay made with .trace = True (synchronises)"""
+        torch.cuda.synchronize()
+        t0 = self._marks[0][1]
+        return [(n, t0.elapsed_time(e)) for n, e in self._marks]
+
+    # -- ops._SEG interface (only while capturing)
+    def cut(self, x):
+        if not self.cutting:           # (only the trainable trunk is cut: its weight gradients are what the cuts release)
+            return x
+        leaf = x.detach().requires_grad_()
+        self.cuts.append((x, leaf))
+        return leaf
+
+    def defer(self, fn, tensors, sink):
+        if self.inline:
+            return fn()
+        self.deferred.append((fn, tensors, sink))
+        return None
+
+    def __call__(self, img, ids, neg):
+        main, text, wg, ev = torch.cuda.current_stream(), self.text, self.wg, self.ev
+        tm = self._marks = [] if self.trace else None
+
+        def mark(name, stream=main):
+            if tm is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                tm.append((name, e))
+        mark("start")
+        self.s_img.copy_(img, non_blocking=True)
+        self.s_ids.copy_(ids, non_blocking=True)
+        if self.s_neg is not None:
+            self.s_neg.copy_(neg, non_blocking=True)
+        opt = self.optimizer
+        opt._steps += 1
+        opt.push_hyper()
+        ev[0].record(main)
+        fm = self.fwd_marks
+        for i, g in enumerate(self.fwd):
+            if i == fm.get("text", 0):          # the TRIS text encoder starts behind this point of the trunk
+                if i:
+                    ev[0].record(main)
+                text.wait_event(ev[0])
+                with torch.cuda.stream(text):
+                    self.g_ftext.replay()
+                    ev[1].record(text)
+                    mark("text_fwd_done", text)
+            if i == fm["trunk"]:                # trunk issued: the heads need the sentence features
+                mark("trunk_fwd_done")
+                main.wait_event(ev[1])
+            if i == fm["heads"]:                # TRIS forward issued: the frozen aux text tower goes under the aux ViT
+                e = ev[6 + len(self.back)]
+                e.record(main)
+                text.wait_event(e)
+                with torch.cuda.stream(text):
+                    self.g_faux.replay()
+                    ev[7 + len(self.back)].record(text)
+            if i == fm["loss"]:
+                main.wait_event(ev[7 + len(self.back)])
+            g.replay()
+        mark("heads_fwd_done")
+        wg.wait_event(ev[0])
+        for i, (gb, gw, gt) in enumerate(self.back):
+            gb.replay()
+            e = ev[6 + i]
+            e.record(main)
+            mark(f"b{i}_done")
+            if i == 0:
+                text.wait_event(e)
+                with torch.cuda.stream(text):
+                    self.g_btext.replay()
+                    ev[2].record(text)
+                    mark("text_bwd_done", text)
+            if gw is not None:
+                wg.wait_event(e)
+                with torch.cuda.stream(wg):
+                    gw.replay()
+                    mark(f"w{i}_done", wg)
+            if gt is not None:
+                text.wait_event(e)
+                with torch.cuda.stream(text):
+                    gt.replay()
+                    mark(f"w{i}t_done", text)
+            if i == self.first_late - 1:
+                ev[4].record(wg)        # every weight gradient outside the late span is behind this
+        if self.g_opt_early is not None:
+            main.wait_event(ev[4])
+            main.wait_event(ev[2])
+            self.g_opt_early.replay()
+            mark("opt_early_done")
+        ev[3].record(wg)
+        ev[5].record(text)
+        main.wait_event(ev[3])
+        main.wait_event(ev[5])
+        mark("joined")
+        self.g_opt.replay()
+        mark("opt_done")
         for m in self.bns:
             m._nbt_pending += 1
         if self.sched is not None:

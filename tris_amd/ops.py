@@ -192,8 +192,24 @@ def streams_allowed():
     return _CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()
 
 
+# Segmented capture (tris_amd.graphs.SegmentedTrainStep): the step is captured as a chain of SINGLE-STREAM hipGraphs (the form
+# the ROCm runtime launches through its packet path), cut at autograd boundaries; weight-gradient work is not forked onto its
+# stream from inside a capture but handed to the capturing object, which records it as a graph of its own for that stream.
+_SEG = None
+
+
+def cut(x):
+    """Autograd segment boundary.  A no-op (returns x) except while a segmented capture is being recorded: there the returned
+    tensor is a fresh leaf on x's storage, and the capture drives the backward segment by segment (x <- leaf.grad)."""
+    if _SEG is None or not x.requires_grad or not torch.is_grad_enabled():
+        return x
+    return _SEG.cut(x)
+
+
 def _wgrad_enabled():
     import os
+    if _SEG is not None:
+        return True
     return os.environ.get("TRIS_WGRAD_STREAM", "1") != "0" and streams_allowed()
 
 
@@ -342,9 +358,12 @@ def _wgrad_stream():
     return _WG[dev]
 
 
-def on_wgrad_stream(fn, *tensors):
+def on_wgrad_stream(fn, *tensors, sink=None):
     """Run `fn()` (kernel launches only) on the weight-gradient stream after everything queued so far on the current
-    stream; `tensors` are the buffers it reads (kept alive for the side stream via record_stream)."""
+    stream; `tensors` are the buffers it reads (kept alive for the side stream via record_stream); sink: the gradient-arena
+    view it writes."""
+    if _SEG is not None:
+        return _SEG.defer(fn, tensors, sink)
     if not _wgrad_enabled():
         return fn()
     main, side = torch.cuda.current_stream(), _wgrad_stream()
@@ -374,6 +393,8 @@ def wgrad_join(into=None):
     weight-gradient stream and the named side streams): call before anything consumes the gradient arenas (optimiser,
     all-reduce).  `into`: the stream that should wait -- the data-parallel reducer passes its own stream so that the COMPUTE
     stream is not stalled in the middle of backward."""
+    if _SEG is not None:
+        return  # segmented capture: the streams are joined between the graphs, by the object that replays them
     if not _WG and not _SIDE_STREAMS:
         return  # nothing was ever issued on an auxiliary stream (also: host-only / CPU test contexts)
     cur = torch.cuda.current_stream() if into is None else into
@@ -655,7 +676,8 @@ class LinearFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
-                on_wgrad_stream(lambda: _wgrad_arith(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False)), dy, x)
+                on_wgrad_stream(lambda: _wgrad_arith(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False)), dy, x,
+                                sink=_sink(pw))
             else:
                 dw = _emit(pw, lambda o: _wgrad_arith(lambda: gemm(dy, x, o, N, K, M, N, K, K, True, False)), True)
         db = None
@@ -866,7 +888,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
             if sk is not None:
-                on_wgrad_stream(lambda: wgrad(sk), dy, x, *((mean, invstd) if ctx.lazy else ()))
+                on_wgrad_stream(lambda: wgrad(sk), dy, x, *((mean, invstd) if ctx.lazy else ()), sink=sk)
             else:
                 dw = _emit(ctx.params[0], wgrad, True)
         return dx, dw, None, None, None

@@ -87,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def push_hyper(self, step_count=None):
         """{lr, 1 - beta1^t, sqrt(1 - beta2^t)} of every group for the 1-based step t -> device (async, current stream)"""
         import math
+        import struct
         t = self._steps if step_count is None else step_count
         slot = self._ring_i % self.RING
         self._ring_i += 1
@@ -95,7 +96,8 @@ class FusedAdamW(torch.optim.Optimizer):
             ev.synchronize()
         row = self._ring[slot]
         for gi, g in enumerate(self.param_groups):
-            b1, b2 = g["betas"]
+            # (the betas as the kernels receive them -- C floats -- so that these are the very numbers tris_adamw_f32 computes)
+            b1, b2 = (struct.unpack("f", struct.pack("f", b))[0] for b in g["betas"])
             row[gi, 0] = float(g["lr"])
             row[gi, 1] = 1.0 - b1 ** t
             row[gi, 2] = math.sqrt(1.0 - b2 ** t)
@@ -114,19 +116,42 @@ class FusedAdamW(torch.optim.Optimizer):
                     p.grad.zero_()
         return None
 
+    def span(self, params):
+        """(group index, lo, hi): the arena range [lo, hi) that holds exactly `params`, or None if they are not one contiguous
+        run of one group's arena (used to update part of a group early, tris_amd.graphs.SegmentedTrainStep)"""
+        want = {id(p) for p in params if getattr(p, "_tris_sink", False)}
+        for gi, a in enumerate(self.arenas):
+            idx = [i for i, p in enumerate(a.params) if id(p) in want]
+            if not idx:
+                continue
+            if len(idx) != len(want) or idx != list(range(idx[0], idx[-1] + 1)):
+                return None
+            hi = a.offsets[idx[-1] + 1] if idx[-1] + 1 < len(a.params) else a.numel
+            return gi, a.offsets[idx[0]], hi
+        return None
+
     @torch.no_grad()
-    def step(self, closure=None, device_hyper=False):
+    def step(self, closure=None, device_hyper=False, ranges=None):
         """device_hyper=True: the launches read lr / bias corrections from the device tensor of enable_device_hyper() and the
-        step counter is NOT advanced here (the caller -- a captured step's replay loop -- advances it and calls push_hyper)."""
+        step counter is NOT advanced here (the caller -- a captured step's replay loop -- advances it and calls push_hyper).
+        ranges (device_hyper only): [(group index, lo, hi)] arena ranges to update instead of every group in full (the update is
+        element-wise: any partition of the arenas gives the same result as one launch per group)."""
         ops.wgrad_join()  # weight gradients are produced on their own stream
         st = torch.cuda.current_stream().cuda_stream
         if device_hyper:
             hy = self.enable_device_hyper()
-            for gi, (g, a) in enumerate(zip(self.param_groups, self.arenas)):
+            if ranges is None:
+                ranges = [(gi, 0, a.numel) for gi, a in enumerate(self.arenas)]
+            for gi, lo, hi in ranges:
+                if hi <= lo:
+                    continue
+                g, a = self.param_groups[gi], self.arenas[gi]
                 b1, b2 = g["betas"]
-                _lib.call("tris_adamw_dev_f32", a.p.data_ptr(), a.g.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.numel,
-                          hy[gi].data_ptr(), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), st)
+                o = lo * 4
+                _lib.call("tris_adamw_dev_f32", a.p.data_ptr() + o, a.g.data_ptr() + o, a.m.data_ptr() + o, a.v.data_ptr() + o,
+                          hi - lo, hy[gi].data_ptr(), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), st)
             return
+        assert ranges is None
         self._steps += 1
         for g, a in zip(self.param_groups, self.arenas):
             b1, b2 = g["betas"]

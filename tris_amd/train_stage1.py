@@ -59,6 +59,19 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
         side.wait_event(ready)
         with torch.cuda.stream(side), torch.no_grad():
             f_all = frozen_text(clip_model, ids_all)
+    def joined():       # called where the loss needs the features: the aux ViT forward is issued (and runs) before the wait
+        torch.cuda.current_stream().wait_stream(_side_stream(img.device))
+        f_all.record_stream(torch.cuda.current_stream())
+        return f_all
+    losses = stage1_loss_block(clip_model, img, cls, sig_out, joined if f_all is not None else None, ids_all, K, args)
+    return losses, cls, sig_out
+
+
+def stage1_loss_block(clip_model, img, cls, sig_out, f_all, ids_all, K, args):
+    """train_stage1.py:336-364 after the TRIS forward: foreground image -> aux ViT -> the three losses.  f_all: the frozen aux
+    text features of all B + B*K sentences if the caller already has them (or a callable returning them: a side-stream join), else
+    None."""
+    B = img.shape[0]
     if img.shape[2] != CLIP_INPUT:
         cam = ops.resize_bilinear(sig_out, (CLIP_INPUT, CLIP_INPUT), True)
         with torch.no_grad():
@@ -70,13 +83,11 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     with torch.no_grad():
         if f_all is None:
             f_all = clip_model.encode_text(ids_all)[1]
-        else:
-            torch.cuda.current_stream().wait_stream(_side_stream(img.device))
-            f_all.record_stream(torch.cuda.current_stream())
+        elif callable(f_all):
+            f_all = f_all()
         f_t = f_all[:B].contiguous()
         f_neg = f_all[B:].reshape(B, K, -1).contiguous() if K > 0 else None
-    losses = ops.stage1_loss(cls, f_i, f_t, f_neg, float(args.w1), float(args.w4), float(args.w5))
-    return losses, cls, sig_out
+    return ops.stage1_loss(cls, f_i, f_t, f_neg, float(args.w1), float(args.w4), float(args.w5))
 
 
 def _weight_planes(module, frozen):
@@ -117,7 +128,9 @@ def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
         optimizer.step(device_hyper=device_hyper)
     else:
         ops.wgrad_join()
-    return losses
+    # detached: a caller that keeps the returned tensor must not keep the step's autograd nodes alive with it (AccumulateGrad
+    # nodes remember the stream they were created on: a stale one breaks a later stream capture of the step)
+    return losses.detach()
 
 
 def _env_key():
@@ -126,7 +139,7 @@ def _env_key():
 
 def _graphable(model, optimizer, img, reducer):
     """may this step be replayed from a hipGraph?  Opt-in (TRIS_STEP_GRAPH=1): see train_step"""
-    if os.environ.get("TRIS_STEP_GRAPH", "0") != "1" or reducer is not None or ops._PROF is not None:
+    if os.environ.get("TRIS_STEP_GRAPH", "0") not in ("1", "seg") or reducer is not None or ops._PROF is not None:
         return False
     if not img.is_cuda or not hasattr(optimizer, "enable_device_hyper") or torch.cuda.is_current_stream_capturing():
         return False
@@ -154,8 +167,9 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
                ops._BWD_MODE, ops._WGRAD_MODE, _env_key())
         slot = net.__dict__.get("_tris_step_graph")
         if slot is None:
-            from .graphs import GraphedTrainStep
-            g = GraphedTrainStep(model, clip_model, optimizer, args, (img, word_ids, neg_word_ids), lr_scheduler)
+            from .graphs import GraphedTrainStep, SegmentedTrainStep
+            cls = SegmentedTrainStep if os.environ.get("TRIS_STEP_GRAPH") == "seg" else GraphedTrainStep
+            g = cls(model, clip_model, optimizer, args, (img, word_ids, neg_word_ids), lr_scheduler)
             slot = net.__dict__["_tris_step_graph"] = (key, g)
         if slot[0] == key:
             return slot[1](img, word_ids, neg_word_ids)
