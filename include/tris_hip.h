@@ -129,6 +129,17 @@ int tris_bn_apply_f32(const float* X, const float* mean, const float* invstd, co
  * for bit -- and Y is not read (one 4-byte stream less in each of the two passes).  reduce, dz_out != NULL: the masked
  * gradient dz is also written; tris_bn_bwd_apply_f32 may then be given dY = dz_out, Y = NULL, dZ = NULL (dz is already
  * the residual branch's gradient): 7 activation-sized streams over the two passes instead of 8. */
+/* The reduce pass fused into the PRODUCER of dY where that is a 1x1-convolution / Linear data gradient (the next layer's
+ * backward, CLIP/clip/model.py:42-55 read in reverse): dZ[M,N] = mask(dY[M,K] . Wt[K,N] (+ resid)) with the mask of the
+ * BatchNorm(+ReLU) whose raw input is bn_x [M,N] -- from its output bn_y (residual form), or, bn_y == NULL, recomputed from
+ * bn_x / gamma / beta -- and part <- [rows][2][N] fp64 partial (sum dz, sum dz*xhat), *part_rows (HOST int) <- rows, or 0 when
+ * the shape is not eligible (nothing launched: run tris_gemm_f32 + tris_bn_bwd_reduce_f32).  part capacity: ceil(M/128)*2*N
+ * doubles.  Finish with tris_part_finalize_f32 -> sum_dz, sum_dzx, then tris_bn_bwd_apply_f32(dY = dZ, Y = NULL, dZ = NULL,
+ * beta_mask = NULL).  One activation-sized read and one write less than the separate reduce pass. */
+int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int M, int N, int K, const float* resid, long ldr,
+                        const float* bn_x, const float* bn_y, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, double* part, int* part_rows, void* stream);
+int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream);
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                            long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,
                            const float* beta_mask, float* dz_out, void* stream);

@@ -306,6 +306,67 @@ def test_batchnorm_train(ops, shape, res, relu):
         close(ops.batch_norm(gx, gg, gb, grm, grv, None, False, False), ye, name="eval")
 
 
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("shape,N", [((3, 20, 20, 64), 256), ((2, 9, 9, 128), 32), ((2, 40, 40, 32), 64), ((1, 10, 10, 256), 64)])
+def test_batchnorm_backward_reduced_in_the_consuming_1x1_convolution(ops, shape, N, res, monkeypatch):
+    """relu(bn(x) [+ r]) -> 1x1 convolution: with bwd_link=True the BatchNorm's backward sums come out of the convolution's
+    data-gradient epilogue (tris_gemm_bnbwd_f32) instead of a reduction pass of their own; every gradient must match both the
+    torch reference and the unfused path, and the fused entry point must really have run where the shape allows it"""
+    from tris_amd import _lib
+    C = shape[-1]
+    x, g, b, w = leaf(*shape), leaf(C), leaf(C), leaf(N, C, scale=0.2)
+    x.data = x.data * 2 + 1
+    r = leaf(*shape, seed=5) if res else None
+    y = F.batch_norm(x.permute(0, 3, 1, 2), torch.zeros(C), torch.ones(C), g, b, True, 0.1, 1e-5).permute(0, 2, 3, 1)
+    y = F.relu(y + r if res else y)
+    z = y @ w.t()
+    (z * z).sum().backward()
+
+    def run(link):
+        monkeypatch.setenv("TRIS_BN_BWD_FUSE", "1" if link else "0")
+        gx, gg, gb, gw = gpu_leaf(x), gpu_leaf(g), gpu_leaf(b), gpu_leaf(w)
+        gr = gpu_leaf(r) if res else None
+        gy = ops.batch_norm(gx, gg, gb, torch.zeros(C).cuda(), torch.ones(C).cuda(), gr, True, True, bwd_link=True)
+        assert hasattr(gy, "_bn_link") == link
+        gz = ops.linear(gy, gw)
+        (gz * gz).sum().backward()
+        return gz, gx.grad, gg.grad, gb.grad, gw.grad, (gr.grad if res else None)
+    calls = []
+    real = _lib.call
+
+    def spy(name, *a):
+        if name == "tris_gemm_bnbwd_f32":
+            calls.append(name)
+        return real(name, *a)
+    monkeypatch.setattr(ops, "call", spy)
+    fills = []
+    real_fill = ops._BnBwdLink.fill
+    monkeypatch.setattr(ops._BnBwdLink, "fill", lambda self, *a: (fills.append(1), real_fill(self, *a))[1])
+    fused = run(True)
+    M = x.numel() // C
+    assert len(calls) == 1
+    assert len(fills) == (1 if M >= 128 else 0)     # (fewer rows than one tile: the entry point declines, the two passes run)
+    plain = run(False)
+    assert len(calls) == 1 and len(fills) <= 1
+    for name, a, b_, ref in zip(("z", "dx", "dgamma", "dbeta", "dw", "dresid"), fused, plain, (z, x.grad, g.grad, b.grad, w.grad,
+                                                                                               r.grad if res else None)):
+        if ref is None:
+            continue
+        close(a, ref, 5e-4, name=name + " (fused) vs torch")
+        close(a, b_, 2e-5, name=name + " fused vs separate passes")
+
+
+def test_batchnorm_link_refuses_a_second_consumer(ops):
+    """bwd_link=True is a promise (one autograd consumer); a broken promise must raise, not produce a masked gradient twice"""
+    C = 64
+    gx = gpu_leaf(leaf(2, 16, 16, C))
+    gg, gb, gw = gpu_leaf(leaf(C)), gpu_leaf(leaf(C)), gpu_leaf(leaf(128, C, scale=0.2))
+    gy = ops.batch_norm(gx, gg, gb, torch.zeros(C).cuda(), torch.ones(C).cuda(), None, True, True, bwd_link=True)
+    out = (ops.linear(gy, gw) ** 2).sum() + (gy * 3.0).sum()
+    with pytest.raises(RuntimeError, match="second autograd consumer"):
+        out.backward()
+
+
 def test_avgpool_layernorm_gelu(ops):
     x = leaf(2, 8, 6, 16)
     y = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)

@@ -68,12 +68,14 @@ class BatchNorm2d(nn.Module):
             self.num_batches_tracked += self._nbt_pending
             self._nbt_pending = 0
 
-    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False):
+    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False, bwd_link=False):
+        """bwd_link=True: the caller guarantees that the output has exactly ONE autograd consumer; if that is a 1x1 convolution
+        its data gradient does this BatchNorm's backward reduction in its epilogue (ops._BnBwdLink)"""
         if self.training:
             self._nbt_pending += 1
         group = self.process_group if self.training else None
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
-                              self.training, self.momentum, self.eps, group, grad_box, lazy)
+                              self.training, self.momentum, self.eps, group, grad_box, lazy, bwd_link)
 
 
 class AvgPool2d(nn.Module):
@@ -107,8 +109,12 @@ class Bottleneck(nn.Module):
                 ("1", BatchNorm2d(planes * self.expansion)),
             ]))
 
-    def forward(self, x):  # channels-last
+    def forward(self, x, link_out=False):  # channels-last
+        """link_out: the block's output goes to the next block (or one 1x1 convolution) and nowhere else -- its identity use
+        there rides a GradBox -- so bn3's backward reduction may be fused into that consumer's data gradient (needs the
+        GradBox path: with TRIS_GRAD_BOX=0 the residual gradient reaches the output through autograd as a second term)"""
         tr = self.training  # train mode: BatchNorm batch statistics come out of the producing conv's epilogue
+        link_out = link_out and os.environ.get("TRIS_GRAD_BOX", "1") != "0"
         # identity block: x feeds conv1 and the residual add; the residual gradient rides conv1's data-gradient epilogue
         # down-sampling block: the shortcut's input gradient (avg-pool or 1x1 conv backward) rides along the same way
         box = ops.GradBox() if (tr and torch.is_grad_enabled() and x.requires_grad
@@ -117,7 +123,7 @@ class Bottleneck(nn.Module):
         # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
         # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
         out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout))
-        out = self.bn2(self.conv2(out, stats=tr), relu=True)
+        out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: avgpool or conv3
         out = self.avgpool(out)
         out = self.conv3(out, stats=tr)
         if self.downsample is not None:
@@ -126,8 +132,8 @@ class Bottleneck(nn.Module):
             else:
                 idn = self.downsample[1](self.downsample[0](x), stats=tr, grad_box_out=box)
             idn = self.downsample[2](idn)
-            return self.bn3(out, resid=idn, relu=True)
-        return self.bn3(out, resid=x, relu=True, grad_box=box)  # relu(bn3(conv3) + identity), fused
+            return self.bn3(out, resid=idn, relu=True, bwd_link=link_out)
+        return self.bn3(out, resid=x, relu=True, grad_box=box, bwd_link=link_out)  # relu(bn3(conv3) + identity), fused
 
 
 class Linear(nn.Module):
@@ -186,8 +192,10 @@ class ModifiedResNet(nn.Module):
             layers.append(Bottleneck(self._inplanes, planes))
         return nn.Sequential(*layers)
 
-    def forward_cl(self, x, hooks=None):
+    def forward_cl(self, x, hooks=None, taps=True):
         """x [B,3,H,W] (NCHW, as the reference's callers pass it) -> (c1,c2,c3,c4) channels-last [B,h,w,C].
+        taps=False: the caller uses c4 only, and feeds it to ONE 1x1 convolution (TRIS.encode_visual): c1..c3 then have no
+        consumer but the next stage, which lets the last block of every stage link its bn3 backward like the others.
         hooks: optional {"stem" | "layer1" | "layer2" | "layer3" | "layer4": callable} run right after that stage has been ISSUED -- TRIS uses
         it to issue the text encoder (side stream) in the middle of the trunk, see model_stage1.TRIS.forward."""
         x = ops.nchw_to_nhwc(x.float())
@@ -206,8 +214,8 @@ class ModifiedResNet(nn.Module):
             x = red.boundary(x, "layer1")          # backward passing this point => every layer1 gradient is written
         for name, layer in (("layer2", self.layer1), ("layer3", self.layer2), ("layer4", self.layer3),
                             ("heads", self.layer4)):
-            for blk in layer:
-                x = ops.cut(blk(x))
+            for k, blk in enumerate(layer):
+                x = ops.cut(blk(x, link_out=(not taps) or k + 1 < len(layer)))
             if red is not None:
                 x = red.boundary(x, name)          # the boundary AFTER a stage releases the segment of the NEXT one
             outs.append(x)

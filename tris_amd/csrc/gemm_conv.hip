@@ -617,7 +617,7 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
   Cfg h = heuristic_cfg(p, batch, ws, ws_bytes);
   if (!autotune_enabled() || getenv("TRIS_FORCE_TILE")) return run_cfg<AK, BKIND>(p, batch, ws, st, h);
   const bool stat = p.stat_part != nullptr;  // fused BN statistics: 128-row tiles and no split-K are fixed, the tile width is tuned
-  const TuneKey key = {AK, BKIND + (stat ? 16 : 0), p.M, p.N, p.K, batch, g_gemm_mode};
+  const TuneKey key = {AK, BKIND + (stat ? 16 : 0) + (p.bnb_x != nullptr ? 32 : 0), p.M, p.N, p.K, batch, g_gemm_mode};
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
@@ -1070,6 +1070,34 @@ extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, in
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   *stat_rows = p.stat_part ? cdiv(M, 128) : 0;
   return launch_cfg<A_ROWK, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+// Data gradient of a 1x1 convolution / Linear, dZ[M,N] = mask(dY[M,K] . W[K,N] (+ resid)), with the reduction pass of the
+// BatchNorm(+ReLU) BACKWARD that consumes it fused into the epilogue (GemmParams::bnb_*): bn_x [M,N] is that BatchNorm's raw
+// input, bn_y its output (residual form: the mask is y > 0) or NULL (the mask is recomputed from bn_x, gamma, beta).  part receives
+// [*part_rows][2][N] fp64 partial (sum dz, sum dz * xhat) -- finish with tris_part_finalize_f32; *part_rows = 0: the shape is not
+// eligible (nothing was launched; the caller runs tris_gemm_f32 + tris_bn_bwd_reduce_f32 as usual).
+extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int M, int N, int K, const float* resid,
+                                   long ldr, const float* bn_x, const float* bn_y, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, double* part, int* part_rows, void* stream) {
+  *part_rows = 0;
+  if (M <= 0 || N <= 0 || K <= 0 || bn_x == nullptr || part == nullptr) return (int)hipErrorInvalidValue;
+  if (bn_y == nullptr && (gamma == nullptr || beta == nullptr)) return (int)hipErrorInvalidValue;
+  GemmParams p = {};
+  p.A = dY; p.B = Wt; p.C = dZ; p.M = M; p.N = N; p.K = K;
+  p.lda = K; p.ldb = N; p.ldc = N; p.alpha = 1.f;
+  p.resid = resid; p.ldr = ldr;
+  p.vecA = al16(dY) && (K % 4 == 0);
+  p.vecB = al16(Wt) && (N % 4 == 0);
+  p.fastA = p.vecA;
+  p.fastB = p.vecB;
+  const bool al = al16(dZ) && al16(bn_x) && (bn_y == nullptr || al16(bn_y)) && (resid == nullptr || (al16(resid) && ldr % 4 == 0)) &&
+                  al16(mean) && al16(invstd) && (gamma == nullptr || al16(gamma)) && (beta == nullptr || al16(beta));
+  if (!stats_eligible(p) || !al || N % 4 != 0) return 0;
+  p.stat_part = part;
+  p.bnb_x = bn_x; p.bnb_y = bn_y; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
+  *part_rows = cdiv(M, 128);
+  return launch_cfg<A_ROWK, B_KN>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin,

@@ -821,6 +821,16 @@ void gemm_fast_kernel(GemmParams p) {
         const int col = n0 + wn * WN + j * 32 + ec;
         float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI == EPI_STD && p.bias_mode == 1 && col < p.N) bc = ld4(p.bias + col);
+        float4 nmu = bc, nis = bc, nsc = bc, nbe = bc;   // fused BatchNorm-backward reduction: the columns' constants
+        if (EPI == EPI_STD && p.bnb_x != nullptr && col < p.N) {
+          nmu = ld4(p.bnb_mean + col);
+          nis = ld4(p.bnb_invstd + col);
+          if (p.bnb_y == nullptr) {
+            const float4 ga = ld4(p.bnb_gamma + col);
+            nbe = ld4(p.bnb_beta + col);
+            nsc = make_float4(nis.x * ga.x, nis.y * ga.y, nis.z * ga.z, nis.w * ga.w);
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = grow(wm * WM + i * 32 + er + 8 * t);
@@ -842,9 +852,30 @@ void gemm_fast_kernel(GemmParams p) {
                 const float4 rr = ld4(p.resid + (long)zb * p.sR + (long)row * p.ldr + col);
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
               }
+              if (p.bnb_x != nullptr) {
+                const long o = (long)row * p.ldc + col;
+                const float4 xx = ld4(p.bnb_x + o);
+                if (p.bnb_y != nullptr) {
+                  const float4 yy = ld4(p.bnb_y + o);
+                  if (!(yy.x > 0.f)) v.x = 0.f;
+                  if (!(yy.y > 0.f)) v.y = 0.f;
+                  if (!(yy.z > 0.f)) v.z = 0.f;
+                  if (!(yy.w > 0.f)) v.w = 0.f;
+                } else {
+                  if (!((xx.x - nmu.x) * nsc.x + nbe.x > 0.f)) v.x = 0.f;
+                  if (!((xx.y - nmu.y) * nsc.y + nbe.y > 0.f)) v.y = 0.f;
+                  if (!((xx.z - nmu.z) * nsc.z + nbe.z > 0.f)) v.z = 0.f;
+                  if (!((xx.w - nmu.w) * nsc.w + nbe.w > 0.f)) v.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(p.C + o) = v;
+                vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
+                vs_q[j].x += v.x * ((xx.x - nmu.x) * nis.x); vs_q[j].y += v.y * ((xx.y - nmu.y) * nis.y);
+                vs_q[j].z += v.z * ((xx.z - nmu.z) * nis.z); vs_q[j].w += v.w * ((xx.w - nmu.w) * nis.w);
+              } else {
               *reinterpret_cast<float4*>(p.C + (long)zb * p.sC + (long)row * p.ldc + col) = v;
               vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
               vs_q[j].x += v.x * v.x; vs_q[j].y += v.y * v.y; vs_q[j].z += v.z * v.z; vs_q[j].w += v.w * v.w;
+              }
             }
           }
         }
@@ -871,9 +902,20 @@ void gemm_fast_kernel(GemmParams p) {
             if (p.act == 1) v = fmaxf(v, 0.f);
             else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
             if (p.resid) v += p.resid[(long)zb * p.sR + (long)row * p.ldr + col];
+            if (p.bnb_x != nullptr) {   // (fused BatchNorm-backward reduction, scalar form: see the vector epilogue)
+              const long o = (long)row * p.ldc + col;
+              const float xx = p.bnb_x[o], mu1 = p.bnb_mean[col], is1 = p.bnb_invstd[col];
+              const bool on = p.bnb_y != nullptr ? (p.bnb_y[o] > 0.f)
+                                                 : ((xx - mu1) * (is1 * p.bnb_gamma[col]) + p.bnb_beta[col] > 0.f);
+              if (!on) v = 0.f;
+              p.C[o] = v;
+              st_s[j] += v;
+              st_q[j] += v * ((xx - mu1) * is1);
+            } else {
             p.C[(long)zb * p.sC + (long)row * p.ldc + col] = v;
             st_s[j] += v;
             st_q[j] += v * v;
+            }
           }
         }
       }
@@ -882,8 +924,50 @@ void gemm_fast_kernel(GemmParams p) {
   if (EPI == EPI_STD && p.stat_part != nullptr) {
     // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the NWM waves along M:
     // shuffle, then LDS, then one fp64 partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
-    static_assert(NWM * BN * 2 <= AS_ALL, "statistics scratch does not fit the staging buffer");
+    static_assert(NWM * BN * 4 <= AS_ALL, "statistics scratch does not fit the staging buffer");
     float* red = As;
+    if (p.bnb_x != nullptr) {
+      // BatchNorm-backward sums cancel (dx = k1 * (dz - mean(dz) - xhat * mean(dz * xhat))): a lane's <= 16 products are summed in
+      // fp32, everything beyond that -- lanes, waves, tiles -- in fp64 (col_partial_kernel<1> accumulates in fp64 throughout)
+      double* redd = reinterpret_cast<double*>(As);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if (vec_epi) {
+          double a[4] = {vs_s[j].x, vs_s[j].y, vs_s[j].z, vs_s[j].w}, b[4] = {vs_q[j].x, vs_q[j].y, vs_q[j].z, vs_q[j].w};
+#pragma unroll
+          for (int sh = 8; sh < 64; sh <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += __shfl_xor(a[e], sh, 64); b[e] += __shfl_xor(b[e], sh, 64); }
+          if (lane < 8) {
+            const int cl = wn * WN + j * 32 + lane * 4;
+            double* o = redd + (wm * BN + cl) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[2 * e] = a[e]; o[2 * e + 1] = b[e]; }
+          }
+        } else {
+          double a = st_s[j], b = st_q[j];
+          a += __shfl_xor(a, 32, 64);
+          b += __shfl_xor(b, 32, 64);
+          if (kh == 0) {
+            const int cl = wn * WN + j * 32 + li;
+            redd[(wm * BN + cl) * 2 + 0] = a;
+            redd[(wm * BN + cl) * 2 + 1] = b;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        const int tm = tile / p.tiles_n;
+        double* o = p.stat_part + (long)tm * 2 * p.N;
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) { s += redd[(w * BN + tid) * 2]; q += redd[(w * BN + tid) * 2 + 1]; }
+        o[n0 + tid] = s;
+        o[p.N + n0 + tid] = q;
+      }
+      return;
+    }
     if (vec_epi) {
       __syncthreads();  // the other waves' epilogue blocks live in the staging buffers
 #pragma unroll

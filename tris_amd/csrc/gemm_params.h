@@ -34,6 +34,13 @@ struct GemmParams {
   int hmode;        // A_HALO: window shape, 1 = BM consecutive pixels in padded coordinates, 2 = (BM/16) x 16 patches
   // A_HALO, optional: the gathered tensor is the raw input x of a BatchNorm + ReLU; the kernel forms relu(bn(x)) in its window
   const float *in_mean, *in_invstd, *in_gamma, *in_beta;
+  // Optional fused BatchNorm-BACKWARD reduction (EPI_STD, no split-K, with stat_part): C is the gradient of the OUTPUT of a
+  // train-mode BatchNorm (+ReLU) whose raw input is bnb_x [M, N] (same leading dimension as C).  The epilogue masks the value
+  // with that ReLU -- from the BatchNorm's output bnb_y where given (residual form: y = relu(bn(x) + identity)), else recomputed
+  // from bnb_x with bn_apply_kernel's own expression (bnb_gamma / bnb_beta) -- stores the MASKED gradient dz, and accumulates
+  // sum(dz), sum(dz * xhat) per column into stat_part [tiles_m][2][N] (fp64 across lanes / waves / tiles), i.e. exactly what
+  // col_partial_kernel<1> computes in a pass of its own.
+  const float *bnb_x, *bnb_y, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -700,6 +700,15 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   return 0;
 }
 
+// finish fp64 partial rows [rows][2][C] (a fused producer's epilogue, e.g. tris_gemm_bnbwd_f32) -> out0[C], out1[C]
+extern "C" int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream) {
+  if (rows < 1 || C < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, rows)), dim3(fin_block(rows)), 0, (hipStream_t)stream, part, rows,
+                     C, out0, out1);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const float* mean,
                                      const float* invstd, const float* gamma, const float* sum_dz, const float* sum_dzx,
                                      float inv_count, float* dX, float* dZ, long M, int C, const float* beta_mask,

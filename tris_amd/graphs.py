@@ -392,6 +392,9 @@ class SegmentedTrainStep:
         if not self.cutting:           # (only the trainable trunk is cut: its weight gradients are what the cuts release)
             return x
         leaf = x.detach().requires_grad_()
+        link = getattr(x, "_bn_link", None)    # (ops._BnBwdLink rides on the tensor: the cut is an identity)
+        if link is not None:
+            leaf._bn_link = link
         self.cuts.append((x, leaf))
         return leaf
 

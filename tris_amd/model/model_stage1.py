@@ -84,7 +84,7 @@ class TRIS(nn.Module):
                     h()
             c4 = self.backbone.visual.forward_spatial(x)[1]             # [B,h,w,768] channels-last
         else:
-            c4 = self.backbone.visual.forward_cl(x, hooks)[3]           # [B,h,w,2048] channels-last
+            c4 = self.backbone.visual.forward_cl(x, hooks, taps=False)[3]   # [B,h,w,2048] channels-last
         h_, w_ = c4.shape[1:3]
         vis = self.vis_project(c4).reshape(B, h_ * w_, -1)              # [B,P,C]
         return ops.l2norm(vis), h_, w_

@@ -589,13 +589,55 @@ class GradBox:
 
 
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
+class _BnBwdLink:
+    """Hand-off between a train-mode BatchNorm(+ReLU) and the 1x1 convolution / Linear that consumes its output.
+
+    The BatchNorm backward needs sum(dz), sum(dz * xhat) over the whole batch before it can form dx -- a reduction pass over dy
+    and x of its own (col_partial_kernel<1>).  Where dy is produced by a 1x1-convolution data gradient, that GEMM's epilogue has
+    every dy value in registers: tris_gemm_bnbwd_f32 masks it there, stores the masked gradient dz and leaves the two sums as
+    per-tile fp64 partial rows, and the BatchNorm backward is the apply pass alone.  Forward: BatchNormFn.forward hangs a link on
+    its output tensor, ops.linear picks it up from its input.  Backward: LinearFn.backward fills it (dz tensor, partial rows),
+    BatchNormFn.backward uses it iff the gradient it is handed IS that tensor, unmodified (same storage, same version counter:
+    a second consumer's gradient accumulated into it by autograd changes one of the two) -- otherwise the usual two passes run
+    on whatever arrived, which is why the masked gradient is only ever produced when the BatchNorm is known to be behind it.
+    The model marks the BatchNorms whose output has exactly one autograd consumer (Bottleneck: bn2 -> conv3; bn3 -> the next
+    block's conv1, the residual branch rides a GradBox) with bwd_link=True."""
+    __slots__ = ("x", "mean", "invstd", "gamma", "beta", "from_y", "dz", "part", "rows")
+
+    def __init__(self, x, mean, invstd, gamma, beta, from_y):
+        # (no reference to the BatchNorm's OUTPUT, which carries this object: the consumer has that tensor as its own input)
+        self.x, self.mean, self.invstd, self.gamma, self.beta, self.from_y = x, mean, invstd, gamma, beta, from_y
+        self.dz = self.part = None
+        self.rows = 0
+
+    def fill(self, dz, part, rows):
+        # (identity of the gradient tensor, not a reference to it: autograd hands a sole-owner gradient on without a copy)
+        self.dz, self.part, self.rows = (dz.data_ptr(), dz._version, tuple(dz.shape)), part, rows
+
+    def take(self, dy):
+        """(part, rows) if dy is the masked gradient this link's GEMM produced; None if no GEMM filled the link; one use"""
+        dz, part, rows = self.dz, self.part, self.rows
+        self.dz = self.part = None
+        if dz is None:
+            return None
+        if (dy.data_ptr(), dy._version, tuple(dy.shape)) != dz:
+            raise RuntimeError("a BatchNorm output marked bwd_link=True has a second autograd consumer: the masked gradient "
+                               "its 1x1 convolution produced was replaced or modified before it reached the BatchNorm backward")
+        return part, rows
+
+
+def _bn_bwd_fuse_enabled():
+    return os.environ.get("TRIS_BN_BWD_FUSE", "1") != "0"
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
+    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None, bn_link=None):
         _chk(x, w, b, resid)
         ctx.grad_box, ctx.grad_box_out, ctx.grad_box_res = grad_box, grad_box_out, grad_box_res
+        ctx.bn_link = bn_link if (bn_link is not None and x.is_contiguous() and bn_link.x.shape == x.shape) else None
         x = x.contiguous()
         K = x.shape[-1]
         N = w.numel() // K
@@ -665,7 +707,22 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             wp = _planes(pw)
             ws = workspace(0)
-            if wp is None or not _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
+            link, fused = ctx.bn_link, False
+            if link is not None and wp is None:
+                # x is the output of a BatchNorm(+ReLU) that has no other consumer: mask dx and reduce it for that BatchNorm's
+                # backward in this product's epilogue (_BnBwdLink)
+                import ctypes
+                part = torch.empty(((M + 127) // 128) * 2 * K, device=x.device, dtype=torch.float64)
+                rows = ctypes.c_int(0)
+                _timed("gemm", 2.0 * M * N * K, lambda: call(
+                    "tris_gemm_bnbwd_f32", P(dy), P(w), P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
+                    P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()))
+                if rows.value > 0:
+                    fused = True
+                    link.fill(dx, part, rows.value)
+            if fused:
+                pass
+            elif wp is None or not _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
                     "tris_gemm_wp_f32", P(dy), wp[2], wp[3], P(dx), M, K, N, None, P(extra), 0, P(ws), ws.numel() * 4, None,
                     None, _stream())):
                 gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K)
@@ -683,11 +740,14 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
-        return dx, dw, db, d_res, None, None, None, None, None
+        return dx, dw, db, d_res, None, None, None, None, None, None
 
 
 def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
-    return LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res)
+    link = getattr(x, "_bn_link", None)
+    if link is not None and not (torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled()):
+        link = None
+    return LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res, link)
 
 
 class MatmulFn(torch.autograd.Function):
@@ -913,7 +973,7 @@ class BatchNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None, grad_box=None,
-                lazy=False):
+                lazy=False, bwd_link=False):
         _chk(x, gamma, beta, rmean, rvar, resid)
         x = x.contiguous()
         C = x.shape[-1]
@@ -965,9 +1025,13 @@ class BatchNormFn(torch.autograd.Function):
         ctx.grad_box = grad_box
         ctx.params = (gamma, beta)
         ctx.training = bool(training)
+        ctx.link = None
         if training:
             keep_y = relu and (resid is not None or os.environ.get("TRIS_BN_MASK_X", "1") == "0")   # (env: developer A/B knob)
             ctx.save_for_backward(x, gamma, beta, mean, invstd, y if keep_y else None)
+            if bwd_link and relu and not lazy:
+                # the consumer (ops.linear) may reduce this BatchNorm's backward sums in its data-gradient epilogue: _BnBwdLink
+                ctx.link = y._bn_link = _BnBwdLink(x, mean, invstd, gamma, beta, keep_y)
         return y
 
     @staticmethod
@@ -1002,11 +1066,17 @@ class BatchNormFn(torch.autograd.Function):
         mask_x = relu and not has_res and y is None
         # residual blocks (out = relu(bn(x) + identity)): the reduce pass writes the masked gradient dz -- which IS the identity
         # branch's gradient -- and the apply pass reads it back instead of masking dy from y a second time
-        dz_first = want_dz and relu and y is not None and os.environ.get("TRIS_BN_DZ_FIRST", "1") != "0"   # (env: developer A/B knob)
+        got = ctx.link.take(dy) if ctx.link is not None else None
+        dz_first = (got is None and want_dz and relu and y is not None
+                    and os.environ.get("TRIS_BN_DZ_FIRST", "1") != "0")   # (env: developer A/B knob)
         if dz_first:
             d_res = torch.empty_like(x)
-        call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
-             P(gamma) if mask_x else None, P(beta) if mask_x else None, P(d_res) if dz_first else None, _stream())
+        if got is not None:
+            # dy came out of the consuming 1x1 convolution's data gradient already MASKED, with the two sums as partial rows
+            call("tris_part_finalize_f32", got[0].data_ptr(), got[1], C, p_dz, p_dzx, _stream())
+        else:
+            call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
+                 P(gamma) if mask_x else None, P(beta) if mask_x else None, P(d_res) if dz_first else None, _stream())
         if mb is not None:
             # SyncBatchNorm: the arena keeps this rank's dbeta / dgamma (the data-parallel reducer averages them like every
             # other gradient); the sums over ALL ranks that dX needs come from one peer-mailbox launch reading the arena
@@ -1020,7 +1090,14 @@ class BatchNormFn(torch.autograd.Function):
                 from . import comm
                 comm.syncbn_all_reduce_sum(sums, group=group)
         dx = None
-        if dz_first:
+        if got is not None:
+            if want_dz:
+                d_res = dy          # the masked gradient IS the identity branch's gradient
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                call("tris_bn_bwd_apply_f32", P(dy), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
+                     1.0 / float(count), P(dx), None, M, C, None, _stream())
+        elif dz_first:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 call("tris_bn_bwd_apply_f32", P(d_res), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
@@ -1033,15 +1110,17 @@ class BatchNormFn(torch.autograd.Function):
                  1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
         if ctx.grad_box is not None and d_res is not None and ctx.grad_box.deposit(d_res):
             d_res = None   # handed to the block's first conv
-        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-               grad_box=None, lazy=False):
+               grad_box=None, lazy=False, bwd_link=False):
     """lazy=True (train-mode BatchNorm + ReLU whose ONLY consumer is ops.conv3x3, and conv3x3_bnin_ok said yes): the returned
     tensor is an unwritten buffer carrying `_bn_lazy`; pass it to ops.conv3x3 and nowhere else."""
     part = getattr(x, "_bn_part", None) if training else None
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy)
+    bwd_link = bool(bwd_link and training and torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled())
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy,
+                             bwd_link)
 
 
 class AvgPool2Fn(torch.autograd.Function):

@@ -214,7 +214,11 @@ class GradReducer:
     def boundary(self, x, key):
         if not self.active or not torch.is_grad_enabled() or not x.requires_grad:
             return x
-        return _Boundary.apply(x, self, key)
+        y = _Boundary.apply(x, self, key)
+        link = getattr(x, "_bn_link", None)   # (ops._BnBwdLink rides on the tensor: the boundary is an identity)
+        if link is not None:
+            y._bn_link = link
+        return y
 
     def finish(self):
         """Launch every segment not yet launched, wait for all, reset for the next step."""
