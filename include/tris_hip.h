@@ -139,6 +139,11 @@ int tris_bn_apply_f32(const float* X, const float* mean, const float* invstd, co
 int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int M, int N, int K, const float* resid, long ldr,
                         const float* bn_x, const float* bn_y, const float* mean, const float* invstd, const float* gamma,
                         const float* beta, double* part, int* part_rows, void* stream);
+/* the same for a 3x3 convolution's data gradient (stride 1, pad 1; bn1 -> conv2 of Bottleneck, the stem's bn1/bn2): the input
+ * of the convolution is relu(bn(bn_x)), no residual, mask recomputed from bn_x. */
+int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int B, int H, int W, int Cin, int Cout,
+                                 const float* bn_x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, double* part, int* part_rows, void* stream);
 int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream);
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                            long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,

@@ -356,6 +356,41 @@ def test_batchnorm_backward_reduced_in_the_consuming_1x1_convolution(ops, shape,
         close(a, b_, 2e-5, name=name + " fused vs separate passes")
 
 
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("shape,Cout", [((2, 16, 16, 64), 64), ((3, 20, 20, 32), 64), ((1, 12, 12, 128), 32)])
+def test_batchnorm_backward_reduced_in_the_consuming_3x3_convolution(ops, shape, Cout, lazy, monkeypatch):
+    """relu(bn(x)) -> 3x3 convolution (stride 1), also with the BatchNorm folded into the convolution (lazy): the backward sums
+    come out of the data-gradient epilogue (tris_conv3x3_dgrad_bnbwd_f32); gradients vs torch and vs the separate passes"""
+    C = shape[-1]
+    x, g, b = leaf(*shape), leaf(C), leaf(C)
+    x.data = x.data * 2 + 1
+    w = leaf(Cout, C, 3, 3, scale=0.1)
+    y = F.relu(F.batch_norm(x.permute(0, 3, 1, 2), torch.zeros(C), torch.ones(C), g, b, True, 0.1, 1e-5))
+    z = F.conv2d(y, w, padding=1).permute(0, 2, 3, 1)
+    (z * z).sum().backward()
+    fills = []
+    real_fill = ops._BnBwdLink.fill
+    monkeypatch.setattr(ops._BnBwdLink, "fill", lambda self, *a: (fills.append(1), real_fill(self, *a))[1])
+
+    def run(link):
+        monkeypatch.setenv("TRIS_BN_BWD_FUSE", "1" if link else "0")
+        gx, gg, gb = gpu_leaf(x), gpu_leaf(g), gpu_leaf(b)
+        gw = w.detach().clone().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ok = lazy and ops.conv3x3_bnin_ok(gx.shape, Cout)
+        gy = ops.batch_norm(gx, gg, gb, torch.zeros(C).cuda(), torch.ones(C).cuda(), None, True, True, lazy=ok, bwd_link=True)
+        gz = ops.conv3x3(gy, gw)
+        (gz * gz).sum().backward()
+        return gz, gx.grad, gg.grad, gb.grad, gw.grad
+    fused = run(True)
+    M = x.numel() // C
+    assert len(fills) == (1 if M >= 128 else 0)
+    plain = run(False)
+    assert len(fills) <= 1
+    for name, a, b_, ref in zip(("z", "dx", "dgamma", "dbeta", "dw"), fused, plain, (z, x.grad, g.grad, b.grad, w.grad)):
+        close(a, ref, 5e-4, name=name + " (fused) vs torch")
+        close(a, b_, 2e-5, name=name + " fused vs separate passes")
+
+
 def test_batchnorm_link_refuses_a_second_consumer(ops):
     """bwd_link=True is a promise (one autograd consumer); a broken promise must raise, not produce a masked gradient twice"""
     C = 64

@@ -122,7 +122,7 @@ class Bottleneck(nn.Module):
         out = self.conv1(x, stats=tr, grad_box=box)
         # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
         # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
-        out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout))
+        out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout), bwd_link=True)
         out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: avgpool or conv3
         out = self.avgpool(out)
         out = self.conv3(out, stats=tr)
@@ -201,9 +201,9 @@ class ModifiedResNet(nn.Module):
         x = ops.nchw_to_nhwc(x.float())
         tr = self.training
         x = self.conv1(x, stats=tr)                        # (conv1 has Cin=3: not eligible, separate statistics pass)
-        x = self.bn1(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout))   # folded into conv2 where possible
+        x = self.bn1(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout), bwd_link=True)   # folded into conv2 where possible
         x = self.conv2(x, stats=tr)
-        x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout))   # ... into conv3
+        x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout), bwd_link=True)   # ... into conv3
         x = self.bn3(self.conv3(x, stats=tr), relu=True)
         x = ops.cut(self.avgpool(x))                       # (segment boundary of a segmented capture; otherwise x itself)
         if hooks and "stem" in hooks:

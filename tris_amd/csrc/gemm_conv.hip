@@ -759,7 +759,8 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_on
   bool any = false;
   for (int id = 1; id < kHaloN; ++id) any = any || halo_ok(p, id);
   if (!any) return im2col();
-  const TuneKey key = {A_HALO, BKIND + (stat ? 16 : 0) + (direct_only ? 32 : 0), p.M, p.N, p.K, p.gH * 4096 + p.gW, g_gemm_mode};
+  const TuneKey key = {A_HALO, BKIND + (stat ? 16 : 0) + (direct_only ? 32 : 0) + (p.bnb_x != nullptr ? 64 : 0), p.M, p.N, p.K,
+                       p.gH * 4096 + p.gW, g_gemm_mode};
   int cached = -1;
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);   // (released before the launch: the implicit GEMM looks up its own tile under it)
@@ -816,6 +817,11 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_on
 
 }  // namespace
 
+// may the fused-statistics epilogue of the fast kernel serve this product?
+static bool stats_eligible(const GemmParams& p) {
+  return p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 128 && p.N >= 4;
+}
+
 extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
                              long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
                              const float* bias, int bias_mode, const float* resid, long ldr, long sR, int act,
@@ -871,6 +877,32 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   p.fastB = p.vecB;
   if (Cout % 16 != 0) return (int)hipErrorInvalidValue;  // k tile must not straddle taps for the B loader
   return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, nullptr);
+}
+
+// Data gradient of a 3x3 convolution whose INPUT is the output of a train-mode BatchNorm + ReLU (no residual): the reduction
+// pass of that BatchNorm's backward rides in the epilogue, as in tris_gemm_bnbwd_f32 (mask recomputed from bn_x / gamma / beta).
+// dZ[B,H,W,Cin] <- masked gradient; part <- [*part_rows][2][Cin] fp64 partial; *part_rows = 0: not eligible, nothing launched.
+extern "C" int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int B, int H, int W, int Cin, int Cout,
+                                            const float* bn_x, const float* mean, const float* invstd, const float* gamma,
+                                            const float* beta, double* part, int* part_rows, void* stream) {
+  *part_rows = 0;
+  if (bn_x == nullptr || part == nullptr || gamma == nullptr || beta == nullptr) return (int)hipErrorInvalidValue;
+  GemmParams p = {};
+  p.A = dY; p.B = Wt; p.C = dZ;
+  p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
+  p.ldc = Cin; p.alpha = 1.f;
+  p.gH = H; p.gW = W; p.gC = Cout; p.gHo = H; p.gWo = W; p.gStride = 1; p.gB = B;
+  p.wCin = Cin; p.wCout = Cout;
+  p.vecA = al16(dY) && (Cout % 16 == 0);
+  p.vecB = al16(Wt) && (Cin % 4 == 0);
+  p.fastA = al16(dY) && (Cout % 32 == 0);
+  p.fastB = p.vecB;
+  if (Cout % 16 != 0) return (int)hipErrorInvalidValue;
+  const bool al = al16(dZ) && al16(bn_x) && al16(mean) && al16(invstd) && al16(gamma) && al16(beta) && Cin % 4 == 0;
+  if (!stats_eligible(p) || !al) return 0;
+  p.stat_part = part;
+  p.bnb_x = bn_x; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
+  return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, part_rows);
 }
 
 // ---- weight gradient of the stem's first convolution (Cin = 3: the 27-wide "N" does not fit the tiled kernels) -----------
@@ -1054,9 +1086,6 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
 // Conv / 1x1-conv (GEMM) forward with the BatchNorm batch statistics of the OUTPUT fused into the epilogue.
 // stat_part receives [stat_rows][2][N] fp64 partial (sum, sum of squares); *stat_rows (host) = number of partial rows,
 // or 0 when the shape is not eligible for the fused path (then the caller runs tris_bn_stats_f32 as usual).
-static bool stats_eligible(const GemmParams& p) {
-  return p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 128 && p.N >= 4;
-}
 
 extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, int M, int N, int K, double* stat_part,
                                     int* stat_rows, void* stream) {

@@ -847,11 +847,15 @@ class Conv3x3Fn(torch.autograd.Function):
     """x [B,H,W,Cin] channels-last, w [Cout,Cin,3,3] in channels_last memory, pad 1, stride 1|2."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, stats=False, lazy=None):
-        """lazy = (x_raw, mean, invstd, gamma, beta): `x` is the NOT-YET-WRITTEN output buffer of a BatchNorm + ReLU over x_raw
+    def forward(ctx, x, w, stride, stats=False, lazy=None, bn_link=None):
+        """bn_link: x is the output of a BatchNorm + ReLU with no other consumer (_BnBwdLink): the data gradient reduces that
+        BatchNorm's backward sums in its epilogue.
+        lazy = (x_raw, mean, invstd, gamma, beta): `x` is the NOT-YET-WRITTEN output buffer of a BatchNorm + ReLU over x_raw
         (batch_norm(..., lazy=True)); the direct kernels normalise x_raw while they stage it and `x` is never written -- or, when
         they cannot serve the shape after all, it is written here first and everything proceeds as usual."""
         _chk(x, w)
+        ctx.bn_link = bn_link if (bn_link is not None and stride == 1 and not bn_link.from_y and x.is_contiguous()
+                                  and bn_link.x.shape == x.shape) else None
         x = x.contiguous()
         ctx.params = (w,)
         w = cl_weight(w)
@@ -922,8 +926,21 @@ class Conv3x3Fn(torch.autograd.Function):
             dx = torch.empty_like(x)
             wp = _planes(ctx.params[0])
             fl = 2.0 * B * H * W * Cout * 9 * Cin
+            link, fused = ctx.bn_link, False
+            if link is not None and wp is None:   # (see LinearFn.backward)
+                import ctypes
+                part = torch.empty(((B * H * W + 127) // 128) * 2 * Cin, device=x.device, dtype=torch.float64)
+                rows = ctypes.c_int(0)
+                _timed("conv3x3_dgrad", fl, lambda: call(
+                    "tris_conv3x3_dgrad_bnbwd_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
+                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()))
+                if rows.value > 0:
+                    fused = True
+                    link.fill(dx, part, rows.value)
             # with the transposed, tap-mirrored planes the data gradient is a plain 3x3 convolution of dY
-            if wp is None or not _timed("conv3x3_dgrad", fl, lambda: _wp_call(
+            if fused:
+                pass
+            elif wp is None or not _timed("conv3x3_dgrad", fl, lambda: _wp_call(
                     "tris_conv3x3_wp_fwd_f32", P(dy), wp[2], wp[3], P(dx), B, H, W, Cout, Cin, 1, None, None, _stream())):
                 _timed("conv3x3_dgrad", fl,
                        lambda: call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))
@@ -951,7 +968,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 on_wgrad_stream(lambda: wgrad(sk), dy, x, *((mean, invstd) if ctx.lazy else ()), sink=sk)
             else:
                 dw = _emit(ctx.params[0], wgrad, True)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def conv3x3_bnin_ok(xshape, Cout):
@@ -961,7 +978,11 @@ def conv3x3_bnin_ok(xshape, Cout):
 
 
 def conv3x3(x, w, stride=1, stats=False):
-    return Conv3x3Fn.apply(x, w, stride, stats, getattr(x, "_bn_lazy", None))
+    link = getattr(x, "_bn_link", None)
+    if link is not None and not (torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled()
+                                 and os.environ.get("TRIS_BN_BWD_FUSE") != "lin"):   # ("lin": developer A/B, 1x1 consumers only)
+        link = None
+    return Conv3x3Fn.apply(x, w, stride, stats, getattr(x, "_bn_lazy", None), link)
 
 
 # ----------------------------------------------------------------------------------------------- BatchNorm
@@ -1029,7 +1050,7 @@ class BatchNormFn(torch.autograd.Function):
         if training:
             keep_y = relu and (resid is not None or os.environ.get("TRIS_BN_MASK_X", "1") == "0")   # (env: developer A/B knob)
             ctx.save_for_backward(x, gamma, beta, mean, invstd, y if keep_y else None)
-            if bwd_link and relu and not lazy:
+            if bwd_link and relu:
                 # the consumer (ops.linear) may reduce this BatchNorm's backward sums in its data-gradient epilogue: _BnBwdLink
                 ctx.link = y._bn_link = _BnBwdLink(x, mean, invstd, gamma, beta, keep_y)
         return y
