@@ -169,6 +169,18 @@ int tris_layernorm_bwd_f32(const float* dY, const float* X, const float* gamma, 
                            float* dX, float* dgamma, float* dbeta, long rows, int W, float* workspace, const float* extra /* optional: added to dX */, void* stream);
 
 /* ---- pooling / elementwise / layout -------------------------------------------------------------------------------- */
+/* BatchNorm + ReLU + AvgPool2d(2) as ONE op (the stem's bn3 -> avgpool, model.py:29-31,231-237; bn2 -> avgpool of the stride-2
+ * Bottlenecks, :21-25,46-49): Yp [B,H/2,W/2,C] = avgpool2(relu(bn(X))) -- the full-size activation is never written; backward:
+ * the two passes read the POOLED upstream gradient dYp (a row's gradient is a quarter of its pooled pixel's), the ReLU mask is
+ * recomputed from X.  H and W even. */
+int tris_bn_apply_pool_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           float* Yp, int B, int H, int W, int C, void* stream);
+int tris_bn_bwd_reduce_pool_f32(const float* dYp, const float* X, const float* mean, const float* invstd, int B, int H, int W,
+                                int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma, const float* beta,
+                                void* stream);
+int tris_bn_bwd_apply_pool_f32(const float* dYp, const float* X, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, const float* sum_dz, const float* sum_dzx, float inv_count, float* dX, int B,
+                               int H, int W, int C, void* stream);
 int tris_avgpool2_fwd_f32(const float* X, float* Y, int B, int H, int W, int C, void* stream); /* model.py:25,37,231 */
 int tris_avgpool2_bwd_f32(const float* dY, float* dX, int B, int H, int W, int C, void* stream);
 #define TRIS_EW_ADD 0       /* O = A + B */

@@ -35,11 +35,12 @@ def _install_standins(mp):
         return y if resid is None else y + resid
 
     def batch_norm(x, g, b, rm, rv, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-                   grad_box=None, lazy=False, bwd_link=False):
+                   grad_box=None, lazy=False, bwd_link=False, pool=False):
         y = x * g + b          # (statistics are irrelevant for the order of the graph)
         if resid is not None:
             y = y + resid
-        return torch.relu(y) if relu else y
+        y = torch.relu(y) if relu else y
+        return F.avg_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous() if pool else y
 
     def avgpool2(x, grad_box_out=None):
         return F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()

@@ -391,6 +391,35 @@ def test_batchnorm_backward_reduced_in_the_consuming_3x3_convolution(ops, shape,
         close(a, b_, 2e-5, name=name + " fused vs separate passes")
 
 
+@pytest.mark.parametrize("shape", [(2, 10, 10, 64), (3, 40, 36, 32), (2, 6, 8, 256), (1, 160, 160, 64)])
+def test_batchnorm_relu_avgpool_as_one_op(ops, shape, monkeypatch):
+    """avgpool2(relu(bn(x))) with the full-size activation never written (tris_bn_apply_pool_f32) and a backward that reads the
+    pooled gradient in both passes: vs torch, and vs the two separate ops (TRIS_BN_POOL=0)"""
+    C = shape[-1]
+    x, g, b = leaf(*shape), leaf(C), leaf(C)
+    x.data = x.data * 2 + 1
+    y = F.avg_pool2d(F.relu(F.batch_norm(x.permute(0, 3, 1, 2), torch.zeros(C), torch.ones(C), g, b, True, 0.1, 1e-5)), 2)
+    y = y.permute(0, 2, 3, 1)
+    (y * y).sum().backward()
+
+    def run(fused):
+        monkeypatch.setenv("TRIS_BN_POOL", "1" if fused else "0")
+        gx, gg, gb = gpu_leaf(x), gpu_leaf(g), gpu_leaf(b)
+        rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+        gy = ops.batch_norm(gx, gg, gb, rm, rv, None, True, True, pool=True)
+        (gy * gy).sum().backward()
+        return gy, gx.grad, gg.grad, gb.grad, rm, rv
+    fused, plain = run(True), run(False)
+    for name, a, b_, ref in zip(("y", "dx", "dgamma", "dbeta"), fused, plain, (y, x.grad, g.grad, b.grad)):
+        close(a, ref, 5e-4, name=name + " vs torch")
+        close(a, b_, 2e-6, name=name + " fused vs two ops")
+    assert torch.equal(fused[4], plain[4]) and torch.equal(fused[5], plain[5])
+    with torch.no_grad():   # eval mode: running statistics, two ops
+        ye = F.avg_pool2d(F.relu(F.batch_norm(x.permute(0, 3, 1, 2), fused[4].cpu(), fused[5].cpu(), g, b, False, 0.1, 1e-5)), 2)
+        close(ops.batch_norm(x.cuda(), g.detach().cuda(), b.detach().cuda(), fused[4], fused[5], None, True, False, pool=True),
+              ye.permute(0, 2, 3, 1), name="eval")
+
+
 def test_batchnorm_link_refuses_a_second_consumer(ops):
     """bwd_link=True is a promise (one autograd consumer); a broken promise must raise, not produce a masked gradient twice"""
     C = 64

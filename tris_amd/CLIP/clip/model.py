@@ -68,14 +68,16 @@ class BatchNorm2d(nn.Module):
             self.num_batches_tracked += self._nbt_pending
             self._nbt_pending = 0
 
-    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False, bwd_link=False):
-        """bwd_link=True: the caller guarantees that the output has exactly ONE autograd consumer; if that is a 1x1 convolution
+    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False, bwd_link=False, pool=False):
+        """pool=True: returns avgpool2(relu(bn(x))) -- the AvgPool2d(2) that follows is part of the op (train mode: one kernel,
+        the full-size activation is never written).
+        bwd_link=True: the caller guarantees that the output has exactly ONE autograd consumer; if that is a 1x1 convolution
         its data gradient does this BatchNorm's backward reduction in its epilogue (ops._BnBwdLink)"""
         if self.training:
             self._nbt_pending += 1
         group = self.process_group if self.training else None
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
-                              self.training, self.momentum, self.eps, group, grad_box, lazy, bwd_link)
+                              self.training, self.momentum, self.eps, group, grad_box, lazy, bwd_link, pool)
 
 
 class AvgPool2d(nn.Module):
@@ -123,8 +125,10 @@ class Bottleneck(nn.Module):
         # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
         # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
         out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout), bwd_link=True)
-        out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: avgpool or conv3
-        out = self.avgpool(out)
+        if self.stride > 1:   # bn2 + ReLU + AvgPool2d(stride) as one op
+            out = self.bn2(self.conv2(out, stats=tr), relu=True, pool=True)
+        else:
+            out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: conv3
         out = self.conv3(out, stats=tr)
         if self.downsample is not None:
             if isinstance(self.downsample[0], AvgPool2d):
@@ -204,8 +208,8 @@ class ModifiedResNet(nn.Module):
         x = self.bn1(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout), bwd_link=True)   # folded into conv2 where possible
         x = self.conv2(x, stats=tr)
         x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout), bwd_link=True)   # ... into conv3
-        x = self.bn3(self.conv3(x, stats=tr), relu=True)
-        x = ops.cut(self.avgpool(x))                       # (segment boundary of a segmented capture; otherwise x itself)
+        x = self.bn3(self.conv3(x, stats=tr), relu=True, pool=True)   # bn3 + ReLU + AvgPool2d(2) as one op
+        x = ops.cut(x)                                     # (segment boundary of a segmented capture; otherwise x itself)
         if hooks and "stem" in hooks:
             hooks["stem"]()
         outs = []

@@ -23,14 +23,24 @@ __device__ __forceinline__ void st4d(double* p, d4 v) { p[0] = v.x; p[1] = v.y; 
 
 // Accumulators are fp64: these reductions feed train-mode BatchNorm, whose backward cancels large terms, and the
 // CPU oracle (ATen) accumulates them in double as well.  fp64 VALU adds are free next to the HBM stream.
-template <int MODE>
+// POOL (MODE 1): dY is the gradient of avgpool2(relu(bn(X))) -- [B, H/2, W/2, C] against X [B, H, W, C] (pool_h = H, pool_w = W):
+// the gradient of a row is a quarter of its pooled pixel's, read in place of a full-size tensor that is never written.
+__device__ __forceinline__ long pooled_row(long r, int H, int W) {
+  const int w = (int)(r % W);
+  const long t = r / W;
+  const int h = (int)(t % H);
+  const long b = t / H;
+  return (b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
+}
+
+template <int MODE, bool POOL = false>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                           const float* __restrict__ Y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, long M, int C, long ld,
                                                           long rows_per_block, double* __restrict__ part,
                                                           const float* __restrict__ gamma = nullptr,
                                                           const float* __restrict__ beta = nullptr,
-                                                          float* __restrict__ dZ = nullptr) {
+                                                          float* __restrict__ dZ = nullptr, int pool_h = 0, int pool_w = 0) {
   __shared__ d4 l0[256];
   __shared__ d4 l1[256];
   const int CV = C >> 2;
@@ -90,7 +100,12 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         for (int u = 0; u < 4; ++u) {
           const long o = (r + (long)u * RS) * ld + c;
           x[u] = ld4(X + o);
-          g[u] = (MODE == 1) ? ld4(dY + o) : z4;
+          if (POOL) {
+            g[u] = ld4(dY + pooled_row(r + (long)u * RS, pool_h, pool_w) * ld + c);
+            g[u].x *= 0.25f; g[u].y *= 0.25f; g[u].z *= 0.25f; g[u].w *= 0.25f;
+          } else {
+            g[u] = (MODE == 1) ? ld4(dY + o) : z4;
+          }
           y[u] = (MODE == 1 && Y) ? ld4(Y + o) : z4;
         }
 #pragma unroll
@@ -98,7 +113,14 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       }
       for (; r < rend; r += RS) {
         const long o = r * ld + c;
-        accum(ld4(X + o), (MODE == 1) ? ld4(dY + o) : z4, (MODE == 1 && Y) ? ld4(Y + o) : z4, o);
+        float4 g1 = z4;
+        if (POOL) {
+          g1 = ld4(dY + pooled_row(r, pool_h, pool_w) * ld + c);
+          g1.x *= 0.25f; g1.y *= 0.25f; g1.z *= 0.25f; g1.w *= 0.25f;
+        } else if (MODE == 1) {
+          g1 = ld4(dY + o);
+        }
+        accum(ld4(X + o), g1, (MODE == 1 && Y) ? ld4(Y + o) : z4, o);
       }
     }
     __syncthreads();
@@ -258,7 +280,38 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   if (i < n4) st4(Y + i * 4, one(ld4(X + i * 4), resid ? ld4(resid + i * 4) : z4));
 }
 
+// Yp[b, oy, ox, :] = avgpool2(relu(bn(X)))  -- the stem's bn3 and the stride-2 Bottlenecks' bn2 feed an AvgPool2d(2) and nothing
+// else: the full-size activation is never written (avgpool2_fwd_kernel's own expression on the four normalised pixels)
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ X, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ Yp, int B, int H,
+                                                            int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  const long n = (long)B * Ho * Wo * C4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float4 mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+    const float4 sc = make_float4(is.x * g.x, is.y * g.y, is.z * g.z, is.w * g.w);
+    auto act = [&](const float4 x) {
+      return make_float4(fmaxf((x.x - mu.x) * sc.x + be.x, 0.f), fmaxf((x.y - mu.y) * sc.y + be.y, 0.f),
+                         fmaxf((x.z - mu.z) * sc.z + be.z, 0.f), fmaxf((x.w - mu.w) * sc.w + be.w, 0.f));
+    };
+    const float* p = X + (((long)b * H + oy * 2) * W + ox * 2) * C + c;
+    const float4 a = act(ld4(p)), b4 = act(ld4(p + C)), cc = act(ld4(p + (long)W * C)), d = act(ld4(p + (long)W * C + C));
+    st4(Yp + i * 4, make_float4(0.25f * (a.x + b4.x + cc.x + d.x), 0.25f * (a.y + b4.y + cc.y + d.y),
+                                0.25f * (a.z + b4.z + cc.z + d.z), 0.25f * (a.w + b4.w + cc.w + d.w)));
+  }
+}
+
 // dx = gamma * invstd * (dz - sum_dz/cnt - xhat * sum_dzxhat/cnt),  dz = dY * (Y>0 if Y); optional dZ <- dz
+// POOL: dY is the pooled gradient (see col_partial_kernel), pool_h / pool_w the full-size map.
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                            const float* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -266,7 +319,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sum_dz,
                                                            const float* __restrict__ sum_dzx, float inv_cnt,
                                                            float* __restrict__ dX, float* __restrict__ dZ, long n4,
-                                                           int C, const float* __restrict__ beta_mask) {
+                                                           int C, const float* __restrict__ beta_mask, int pool_h = 0,
+                                                           int pool_w = 0) {
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)((i * 4) % C);
@@ -278,7 +332,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float4 k2 = make_float4(a.x * inv_cnt, a.y * inv_cnt, a.z * inv_cnt, a.w * inv_cnt);
   const float4 k3 = make_float4(is.x * b.x * inv_cnt, is.y * b.y * inv_cnt, is.z * b.z * inv_cnt, is.w * b.w * inv_cnt);
   auto one = [&](long j) {
-    float4 g = ld4(dY + j * 4);
+    float4 g;
+    if (POOL) {
+      g = ld4(dY + pooled_row(j * 4 / C, pool_h, pool_w) * C + c);
+      g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+    } else {
+      g = ld4(dY + j * 4);
+    }
     const float4 x = ld4(X + j * 4);
     if (beta_mask) {
       if (!((x.x - mu.x) * k1.x + be.x > 0.f)) g.x = 0.f;   // k1 = invstd * gamma = the forward's scale
@@ -700,6 +760,44 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   return 0;
 }
 
+// BatchNorm + ReLU + AvgPool2d(2) as one op: forward, and the two backward passes reading the POOLED upstream gradient
+extern "C" int tris_bn_apply_pool_f32(const float* X, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, float* Yp, int B, int H, int W, int C, void* stream) {
+  if (C % 4 || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+  const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta, Yp,
+                     B, H, W, C);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_bn_bwd_reduce_pool_f32(const float* dYp, const float* X, const float* mean, const float* invstd, int B, int H,
+                                           int W, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma,
+                                           const float* beta, void* stream) {
+  if (C % 4 || (H & 1) || (W & 1) || gamma == nullptr || beta == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const long M = (long)B * H * W;
+  ColPlan p = col_plan(M, C);
+  hipLaunchKernelGGL((col_partial_kernel<1, true>), dim3(p.nb), dim3(256), 0, st, X, dYp, (const float*)nullptr, mean, invstd, M, C,
+                     (long)C, p.rpb, (double*)workspace, gamma, beta, (float*)nullptr, H, W);
+  TRIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace,
+                     p.nb, C, sum_dz, sum_dzx);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_bn_bwd_apply_pool_f32(const float* dYp, const float* X, const float* mean, const float* invstd,
+                                          const float* gamma, const float* beta, const float* sum_dz, const float* sum_dzx,
+                                          float inv_count, float* dX, int B, int H, int W, int C, void* stream) {
+  if (C % 4 || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+  const long n4 = (long)B * H * W * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dYp, (const float*)nullptr, X,
+                     mean, invstd, gamma, sum_dz, sum_dzx, inv_count, dX, (float*)nullptr, n4, C, beta, H, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 // finish fp64 partial rows [rows][2][C] (a fused producer's epilogue, e.g. tris_gemm_bnbwd_f32) -> out0[C], out1[C]
 extern "C" int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream) {
   if (rows < 1 || C < 1) return (int)hipErrorInvalidValue;
@@ -714,7 +812,7 @@ extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const floa
                                      float inv_count, float* dX, float* dZ, long M, int C, const float* beta_mask,
                                      void* stream) {
   long n4 = M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean, invstd,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean, invstd,
                      gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask);
   TRIS_LAUNCH_CHECK();
   return 0;

@@ -630,6 +630,12 @@ def _bn_bwd_fuse_enabled():
     return os.environ.get("TRIS_BN_BWD_FUSE", "1") != "0"
 
 
+def _bn_bwd_fuse_rows(M):
+    """fuse for this many rows?  The fused product cannot split K (its epilogue needs complete sums): below a few thousand rows
+    -- the 10 x 10 stage -- a split-K data gradient + the separate reduction pass is the faster pair (TRIS_BN_BWD_FUSE_MIN_M)"""
+    return M >= int(os.environ.get("TRIS_BN_BWD_FUSE_MIN_M", "0"))
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
@@ -708,7 +714,7 @@ class LinearFn(torch.autograd.Function):
             wp = _planes(pw)
             ws = workspace(0)
             link, fused = ctx.bn_link, False
-            if link is not None and wp is None:
+            if link is not None and wp is None and _bn_bwd_fuse_rows(M):
                 # x is the output of a BatchNorm(+ReLU) that has no other consumer: mask dx and reduce it for that BatchNorm's
                 # backward in this product's epilogue (_BnBwdLink)
                 import ctypes
@@ -927,7 +933,7 @@ class Conv3x3Fn(torch.autograd.Function):
             wp = _planes(ctx.params[0])
             fl = 2.0 * B * H * W * Cout * 9 * Cin
             link, fused = ctx.bn_link, False
-            if link is not None and wp is None:   # (see LinearFn.backward)
+            if link is not None and wp is None and _bn_bwd_fuse_rows(B * H * W):   # (see LinearFn.backward)
                 import ctypes
                 part = torch.empty(((B * H * W + 127) // 128) * 2 * Cin, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
@@ -994,12 +1000,15 @@ class BatchNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None, grad_box=None,
-                lazy=False, bwd_link=False):
+                lazy=False, bwd_link=False, pool=False):
         _chk(x, gamma, beta, rmean, rvar, resid)
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
-        y = torch.empty_like(x)
+        # pool: the output is avgpool2(relu(bn(x))) -- BatchNorm + ReLU + AvgPool2d(2) as one op, the full-size tensor never written
+        pool = bool(pool)   # (ops.batch_norm has checked: train mode, ReLU, no residual, even map)
+        y = (torch.empty(x.shape[0], x.shape[1] // 2, x.shape[2] // 2, C, device=x.device, dtype=torch.float32) if pool
+             else torch.empty_like(x))
         if resid is not None:
             resid = resid.contiguous()
         count = M
@@ -1037,7 +1046,10 @@ class BatchNormFn(torch.autograd.Function):
             invstd = torch.rsqrt(rvar + eps)
         # lazy: y stays UNWRITTEN -- its only consumer (a 3x3 convolution with direct kernels) normalises x while staging it
         lazy = bool(lazy and training and relu and resid is None and os.environ.get("TRIS_BN_MASK_X", "1") != "0")
-        if not lazy:
+        if pool:
+            call("tris_bn_apply_pool_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), x.shape[0], x.shape[1], x.shape[2], C,
+                 _stream())
+        elif not lazy:
             call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
                  _stream())
         if lazy:   # the hand-off to ops.conv3x3 rides on the (unwritten) output tensor itself
@@ -1047,10 +1059,11 @@ class BatchNormFn(torch.autograd.Function):
         ctx.params = (gamma, beta)
         ctx.training = bool(training)
         ctx.link = None
+        ctx.pool = pool
         if training:
-            keep_y = relu and (resid is not None or os.environ.get("TRIS_BN_MASK_X", "1") == "0")   # (env: developer A/B knob)
+            keep_y = relu and not pool and (resid is not None or os.environ.get("TRIS_BN_MASK_X", "1") == "0")   # (env: developer A/B knob)
             ctx.save_for_backward(x, gamma, beta, mean, invstd, y if keep_y else None)
-            if bwd_link and relu:
+            if bwd_link and relu and not pool:
                 # the consumer (ops.linear) may reduce this BatchNorm's backward sums in its data-gradient epilogue: _BnBwdLink
                 ctx.link = y._bn_link = _BnBwdLink(x, mean, invstd, gamma, beta, keep_y)
         return y
@@ -1088,14 +1101,18 @@ class BatchNormFn(torch.autograd.Function):
         # residual blocks (out = relu(bn(x) + identity)): the reduce pass writes the masked gradient dz -- which IS the identity
         # branch's gradient -- and the apply pass reads it back instead of masking dy from y a second time
         got = ctx.link.take(dy) if ctx.link is not None else None
-        dz_first = (got is None and want_dz and relu and y is not None
+        if ctx.pool:   # dy is the POOLED gradient: both passes read it in place of a full-size tensor (mask from x)
+            Bn, H, W = x.shape[0], x.shape[1], x.shape[2]
+            call("tris_bn_bwd_reduce_pool_f32", P(dy), P(x), P(mean), P(invstd), Bn, H, W, C, p_dz, p_dzx, P(ws), P(gamma), P(beta),
+                 _stream())
+        dz_first = (got is None and not ctx.pool and want_dz and relu and y is not None
                     and os.environ.get("TRIS_BN_DZ_FIRST", "1") != "0")   # (env: developer A/B knob)
         if dz_first:
             d_res = torch.empty_like(x)
         if got is not None:
             # dy came out of the consuming 1x1 convolution's data gradient already MASKED, with the two sums as partial rows
             call("tris_part_finalize_f32", got[0].data_ptr(), got[1], C, p_dz, p_dzx, _stream())
-        else:
+        elif not ctx.pool:
             call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
                  P(gamma) if mask_x else None, P(beta) if mask_x else None, P(d_res) if dz_first else None, _stream())
         if mb is not None:
@@ -1111,7 +1128,12 @@ class BatchNormFn(torch.autograd.Function):
                 from . import comm
                 comm.syncbn_all_reduce_sum(sums, group=group)
         dx = None
-        if got is not None:
+        if ctx.pool:
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                call("tris_bn_bwd_apply_pool_f32", P(dy), P(x), P(mean), P(invstd), P(gamma), P(beta), p_dz, p_dzx,
+                     1.0 / float(count), P(dx), x.shape[0], x.shape[1], x.shape[2], C, _stream())
+        elif got is not None:
             if want_dz:
                 d_res = dy          # the masked gradient IS the identity branch's gradient
             if ctx.needs_input_grad[0]:
@@ -1131,17 +1153,22 @@ class BatchNormFn(torch.autograd.Function):
                  1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
         if ctx.grad_box is not None and d_res is not None and ctx.grad_box.deposit(d_res):
             d_res = None   # handed to the block's first conv
-        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-               grad_box=None, lazy=False, bwd_link=False):
+               grad_box=None, lazy=False, bwd_link=False, pool=False):
     """lazy=True (train-mode BatchNorm + ReLU whose ONLY consumer is ops.conv3x3, and conv3x3_bnin_ok said yes): the returned
     tensor is an unwritten buffer carrying `_bn_lazy`; pass it to ops.conv3x3 and nowhere else."""
     part = getattr(x, "_bn_part", None) if training else None
     bwd_link = bool(bwd_link and training and torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled())
+    if pool and not (training and relu and resid is None and not lazy and x.dim() == 4 and x.shape[1] % 2 == 0
+                     and x.shape[2] % 2 == 0 and os.environ.get("TRIS_BN_POOL", "1") != "0"):
+        # eval mode / shapes the fused op does not take: the two ops one after the other
+        return avgpool2(BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box,
+                                          lazy, bwd_link, False))
     return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy,
-                             bwd_link)
+                             bwd_link, pool)
 
 
 class AvgPool2Fn(torch.autograd.Function):
