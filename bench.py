@@ -212,6 +212,10 @@ def main():
                            "peak = 2500 / 3"),
             "kernel": "gemm_fast_kernel<BM,BN,A,B,EPI,PREC> (MFMA GEMM / implicit-GEMM conv family)",
             "launches_per_step": len(rec), "kernel_ms_per_step": round(ms, 3),
+            "fused_epilogue_note": ("kinds *_bnbwd are data-gradient products whose epilogue also does the reduction pass of the "
+                                    "BatchNorm backward that consumes them (two more activation-sized streams per launch, no FLOPs "
+                                    "counted for it): they lower this family's rate by ~3 % and remove 29 reduction launches "
+                                    "(-1.0 ms per step, DESIGN.md section 3 'Round 3')"),
             "algorithmic_gflop_per_step": round(fl / 1e9, 1),
             "by_kind": {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
                             "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}

@@ -720,9 +720,10 @@ class LinearFn(torch.autograd.Function):
                 import ctypes
                 part = torch.empty(((M + 127) // 128) * 2 * K, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("gemm", 2.0 * M * N * K, lambda: call(
+                _timed("gemm_bnbwd", 2.0 * M * N * K, lambda: (call(
                     "tris_gemm_bnbwd_f32", P(dy), P(w), P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
-                    P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()))
+                    P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()),
+                    rows.value > 0)[1])     # (False: the entry point declined the shape, nothing was launched)
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
@@ -937,9 +938,9 @@ class Conv3x3Fn(torch.autograd.Function):
                 import ctypes
                 part = torch.empty(((B * H * W + 127) // 128) * 2 * Cin, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("conv3x3_dgrad", fl, lambda: call(
+                _timed("conv3x3_dgrad_bnbwd", fl, lambda: (call(
                     "tris_conv3x3_dgrad_bnbwd_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
-                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()))
+                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()), rows.value > 0)[1])
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
