@@ -30,8 +30,13 @@ __global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void pipe
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
+  // ABL & 16: PERSISTENT form -- the grid is one wave of workgroups, each walks tiles blockIdx.x, + gridDim.x, ...; the first
+  // global loads of the NEXT tile are issued before the epilogue of the current one (they fly under its stores)
+  constexpr bool PERSIST = (ABL & 16) != 0;
   const int tiles_n = (N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int ntiles = ((M + BM - 1) / BM) * tiles_n;
+  int tile = blockIdx.x;
+  int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   // rows visited so that the ds_write_b64 groups (16 contiguous lanes) hit disjoint banks (see gemm_fast.h / DESIGN.md)
   int trow;
   if (KL == 8) trow = ((tid >> 3) & ~7) | (((tid >> 3) & 1) << 2) | ((tid >> 4) & 3);
@@ -39,18 +44,15 @@ __global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void pipe
   const int kq = (tid % KL) * 4;
   const float* a_src[PA];
   const float* b_src[PB];
+  auto point = [&](int tm0, int tn0) {
 #pragma unroll
-  for (int q = 0; q < PA; ++q) a_src[q] = A + (long)min(m0 + trow + q * RPASS, M - 1) * K + kq;
+    for (int q = 0; q < PA; ++q) a_src[q] = A + (long)min(tm0 + trow + q * RPASS, M - 1) * K + kq;
 #pragma unroll
-  for (int q = 0; q < PB; ++q) b_src[q] = B + (long)min(n0 + trow + q * RPASS, N - 1) * K + kq;
+    for (int q = 0; q < PB; ++q) b_src[q] = B + (long)min(tn0 + trow + q * RPASS, N - 1) * K + kq;
+  };
+  point(m0, n0);
 
   f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int li = lane & 31, kh = lane >> 5;
 
   float4 r0[PA + PB], r1[PA + PB];  // two register sets: tiles of even / odd index
@@ -141,6 +143,13 @@ __global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void pipe
   const int nk = K / FBK;
   const int klast = (nk - 1) * FBK;
   load(r0, 0);
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) store_chunk(r0, As0, Bs0, c);
   load(r1, min(FBK, klast));
@@ -159,19 +168,32 @@ __global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void pipe
     __syncthreads();
   }
   if (kt < nk) step(As0, Bs0, As1, Bs1, r1, false);  // odd tile count: the last tile sits in stage 0
+  const int cm0 = m0, cn0 = n0;
+  const int next = tile + (int)gridDim.x;
+  const bool more = PERSIST && next < ntiles;
+  if (more) {   // the next tile's first loads fly under this tile's epilogue
+    tile = next;
+    m0 = (tile / tiles_n) * BM;
+    n0 = (tile % tiles_n) * BN;
+    point(m0, n0);
+    load(r0, 0);
+  }
 
   // plain epilogue (probe): accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wn * WN + j * 32 + li;
+      const int col = cn0 + wn * WN + j * 32 + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = cm0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row < M && col < N) C[(long)row * N + col] = acc[i][j][r];
       }
     }
+  if (!more) break;
+  __syncthreads();   // every wave is done with the stages before the next tile's first store
+  }
 }
 
 // ---- wave-specialised variant: NC = NWM*NWN consumer waves (fragment reads + MFMA only) and NP producer waves (global loads,
@@ -316,7 +338,8 @@ static void fill(std::vector<float>& v, unsigned seed) {
 template <int BM, int BN, int FBK, int NWM, int NWN, int OCC, int ABL = 0>
 static void run(const char* name, int M, int N, int K, const float* dA, const float* dB, float* dC, const std::vector<float>& hA,
                 const std::vector<float>& hB, bool check) {
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if ((ABL & 16) && tiles > 256 * OCC) tiles = 256 * OCC;   // persistent: one wave of workgroups
   auto launch = [&]() { hipLaunchKernelGGL((pipe_kernel<BM, BN, FBK, NWM, NWN, OCC, ABL>), dim3(tiles), dim3(NWM * NWN * 64), 0, 0, dA, dB, dC, M, N, K); };
   for (int i = 0; i < 3; ++i) launch();
   if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed: %s\n", name, hipGetErrorString(hipGetLastError())); return; }
@@ -403,6 +426,16 @@ int main(int argc, char** argv) {
       run_ws<256, 128, 16, 4, 2, 4, 1>("ws 256x128 k16 8c+4p occ1", M, N, K, dA, dB, dC, hA, hB, chk);
       run_ws<256, 256, 16, 2, 4, 4, 1>("ws 256x256 k16 8c+4p occ1", M, N, K, dA, dB, dC, hA, hB, chk);
       run_ws<256, 256, 16, 2, 4, 8, 1>("ws 256x256 k16 8c+8p occ1", M, N, K, dA, dB, dC, hA, hB, chk);
+      hipFree(dA); hipFree(dB); hipFree(dC);
+      continue;
+    }
+    if (argc > 1 && argv[1][0] == 'p') {  // persistent form (one wave of workgroups walking the tiles) next to one tile per workgroup
+      run<128, 128, 32, 2, 4, 1, 0>("128x128 k32 occ1", M, N, K, dA, dB, dC, hA, hB, chk);
+      run<128, 128, 32, 2, 4, 1, 16>("128x128 k32 occ1 persistent", M, N, K, dA, dB, dC, hA, hB, chk);
+      run<128, 128, 16, 2, 4, 2, 0>("128x128 k16 occ2", M, N, K, dA, dB, dC, hA, hB, chk);
+      run<128, 128, 16, 2, 4, 2, 16>("128x128 k16 occ2 persistent", M, N, K, dA, dB, dC, hA, hB, chk);
+      run<256, 128, 16, 4, 2, 1, 0>("256x128 k16 occ1", M, N, K, dA, dB, dC, hA, hB, chk);
+      run<256, 128, 16, 4, 2, 1, 16>("256x128 k16 occ1 persistent", M, N, K, dA, dB, dC, hA, hB, chk);
       hipFree(dA); hipFree(dB); hipFree(dC);
       continue;
     }
