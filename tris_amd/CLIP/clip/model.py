@@ -206,8 +206,9 @@ class ModifiedResNet(nn.Module):
         tr = self.training
         x = self.conv1(x, stats=tr)                        # (conv1 has Cin=3: not eligible, separate statistics pass)
         x = self.bn1(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout), bwd_link=True)   # folded into conv2 where possible
-        x = self.conv2(x, stats=tr)
+        x = self.conv2(ops.cut(x), stats=tr)    # (cuts: the stem is the END of backward -- a segmented capture releases each of its
         x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout), bwd_link=True)   # ... into conv3
+        x = ops.cut(x)                          # weight gradients behind its own convolution, not behind the whole stem)
         x = self.bn3(self.conv3(x, stats=tr), relu=True, pool=True)   # bn3 + ReLU + AvgPool2d(2) as one op
         x = ops.cut(x)                                     # (segment boundary of a segmented capture; otherwise x itself)
         if hooks and "stem" in hooks:

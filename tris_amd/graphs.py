@@ -325,7 +325,7 @@ class SegmentedTrainStep:
             self.g_btext = G()
             _capture(self.g_btext, self.text, pool_t, lambda: torch.autograd.backward(hidden, h.grad))
             self.inline = False
-            n_late = min(int(os.environ.get("TRIS_SEG_LATE", "4")), len(trunk_cuts))
+            n_late = min(int(os.environ.get("TRIS_SEG_LATE", "6")), len(trunk_cuts))
             split = os.environ.get("TRIS_SEG_SPLIT", "1") != "0"
             late_sinks = []
             for k, (x, leaf) in enumerate(reversed(trunk_cuts)):
@@ -392,9 +392,10 @@ class SegmentedTrainStep:
         if not self.cutting:           # (only the trainable trunk is cut: its weight gradients are what the cuts release)
             return x
         leaf = x.detach().requires_grad_()
-        link = getattr(x, "_bn_link", None)    # (ops._BnBwdLink rides on the tensor: the cut is an identity)
-        if link is not None:
-            leaf._bn_link = link
+        for attr in ("_bn_link", "_bn_lazy"):  # (hand-offs that ride on the tensor: the cut is an identity)
+            v = getattr(x, attr, None)
+            if v is not None:
+                setattr(leaf, attr, v)
         self.cuts.append((x, leaf))
         return leaf
 
