@@ -125,11 +125,12 @@ class Bottleneck(nn.Module):
         # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
         # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
         out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout), bwd_link=True)
+        out = ops.cut_fine(out)   # (optional finer segment boundaries of a segmented capture: TRIS_SEG_FINE=1)
         if self.stride > 1:   # bn2 + ReLU + AvgPool2d(stride) as one op
             out = self.bn2(self.conv2(out, stats=tr), relu=True, pool=True)
         else:
             out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: conv3
-        out = self.conv3(out, stats=tr)
+        out = self.conv3(ops.cut_fine(out), stats=tr)
         if self.downsample is not None:
             if isinstance(self.downsample[0], AvgPool2d):
                 idn = self.downsample[1](self.downsample[0](x, grad_box_out=box), stats=tr)

@@ -244,6 +244,7 @@ class SegmentedTrainStep:
         pool_c, pool_t, pool_w = (torch.cuda.graph_pool_handle() for _ in range(3))
         G = torch.cuda.CUDAGraph
         self.cuts, self.deferred, self.inline, self.cutting, keep = [], [], False, False, []
+        self.fine = os.environ.get("TRIS_SEG_FINE", "0") == "1"   # cuts inside the Bottlenecks too (ops.cut_fine)
         B = self.s_img.shape[0]
         K = self.s_neg.shape[1] if (self.s_neg is not None and args.negative_samples > 0) else 0
 

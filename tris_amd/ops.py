@@ -206,6 +206,13 @@ def cut(x):
     return _SEG.cut(x)
 
 
+def cut_fine(x):
+    """a second class of segment boundaries (inside the Bottlenecks): only where the capture asks for them"""
+    if _SEG is None or not getattr(_SEG, "fine", False):
+        return x
+    return cut(x)
+
+
 def _wgrad_enabled():
     import os
     if _SEG is not None:
