@@ -257,7 +257,7 @@ def main():
                   "single_launch": bool(fused and len(fused) == len(xa)),
                   "bound_note": ("B x 8 = 384 workgroups on 256 CUs: the doubly-loaded CUs fetch 2 x 1.6 MB at ~24 GB/s per CU "
                                  "(~19 us floor before the exchange); measured timeline per workgroup 31 us, 42-45 us per call "
-                                 "(csrc/xattn_fused.hip header, DESIGN.md 4.6): 0.60 of 8 TB/s is not reachable at this size"),
+                                 "(csrc/xattn_fused.hip header, DESIGN.md section 3 'Round 3'): 0.60 of 8 TB/s is not reachable at this size"),
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
 
