@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(mode, steps=4, B=3):
+def _run(mode, steps=4, B=3, backbone="clip-RN50"):
     from tris_amd.args import get_parser
     from tris_amd.CLIP import clip
     from tris_amd.model.model_stage1 import TRIS
@@ -20,7 +20,7 @@ def _run(mode, steps=4, B=3):
     old = os.environ.get("TRIS_STEP_GRAPH")
     os.environ["TRIS_STEP_GRAPH"] = mode
     try:
-        args = get_parser().parse_args(["--size", "320", "--negative_samples", "3", "--max_query_len", "20"])
+        args = get_parser().parse_args(["--backbone", backbone, "--size", "320", "--negative_samples", "3", "--max_query_len", "20"])
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             model = TRIS(args).cuda().train()
@@ -74,6 +74,18 @@ def test_replayed_step_equals_the_eager_step(eager, mode):
     for (rm, rv, n), (rm0, rv0, n0) in zip(state["bn"], eager[1]["bn"]):
         assert torch.equal(rm, rm0) and torch.equal(rv, rv0) and n == n0
     assert state["lr"] == eager[1]["lr"] and state["steps"] == eager[1]["steps"]
+
+
+def test_segmented_step_of_the_vit_trunk_equals_the_eager_step():
+    """BASELINE configs[4]: the ViT-B/16 trunk is cut behind every transformer block (ops.cut in Transformer.forward)"""
+    le, se, replayed = _run("0", steps=3, B=2, backbone="clip-ViT-B/16")
+    assert not replayed
+    lg, sg, replayed = _run("seg", steps=3, B=2, backbone="clip-ViT-B/16")
+    assert replayed
+    assert torch.equal(le, lg), (le - lg).abs().max()
+    for k in ("p", "m", "v"):
+        for a, b in zip(sg[k], se[k]):
+            assert torch.equal(a, b), (k, float((a - b).abs().max()))
 
 
 def test_segmented_step_updates_every_arena_element_once():
