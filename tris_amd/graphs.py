@@ -210,9 +210,13 @@ class SegmentedTrainStep:
     streams fork and join, every piece is captured on ONE stream, and the pieces are replayed on the three streams with
     ordinary events between them -- dependencies only ever cross at graph boundaries, where stream order defines them:
 
-        text    : [F_text: TRIS text encoder + frozen aux text tower] ................ [B_text: text encoder backward]
-        compute : [F_trunk] -> wait F_text -> [F_heads + losses] -> [B_heads] -> [B_seg n] -> ... -> [B_seg 0] -> join -> [AdamW]
-        wgrad   :                                                      [W_heads]   [W_seg n]   ...    [W_seg 0]
+        text    : .. [F_text: TRIS text encoder] ........ [F_aux: frozen aux text tower] ........ [B_text: text encoder backward] (W_late)
+        compute : [F_trunk a][F_trunk b] -> wait F_text -> [F_heads + aux ViT] -> wait F_aux -> [losses] -> [B_heads] -> [B_seg n] ..
+                  .. -> [B_seg 0] -> [AdamW early] -> join -> [AdamW late]
+        wgrad   :                                                                             [W_heads]  [W_seg n]   ...  [W_seg 0]
+
+    (F_text starts behind a trunk stage, TRIS_SEG_TEXT_AT, default layer2 -- the trunk's forward graph is cut there; F_aux
+    starts behind the TRIS forward and is joined right before the loss: the issue points of the eager step.)
 
     The backward is cut at autograd level: ops.cut() (behind the stem and every Bottleneck) hands the next layer a fresh leaf
     during capture, and the capture runs torch.autograd.backward segment by segment, feeding each the .grad of the leaf above.
