@@ -145,6 +145,15 @@ int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, float* dZ, in
                                  const float* bn_x, const float* mean, const float* invstd, const float* gamma,
                                  const float* beta, double* part, int* part_rows, void* stream);
 int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream);
+
+/* Opt-in arithmetic "h2" for single dense products: two fp16 pieces per operand, three f16 MFMAs per
+ * product (half the matrix work of the x3 default), operands scaled by a power of two so that fp16's exponent range holds them.
+ * tris_amax_bits_f32: atomic max of |x| as a bit pattern into *out (zero it first).  tris_h2_next: arms the CALLING THREAD -- the
+ * next tris_gemm_f32 / tris_gemm_bnstat_f32 / tris_gemm_bnbwd_f32 it launches runs in h2 with operand A scaled from *amaxA (or,
+ * amaxA == NULL, by scaleA; 0 = 1.0) and B likewise; products the fast kernel does not serve run as usual.  One shot.
+ * tris_set_gemm_mode(3) selects h2 process-wide with unit scales (tests). */
+int tris_amax_bits_f32(const float* x, long n, unsigned* out, void* stream);
+int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB);
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                            long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,
                            const float* beta_mask, float* dz_out, void* stream);

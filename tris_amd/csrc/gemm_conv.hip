@@ -400,6 +400,25 @@ static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")
 
 #include "gemm_fast.h"
 
+// "h2" for ONE product: tris_h2_next() arms the calling thread; the next dense product launched from it (tris_gemm_f32,
+// tris_gemm_bnstat_f32, tris_gemm_bnbwd_f32) runs with two fp16 pieces per operand (PREC 3) and these operand scales, whatever
+// the process-wide mode -- if the fast kernel serves its shape; otherwise it runs as usual.  One shot.
+struct H2Next { const unsigned* a; const unsigned* b; float sa, sb; bool armed; };
+static thread_local H2Next g_h2_next = {nullptr, nullptr, 0.f, 0.f, false};
+struct H2Guard {
+  int saved;
+  bool on;
+  explicit H2Guard(GemmParams& p) : saved(g_mode_thread), on(false) {
+    if (!g_h2_next.armed) return;
+    g_h2_next.armed = false;
+    if (!(p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4)) return;
+    p.h2_amaxA = g_h2_next.a; p.h2_amaxB = g_h2_next.b; p.h2_sA = g_h2_next.sa; p.h2_sB = g_h2_next.sb;
+    g_mode_thread = 3;
+    on = true;
+  }
+  ~H2Guard() { if (on) g_mode_thread = saved; }
+};
+
 // TRIS_FORCE_PIPE=0|1 (read per call: tests switch it at run time) overrides the loop structure of the x3 products
 static int forced_pipe() {
   const char* e = getenv("TRIS_FORCE_PIPE");
@@ -457,7 +476,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
       if (c == 3 && !(p.N <= 32 && fastk)) continue;  // 32-wide outputs (stem convolutions): half of a 64-wide tile would be padding
       const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
       // MFMA cycles of one 32x32 fragment pair per 32-deep step: 16 f32 MFMAs x 64, or 12 bf16 MFMAs x 32 (x3 mode)
-      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 2 ? 192.0 + 200.0 : 1024.0) * pen[c];
+      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : (g_gemm_mode == 2 || g_gemm_mode == 3) ? 192.0 + 200.0 : 1024.0) * pen[c];
       const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
       for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
         if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
@@ -526,10 +545,12 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
         p.C = ws;                                                                                  \
         if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_SLAB, 1);                                    \
         else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_SLAB, 2);                               \
+        else if (g_gemm_mode == 3) TRIS_FAST(BM_, BN_, EPI_SLAB, 3);                               \
         else hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 0>), grid, dim3(256), 0, st, p); \
       } else {                                                                                     \
         if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_STD, 1);                                     \
         else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_STD, 2);                                \
+        else if (g_gemm_mode == 3) TRIS_FAST(BM_, BN_, EPI_STD, 3);                                \
         else hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 0>), grid, dim3(256), 0, st, p);  \
       }                                                                                            \
     } else if (splitk > 1) {                                                                       \
@@ -545,10 +566,12 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg) {
       p.C = ws;                                                                                    \
       if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_SLAB, 1);                                      \
       else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_SLAB, 2);                                 \
+      else if (g_gemm_mode == 3) TRIS_FAST(BM_, BN_, EPI_SLAB, 3);                                 \
       else TRIS_FAST(BM_, BN_, EPI_SLAB, 0);                                                       \
     } else {                                                                                       \
       if (g_gemm_mode == 1) TRIS_FAST(BM_, BN_, EPI_STD, 1);                                       \
       else if (g_gemm_mode == 2) TRIS_FAST(BM_, BN_, EPI_STD, 2);                                  \
+      else if (g_gemm_mode == 3) TRIS_FAST(BM_, BN_, EPI_STD, 3);                                  \
       else TRIS_FAST(BM_, BN_, EPI_STD, 0);                                                        \
     }                                                                                              \
   } while (0)
@@ -838,6 +861,7 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.fastA = p.vecA && (!transA || M % 4 == 0);
   p.fastB = p.vecB && (transB || N % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  H2Guard h2(p);
   if (!transA && transB) return launch_cfg<A_ROWK, B_NK>(p, batch, workspace, ws_bytes, st);
   if (!transA && !transB) return launch_cfg<A_ROWK, B_KN>(p, batch, workspace, ws_bytes, st);
   if (transA && !transB) return launch_cfg<A_COLK, B_KN>(p, batch, workspace, ws_bytes, st);
@@ -1098,6 +1122,7 @@ extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, in
   p.fastB = p.vecB;
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   *stat_rows = p.stat_part ? cdiv(M, 128) : 0;
+  H2Guard h2(p);
   return launch_cfg<A_ROWK, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -1126,6 +1151,7 @@ extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, 
   p.stat_part = part;
   p.bnb_x = bn_x; p.bnb_y = bn_y; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
   *part_rows = cdiv(M, 128);
+  H2Guard h2(p);
   return launch_cfg<A_ROWK, B_KN>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -1322,12 +1348,12 @@ extern "C" int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long
 }
 
 extern "C" int tris_set_gemm_mode(int mode) {
-  if (mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  if (mode < 0 || mode > 3) return (int)hipErrorInvalidValue;
   g_mode_default = mode;
   return 0;
 }
 extern "C" int tris_set_gemm_mode_thread(int mode) {
-  if (mode < -1 || mode > 2) return (int)hipErrorInvalidValue;
+  if (mode < -1 || mode > 3) return (int)hipErrorInvalidValue;
   g_mode_thread = mode;
   return 0;
 }
@@ -1337,5 +1363,10 @@ extern "C" int tris_set_autotune(int on) {
 }
 
 extern "C" int tris_get_gemm_mode(void) { return g_gemm_mode; }
+
+extern "C" int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB) {
+  g_h2_next = H2Next{amaxA, amaxB, scaleA, scaleB, true};
+  return 0;
+}
 
 extern "C" long tris_direct_launches(int kind) { return (kind == 0 || kind == 1) ? g_direct_launches[kind] : -1; }

@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8 tr_frag8(const char* plane, int ks, int k0, in
 
 // LDS bytes of one operand stage (host + device): see the layout notes in the kernel
 constexpr int gf_stage_floats(int BMN, int FBK, int PREC, bool row_major) {
-  const int NPLN = PREC == 2 ? 2 : 3;
+  const int NPLN = (PREC == 2 || PREC == 3) ? 2 : 3;
   return PREC >= 1 ? (row_major ? BMN * (2 * FBK + 16) * NPLN / 4 : NPLN * FBK * (2 * BMN + 64) / 4)
                    : (row_major ? BMN * (FBK + 4) : FBK * (BMN + 4));
 }
@@ -107,7 +107,7 @@ void gemm_fast_kernel(GemmParams p) {
   // lanes of a ds_read_b128 service group fall on 16 distinct slots).  PREC 2 = x2: two pieces, three products
   // hi.hi + hi.mid + mid.hi (16 significand bits per operand, relative product error <= 2^-15: between fp32 and TF32).
   constexpr bool A_PL = (PREC >= 1), B_PL = (PREC >= 1);
-  constexpr int NPLN = PREC == 2 ? 2 : 3;  // bf16 planes per operand
+  constexpr int NPLN = (PREC == 2 || PREC == 3) ? 2 : 3;  // 16-bit planes per operand (PREC 3: fp16 pieces)
   // m-/n-contiguous operands: 16-byte loads along the contiguous dimension, split, 8-byte LDS stores into k-major planes
   // [plane][k][m], and the MFMA fragments (8 consecutive k per lane) are gathered by the LDS transpose read
   // ds_read_b64_tr_b16: per 16-lane group, lane i points at the 8-byte piece [k0 + i/4][m0 + 4(i%4) ..+3] and receives
@@ -409,16 +409,25 @@ void gemm_fast_kernel(GemmParams p) {
     }
   };
 
+  // PREC 3 ("h2"): power-of-two operand scales (gemm_params.h); the epilogue takes them out again
+  float h2a = 1.f, h2b = 1.f;
+  if constexpr (PREC == 3) {
+    h2a = p.h2_amaxA ? h2_scale_from_bits(*p.h2_amaxA) : (p.h2_sA != 0.f ? p.h2_sA : 1.f);
+    h2b = p.h2_amaxB ? h2_scale_from_bits(*p.h2_amaxB) : (p.h2_sB != 0.f ? p.h2_sB : 1.f);
+  }
+  const float h2inv = 1.0f / (h2a * h2b);
+  auto splitA = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2a); else return split4(v); };
+  auto splitB = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2b); else return split4(v); };
   // ---- LDS stores: one 16-byte piece (chunk) of a tile at a time, so that the pipelined loop can spread them -----------
   auto store_A = [&](float* Ad, const float4& v, int q) {
     if (A_TR) {
-      const Split4 sp = split4(v);
+      const Split4 sp = splitA(v);
       char* d = reinterpret_cast<char*>(Ad) + (tid / AF4 + q * ARPP) * A_KS + (tid % AF4) * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
       *reinterpret_cast<uint2*>(d + FBK * A_KS) = sp.mid;
       if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * FBK * A_KS) = sp.lo;
     } else if (A_PL) {
-      const Split4 sp = split4(v);
+      const Split4 sp = splitA(v);
       char* d = reinterpret_cast<char*>(Ad) + (trow + q * RPASS) * PLB + (tid % KL) * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
       *reinterpret_cast<uint2*>(d + BM * PLB) = sp.mid;
@@ -431,7 +440,7 @@ void gemm_fast_kernel(GemmParams p) {
   };
   auto store_B = [&](float* Bd, const float4& v, int q) {
     if (B_TR) {
-      const Split4 sp = split4(v);
+      const Split4 sp = splitB(v);
       char* d = reinterpret_cast<char*>(Bd) + (tid / BF4 + q * BRPP) * B_KS + (tid % BF4) * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
       *reinterpret_cast<uint2*>(d + FBK * B_KS) = sp.mid;
@@ -443,7 +452,7 @@ void gemm_fast_kernel(GemmParams p) {
       sp.mid = make_uint2(__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
       sp.lo = sp.hi;
 #else
-      const Split4 sp = split4(v);
+      const Split4 sp = splitB(v);
 #endif
       char* d = reinterpret_cast<char*>(Bd) + (trow + q * RPASS) * PLB + (tid % KL) * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
@@ -506,6 +515,14 @@ void gemm_fast_kernel(GemmParams p) {
     return s;
   };
   auto mfma_x = [&](const Split8& a, const Split8& b, f32x16& c) {  // smallest terms first
+    if constexpr (PREC == 3) {   // two fp16 pieces: lo x hi, hi x lo, hi x hi
+      const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.mid);
+      const f16x8 bh = __builtin_bit_cast(f16x8, b.hi), bl = __builtin_bit_cast(f16x8, b.mid);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+      return;
+    }
     if (NPLN == 3) {
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
@@ -783,6 +800,7 @@ void gemm_fast_kernel(GemmParams p) {
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ---------------------
   // (both loops end on a barrier: the staging buffers are free)
+  const float alpha_e = (PREC == 3) ? p.alpha * h2inv : p.alpha;   // (h2: the operand scales leave with alpha; slabs likewise)
   float st_s[FN], st_q[FN];  // fused BatchNorm statistics: per-column sum / sum of squares of this block's rows
 #pragma unroll
   for (int j = 0; j < FN; ++j) st_s[j] = st_q[j] = 0.f;
@@ -837,9 +855,10 @@ void gemm_fast_kernel(GemmParams p) {
           float4 v = *reinterpret_cast<const float4*>(stg + (er + 8 * t) * ELD + ec);
           if (row < p.M && col < p.N) {  // N % 4 == 0: a vector never straddles the edge
             if (EPI == EPI_SLAB) {
+              if (PREC == 3) { v.x *= h2inv; v.y *= h2inv; v.z *= h2inv; v.w *= h2inv; }
               *reinterpret_cast<float4*>(p.C + ((long)bid_z * p.M + row) * p.N + col) = v;
             } else {
-              v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+              v.x *= alpha_e; v.y *= alpha_e; v.z *= alpha_e; v.w *= alpha_e;
               if (p.bias_mode == 1) { v.x += bc.x; v.y += bc.y; v.z += bc.z; v.w += bc.w; }
               else if (p.bias_mode == 2) { const float bb = p.bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
               if (p.act == 1) {
@@ -894,9 +913,9 @@ void gemm_fast_kernel(GemmParams p) {
         if (row < p.M && col < p.N) {
           float v = acc[i][j][r];
           if (EPI == EPI_SLAB) {
-            p.C[((long)bid_z * p.M + row) * p.N + col] = v;
+            p.C[((long)bid_z * p.M + row) * p.N + col] = (PREC == 3) ? v * h2inv : v;
           } else {
-            v *= p.alpha;
+            v *= alpha_e;
             if (p.bias_mode == 1) v += p.bias[col];
             else if (p.bias_mode == 2) v += p.bias[row];
             if (p.act == 1) v = fmaxf(v, 0.f);

@@ -41,6 +41,11 @@ struct GemmParams {
   // sum(dz), sum(dz * xhat) per column into stat_part [tiles_m][2][N] (fp64 across lanes / waves / tiles), i.e. exactly what
   // col_partial_kernel<1> computes in a pass of its own.
   const float *bnb_x, *bnb_y, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
+  // PREC 3 ("h2": two fp16 pieces per operand, three f16 MFMAs per product): per-operand power-of-two scales, either derived in
+  // the kernel from the bit pattern of the tensor's largest magnitude in device memory (h2_amaxA / h2_amaxB, written by
+  // tris_amax_bits_f32) or, where that pointer is NULL, given by the host (h2_sA / h2_sB; 0 = 1.0)
+  const unsigned *h2_amaxA, *h2_amaxB;
+  float h2_sA, h2_sB;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -798,6 +798,39 @@ extern "C" int tris_bn_bwd_apply_pool_f32(const float* dYp, const float* X, cons
   return 0;
 }
 
+// largest magnitude of a tensor as a bit pattern (positive floats order like unsigned integers): atomicMax into *out, which the
+// caller zeroes beforehand -- the operand scale of an "h2" product is derived from it inside the GEMM kernel (x3_split.h)
+__global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  __shared__ unsigned sh[4];
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  unsigned m = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = ld4(x + i * 4);
+    m = max(max(m, __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu), __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu);
+    m = max(max(m, __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu), __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu);
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+    if (m) atomicMax(out, m);
+  }
+}
+
+extern "C" int tris_amax_bits_f32(const float* x, long n, unsigned* out, void* stream) {
+  if (n < 1 || (((uintptr_t)x) & 15)) return (int)hipErrorInvalidValue;
+  long g = (n / 4 + 255) / 256;
+  g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
+  hipLaunchKernelGGL(amax_bits_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 // finish fp64 partial rows [rows][2][C] (a fused producer's epilogue, e.g. tris_gemm_bnbwd_f32) -> out0[C], out1[C]
 extern "C" int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream) {
   if (rows < 1 || C < 1) return (int)hipErrorInvalidValue;

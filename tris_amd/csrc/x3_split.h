@@ -53,3 +53,36 @@ __device__ __forceinline__ Split4 split4(const float4 u) {
   return o;
 }
 
+
+// ---- two-piece fp16 split ("h2"): x * scale = hi + lo with hi, lo fp16 (11 + 11 significand bits), both round-to-nearest.  The
+// caller's scale is a power of two that brings the tensor's largest magnitude to [2^13, 2^14): hi cannot overflow, the lo piece
+// of everything within 2^-16 of the maximum stays a normal number.  The pieces travel in the same 16-bit planes as the bf16 ones.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 h = __builtin_convertvector(v, f16x2);  // v_cvt_f16_f32 (RNE) x 2
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ f32x2 unpk_f16(unsigned u) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, u), f32x2);
+}
+__device__ __forceinline__ Split4 split4h(const float4 u, const float s) {
+  Split4 o;
+  const float x0 = u.x * s, x1 = u.y * s, x2 = u.z * s, x3 = u.w * s;
+  o.hi.x = pk_f16(x0, x1);
+  o.hi.y = pk_f16(x2, x3);
+  const f32x2 h0 = unpk_f16(o.hi.x), h1 = unpk_f16(o.hi.y);
+  o.mid.x = pk_f16(x0 - h0[0], x1 - h0[1]);
+  o.mid.y = pk_f16(x2 - h1[0], x3 - h1[1]);
+  o.lo = o.mid;
+  return o;
+}
+// scale for a tensor whose largest magnitude has the bit pattern `amax_bits` (0: empty or all-zero tensor -> 1)
+__device__ __forceinline__ float h2_scale_from_bits(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xffu) - 127;        // floor(log2(amax)) for normal numbers
+  if (amax_bits == 0u || e < -100) return 1.0f;
+  int se = 13 - e;
+  se = se > 120 ? 120 : (se < -120 ? -120 : se);
+  return __builtin_bit_cast(float, (unsigned)(se + 127) << 23);
+}

@@ -71,7 +71,7 @@ def set_gemm_mode(mode):
     """'f32' = f32-input MFMA (bit-equal to an fmaf chain); 'x3' = split-bf16 (three bf16 pieces per fp32 operand, six
     bf16 MFMAs per product, fp32 accumulate): fp32-class accuracy at ~2.6x the f32-MFMA rate; 'x2' = two pieces, three
     MFMAs: 16-bit significands (relative product error <= 2^-15, between fp32 and TF32) -- a throughput mode, NOT the default."""
-    call("tris_set_gemm_mode", {"f32": 0, "x3": 1, "x2": 2}[mode])
+    call("tris_set_gemm_mode", {"f32": 0, "x3": 1, "x2": 2, "h2": 3}[mode])
 
 
 _BWD_MODE = None
@@ -84,7 +84,7 @@ def _set_thread_mode(mode):
     """per-thread arithmetic override of the dense products (None = none); returns the previous override"""
     prev = getattr(_TLS, "mode", None)
     _TLS.mode = mode
-    call("tris_set_gemm_mode_thread", -1 if mode is None else {"f32": 0, "x3": 1, "x2": 2}[mode])
+    call("tris_set_gemm_mode_thread", -1 if mode is None else {"f32": 0, "x3": 1, "x2": 2, "h2": 3}[mode])
     return prev
 
 
@@ -161,7 +161,7 @@ def set_autotune(on):
 
 
 def get_gemm_mode():
-    return ("f32", "x3", "x2")[_lib.load().tris_get_gemm_mode()]
+    return ("f32", "x3", "x2", "h2")[_lib.load().tris_get_gemm_mode()]
 
 
 _init_mode_from_env()
