@@ -148,11 +148,18 @@ int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, flo
 
 /* Opt-in arithmetic "h2" for single dense products: two fp16 pieces per operand, three f16 MFMAs per
  * product (half the matrix work of the x3 default), operands scaled by a power of two so that fp16's exponent range holds them.
- * tris_amax_bits_f32: atomic max of |x| as a bit pattern into *out (zero it first).  tris_h2_next: arms the CALLING THREAD -- the
+ * An amax word is 2048 unsigned words (8 KB: 8 XCDs x 16 cache lines with one used word each; the consumer takes the max).
+ * tris_amax_bits_f32: atomic max of |x| as a bit pattern into that block (zero it first).  tris_h2_next: arms the CALLING THREAD -- the
  * next tris_gemm_f32 / tris_gemm_bnstat_f32 / tris_gemm_bnbwd_f32 it launches runs in h2 with operand A scaled from *amaxA (or,
  * amaxA == NULL, by scaleA; 0 = 1.0) and B likewise; products the fast kernel does not serve run as usual.  One shot.
  * tris_set_gemm_mode(3) selects h2 process-wide with unit scales (tests). */
 int tris_amax_bits_f32(const float* x, long n, unsigned* out, void* stream);
+/* the same for nseg tensors base + offs[i] (sizes[i] floats; device arrays) in one launch -> slots[i]: the weights of an arena */
+int tris_amax_segments_f32(const float* base, const long* offs, const long* sizes, int nseg, unsigned* slots, void* stream);
+/* one shot, calling thread: the next tris_bn_apply_f32 / tris_bn_apply_pool_f32 / tris_bn_bwd_apply_f32 /
+ * tris_bn_bwd_apply_pool_f32 / tris_layernorm_fwd_f32 / tris_layernorm_bwd_f32 (dX) / tris_elementwise_f32 also maxes the magnitude bits of what it WRITES into *out (zeroed by the caller): the amax of an
+ * h2 operand as a by-product of the pass that produces the tensor, instead of a pass of its own */
+int tris_amax_next(unsigned* out);
 int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB);
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                            long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,

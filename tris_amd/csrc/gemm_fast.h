@@ -412,8 +412,8 @@ void gemm_fast_kernel(GemmParams p) {
   // PREC 3 ("h2"): power-of-two operand scales (gemm_params.h); the epilogue takes them out again
   float h2a = 1.f, h2b = 1.f;
   if constexpr (PREC == 3) {
-    h2a = p.h2_amaxA ? h2_scale_from_bits(*p.h2_amaxA) : (p.h2_sA != 0.f ? p.h2_sA : 1.f);
-    h2b = p.h2_amaxB ? h2_scale_from_bits(*p.h2_amaxB) : (p.h2_sB != 0.f ? p.h2_sB : 1.f);
+    h2a = p.h2_amaxA ? h2_scale_from_bits(h2_amax_of(p.h2_amaxA, lane)) : (p.h2_sA != 0.f ? p.h2_sA : 1.f);
+    h2b = p.h2_amaxB ? h2_scale_from_bits(h2_amax_of(p.h2_amaxB, lane)) : (p.h2_sB != 0.f ? p.h2_sB : 1.f);
   }
   const float h2inv = 1.0f / (h2a * h2b);
   auto splitA = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2a); else return split4(v); };

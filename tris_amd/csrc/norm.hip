@@ -249,18 +249,56 @@ __global__ void bn_sync_combine_kernel(const float* __restrict__ gathered, int W
   }
 }
 
+// ---- optional by-product of the BatchNorm apply passes: the largest magnitude of what they WRITE, as a bit pattern, atomically
+// maxed into a caller-zeroed word (the operand scale of an "h2" product that consumes the tensor: include/tris_hip.h).  Armed per
+// launch by tris_amax_next() on the calling thread; unarmed launches pass NULL and skip it.
+__device__ __forceinline__ unsigned abits4(const float4 v) {
+  return max(max(__builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu),
+             max(__builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu));
+}
+// An amax "word" is 128 cache lines (8 KB): 8 XCDs x 16 lines, one unsigned used in each.  Device-scope atomics are served
+// memory-side (the eight L2s are not coherent) at a few hundred per microsecond -- a launch has thousands of waves.  Instead a
+// wave (or, where every thread reaches the end, a block) maxes into a line of ITS XCD with a workgroup-scope atomic, which the
+// XCD's own L2 serves (all CUs of an XCD share it, so every line is exact for what its writers saw); sixteen lines per XCD keep
+// the queue per address short.  The dirty lines reach memory at the end of the kernel like any other output, and the consumer
+// takes the max over the 128 (x3_split.h h2_amax_of).  Writers that would not raise their line skip the atomic.
+__device__ __forceinline__ void amax_raise(unsigned m, unsigned* __restrict__ out) {   // one lane
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID, bits [3:0]
+  unsigned* w = out + (xcc * 16 + ((blockIdx.x >> 3) & 15)) * 16;
+  if (m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+    __hip_atomic_fetch_max(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned* __restrict__ out) {   // per wave; no barrier
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
+  if ((threadIdx.x & 63) == 0 && m != 0u) amax_raise(m, out);
+}
+__device__ __forceinline__ void amax_commit_block(unsigned m, unsigned* __restrict__ out) {   // ALL threads of a <= 256-thread block
+  __shared__ unsigned sh_amax[4];
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
+  if ((threadIdx.x & 63) == 0) sh_amax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = max(m, sh_amax[w]);
+    if (m != 0u) amax_raise(m, out);
+  }
+}
+
 // y = (x - mean) * invstd * gamma + beta (+ resid) (relu)
 // The launch keeps gridDim*blockDim a multiple of C/4, so a thread sees ONE channel vector for its whole grid-stride walk:
 // the per-channel constants are folded to (scale, shift) once and the loop is a pure 16-byte stream, two vectors per trip.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ resid,
-                                                       float* __restrict__ Y, long n4, int C, int relu) {
+                                                       float* __restrict__ Y, long n4, int C, int relu,
+                                                       unsigned* __restrict__ amax = nullptr) {
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)((i * 4) % C);
   const float4 mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
   const float4 sc = make_float4(is.x * g.x, is.y * g.y, is.z * g.z, is.w * g.w);
+  unsigned am = 0u;
   auto one = [&](const float4 x, const float4 r) {
     float4 y;
     y.x = (x.x - mu.x) * sc.x + b.x + r.x;
@@ -268,6 +306,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     y.z = (x.z - mu.z) * sc.z + b.z + r.z;
     y.w = (x.w - mu.w) * sc.w + b.w + r.w;
     if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    am = max(am, abits4(y));
     return y;
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
@@ -278,6 +317,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     st4(Y + (i + stride) * 4, one(x1, r1));
   }
   if (i < n4) st4(Y + i * 4, one(ld4(X + i * 4), resid ? ld4(resid + i * 4) : z4));
+  if (amax != nullptr) amax_commit_block(am, amax);
 }
 
 // Yp[b, oy, ox, :] = avgpool2(relu(bn(X)))  -- the stem's bn3 and the stride-2 Bottlenecks' bn2 feed an AvgPool2d(2) and nothing
@@ -285,10 +325,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ X, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ Yp, int B, int H,
-                                                            int W, int C) {
+                                                            int W, int C, unsigned* __restrict__ amax = nullptr) {
   const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
   const long n = (long)B * Ho * Wo * C4;
   const long stride = (long)gridDim.x * blockDim.x;
+  unsigned am = 0u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int c = (int)(i % C4) * 4;
     long t = i / C4;
@@ -304,9 +345,12 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
     };
     const float* p = X + (((long)b * H + oy * 2) * W + ox * 2) * C + c;
     const float4 a = act(ld4(p)), b4 = act(ld4(p + C)), cc = act(ld4(p + (long)W * C)), d = act(ld4(p + (long)W * C + C));
-    st4(Yp + i * 4, make_float4(0.25f * (a.x + b4.x + cc.x + d.x), 0.25f * (a.y + b4.y + cc.y + d.y),
-                                0.25f * (a.z + b4.z + cc.z + d.z), 0.25f * (a.w + b4.w + cc.w + d.w)));
+    const float4 o = make_float4(0.25f * (a.x + b4.x + cc.x + d.x), 0.25f * (a.y + b4.y + cc.y + d.y),
+                                 0.25f * (a.z + b4.z + cc.z + d.z), 0.25f * (a.w + b4.w + cc.w + d.w));
+    st4(Yp + i * 4, o);
+    am = max(am, abits4(o));
   }
+  if (amax != nullptr) amax_commit_block(am, amax);
 }
 
 // dx = gamma * invstd * (dz - sum_dz/cnt - xhat * sum_dzxhat/cnt),  dz = dY * (Y>0 if Y); optional dZ <- dz
@@ -320,7 +364,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sum_dzx, float inv_cnt,
                                                            float* __restrict__ dX, float* __restrict__ dZ, long n4,
                                                            int C, const float* __restrict__ beta_mask, int pool_h = 0,
-                                                           int pool_w = 0) {
+                                                           int pool_w = 0, unsigned* __restrict__ amax = nullptr) {
+  unsigned am = 0u;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)((i * 4) % C);
@@ -359,12 +404,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     o.z = k1.z * (g.z - k2.z - (x.z - mu.z) * k3.z);
     o.w = k1.w * (g.w - k2.w - (x.w - mu.w) * k3.w);
     st4(dX + j * 4, o);
+    am = max(am, abits4(o));
   };
   for (; i + stride < n4; i += 2 * stride) {
     one(i);
     one(i + stride);
   }
   if (i < n4) one(i);
+  if (amax != nullptr) amax_commit_block(am, amax);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -445,10 +492,11 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ Y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            long rows, int W, float eps) {
+                                                            long rows, int W, float eps, unsigned* __restrict__ amax = nullptr) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  unsigned am = 0u;
   const int W4 = W >> 2;
   float4 v[4];
   float s = 0.f;
@@ -479,8 +527,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.z = (v[q].z - mean) * rstd * g.z + b.z;
       o.w = (v[q].w - mean) * rstd * g.w + b.w;
       st4(Y + row * W + i * 4, o);
+      am = max(am, abits4(o));
     }
   }
+  if (amax != nullptr) amax_commit(am, amax);
   if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
@@ -490,7 +540,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, float* __restrict__ dX,
                                                             float* __restrict__ part, long rows, int W,
-                                                            long rows_per_block, const float* __restrict__ extra) {
+                                                            long rows_per_block, const float* __restrict__ extra,
+                                                            unsigned* __restrict__ amax = nullptr) {
+  unsigned am = 0u;
   __shared__ float4 lg[4][256];
   __shared__ float4 lb[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -534,10 +586,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
           }
           st4(dX + row * W + i * 4, o);
+          am = max(am, abits4(o));
         }
       }
     }
   }
+  if (amax != nullptr) amax_commit_block(am, amax);
   if (!part) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { lg[wv][lane + q * 64] = ag[q]; lb[wv][lane + q * 64] = ab[q]; }
@@ -624,15 +678,23 @@ __device__ __forceinline__ float ew1(int op, float a, float b, float s) {
   }
 }
 __global__ void ew_kernel(int op, const float* __restrict__ A, const float* __restrict__ Bp, float* __restrict__ O,
-                          long n, float s) {
+                          long n, float s, unsigned* __restrict__ amax = nullptr) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
+  unsigned am = 0u;
   for (long j = i; j < n4; j += stride) {
     float4 a = ld4(A + j * 4), b = Bp ? ld4(Bp + j * 4) : make_float4(0, 0, 0, 0);
-    st4(O + j * 4, make_float4(ew1(op, a.x, b.x, s), ew1(op, a.y, b.y, s), ew1(op, a.z, b.z, s), ew1(op, a.w, b.w, s)));
+    const float4 o = make_float4(ew1(op, a.x, b.x, s), ew1(op, a.y, b.y, s), ew1(op, a.z, b.z, s), ew1(op, a.w, b.w, s));
+    st4(O + j * 4, o);
+    am = max(am, abits4(o));
   }
-  for (long j = n4 * 4 + i; j < n; j += stride) O[j] = ew1(op, A[j], Bp ? Bp[j] : 0.f, s);
+  for (long j = n4 * 4 + i; j < n; j += stride) {
+    const float o = ew1(op, A[j], Bp ? Bp[j] : 0.f, s);
+    O[j] = o;
+    am = max(am, __builtin_bit_cast(unsigned, o) & 0x7fffffffu);
+  }
+  if (amax != nullptr) amax_commit_block(am, amax);
 }
 
 // NCHW [B,C,H,W] <-> NHWC [B,H,W,C] (C tiny: the 3-channel input image)
@@ -695,6 +757,17 @@ inline ColPlan col_plan(long M, int C) {
 
 }  // namespace
 
+static thread_local unsigned* g_amax_next = nullptr;
+static unsigned* take_amax_next() {
+  unsigned* p = g_amax_next;
+  g_amax_next = nullptr;
+  return p;
+}
+extern "C" int tris_amax_next(unsigned* out) {
+  g_amax_next = out;
+  return 0;
+}
+
 extern "C" long tris_col_workspace_bytes(long M, int C) {
   ColPlan p = col_plan(M, C);
   return (long)p.nb * 2 * C * sizeof(double);
@@ -738,7 +811,7 @@ extern "C" int tris_bn_apply_f32(const float* X, const float* mean, const float*
   if (C % 4) return (int)hipErrorInvalidValue;
   long n4 = M * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma,
-                     beta, resid, Y, n4, C, relu);
+                     beta, resid, Y, n4, C, relu, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -766,7 +839,7 @@ extern "C" int tris_bn_apply_pool_f32(const float* X, const float* mean, const f
   if (C % 4 || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
   const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta, Yp,
-                     B, H, W, C);
+                     B, H, W, C, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -793,7 +866,7 @@ extern "C" int tris_bn_bwd_apply_pool_f32(const float* dYp, const float* X, cons
   if (C % 4 || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
   const long n4 = (long)B * H * W * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dYp, (const float*)nullptr, X,
-                     mean, invstd, gamma, sum_dz, sum_dzx, inv_count, dX, (float*)nullptr, n4, C, beta, H, W);
+                     mean, invstd, gamma, sum_dz, sum_dzx, inv_count, dX, (float*)nullptr, n4, C, beta, H, W, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -801,7 +874,6 @@ extern "C" int tris_bn_bwd_apply_pool_f32(const float* dYp, const float* X, cons
 // largest magnitude of a tensor as a bit pattern (positive floats order like unsigned integers): atomicMax into *out, which the
 // caller zeroes beforehand -- the operand scale of an "h2" product is derived from it inside the GEMM kernel (x3_split.h)
 __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
-  __shared__ unsigned sh[4];
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   unsigned m = 0u;
@@ -812,14 +884,29 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict_
   }
   for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
-#pragma unroll
-  for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
-    if (m) atomicMax(out, m);
-  }
+  amax_commit_block(m, out);
+}
+
+// the same for many tensors of one flat buffer in ONE launch (the weights of an optimiser arena): grid (chunks, segments)
+__global__ __launch_bounds__(256) void amax_segments_kernel(const float* __restrict__ base, const long* __restrict__ offs,
+                                                            const long* __restrict__ sizes, unsigned* __restrict__ slots) {
+  const long n = sizes[blockIdx.y];
+  const float* x = base + offs[blockIdx.y];
+  const long n4 = n >> 2;   // (arena slots are 256-byte aligned)
+  const long stride = (long)gridDim.x * blockDim.x;
+  unsigned m = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) m = max(m, abits4(ld4(x + i * 4)));
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
+  amax_commit_block(m, slots + (long)blockIdx.y * 2048);
+}
+
+extern "C" int tris_amax_segments_f32(const float* base, const long* offs, const long* sizes, int nseg, unsigned* slots,
+                                      void* stream) {
+  if (nseg < 1 || (((uintptr_t)base) & 15)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(amax_segments_kernel, dim3(16, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, base, offs, sizes, slots);
+  TRIS_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int tris_amax_bits_f32(const float* x, long n, unsigned* out, void* stream) {
@@ -846,7 +933,7 @@ extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const floa
                                      void* stream) {
   long n4 = M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean, invstd,
-                     gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask);
+                     gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask, 0, 0, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -889,7 +976,7 @@ extern "C" int tris_layernorm_fwd_f32(const float* X, const float* gamma, const 
                                       float* rstd, long rows, int W, float eps, void* stream) {
   if (W % 4 || W > 1024) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, X, gamma, beta, Y,
-                     mean, rstd, rows, W, eps);
+                     mean, rstd, rows, W, eps, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -911,7 +998,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
   int nb = (int)((rows + rpb - 1) / rpb);
   float* part = dgamma ? workspace : nullptr;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dY, X, gamma, mean, rstd, dX, part, rows, W,
-                     rpb, extra);
+                     rpb, extra, take_amax_next());
   TRIS_LAUNCH_CHECK();
   if (dgamma) {
     hipLaunchKernelGGL(part_finalize_kernel<float>, dim3(fin_grid(W, nb)), dim3(fin_block(nb)), 0, st, (const float*)workspace, nb, W, dgamma, dbeta);
@@ -937,7 +1024,8 @@ extern "C" int tris_avgpool2_bwd_f32(const float* dY, float* dX, int B, int H, i
 }
 
 extern "C" int tris_elementwise_f32(int op, const float* A, const float* B, float* O, long n, float s, void* stream) {
-  hipLaunchKernelGGL(ew_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, op, A, B, O, n, s);
+  hipLaunchKernelGGL(ew_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, op, A, B, O, n, s,
+                     take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }

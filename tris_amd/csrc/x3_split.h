@@ -78,6 +78,13 @@ __device__ __forceinline__ Split4 split4h(const float4 u, const float s) {
   o.lo = o.mid;
   return o;
 }
+// an amax "word" is 128 cache lines (2048 words) with one used word each (csrc/norm.hip amax_raise)
+__device__ __forceinline__ unsigned h2_amax_of(const unsigned* __restrict__ slots, int lane) {
+  unsigned m = max(slots[lane * 16], slots[(lane + 64) * 16]);
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
+  return m;
+}
 // scale for a tensor whose largest magnitude has the bit pattern `amax_bits` (0: empty or all-zero tensor -> 1)
 __device__ __forceinline__ float h2_scale_from_bits(unsigned amax_bits) {
   const int e = (int)((amax_bits >> 23) & 0xffu) - 127;        // floor(log2(amax)) for normal numbers

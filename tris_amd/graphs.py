@@ -272,6 +272,8 @@ class SegmentedTrainStep:
                 self.inline = False
             return out[0], out[1], [sk for _, _, sk in fns]
 
+        self.h2_pool = ops.h2_begin_step()   # (TRIS_LINEAR_MODE=h2: the amax pool the captured launches write; zeroed per replay)
+        self.h2_arenas = list(ops._H2.get("arenas", [])) if self.h2_pool is not None else []
         ops._SEG = self
         try:
             # ---- forward.  Where the two text towers START relative to the trunk is chosen as in the eager step (model_stage1.
@@ -361,6 +363,7 @@ class SegmentedTrainStep:
             _capture(self.g_opt, self.cap, pool_c, lambda: optimizer.step(device_hyper=True, ranges=rest))
         finally:
             ops._SEG = None
+            ops.h2_end_step()
             self.cuts, self.deferred = [], []
         del keep, trunk_cuts, h, hidden, vis, late_sinks, fwd
         for m, n in zip(self.bns, nbt):          # (capture launched nothing: the forward's host-side count is taken back)
@@ -411,6 +414,7 @@ class SegmentedTrainStep:
         return None
 
     def __call__(self, img, ids, neg):
+        from . import ops
         main, text, wg, ev = torch.cuda.current_stream(), self.text, self.wg, self.ev
         tm = self._marks = [] if self.trace else None
 
@@ -420,6 +424,9 @@ class SegmentedTrainStep:
                 e.record(stream)
                 tm.append((name, e))
         mark("start")
+        if self.h2_pool is not None:    # TRIS_LINEAR_MODE=h2: a fresh amax pool, the weights' amaxes (the captured launches
+            self.h2_pool.zero_()        # write / read the same words every replay)
+            ops.h2_weights_amax(self.h2_arenas)
         self.s_img.copy_(img, non_blocking=True)
         self.s_ids.copy_(ids, non_blocking=True)
         if self.s_neg is not None:

@@ -88,6 +88,10 @@ def _set_thread_mode(mode):
     return prev
 
 
+def _thread_mode_is_set():
+    return getattr(_TLS, "mode", None) is not None
+
+
 def set_backward_gemm_mode(mode):
     """Arithmetic of the dense products launched from backward (data and weight gradients): None = same as forward,
     or 'x2' / 'x3' / 'f32'.  Forward results (response maps, losses -- the parity bar) do not depend on it.  Env:
@@ -512,6 +516,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
         C.reshape(M, N).copy_(C4[:M])
         return C
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
+    if _H2["live"] and batch == 1:
+        h2_arm(A, B)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
@@ -528,6 +534,7 @@ def colsum(X, M, N, out):
 def ew(op, A, B=None, s=0.0, out=None):
     _chk(A, B)
     out = torch.empty_like(A) if out is None else out
+    h2_mark_next(out)
     call("tris_elementwise_f32", EW[op], P(A), P(B), P(out), A.numel(), float(s), _stream())
     return out
 
@@ -596,6 +603,130 @@ class GradBox:
 
 
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
+# ---- "h2" products (opt-in: TRIS_LINEAR_MODE=h2) -----------------------------------------------------------
+# Linear / 1x1-convolution products of the TRAINING STEP with two fp16 pieces per operand and three f16 MFMAs (half the matrix
+# work of x3).  fp16 holds 11 significand bits per piece but only 5 exponent bits, so every operand is scaled by a power of two
+# derived -- inside the GEMM kernel -- from the tensor's largest magnitude.  That amax is a word in a per-step pool, written
+# either by the pass that PRODUCES the tensor (BatchNorm apply / backward apply: h2_mark_next, no extra traffic) or, for tensors
+# up to 64 MB, by a small pre-pass (tris_amax_bits_f32).  A product whose operands have no amax this step runs in x3 as usual.
+# Measured on the real operands of a step: error indistinguishable from a plain fp32 product (tools/h2_study.py).
+_H2 = {"live": False, "pool": None, "next": 0, "step": 0}
+H2_SLOTS = 2048          # amax words per step; a word is H2_SUB unsigned words (csrc/norm.hip amax_raise)
+H2_SUB = 2048
+H2_PREPASS_MAX = 1 << 25
+
+
+def h2_wanted():
+    return os.environ.get("TRIS_LINEAR_MODE", "") == "h2" and get_gemm_mode() == "x3"
+
+
+_H2_ARENAS = []   # weak references to the optimiser arenas whose parameters get their amax from ONE launch per step
+
+
+def h2_register_arena(arena):
+    """an optimiser arena (tris_amd.optim.Arena: .p flat parameter buffer, .params, .offsets)"""
+    import weakref
+    _H2_ARENAS.append(weakref.ref(arena))
+
+
+def _h2_live_arenas():
+    out = []
+    for r in list(_H2_ARENAS):
+        a = r()
+        if a is None:
+            _H2_ARENAS.remove(r)
+        elif _H2["pool"] is not None and a.p.device == _H2["pool"].device:
+            out.append(a)
+    return out
+
+
+def h2_weights_amax(arenas=None):
+    """(re)compute the amax words of the arenas' parameters: the first words of the pool, in order.  arenas: the list a
+    captured step recorded (its launches read those words); default: the live registered ones"""
+    base = 0
+    for a in (_h2_live_arenas() if arenas is None else arenas):
+        if not hasattr(a, "_h2_dev"):
+            a._h2_dev = (torch.tensor(list(a.offsets), device=a.p.device, dtype=torch.int64),
+                         torch.tensor([p.numel() for p in a.params], device=a.p.device, dtype=torch.int64))
+        call("tris_amax_segments_f32", P(a.p), a._h2_dev[0].data_ptr(), a._h2_dev[1].data_ptr(), len(a.params),
+             _H2["pool"].data_ptr() + 4 * H2_SUB * base, _stream())
+        base += len(a.params)
+    return base
+
+
+def h2_begin_step():
+    """start of a training step: a fresh amax pool (one memset) + the weights' amaxes (one launch per optimiser arena).
+    Returns the pool (or None when h2 is off)"""
+    if not h2_wanted():
+        _H2["live"] = False
+        return None
+    if _H2["pool"] is None or _H2["pool"].device != torch.device("cuda", torch.cuda.current_device()):
+        _H2["pool"] = torch.zeros(H2_SLOTS * H2_SUB, device="cuda", dtype=torch.int32)
+    else:
+        _H2["pool"].zero_()
+    _H2["step"] += 1
+    _H2["live"] = True
+    base = 0
+    arenas = _h2_live_arenas()
+    for a in arenas:
+        for i, p in enumerate(a.params):
+            p._h2 = (_H2["step"], _H2["pool"].data_ptr() + 4 * H2_SUB * (base + i), p._version)
+        base += len(a.params)
+    _H2["next"] = base
+    _H2["arenas"] = arenas
+    h2_weights_amax(arenas)
+    return _H2["pool"]
+
+
+def h2_end_step():
+    _H2["live"] = False
+
+
+def _h2_slot():
+    i = _H2["next"]
+    if i >= H2_SLOTS:
+        raise RuntimeError("h2: amax pool exhausted (more than H2_SLOTS tagged tensors in one step)")
+    _H2["next"] = i + 1
+    return _H2["pool"].data_ptr() + 4 * H2_SUB * i
+
+
+def h2_mark_next(t):
+    """call right BEFORE the BatchNorm apply-type launch that writes `t`: that launch also leaves t's amax in a pool word"""
+    if not _H2["live"]:
+        return
+    slot = _h2_slot()
+    call("tris_amax_next", slot)
+    t._h2 = (_H2["step"], slot, t._version)
+
+
+def _h2_amax(t):
+    tag = getattr(t, "_h2", None)
+    if tag is not None and tag[0] == _H2["step"] and tag[2] == t._version:
+        return tag[1]
+    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    if t.numel() <= H2_PREPASS_MAX and dense and t.data_ptr() % 16 == 0 and t.numel() > 0:
+        slot = _h2_slot()
+        call("tris_amax_bits_f32", P(t), t.numel(), slot, _stream())
+        try:
+            t._h2 = (_H2["step"], slot, t._version)
+        except AttributeError:
+            pass
+        return slot
+    return None
+
+
+def h2_arm(A, B):
+    """before a dense product of A and B: run it in h2 if both operands have an amax this step (one shot, this thread)"""
+    if not _H2["live"] or _thread_mode_is_set():
+        return False
+    a = _h2_amax(A)
+    b = _h2_amax(B) if a is not None else None
+    if a is None or b is None:
+        return False
+    call("tris_h2_next", a, b, 0.0, 0.0)
+    return True
+
+
 class _BnBwdLink:
     """Hand-off between a train-mode BatchNorm(+ReLU) and the 1x1 convolution / Linear that consumes its output.
 
@@ -678,8 +809,8 @@ class LinearFn(torch.autograd.Function):
             pass
         elif want_stats:
             _launch_with_stats(y, M, N, lambda part, rows: _timed(
-                "gemm", 2.0 * M * N * K, lambda: call("tris_gemm_bnstat_f32", P(x), P(w), P(y), M, N, K, part.data_ptr(),
-                                                      rows, _stream())))
+                "gemm", 2.0 * M * N * K, lambda: (h2_arm(x, w), call("tris_gemm_bnstat_f32", P(x), P(w), P(y), M, N, K,
+                                                                     part.data_ptr(), rows, _stream()))[1]))
         else:
             gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid,
                  ldr=N, act=act)
@@ -727,10 +858,10 @@ class LinearFn(torch.autograd.Function):
                 import ctypes
                 part = torch.empty(((M + 127) // 128) * 2 * K, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("gemm_bnbwd", 2.0 * M * N * K, lambda: (call(
+                _timed("gemm_bnbwd", 2.0 * M * N * K, lambda: (h2_arm(dy, w), call(
                     "tris_gemm_bnbwd_f32", P(dy), P(w), P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
                     P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()),
-                    rows.value > 0)[1])     # (False: the entry point declined the shape, nothing was launched)
+                    rows.value > 0)[2])     # (False: the entry point declined the shape, nothing was launched)
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
@@ -1055,9 +1186,11 @@ class BatchNormFn(torch.autograd.Function):
         # lazy: y stays UNWRITTEN -- its only consumer (a 3x3 convolution with direct kernels) normalises x while staging it
         lazy = bool(lazy and training and relu and resid is None and os.environ.get("TRIS_BN_MASK_X", "1") != "0")
         if pool:
+            h2_mark_next(y)
             call("tris_bn_apply_pool_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), x.shape[0], x.shape[1], x.shape[2], C,
                  _stream())
         elif not lazy:
+            h2_mark_next(y)
             call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
                  _stream())
         if lazy:   # the hand-off to ops.conv3x3 rides on the (unwritten) output tensor itself
@@ -1139,6 +1272,7 @@ class BatchNormFn(torch.autograd.Function):
         if ctx.pool:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
+                h2_mark_next(dx)
                 call("tris_bn_bwd_apply_pool_f32", P(dy), P(x), P(mean), P(invstd), P(gamma), P(beta), p_dz, p_dzx,
                      1.0 / float(count), P(dx), x.shape[0], x.shape[1], x.shape[2], C, _stream())
         elif got is not None:
@@ -1146,17 +1280,20 @@ class BatchNormFn(torch.autograd.Function):
                 d_res = dy          # the masked gradient IS the identity branch's gradient
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
+                h2_mark_next(dx)
                 call("tris_bn_bwd_apply_f32", P(dy), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
                      1.0 / float(count), P(dx), None, M, C, None, _stream())
         elif dz_first:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
+                h2_mark_next(dx)
                 call("tris_bn_bwd_apply_f32", P(d_res), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
                      1.0 / float(count), P(dx), None, M, C, None, _stream())
         elif ctx.needs_input_grad[0] or want_dz:
             dx = torch.empty_like(x)
             if want_dz:
                 d_res = torch.empty_like(x)
+            h2_mark_next(dx)
             call("tris_bn_bwd_apply_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
                  1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
         if ctx.grad_box is not None and d_res is not None and ctx.grad_box.deposit(d_res):
@@ -1217,6 +1354,7 @@ class LayerNormFn(torch.autograd.Function):
         rows = x.numel() // W
         y = torch.empty_like(x)
         st = torch.empty(2, rows, device=x.device, dtype=torch.float32)
+        h2_mark_next(y)
         call("tris_layernorm_fwd_f32", P(x), P(g), P(b), P(y), P(st), P(st, rows), rows, W, eps, _stream())
         ctx.dims = (rows, W)
         ctx.params = (g, b)
@@ -1240,10 +1378,12 @@ class LayerNormFn(torch.autograd.Function):
         ws = workspace(query("tris_layernorm_bwd_workspace_bytes", rows, W))
         sg, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
         if need_p and sg is not None and sb is not None and sg.is_contiguous() and sb.is_contiguous():
+            h2_mark_next(dx)
             call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(sg), P(sb), rows, W, P(ws),
                  P(extra), _stream())
             return dx, None, None, None, None
         dgb = torch.empty(2, W, device=x.device, dtype=torch.float32) if need_p else None
+        h2_mark_next(dx)
         call("tris_layernorm_bwd_f32", P(dy), P(x), P(g), P(st), P(st, rows), P(dx), P(dgb), P(dgb, W),
              rows, W, P(ws), P(extra), _stream())
         dg = _emit(ctx.params[0], lambda o: o.copy_(dgb[0]), ctx.needs_input_grad[1])

@@ -64,6 +64,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if not all(p.is_cuda for p in g["params"]):
                 raise ops.NoGpuError("FusedAdamW needs the model on the GPU before construction")
             self.arenas.append(Arena(g["params"]))
+        for a in self.arenas:   # (TRIS_LINEAR_MODE=h2: the weights' amaxes in one launch per arena and step)
+            ops.h2_register_arena(a)
         self._steps = 0
         self._hyper = None      # device copy of the step-dependent scalars (enable_device_hyper)
 

@@ -110,6 +110,7 @@ def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
     tris_amd.graphs.GraphedTrainStep captures).  device_hyper: the optimiser reads lr / bias corrections from device memory."""
     import contextlib
     from .planes import WeightPlanes
+    ops.h2_begin_step()   # (TRIS_LINEAR_MODE=h2: a fresh amax pool; no-op otherwise)
     wp = _weight_planes(model, frozen=False)
     wa = _weight_planes(clip_model, frozen=True)
     if wp is not None:
@@ -128,6 +129,7 @@ def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
         optimizer.step(device_hyper=device_hyper)
     else:
         ops.wgrad_join()
+    ops.h2_end_step()
     # detached: a caller that keeps the returned tensor must not keep the step's autograd nodes alive with it (AccumulateGrad
     # nodes remember the stream they were created on: a stale one breaks a later stream capture of the step)
     return losses.detach()
