@@ -405,14 +405,20 @@ static int g_x3_waves = (getenv("TRIS_X3_WAVES") && atoi(getenv("TRIS_X3_WAVES")
 // the process-wide mode -- if the fast kernel serves its shape; otherwise it runs as usual.  One shot.
 struct H2Next { const unsigned* a; const unsigned* b; float sa, sb; bool armed; };
 static thread_local H2Next g_h2_next = {nullptr, nullptr, 0.f, 0.f, false};
+// every entry point that honours the arming TAKES it first thing (h2_take), whether or not it then launches anything: an arming
+// never survives the call it was made for
+static H2Next h2_take() {
+  H2Next n = g_h2_next;
+  g_h2_next.armed = false;
+  return n;
+}
 struct H2Guard {
   int saved;
   bool on;
-  explicit H2Guard(GemmParams& p) : saved(g_mode_thread), on(false) {
-    if (!g_h2_next.armed) return;
-    g_h2_next.armed = false;
+  H2Guard(GemmParams& p, const H2Next& n) : saved(g_mode_thread), on(false) {
+    if (!n.armed) return;
     if (!(p.fastA && p.fastB && p.K % 32 == 0 && p.M >= 4 && p.N >= 4)) return;
-    p.h2_amaxA = g_h2_next.a; p.h2_amaxB = g_h2_next.b; p.h2_sA = g_h2_next.sa; p.h2_sB = g_h2_next.sb;
+    p.h2_amaxA = n.a; p.h2_amaxB = n.b; p.h2_sA = n.sa; p.h2_sB = n.sb;
     g_mode_thread = 3;
     on = true;
   }
@@ -849,6 +855,7 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
                              long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
                              const float* bias, int bias_mode, const float* resid, long ldr, long sR, int act,
                              float alpha, float* workspace, long ws_bytes, void* stream) {
+  const H2Next h2n = h2_take();
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0) return (int)hipErrorInvalidValue;
   GemmParams p = {};
@@ -861,7 +868,7 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.fastA = p.vecA && (!transA || M % 4 == 0);
   p.fastB = p.vecB && (transB || N % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
-  H2Guard h2(p);
+  H2Guard h2(p, h2n);
   if (!transA && transB) return launch_cfg<A_ROWK, B_NK>(p, batch, workspace, ws_bytes, st);
   if (!transA && !transB) return launch_cfg<A_ROWK, B_KN>(p, batch, workspace, ws_bytes, st);
   if (transA && !transB) return launch_cfg<A_COLK, B_KN>(p, batch, workspace, ws_bytes, st);
@@ -1113,6 +1120,7 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
 
 extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, int M, int N, int K, double* stat_part,
                                     int* stat_rows, void* stream) {
+  const H2Next h2n = h2_take();
   GemmParams p = {};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = K; p.ldb = K; p.ldc = N; p.alpha = 1.f;
@@ -1122,7 +1130,7 @@ extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, in
   p.fastB = p.vecB;
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   *stat_rows = p.stat_part ? cdiv(M, 128) : 0;
-  H2Guard h2(p);
+  H2Guard h2(p, h2n);
   return launch_cfg<A_ROWK, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -1134,6 +1142,7 @@ extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, in
 extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int M, int N, int K, const float* resid,
                                    long ldr, const float* bn_x, const float* bn_y, const float* mean, const float* invstd,
                                    const float* gamma, const float* beta, double* part, int* part_rows, void* stream) {
+  const H2Next h2n = h2_take();
   *part_rows = 0;
   if (M <= 0 || N <= 0 || K <= 0 || bn_x == nullptr || part == nullptr) return (int)hipErrorInvalidValue;
   if (bn_y == nullptr && (gamma == nullptr || beta == nullptr)) return (int)hipErrorInvalidValue;
@@ -1151,7 +1160,7 @@ extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, 
   p.stat_part = part;
   p.bnb_x = bn_x; p.bnb_y = bn_y; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
   *part_rows = cdiv(M, 128);
-  H2Guard h2(p);
+  H2Guard h2(p, h2n);
   return launch_cfg<A_ROWK, B_KN>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 

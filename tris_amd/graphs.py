@@ -60,7 +60,10 @@ class GraphedFrozenText:
         self.s_ids = torch.zeros(n, L, device=dev, dtype=torch.int64)
         self.s_ids[:, 0] = 49406
         self.s_ids[:, 1] = 49407
-        with torch.no_grad():
+        from . import ops
+        # (h2 products tag their operands with words of a PER-STEP amax pool: a graph that outlives the step must not hold
+        # such pointers -- this tower is captured, and therefore always runs, in the x3 default: ops.h2_paused)
+        with torch.no_grad(), ops.h2_paused():
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cap):
@@ -290,7 +293,7 @@ class SegmentedTrainStep:
             hidden = _capture(self.g_ftext, self.text, pool_t, lambda: net.backbone.encode_text(self.s_ids)[1])
             self.inline = False
             self.g_faux = G()
-            with torch.no_grad():
+            with torch.no_grad(), ops.h2_paused():
                 ids_all, f_all = _capture(self.g_faux, self.text, pool_t,
                                           lambda: (lambda i: (i, clip_model.encode_text(i)[1]))(ids_all_()))
             at = os.environ.get("TRIS_SEG_TEXT_AT", "layer2")
@@ -506,7 +509,9 @@ def frozen_text(clip_model, ids):
     """encode_text(ids)[1] of a frozen tower through a cached hipGraph (TRIS_HIPGRAPH=0: eager)"""
     import os
     if os.environ.get("TRIS_HIPGRAPH", "1") == "0" or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
-        return clip_model.encode_text(ids)[1]
+        from . import ops
+        with ops.h2_paused():
+            return clip_model.encode_text(ids)[1]
     n, L = ids.shape
     cache = clip_model.__dict__.setdefault("_tris_text_graphs", {})
     key = (n, L, clip_model.token_embedding.weight.data_ptr())

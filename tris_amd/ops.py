@@ -682,6 +682,17 @@ def h2_end_step():
     _H2["live"] = False
 
 
+class h2_paused:
+    """products launched inside run in the default arithmetic (the frozen aux text tower: in the eager step it is replayed from a
+    cached hipGraph, which must not hold pointers into a per-step amax pool -- so it is x3 in every form of the step)"""
+
+    def __enter__(self):
+        self.was, _H2["live"] = _H2["live"], False
+
+    def __exit__(self, *a):
+        _H2["live"] = self.was
+
+
 def _h2_slot():
     i = _H2["next"]
     if i >= H2_SLOTS:
@@ -692,7 +703,7 @@ def _h2_slot():
 
 def h2_mark_next(t):
     """call right BEFORE the BatchNorm apply-type launch that writes `t`: that launch also leaves t's amax in a pool word"""
-    if not _H2["live"]:
+    if not _H2["live"] or os.environ.get("TRIS_H2_PRODUCER", "1") == "0":   # (0: developer A/B, every amax from a pre-pass)
         return
     slot = _h2_slot()
     call("tris_amax_next", slot)
