@@ -333,6 +333,30 @@ def main():
                 out["step_graph_segmented"] = {"error": repr(e)}
             finally:
                 os.environ["TRIS_STEP_GRAPH"] = "0"
+        if world == 1 and not a.no_pipeline and reducer is None and os.environ.get("TRIS_STEP_GRAPH", "0") == "0" \
+                and os.environ.get("TRIS_LINEAR_MODE", "") == "" and mode == "x3":
+            # opt-in arithmetic for the Linear / 1x1 products (TRIS_LINEAR_MODE=h2: two fp16 pieces per operand, three f16 MFMAs
+            # per product instead of six bf16 ones, power-of-two operand scales from device-side amaxes; results on the fp32 noise
+            # floor -- tests/test_gpu_h2.py, profiles/r3_h2_study.txt), timed like `value` on the same model.  NOT `value`.
+            try:
+                os.environ["TRIS_LINEAR_MODE"] = "h2"
+                for _ in range(3):
+                    lh = step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    lh = step()
+                hi = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                dth = time.perf_counter() - t0
+                out["linear_mode_h2"] = {"ms_per_step": round(dth / a.steps * 1e3, 3), "img_per_s": round(a.batch * a.steps / dth, 2),
+                                         "host_issue_ms_per_step": round(hi / a.steps * 1e3, 3), "steps": a.steps,
+                                         "losses_last_step": [round(v, 5) for v in lh.tolist()],
+                                         "note": "opt-in (TRIS_LINEAR_MODE=h2); `value` above is all-x3"}
+            except Exception as e:  # reported, never hidden
+                out["linear_mode_h2"] = {"error": repr(e)}
+            finally:
+                os.environ.pop("TRIS_LINEAR_MODE", None)
         if world == 1 and not a.no_cpu_baseline and a.backbone == "clip-RN50":
             out["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in a.cpu_batches.split(",")))
         line = json.dumps(out)
