@@ -878,6 +878,7 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
 // Y[B,Ho,Wo,Cout] = conv3x3(X[B,H,W,Cin], Wt[Cout][3][3][Cin]), pad 1, stride 1|2, optional fused ReLU-less epilogue.
 extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout,
                                     int stride, void* stream) {
+  const H2Next h2n = h2_take();
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   GemmParams p = {};
   p.A = X; p.B = Wt; p.C = Y;
@@ -890,12 +891,14 @@ extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, i
   p.fastB = p.vecB;
   if (const int rows = run_stem_conv1(X, Wt, Y, B, H, W, Cin, Cout, stride, nullptr, (hipStream_t)stream))
     return rows > 0 ? 0 : (int)hipErrorLaunchFailure;
+  H2Guard h2(p, h2n);   // (armed: the implicit GEMM in h2 -- the direct kernels exist in x3 only)
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, nullptr);
 }
 
 // dX[B,H,W,Cin] = conv3x3_transpose(dY[B,H,W,Cout], Wt), stride 1 only: a 3x3 conv of dY with the taps mirrored.
 extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* dX, int B, int H, int W, int Cin,
                                       int Cout, void* stream) {
+  const H2Next h2n = h2_take();
   GemmParams p = {};
   p.A = dY; p.B = Wt; p.C = dX;
   p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
@@ -907,6 +910,7 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   p.fastA = al16(dY) && (Cout % 32 == 0);
   p.fastB = p.vecB;
   if (Cout % 16 != 0) return (int)hipErrorInvalidValue;  // k tile must not straddle taps for the B loader
+  H2Guard h2(p, h2n);
   return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, nullptr);
 }
 
@@ -916,6 +920,7 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
 extern "C" int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, float* dZ, int B, int H, int W, int Cin, int Cout,
                                             const float* bn_x, const float* mean, const float* invstd, const float* gamma,
                                             const float* beta, double* part, int* part_rows, void* stream) {
+  const H2Next h2n = h2_take();
   *part_rows = 0;
   if (bn_x == nullptr || part == nullptr || gamma == nullptr || beta == nullptr) return (int)hipErrorInvalidValue;
   GemmParams p = {};
@@ -933,6 +938,7 @@ extern "C" int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, fl
   if (!stats_eligible(p) || !al) return 0;
   p.stat_part = part;
   p.bnb_x = bn_x; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
+  H2Guard h2(p, h2n);
   return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, part_rows);
 }
 
@@ -1019,6 +1025,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 // dW[Cout][3][3][Cin] = sum over output pixels of dY (x) gathered X.  Split-K over pixels through `workspace`.
 extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin,
                                       int Cout, int stride, float* workspace, long ws_bytes, void* stream) {
+  const H2Next h2n = h2_take();
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   if (9 * Cin <= 32 && Cout <= 32 && workspace != nullptr) {  // the stem's first conv: dedicated single-tile reduction
     const long total = (long)B * Ho * Wo;
@@ -1045,6 +1052,7 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   p.fastA = p.vecA;
   p.fastB = p.vecB;
   hipStream_t st = (hipStream_t)stream;
+  H2Guard h2(p, h2n);   // (armed: A = dY, B = X; the implicit GEMM in h2)
   auto gemm = [&]() { return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, st); };
   // direct kernel (wgrad3x3_direct_kernel) or the implicit GEMM: timed once per shape.  TRIS_WGRAD_DIRECT=0 keeps the GEMM,
   // =1..5 forces a direct configuration where it applies (tests).
@@ -1166,6 +1174,7 @@ extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, 
 
 extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin,
                                            int Cout, int stride, double* stat_part, int* stat_rows, void* stream) {
+  const H2Next h2n = h2_take();
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   GemmParams p = {};
   p.A = X; p.B = Wt; p.C = Y;
@@ -1181,6 +1190,7 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
     return rows > 0 ? 0 : (int)hipErrorLaunchFailure;
   }
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
+  H2Guard h2(p, h2n);
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, stat_rows);
 }
 

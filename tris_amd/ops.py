@@ -682,6 +682,18 @@ def h2_end_step():
     _H2["live"] = False
 
 
+def h2_arm_conv(A, B, cin, cout, kind):
+    """3x3 convolutions: armed, a product runs as the implicit GEMM in h2 -- against the x3 DIRECT kernels that pays from 128
+    channels up (fwd / dgrad / wgrad +24 ... +40 %), at 64 channels for the forward only, never for the stem
+    (profiles/r3_ab_same_box.txt); TRIS_H2_CONV=0 keeps every 3x3 in x3"""
+    if not _H2["live"] or os.environ.get("TRIS_H2_CONV", "1") == "0":
+        return False
+    c = min(cin, cout)
+    if not (c >= 128 or (c >= 64 and kind == "fwd")):
+        return False
+    return h2_arm(A, B)
+
+
 class h2_paused:
     """products launched inside run in the default arithmetic (the frozen aux text tower: in the eager step it is replayed from a
     cached hipGraph, which must not hold pointers into a per-step amax pool -- so it is x3 in every form of the step)"""
@@ -1056,11 +1068,13 @@ class Conv3x3Fn(torch.autograd.Function):
             pass
         elif stats:
             _launch_with_stats(y, B * Ho * Wo, Cout, lambda part, rows: _timed(
-                "conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnstat_f32", P(x), P(w), P(y), B, H, W, Cin, Cout,
-                                                stride, part.data_ptr(), rows, _stream())))
+                "conv3x3_fwd", fl, lambda: (h2_arm_conv(x, ctx.params[0], Cin, Cout, "fwd"),
+                                            call("tris_conv3x3_fwd_bnstat_f32", P(x), P(w), P(y), B, H, W, Cin, Cout,
+                                                 stride, part.data_ptr(), rows, _stream()))[1]))
         else:
             _timed("conv3x3_fwd", fl,
-                   lambda: call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))
+                   lambda: (h2_arm_conv(x, ctx.params[0], Cin, Cout, "fwd"),
+                            call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))[1])
         ctx.stride = stride
         ctx.save_for_backward(x, w)
         return y
@@ -1087,9 +1101,9 @@ class Conv3x3Fn(torch.autograd.Function):
                 import ctypes
                 part = torch.empty(((B * H * W + 127) // 128) * 2 * Cin, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("conv3x3_dgrad_bnbwd", fl, lambda: (call(
+                _timed("conv3x3_dgrad_bnbwd", fl, lambda: (h2_arm_conv(dy, ctx.params[0], Cin, Cout, "dgrad"), call(
                     "tris_conv3x3_dgrad_bnbwd_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
-                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()), rows.value > 0)[1])
+                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()), rows.value > 0)[2])
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
@@ -1099,7 +1113,8 @@ class Conv3x3Fn(torch.autograd.Function):
             elif wp is None or not _timed("conv3x3_dgrad", fl, lambda: _wp_call(
                     "tris_conv3x3_wp_fwd_f32", P(dy), wp[2], wp[3], P(dx), B, H, W, Cout, Cin, 1, None, None, _stream())):
                 _timed("conv3x3_dgrad", fl,
-                       lambda: call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))
+                       lambda: (h2_arm_conv(dy, ctx.params[0], Cin, Cout, "dgrad"),
+                                call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))[1])
 
         def wgrad(o):
             ws = workspace(0)
@@ -1114,8 +1129,8 @@ class Conv3x3Fn(torch.autograd.Function):
                             Cout, P(ws), ws.numel() * 4, _stream()))
                     xin = torch.empty_like(x)   # materialise relu(bn(x)) after all
                     call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
-                return _timed("conv3x3_wgrad", fl, lambda: call(
-                    "tris_conv3x3_wgrad_f32", P(xin), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))
+                return _timed("conv3x3_wgrad", fl, lambda: (h2_arm_conv(dy, xin, Cin, Cout, "wgrad"), call(
+                    "tris_conv3x3_wgrad_f32", P(xin), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))[1])
             _wgrad_arith(run)
         dw = None
         if ctx.needs_input_grad[1]:
