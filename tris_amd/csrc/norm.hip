@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void amax_segments_kernel(const float* __restr
 extern "C" int tris_amax_segments_f32(const float* base, const long* offs, const long* sizes, int nseg, unsigned* slots,
                                       void* stream) {
   if (nseg < 1 || (((uintptr_t)base) & 15)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(amax_segments_kernel, dim3(16, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, base, offs, sizes, slots);
+  hipLaunchKernelGGL(amax_segments_kernel, dim3(128, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, base, offs, sizes, slots);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
