@@ -12,7 +12,8 @@
  *   - `stream` is a hipStream_t (0 = default stream); launches are asynchronous and re-entrant.  The ONLY state the
  *     library keeps is host-side configuration read at launch time: the arithmetic mode of the dense products (a
  *     process-wide default, tris_set_gemm_mode, plus a per-thread override, tris_set_gemm_mode_thread), the autotune
- *     switch with its per-process cache of tuned (tile, split-K) choices (tris_set_autotune).  No entry point keeps
+ *     switch with its per-process cache of tuned (tile, split-K) choices (tris_set_autotune), and the developer options of
+ *     tris_set_option (read from the environment once, when the library is loaded).  No entry point keeps
  *     device state between calls (the SyncBN mailboxes of tris_mbox_* are caller-owned buffers);
  *   - return value: 0 on success, otherwise a hipError_t.
  */
@@ -43,24 +44,18 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
  * read when a product is launched; tris_get_gemm_mode returns the mode in force for the calling thread.  0 = v_mfma_f32_32x32x2_f32 (f32 in, bit-equal to an fmaf chain);
  * 1 = split-bf16 "x3": every fp32 operand is the exact sum of three bf16 pieces, the six significant piece products
  * run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -> fp32-class accuracy (measured: error vs fp64 <= the f32-MFMA
- * path's) at up to 2.6x the f32-MFMA peak;  2 = split-bf16 "x2": two pieces, three products (16-bit significands, relative
- * product error <= 2^-15 -- between fp32 and TF32): an opt-in throughput mode.  Default: 1. */
+ * path's) at up to 2.6x the f32-MFMA peak;  3 = "h2": two fp16 pieces per operand, three f16 MFMAs, power-of-two operand
+ * scales (see tris_h2_next below; selected process-wide it runs with unit scales: tests).  Default: 1. */
 int tris_set_gemm_mode(int mode);
 int tris_set_gemm_mode_thread(int mode);
-/* Pre-split weight operands (x3 arithmetic).  tris_weight_planes_f32 splits weight matrices once per optimiser step into
- * three bf16 planes P[pl][r*ld + c] (same indexing as the fp32 source) and the transposed planes PT[pl][c*pt_ld + r] the
- * data-gradient products use; `table` is a device int64[entries][10] = {src, src row stride, rows, cols, P, P plane
- * stride, PT (or 0), PT row stride, PT plane stride, first 32x32-tile index}, total_tiles = sum of the entries' tiles.
- * The *_wp products take such planes for their B operand ([3][N][K], plane stride `bpl` elements) and return
- * TRIS_WP_UNSUPPORTED (no launch) when planes cannot serve the shape / arithmetic mode -- the caller then uses the fp32
- * entry point.  Replaces the same reference lines as tris_gemm_f32 / tris_conv3x3_fwd_f32 / tris_conv3x3_dgrad_f32. */
-#define TRIS_WP_UNSUPPORTED (-2)
-int tris_weight_planes_f32(const long* table, int entries, long total_tiles, void* stream);
-int tris_gemm_wp_f32(const float* A, const void* Bplanes, long bpl, float* C, int M, int N, int K, const float* bias,
-                     const float* resid, int act, float* workspace, long workspace_bytes, double* stat_part,
-                     int* stat_rows, void* stream);
-int tris_conv3x3_wp_fwd_f32(const float* X, const void* Wplanes, long bpl, float* Y, int B, int H, int W, int Cin, int Cout,
-                            int stride, double* stat_part, int* stat_rows, void* stream);
+/* Developer options (tests, tools): name = FORCE_TILE (128x128|128x64|64x64|128x32|256x128), FORCE_PIPE (0|1), PIPE (0|1),
+ * CONV_DIRECT (0 = implicit GEMM only, 1..6 = that direct configuration where it applies), WGRAD_DIRECT (0, 1..5), BN_FOLD (0|1),
+ * STEM_CONV1 (0|1), WG_BLOCKS (n), TUNE_LOG (file); a leading "TRIS_" is accepted; value NULL or "" restores the default.  Initial
+ * values come from the environment variables TRIS_<name>, read once when the library is loaded -- nothing reads the environment
+ * per call.  tris_set_conv_direct_thread: CONV_DIRECT for the products of the calling thread only (-1 = none): batch-invariant
+ * evaluation pins the implicit 3x3 kernels this way. */
+int tris_set_option(const char* name, const char* value);
+int tris_set_conv_direct_thread(int value);
 
 /* (tile, split-K) selection of the dense-product kernels: 1 (default; env TRIS_AUTOTUNE) = every admissible pair is timed
  * once per product shape on first use and the fastest is cached for the process; 0 = the static cycle model (deterministic
@@ -146,13 +141,20 @@ int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, float* dZ, in
                                  const float* beta, double* part, int* part_rows, void* stream);
 int tris_part_finalize_f32(const double* part, int rows, int C, float* out0, float* out1, void* stream);
 
-/* Opt-in arithmetic "h2" for single dense products: two fp16 pieces per operand, three f16 MFMAs per
- * product (half the matrix work of the x3 default), operands scaled by a power of two so that fp16's exponent range holds them.
+/* Arithmetic "h2" for single dense products: an operand x, multiplied by a power of two s that brings the
+ * largest magnitude of its TENSOR (or an upper bound of it) to [2^13, 2^14), is held as two fp16 pieces, x s = hi + lo' 2^-11
+ * (hi = fp16(x s), lo' = fp16((x s - hi) 2^11): 22 significand bits + sign); a product is three f16 MFMAs -- hi x hi into one fp32
+ * accumulator, hi x lo' and lo' x hi into a second that joins with the weight 2^-11 in the epilogue -- half the matrix work of the
+ * x3 default.  Because lo' is stored pre-scaled it stays a normal fp16 number as long as hi does: an element keeps all 22 bits
+ * down to 2^-27 of the tensor's maximum; below that the error is absolute, <= 2^-49 of the maximum.  Error of a product:
+ * fp32-class relative term + K amaxA amaxB 2^-49.
  * An amax word is 2048 unsigned words (8 KB: 8 XCDs x 16 cache lines with one used word each; the consumer takes the max).
  * tris_amax_bits_f32: atomic max of |x| as a bit pattern into that block (zero it first).  tris_h2_next: arms the CALLING THREAD -- the
- * next tris_gemm_f32 / tris_gemm_bnstat_f32 / tris_gemm_bnbwd_f32 it launches runs in h2 with operand A scaled from *amaxA (or,
- * amaxA == NULL, by scaleA; 0 = 1.0) and B likewise; products the fast kernel does not serve run as usual.  One shot.
- * tris_set_gemm_mode(3) selects h2 process-wide with unit scales (tests). */
+ * next dense product it launches (tris_gemm_f32, tris_gemm_bnstat_f32, tris_gemm_bnbwd_f32, tris_conv3x3_{fwd,fwd_bnstat,dgrad,
+ * dgrad_bnbwd,wgrad,fwd_bnin,wgrad_bnin}_f32) runs in h2 with operand A scaled from *amaxA (or, amaxA == NULL, by scaleA; 0 = 1.0)
+ * and B likewise; products the fast kernels do not serve run as usual.  One shot: an arming never survives the call it was made for.
+ * Operand order: forward / data gradient A = activation, B = weights; weight gradients A = dY, B = the convolution's input (for the
+ * *_bnin forms: the bound word of tris_bn_out_bound_f32, since relu(bn(X)) is never materialised). */
 int tris_amax_bits_f32(const float* x, long n, unsigned* out, void* stream);
 /* the same for nseg tensors base + offs[i] (sizes[i] floats; device arrays) in one launch -> slots[i]: the weights of an arena */
 int tris_amax_segments_f32(const float* base, const long* offs, const long* sizes, int nseg, unsigned* slots, void* stream);
@@ -161,6 +163,10 @@ int tris_amax_segments_f32(const float* base, const long* offs, const long* size
  * h2 operand as a by-product of the pass that produces the tensor, instead of a pass of its own */
 int tris_amax_next(unsigned* out);
 int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB);
+/* *out (an amax word, zeroed by the caller) <- bits of max over c of |gamma[c]| * xhat_max + |beta[c]|: an upper bound of
+ * |bn(x)| (and of relu(bn(x))) for a train-mode BatchNorm over `count` rows when xhat_max = sqrt(count - 1) (Samuelson's inequality:
+ * no element lies further than sqrt(n - 1) standard deviations from the mean) */
+int tris_bn_out_bound_f32(const float* gamma, const float* beta, int C, float xhat_max, unsigned* out, void* stream);
 int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const float* X, const float* mean, const float* invstd,
                            long M, int C, float* sum_dz, float* sum_dzx, float* workspace, const float* gamma_mask,
                            const float* beta_mask, float* dz_out, void* stream);
@@ -265,7 +271,8 @@ int tris_xattn_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const 
  * words (tris_xattn_fused_sync_words(B) of them), ZEROED once at allocation and then only passed back -- word 0 counts the
  * completed launches (the epoch that tags the exchange flags lives on the device, so a captured launch replays correctly),
  * word 2 != 0 after a launch means a wait timed out (outputs undefined).  One sync buffer per stream that may run the kernel.
- * Returns TRIS_WP_UNSUPPORTED (-2) without launching anything when the shape / arithmetic mode is outside its domain. */
+ * Returns TRIS_DECLINED (-2) without launching anything when the shape / arithmetic mode is outside its domain. */
+#define TRIS_DECLINED (-2)
 long tris_xattn_fused_ws_bytes(int B, int N, int C);
 long tris_xattn_fused_sync_words(int B);
 int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,

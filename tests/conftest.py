@@ -39,3 +39,13 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_options(request):
+    """developer options of the kernel library (tris_amd.ops.set_option) do not leak from one GPU test into the next"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and "tris_amd.ops" in sys.modules:
+        o = sys.modules["tris_amd.ops"]
+        for name in ("FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS"):
+            o.set_option(name, None)

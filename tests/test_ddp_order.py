@@ -125,7 +125,7 @@ def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
     from tris_amd.utils.shapes import _build_tris
     _install_standins(monkeypatch)
     monkeypatch.setattr(model_stage1, "_overlap_enabled", lambda: bool(overlap))
-    monkeypatch.setenv("TRIS_TEXT_AT", "layer2" if overlap == "mid" else "start")
+    monkeypatch.setattr(model_stage1.cfg, "text_at", "layer2" if overlap == "mid" else "start")
     monkeypatch.setattr(model_stage1, "_side_stream", lambda dev: _FakeStream())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _FakeStream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
@@ -207,7 +207,7 @@ def test_round1_plan_would_have_been_caught(monkeypatch):
     from tris_amd.utils.shapes import _build_tris
     _install_standins(monkeypatch)
     monkeypatch.setattr(model_stage1, "_overlap_enabled", lambda: True)
-    monkeypatch.setenv("TRIS_TEXT_AT", "start")
+    monkeypatch.setattr(model_stage1.cfg, "text_at", "start")
     monkeypatch.setattr(model_stage1, "_side_stream", lambda dev: _FakeStream())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _FakeStream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())

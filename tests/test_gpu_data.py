@@ -181,10 +181,8 @@ def test_script_level_main_trains_validates_checkpoints_and_resumes(tmp_path):
     oIoU, mIoU, hit = res[0]
     assert abs(float(mIoU) - best["val_acc"]) < 1e-3 and hit == best["val_hit"]
     # the CPU DataLoader path (the reference's loader) feeds the same loop
-    os.environ["TRIS_HBM_LOADER"] = "0"
-    try:
+    from tris_amd.config import cfg
+    with cfg.override(hbm_loader=False):
         res2 = main(get_parser().parse_args(argv + ["--resume", "--eval", "--pretrain", os.path.basename(best["path"])]),
                     tokenizer=word_hash_tokenize)
-    finally:
-        del os.environ["TRIS_HBM_LOADER"]
     assert abs(float(res2[0][1]) - float(mIoU)) < 1e-4 and res2[0][2] == hit

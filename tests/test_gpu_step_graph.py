@@ -17,9 +17,8 @@ def _run(mode, steps=4, B=3, backbone="clip-RN50"):
     from tris_amd.optim import FusedAdamW
     from tris_amd.train_stage1 import freeze_aux, train_step
     from tris_amd.utils.synth import seed_fill, synthetic_batch
-    old = os.environ.get("TRIS_STEP_GRAPH")
-    os.environ["TRIS_STEP_GRAPH"] = mode
-    try:
+    from tris_amd.config import cfg
+    with cfg.override(step_graph=mode):
         args = get_parser().parse_args(["--backbone", backbone, "--size", "320", "--negative_samples", "3", "--max_query_len", "20"])
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -47,11 +46,6 @@ def _run(mode, steps=4, B=3, backbone="clip-RN50"):
                  "bn": [(m.running_mean.clone(), m.running_var.clone(), int(m.num_batches_tracked)) for m in bns],
                  "lr": [g["lr"] for g in opt.param_groups], "steps": opt._steps}
         return torch.stack(losses), state, replayed
-    finally:
-        if old is None:
-            os.environ.pop("TRIS_STEP_GRAPH")
-        else:
-            os.environ["TRIS_STEP_GRAPH"] = old
 
 
 @pytest.fixture(scope="module")

@@ -17,6 +17,7 @@ from typing import List, Union
 
 import torch
 
+from ...config import cfg
 from .model import ARCH, CLIP, build_model
 
 __all__ = ["available_models", "load", "tokenize", "allow_random_init", "random_init"]
@@ -43,7 +44,7 @@ class random_init:
 
 
 def _random_init_ok():
-    return (os.environ.get("TRIS_RANDOM_INIT") == "1") if _RANDOM_INIT_OK is None else _RANDOM_INIT_OK
+    return cfg.random_init if _RANDOM_INIT_OK is None else _RANDOM_INIT_OK
 
 
 def _tok():

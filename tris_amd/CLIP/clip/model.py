@@ -14,13 +14,13 @@ be constructed, moved and (de)serialised anywhere, `forward` needs the GPU.
 """
 from collections import OrderedDict
 
-import os
 
 import numpy as np
 import torch
 from torch import nn
 
 from ... import ops
+from ...config import cfg
 
 
 class Conv2d(nn.Module):
@@ -116,21 +116,20 @@ class Bottleneck(nn.Module):
         there rides a GradBox -- so bn3's backward reduction may be fused into that consumer's data gradient (needs the
         GradBox path: with TRIS_GRAD_BOX=0 the residual gradient reaches the output through autograd as a second term)"""
         tr = self.training  # train mode: BatchNorm batch statistics come out of the producing conv's epilogue
-        link_out = link_out and os.environ.get("TRIS_GRAD_BOX", "1") != "0"
+        link_out = link_out and cfg.grad_box
         # identity block: x feeds conv1 and the residual add; the residual gradient rides conv1's data-gradient epilogue
         # down-sampling block: the shortcut's input gradient (avg-pool or 1x1 conv backward) rides along the same way
         box = ops.GradBox() if (tr and torch.is_grad_enabled() and x.requires_grad
-                               and os.environ.get("TRIS_GRAD_BOX", "1") != "0") else None
+                               and cfg.grad_box) else None
         out = self.conv1(x, stats=tr, grad_box=box)
         # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
         # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
         out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout), bwd_link=True)
-        out = ops.cut_fine(out)   # (optional finer segment boundaries of a segmented capture: TRIS_SEG_FINE=1)
         if self.stride > 1:   # bn2 + ReLU + AvgPool2d(stride) as one op
             out = self.bn2(self.conv2(out, stats=tr), relu=True, pool=True)
         else:
             out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: conv3
-        out = self.conv3(ops.cut_fine(out), stats=tr)
+        out = self.conv3(out, stats=tr)
         if self.downsample is not None:
             if isinstance(self.downsample[0], AvgPool2d):
                 idn = self.downsample[1](self.downsample[0](x, grad_box_out=box), stats=tr)
@@ -282,7 +281,7 @@ class ResidualAttentionBlock(nn.Module):
         # x feeds a LayerNorm and, through the residual add fused into the closing Linear, the block output.  The Linear's
         # backward runs first (the LayerNorm's depends on it), leaves its residual gradient in a GradBox, and the
         # LayerNorm backward kernel adds it while writing dX: no separate accumulation pass, no copy.
-        use_box = torch.is_grad_enabled() and x.requires_grad and os.environ.get("TRIS_GRAD_BOX", "1") != "0"
+        use_box = torch.is_grad_enabled() and x.requires_grad and cfg.grad_box
         b1 = ops.GradBox() if use_box else None
         b2 = ops.GradBox() if use_box else None
         h = self.ln_1(x, b1)

@@ -11,10 +11,12 @@ SyncBatchNorm statistics.  Both go through the helpers below so that one place d
     only the wire differs.
 """
 import ctypes
-import os
+
 
 import torch
 import torch.distributed as dist
+
+from .config import cfg
 
 
 def backend(group=None):
@@ -78,9 +80,10 @@ class Mailbox:
     _by_group = {}
     CAP = 3 * 4096           # floats per sender block: [mean|invstd|var] of the widest BatchNorm (2048 channels) with headroom
     # polls before an exchange gives up, raises the error flag and poisons its outputs with NaN.  A poll is an uncached
-    # system-scope load + s_sleep 8 (~1-2.5 us): 4e8 polls is ~10 minutes, the scale of the NCCL watchdog (rank 0 alone writes
-    # the checkpoints -- up to two > 1 GB saves per epoch -- while its peers already sit in the next step's first exchange)
-    SPIN_LIMIT = int(os.environ.get("TRIS_MBOX_SPIN", "400000000"))
+    # system-scope load + s_sleep 8 (~1-2.5 us): the default 4e7 polls is about a minute -- a dead peer fails the step instead of
+    # pinning a spinning workgroup on every surviving GPU for long (the slow-rank-0 case, checkpoint saves, is covered by the
+    # barrier train_stage1.main puts behind them); cfg.mbox_spin / TRIS_MBOX_SPIN
+    SPIN_LIMIT = cfg.mbox_spin
 
     def __init__(self, group):
         from . import _lib
@@ -185,7 +188,7 @@ class Mailbox:
         if key in cls._by_group:
             return cls._by_group[key]
         made = None
-        if os.environ.get("TRIS_SYNCBN_COMM", "mailbox") == "mailbox" and not torch.cuda.is_current_stream_capturing():
+        if cfg.syncbn_comm == "mailbox" and not torch.cuda.is_current_stream_capturing():
             made = cls.__new__(cls)
             try:
                 made.__init__(group)     # (always reaches its collective handle exchange, whatever fails locally)

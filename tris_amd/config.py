@@ -1,0 +1,78 @@
+"""Run-time configuration of the package.
+
+Every knob is read from the environment ONCE, when this module is imported, and lives on the object `cfg` as a plain
+attribute.  Product code reads `cfg.<name>` -- nothing reads `os.environ` per call.  Tests and tools change a value by
+assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", False)`) or for a scope with
+`cfg.override(step_graph="seg")`.  Options of the kernel library itself (tile / kernel forcing, tune log) go through
+`tris_amd.ops.set_option` -> `tris_set_option` (include/tris_hip.h), which follows the same rule on the C side.
+
+  attribute          environment variable      meaning
+  step_graph         TRIS_STEP_GRAPH           training step: "seg" = chain of single-stream hipGraphs, "1" = one hipGraph, "0" = eager
+  hipgraph           TRIS_HIPGRAPH             evaluation forwards and the frozen aux text tower replayed from hipGraphs
+  text_stream        TRIS_TEXT_STREAM          text encoders on a side stream
+  wgrad_stream       TRIS_WGRAD_STREAM         weight gradients on a side stream
+  stream_probe       TRIS_STREAM_PROBE         probe side streams onto their own hardware queues (ops.place_streams)
+  stream_probe_log   TRIS_STREAM_PROBE_LOG     print the queue classes found
+  text_at            TRIS_TEXT_AT              where TRIS.forward issues its text encoder: "layer4" | "layer2" | "start"
+  bn_bwd_fuse        TRIS_BN_BWD_FUSE          BatchNorm-backward reductions in the consuming product's epilogue
+  bn_pool            TRIS_BN_POOL              BatchNorm + ReLU + AvgPool2d(2) as one op
+  grad_box           TRIS_GRAD_BOX             residual-branch gradients handed to the consuming product's epilogue
+  mha                TRIS_MHA                  attention kernel: "auto" | "valu" | "mfma"
+  xattn_fused        TRIS_XATTN_FUSED          cross attention as one persistent launch where it applies
+  hbm_loader         TRIS_HBM_LOADER           HBM-resident input pipeline (0: the reference's DataLoader)
+  eval_group         TRIS_EVAL_GROUP           refs per batched evaluation group
+  mbox_spin          TRIS_MBOX_SPIN            bound of the SyncBatchNorm mailbox spin (polls)
+  syncbn_comm        TRIS_SYNCBN_COMM          "mailbox" | "c10d"
+  ddp_check          TRIS_DDP_CHECK            NaN-poison check of the gradient reducer's release order
+  ddp_sparse_embed   TRIS_DDP_SPARSE_EMBED     token-embedding gradient as a sparse (ids, rows) exchange
+  random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
+"""
+import contextlib
+import os
+
+
+def _flag(name, default):
+    v = os.environ.get(name)
+    return default if v is None or v == "" else v != "0"
+
+
+class _Config:
+    def __init__(self):
+        e = os.environ.get
+        self.step_graph = e("TRIS_STEP_GRAPH", "0")
+        self.hipgraph = _flag("TRIS_HIPGRAPH", True)
+        self.text_stream = _flag("TRIS_TEXT_STREAM", True)
+        self.wgrad_stream = _flag("TRIS_WGRAD_STREAM", True)
+        self.stream_probe = _flag("TRIS_STREAM_PROBE", True)
+        self.stream_probe_log = e("TRIS_STREAM_PROBE_LOG") == "1"
+        self.text_at = e("TRIS_TEXT_AT", "layer4")
+        self.bn_bwd_fuse = _flag("TRIS_BN_BWD_FUSE", True)
+        self.bn_pool = _flag("TRIS_BN_POOL", True)
+        self.grad_box = _flag("TRIS_GRAD_BOX", True)
+        self.mha = e("TRIS_MHA", "auto")
+        self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
+        self.hbm_loader = _flag("TRIS_HBM_LOADER", True)
+        self.eval_group = max(1, int(e("TRIS_EVAL_GROUP", "16")))
+        self.mbox_spin = int(e("TRIS_MBOX_SPIN", "40000000"))
+        self.syncbn_comm = e("TRIS_SYNCBN_COMM", "mailbox")
+        self.ddp_check = e("TRIS_DDP_CHECK") == "1"
+        self.ddp_sparse_embed = _flag("TRIS_DDP_SPARSE_EMBED", True)
+        self.random_init = e("TRIS_RANDOM_INIT") == "1"
+
+    @contextlib.contextmanager
+    def override(self, **kw):
+        old = {k: getattr(self, k) for k in kw}   # (AttributeError for an unknown name: no silent typos)
+        try:
+            for k, v in kw.items():
+                setattr(self, k, v)
+            yield self
+        finally:
+            for k, v in old.items():
+                setattr(self, k, v)
+
+    def key(self):
+        """what a captured step depends on (tris_amd.train_stage1: a captured step is re-recorded when it changes)"""
+        return tuple(sorted(self.__dict__.items()))
+
+
+cfg = _Config()

@@ -1,7 +1,7 @@
 // Direct 3x3 convolution kernels and their launchers ("direct 3x3 convolutions"): the A_HALO
 // instantiations of gemm_fast_kernel (forward / data gradient), the direct weight gradient and the stem's first convolution.
-// A translation unit of its own so that it compiles next to gemm_conv.hip, which keeps the dispatch (conv3_dispatch, the
-// entry points) and calls in through the three hidden symbols at the bottom.
+// Translation units of their own (one per arithmetic) so that they compile next to gemm_conv.hip, which keeps the dispatch
+// (conv3_dispatch, the entry points) and calls in through the hidden symbols at the bottom.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -90,8 +90,6 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict
 static int run_stem_conv1(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout, int stride,
                           double* stat_part, hipStream_t st) {
   if (9 * Cin > 28 || Cout > 32 || (stride != 1 && stride != 2)) return 0;
-  static const bool on = !(getenv("TRIS_STEM_CONV1") && getenv("TRIS_STEM_CONV1")[0] == '0');   // developer A/B knob
-  if (!on) return 0;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   const long tiles = cdiv((long)B * Ho * Wo, 32L);
   int nblk = (int)std::min<long>(512, cdiv(tiles, 4L));
@@ -102,7 +100,7 @@ static int run_stem_conv1(const float* X, const float* Wt, float* Y, int B, int 
   return hipGetLastError() == hipSuccess ? nblk : -1;
 }
 
-template <int BKIND>
+template <int BKIND, int PREC>
 int run_halo(GemmParams p, int id, hipStream_t st) {
   const HaloCfg& h = kHalo[id];
   p.hmode = h.hmode;
@@ -110,11 +108,10 @@ int run_halo(GemmParams p, int id, hipStream_t st) {
   p.splitk = 1;
   p.kchunk = p.gC;
   p.xcd_remap = 0;
-  static const bool vec_epi_ok = !(getenv("TRIS_VEC_EPILOGUE") && getenv("TRIS_VEC_EPILOGUE")[0] == '0');
-  p.vecC = vec_epi_ok && (p.N % 4 == 0) && al16(p.C) && (p.ldc % 4 == 0) && (!p.resid || (al16(p.resid) && p.ldr % 4 == 0));
+  p.vecC = (p.N % 4 == 0) && al16(p.C) && (p.ldc % 4 == 0) && (!p.resid || (al16(p.resid) && p.ldr % 4 == 0));
   dim3 grid((unsigned)(halo_tiles_m(p, id) * p.tiles_n), 1, 1);
 #define TRIS_HALO_GO(BM_, BN_, NW_, NWM_, HS_)                                                                          \
-  hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, A_HALO, BKIND, EPI_STD, 1, NW_, 16, 2, NWM_, HS_>), grid, dim3(NW_ * 64), 0, st, p)
+  hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, A_HALO, BKIND, EPI_STD, PREC, NW_, 16, 2, NWM_, HS_>), grid, dim3(NW_ * 64), 0, st, p)
   switch (id) {
     case 1: TRIS_HALO_GO(256, 128, 8, 4, 324); break;
     case 2: TRIS_HALO_GO(256, 64, 4, 4, 324); break;
@@ -141,21 +138,35 @@ int run_halo(GemmParams p, int id, hipStream_t st) {
 // image at nine slot offsets (ds_read_b64_tr_b16 fragments, as in the GEMM's k-major kinds).  Accumulators: 9 taps x 32 x 32
 // per wave (144 registers).  WK > 1: waves share a tile and take alternate window rows (narrow tiles: the stem).
 // Blocks (and the WK waves of a block) write partial tiles to slabs [slice][Co][9 Cin], summed by splitk_reduce_kernel.
-template <int COT, int CIT, int WCO, int WCI, int WK, int R, int OCC = 2, int XW = 16>
+// PREC 3 ("h2", x3_split.h): two fp16 pieces per operand, scales from the amax words of dY and of the convolution's input (for the
+// BatchNorm-folded form: an upper bound of it).  The nine taps' cross products (hi x lo', lo' x hi) do not get nine accumulator
+// sets of their own -- 288 registers -- but ONE transient set per tap and window, folded into the tap's accumulator with its
+// weight 2^-11 before the next tap starts (16 VALU operations per 3 (R x XW / 16 / WK) MFMAs).
+template <int COT, int CIT, int WCO, int WCI, int WK, int R, int OCC = 2, int XW = 16, int PREC = 1>
 __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                                  float* __restrict__ slab, int H, int W, int Ci, int Co,
                                                                  int n_ci_tiles, int units_per_block, int n_units,
                                                                  const float* __restrict__ in_mean, const float* __restrict__ in_invstd,
-                                                                 const float* __restrict__ in_gamma, const float* __restrict__ in_beta) {
+                                                                 const float* __restrict__ in_gamma, const float* __restrict__ in_beta,
+                                                                 const unsigned* __restrict__ amax_dy, const unsigned* __restrict__ amax_x) {
+  constexpr bool H2 = (PREC == 3);
+  constexpr int NPL = H2 ? 2 : 3;   // 16-bit planes per operand
   // XW = window width in pixels: 16 (a 16-pixel k group = one window row) or 8 (= two window rows: W = 40)
   constexpr int NPX = R * XW, NSL = (R + 2) * (XW + 2), PITCH = XW + 2, NG = NPX / 16;
   static_assert(WCO * WCI * WK == 4 && COT == 32 * WCO && CIT == 32 * WCI && NG % WK == 0 && (XW == 16 || XW == 8), "wave layout");
   constexpr int KS_A = COT == 32 ? 64 : 2 * COT + 64, KS_X = CIT == 32 ? 64 : 2 * CIT + 64;  // bytes per k row: odd multiples of 64
   constexpr int PA = NPX * COT / 4 / 256, PX = (NSL * CIT / 4 + 255) / 256;
   static_assert(PA * 256 * 4 == NPX * COT, "dY window / thread count mismatch");
-  __shared__ __attribute__((aligned(16))) char Ash[3 * NPX * KS_A];
-  __shared__ __attribute__((aligned(16))) char Xsh[3 * NSL * KS_X];
+  __shared__ __attribute__((aligned(16))) char Ash[NPL * NPX * KS_A];
+  __shared__ __attribute__((aligned(16))) char Xsh[NPL * NSL * KS_X];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float sc_a = 1.f, sc_x = 1.f;
+  if constexpr (H2) {
+    if (amax_dy != nullptr) sc_a = h2_scale_from_bits(h2_amax_of(amax_dy, lane));
+    if (amax_x != nullptr) sc_x = h2_scale_from_bits(h2_amax_of(amax_x, lane));
+  }
+  auto split_a = [&](const float4& v) { if constexpr (H2) return split4h(v, sc_a); else return split4(v); };
+  auto split_x = [&](const float4& v) { if constexpr (H2) return split4h(v, sc_x); else return split4(v); };
   const int wk = wave % WK, wci = (wave / WK) % WCI, wco = wave / (WK * WCI);
   const int kh = lane >> 5;
   const int co0 = (blockIdx.x / n_ci_tiles) * COT, ci0 = (blockIdx.x % n_ci_tiles) * CIT;
@@ -206,11 +217,11 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
     for (int q = 0; q < PA; ++q) {
       const int j = tid + q * 256;
       const int px = j / (COT / 4), c4 = j - px * (COT / 4);
-      const Split4 sp = split4(ra[q]);
+      const Split4 sp = split_a(ra[q]);
       char* d = Ash + px * KS_A + c4 * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
       *reinterpret_cast<uint2*>(d + NPX * KS_A) = sp.mid;
-      *reinterpret_cast<uint2*>(d + 2 * NPX * KS_A) = sp.lo;
+      if constexpr (!H2) *reinterpret_cast<uint2*>(d + 2 * NPX * KS_A) = sp.lo;
     }
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
@@ -224,11 +235,11 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
           v.z = fmaxf((v.z - x_mu.z) * x_sc.z + x_be.z, 0.f);
           v.w = fmaxf((v.w - x_mu.w) * x_sc.w + x_be.w, 0.f);
         }
-        const Split4 sp = split4(v);
+        const Split4 sp = split_x(v);
         char* d = Xsh + sl * KS_X + c4 * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + NSL * KS_X) = sp.mid;
-        *reinterpret_cast<uint2*>(d + 2 * NSL * KS_X) = sp.lo;
+        if constexpr (!H2) *reinterpret_cast<uint2*>(d + 2 * NSL * KS_X) = sp.lo;
       }
     }
   };
@@ -240,6 +251,34 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
     __syncthreads();
     load_unit(min(u + 1, u_end - 1));   // (unconditional: a load under a branch stalls on itself, see gemm_fast.h)
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (H2) {
+      constexpr int NGW = NG / WK;
+      f16x8 ah[NGW], al[NGW];
+#pragma unroll
+      for (int g = 0; g < NGW; ++g) {
+        const int row = g * WK + wk;
+        ah[g] = __builtin_bit_cast(f16x8, tr_frag8(Ash, KS_A, row * 16 + 8 * kh, m16, lane));
+        al[g] = __builtin_bit_cast(f16x8, tr_frag8(Ash + NPX * KS_A, KS_A, row * 16 + 8 * kh, m16, lane));
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        f32x16 cx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cx[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NGW; ++g) {
+          const int row = g * WK + wk;
+          const int k0 = XW == 16 ? (row + t / 3) * 18 + (t % 3) + 8 * kh : (2 * row + kh + t / 3) * 10 + (t % 3);
+          const f16x8 bh = __builtin_bit_cast(f16x8, tr_frag8(Xsh, KS_X, k0, n16, lane));
+          const f16x8 bl = __builtin_bit_cast(f16x8, tr_frag8(Xsh + NSL * KS_X, KS_X, k0, n16, lane));
+          cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh, cx, 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh, acc[t], 0, 0, 0);
+          cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl, cx, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(cx[r], 1.0f / 2048.0f, acc[t][r]);
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < NG / WK; ++g) {
       const int row = g * WK + wk;   // this wave's k group: 16 pixels = window row `row` (XW 16) or rows 2 row, 2 row + 1 (XW 8)
@@ -289,12 +328,13 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
   if (wk == 0) {
     float* o = slab + (long)blockIdx.y * Co * 9 * Ci;
     const int ci = ci0 + wci * 32 + (lane & 31);
+    const float inv = H2 ? 1.0f / (sc_a * sc_x) : 1.0f;   // (h2: the operand scales leave here -- powers of two, exact)
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        o[((long)co * 9 + t) * Ci + ci] = acc[t][r];
+        o[((long)co * 9 + t) * Ci + ci] = H2 ? acc[t][r] * inv : acc[t][r];
       }
   }
 }
@@ -331,24 +371,29 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+template <int PREC>
 static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co, float* ws,
-                            long ws_bytes, hipStream_t st, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
+                            long ws_bytes, int blocks, hipStream_t st, BnIn bn, const unsigned* amax_dy, const unsigned* amax_x) {
   const WgCfg& c = kWg[id];
-  const int S = wg_slices(id, B, H, W, Ci, Co, ws_bytes);
+  const int S = wg_slices(id, B, H, W, Ci, Co, ws_bytes, blocks);
   if (S < 1) return (int)hipErrorInvalidValue;
   const int units = B * (H / c.r) * (W / kWgXW[id]);
   const int upb = cdiv(units, S);
   const int slices = cdiv(units, upb);
   dim3 grid((unsigned)((Co / c.cot) * (Ci / c.cit)), (unsigned)slices);
   const int nci = Ci / c.cit;
+#define TRIS_WG_GO(...)                                                                                                          \
+  hipLaunchKernelGGL((wgrad3x3_direct_kernel<__VA_ARGS__, PREC>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, \
+                     bn.mean, bn.invstd, bn.gamma, bn.beta, amax_dy, amax_x)
   switch (id) {
-    case 1: hipLaunchKernelGGL((wgrad3x3_direct_kernel<32, 32, 1, 1, 4, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
-    case 2: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 4>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
-    case 3: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 2>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
-    case 4: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 64, 2, 2, 1, 4, 1>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
-    case 5: hipLaunchKernelGGL((wgrad3x3_direct_kernel<64, 32, 2, 1, 2, 8, 2, 8>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, bn.mean, bn.invstd, bn.gamma, bn.beta); break;
+    case 1: TRIS_WG_GO(32, 32, 1, 1, 4, 4, 2, 16); break;
+    case 2: TRIS_WG_GO(64, 32, 2, 1, 2, 4, 2, 16); break;
+    case 3: TRIS_WG_GO(64, 64, 2, 2, 1, 2, 2, 16); break;
+    case 4: TRIS_WG_GO(64, 64, 2, 2, 1, 4, 1, 16); break;
+    case 5: TRIS_WG_GO(64, 32, 2, 1, 2, 8, 2, 8); break;
     default: return (int)hipErrorInvalidValue;
   }
+#undef TRIS_WG_GO
   TRIS_LAUNCH_CHECK();
   const long total = (long)Co * 9 * Ci;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(total / 4, 64)), dim3(256), 0, st, ws, slices, total, dW);
@@ -359,17 +404,29 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
 }  // namespace
 
 #define TRIS_HIDDEN extern "C" __attribute__((visibility("hidden")))
-// params: a GemmParams (same layout in both units: gemm_params.h); dgrad: mirrored-tap weight loader
-TRIS_HIDDEN int tris_internal_run_halo(const void* params, int id, int dgrad, void* stream) {
+// One arithmetic per translation unit (build.sh: -DTRIS_DIRECT_PREC=1 -> x3, =3 -> h2); the stem's first convolution (exact f32
+// MFMA) lives in the x3 unit.
+#ifndef TRIS_DIRECT_PREC
+#error "compile with -DTRIS_DIRECT_PREC=1 or 3"
+#endif
+#define TRIS_CAT2(a, b) a##b
+#define TRIS_DIRECT_NAME(base, prec) TRIS_CAT2(base, prec)
+// params: a GemmParams (same layout in every unit: gemm_params.h); dgrad: mirrored-tap weight loader
+TRIS_HIDDEN int TRIS_DIRECT_NAME(tris_internal_run_halo_p, TRIS_DIRECT_PREC)(const void* params, int id, int dgrad, void* stream) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
-  return dgrad ? run_halo<B_KN_DGRAD>(p, id, (hipStream_t)stream) : run_halo<B_NK>(p, id, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  return dgrad ? run_halo<B_KN_DGRAD, TRIS_DIRECT_PREC>(p, id, st) : run_halo<B_NK, TRIS_DIRECT_PREC>(p, id, st);
 }
-TRIS_HIDDEN int tris_internal_run_wgrad_direct(int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co,
-                                               float* ws, long ws_bytes, void* stream, const float* mean, const float* invstd,
-                                               const float* gamma, const float* beta) {
-  return run_wgrad_direct(id, X, dY, dW, B, H, W, Ci, Co, ws, ws_bytes, (hipStream_t)stream, BnIn{mean, invstd, gamma, beta});
+TRIS_HIDDEN int TRIS_DIRECT_NAME(tris_internal_run_wgrad_direct_p, TRIS_DIRECT_PREC)(
+    int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co, float* ws, long ws_bytes, int blocks,
+    void* stream, const float* mean, const float* invstd, const float* gamma, const float* beta, const unsigned* amax_dy,
+    const unsigned* amax_x) {
+  return run_wgrad_direct<TRIS_DIRECT_PREC>(id, X, dY, dW, B, H, W, Ci, Co, ws, ws_bytes, blocks, (hipStream_t)stream,
+                                            BnIn{mean, invstd, gamma, beta}, amax_dy, amax_x);
 }
+#if TRIS_DIRECT_PREC == 1
 TRIS_HIDDEN int tris_internal_stem_conv1(const float* X, const float* Wt, float* Y, int B, int H, int W, int Cin, int Cout, int stride,
                                          double* stat_part, void* stream) {
   return run_stem_conv1(X, Wt, Y, B, H, W, Cin, Cout, stride, stat_part, (hipStream_t)stream);
 }
+#endif

@@ -38,12 +38,11 @@ static bool wg_ok(int id, int H, int W, int Ci, int Co) {
   const WgCfg& c = kWg[id];
   return W % kWgXW[id] == 0 && H % c.r == 0 && Co % c.cot == 0 && Ci % c.cit == 0 && (id >= 2 || (Co == c.cot && Ci == c.cit));
 }
-// slices: enough blocks for ~3 per CU, bounded by the workspace
-static int wg_slices(int id, int B, int H, int W, int Ci, int Co, long ws_bytes) {
+// slices: enough blocks for ~two per CU (`target` blocks in all), bounded by the workspace
+static int wg_slices(int id, int B, int H, int W, int Ci, int Co, long ws_bytes, int target = 512) {
   const WgCfg& c = kWg[id];
   const int tiles = (Co / c.cot) * (Ci / c.cit);
   const int units = B * (H / c.r) * (W / kWgXW[id]);
-  static const int target = getenv("TRIS_WG_BLOCKS") ? atoi(getenv("TRIS_WG_BLOCKS")) : 512;   // developer knob; 512 = two blocks per CU
   long s = std::max(1, target / tiles);
   s = std::min<long>(s, std::max(1, units / 8));
   const long per = (long)Co * 9 * Ci * (long)sizeof(float);

@@ -10,9 +10,9 @@
 //     16-byte slots (9*i mod 16 is a permutation) -> conflict-free.  The logical k order inside an MFMA is permuted
 //     (lane-half kh, MFMA j  <->  k = 8g + 4kh + j); both operands use the same permutation, the sum is unchanged;
 //     m-contiguous operands (A^T for wgrad, B for dgrad / NN) keep the k-major image and read 4 scalars;
-//   * PREC 1 / 2 (split-bf16 x3 / x2, below): operands are split when the tile is stored, the LDS image is bf16 planes --
-//     row-major [plane][row][FBK + 8] for the k-contiguous kinds, k-major [plane][k][m] read with ds_read_b64_tr_b16 for the
-//     m-contiguous ones;
+//   * PREC 1 (split-bf16 "x3") and PREC 3 (two-piece fp16 "h2", below): operands are split when the tile is stored, the LDS
+//     image is 16-bit planes -- row-major [plane][row][FBK + 8] for the k-contiguous kinds, k-major [plane][k][m] read with
+//     ds_read_b64_tr_b16 for the m-contiguous ones;
 //   * two loop structures:
 //       NSTG = 1 ("classic"): one LDS buffer, register-staged prefetch, two barriers per K tile (compute | store);
 //       NSTG = 2 ("pipelined", PREC >= 1): two LDS stages held in SEPARATE __shared__ objects (so the compiler may interleave
@@ -47,15 +47,16 @@ __device__ __forceinline__ bf16x8 tr_frag8(const char* plane, int ks, int k0, in
 
 // LDS bytes of one operand stage (host + device): see the layout notes in the kernel
 constexpr int gf_stage_floats(int BMN, int FBK, int PREC, bool row_major) {
-  const int NPLN = (PREC == 2 || PREC == 3) ? 2 : 3;
+  const int NPLN = PREC == 3 ? 2 : 3;
   return PREC >= 1 ? (row_major ? BMN * (2 * FBK + 16) * NPLN / 4 : NPLN * FBK * (2 * BMN + 64) / 4)
                    : (row_major ? BMN * (FBK + 4) : FBK * (BMN + 4));
 }
-constexpr int gf_pre_floats(int BN) { return BN * 48; }    // pre-split B stage: BN rows x 64 B x 3 planes, UNPADDED (LDS-DMA image)
-constexpr int gf_halo_floats(int HS) { return HS * 24; }   // HS pixel slots x 3 planes x 16 channels bf16 (no padding)
+constexpr int gf_halo_floats(int HS, int PREC) { return HS * (PREC == 3 ? 16 : 24); }   // HS pixel slots x 3 (h2: 2) planes x 16 channels, 16-bit (no padding)
 constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm, int HS = 0) {
-  if (NSTG == 1) return NW == 8 ? 4 : 2;   // (the classic kernels: two co-resident blocks per CU, as tuned in round 1)
-  const int lds = HS > 0 ? 4 * (gf_halo_floats(HS) + NSTG * gf_stage_floats(BN, FBK, PREC, b_rm))
+  // (the classic kernels: two co-resident 8-wave blocks per CU, as tuned in round 1; h2's 4-wave 128 x 64 / 64 x 64 kernels fit
+  // 128 registers with both accumulator sets and keep four waves per SIMD)
+  if (NSTG == 1) return (NW == 8 || (PREC == 3 && NW == 4 && BM * BN <= 128 * 64)) ? 4 : 2;
+  const int lds = HS > 0 ? 4 * (gf_halo_floats(HS, PREC) + NSTG * gf_stage_floats(BN, FBK, PREC, b_rm))
                          : 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
   const int blocks = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int w = blocks * NW / 4;
@@ -67,7 +68,7 @@ constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, i
 // AK == A_HALO (3x3 convolution, stride 1, x3 arithmetic, FBK 16, NSTG 2, HS > 0): see "direct 3x3" below
 template <int BM, int BN, int AK, int BKIND, int EPI, int PREC, int NW = 4, int FBK = 32, int NSTG = 1, int NWM = 2, int HS = 0>
 __global__ __launch_bounds__(NW * 64, gf_min_waves_per_simd(BM, BN, PREC, NW, FBK, NSTG, AK != A_COLK,
-                                                             BKIND == B_NK || BKIND == B_NK_PRE, HS))
+                                                             BKIND == B_NK, HS))
 void gemm_fast_kernel(GemmParams p) {
   constexpr int NTHR = NW * 64, NWN = NW / NWM;
   // ---- direct 3x3 convolution (A_HALO) ---------------------------------------------------------------------------------------
@@ -82,17 +83,14 @@ void gemm_fast_kernel(GemmParams p) {
   //   1: BM consecutive pixels of the flattened [B, H, W] grid, held in PADDED coordinates (pitch W + 2, one zero row between
   //      images): any H, W; the window is BM + ~2 W slots, so this is for the narrow late stages (W <= 40).
   constexpr bool HALO = (AK == A_HALO);
-  static_assert(!HALO || (PREC == 1 && FBK == 16 && NSTG == 2 && HS % 8 == 4), "A_HALO: x3, 16-channel chunks, pipelined B");
+  static_assert(!HALO || ((PREC == 1 || PREC == 3) && FBK == 16 && NSTG == 2 && HS % 8 == 4), "A_HALO: x3 / h2, 16-channel chunks, pipelined B");
   constexpr int KL = FBK / 4;          // 16-byte pieces per row of a row-major tile
   constexpr int RPASS = NTHR / KL;     // rows of a row-major tile covered per pass
   constexpr int LDK = FBK + 4;
   constexpr bool A_RM = (AK != A_COLK);
-  // B_NK_PRE: the B operand arrives already split -- three bf16 planes [plane][N][K] (weights, split once per step by
-  // tris_weight_planes_f32): 16-byte loads go straight to the LDS planes, no VALU work (x3 only, classic loop only).
-  constexpr bool B_PRE = (BKIND == B_NK_PRE);
-  constexpr bool B_RM = (BKIND == B_NK) || B_PRE;
+  constexpr bool B_RM = (BKIND == B_NK);
+  static_assert(PREC == 0 || PREC == 1 || PREC == 3, "arithmetic: 0 = f32 MFMA, 1 = x3, 3 = h2");
   static_assert(PREC >= 1 || (FBK == 32 && NSTG == 1), "the f32-MFMA path exists as the classic 32-deep loop only");
-  static_assert(!B_PRE || (FBK == 32 && NSTG == 1), "pre-split B planes: 32-deep tiles, one A buffer");   // (launched in x3 arithmetic only)
   static_assert(NW % NWM == 0 && BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0, "wave grid does not tile the block");
   constexpr int WM = BM / NWM, WN = BN / NWN;
   constexpr int FM = WM / 32, FN = WN / 32;
@@ -104,10 +102,9 @@ void gemm_fast_kernel(GemmParams p) {
   const bool b_act = !B_PART || threadIdx.x < BN * FBK / 4;
   // x3 / x2: every operand is split into its bf16 pieces ONCE, when the tile is stored.  Row-major kinds: three planes
   // [plane][row][FBK + 8 pad] (row stride PLB = 2 FBK + 16 bytes: 80 -> 5, 48 -> 3 sixteen-byte slots, both odd, so the 16
-  // lanes of a ds_read_b128 service group fall on 16 distinct slots).  PREC 2 = x2: two pieces, three products
-  // hi.hi + hi.mid + mid.hi (16 significand bits per operand, relative product error <= 2^-15: between fp32 and TF32).
+  // lanes of a ds_read_b128 service group fall on 16 distinct slots).
   constexpr bool A_PL = (PREC >= 1), B_PL = (PREC >= 1);
-  constexpr int NPLN = (PREC == 2 || PREC == 3) ? 2 : 3;  // 16-bit planes per operand (PREC 3: fp16 pieces)
+  constexpr int NPLN = PREC == 3 ? 2 : 3;  // 16-bit planes per operand (PREC 3: fp16 pieces)
   // m-/n-contiguous operands: 16-byte loads along the contiguous dimension, split, 8-byte LDS stores into k-major planes
   // [plane][k][m], and the MFMA fragments (8 consecutive k per lane) are gathered by the LDS transpose read
   // ds_read_b64_tr_b16: per 16-lane group, lane i points at the 8-byte piece [k0 + i/4][m0 + 4(i%4) ..+3] and receives
@@ -116,18 +113,15 @@ void gemm_fast_kernel(GemmParams p) {
   constexpr bool A_TR = (PREC >= 1) && !A_RM, B_TR = (PREC >= 1) && !B_RM;
   constexpr int A_KS = 2 * BM + 64, B_KS = 2 * BN + 64;  // bytes per k row of a k-major plane
   constexpr int PLB = 2 * FBK + 16;                      // bytes per row of one row-major bf16 plane
-  constexpr int A_SZ = HALO ? gf_halo_floats(HS) : gf_stage_floats(BM, FBK, PREC, A_RM);
-  constexpr int B_SZ = B_PRE ? gf_pre_floats(BN) : gf_stage_floats(BN, FBK, PREC, B_RM);
-  // B_PRE: ONE LDS object [A stage | B stage 0 | B stage 1] -- the B stages are filled by LDS-DMA (global_load_lds), and with a
-  // second __shared__ object in the kernel the compiler drains the DMA queue (vmcnt(0)) in front of every fragment read
-  // (cdna_hip_programming.md, "three .s-level traps")
-  constexpr int AS_ALL = B_PRE ? A_SZ + 2 * B_SZ : A_SZ;
+  constexpr int A_SZ = HALO ? gf_halo_floats(HS, PREC) : gf_stage_floats(BM, FBK, PREC, A_RM);
+  constexpr int B_SZ = gf_stage_floats(BN, FBK, PREC, B_RM);
+  constexpr int AS_ALL = A_SZ;
   __shared__ __attribute__((aligned(16))) float As[AS_ALL];
-  __shared__ __attribute__((aligned(16))) float Bs_[B_PRE ? 4 : B_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs_[B_SZ];
   __shared__ __attribute__((aligned(16))) float As1[(NSTG == 2 && !HALO) ? A_SZ : 4];   // second stage (pipelined loop): separate objects
   __shared__ __attribute__((aligned(16))) float Bs1_[NSTG == 2 ? B_SZ : 4];
-  float* const Bs = B_PRE ? As + A_SZ : Bs_;
-  float* const Bs1 = B_PRE ? As + A_SZ + B_SZ : Bs1_;
+  float* const Bs = Bs_;
+  float* const Bs1 = Bs1_;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -206,32 +200,16 @@ void gemm_fast_kernel(GemmParams p) {
   const int bj_ky = bj_tap / 3, bj_kx = bj_tap - (bj_tap / 3) * 3;
 
   int bw_b[PB], bw_oy[PB], bw_ox[PB];  // B_KN_IM2COL / B_KN_DGRAD: running coordinates of this thread's k rows
-  // B_PRE: the B tile (BN rows x 32 k x 3 planes) goes global -> LDS by DMA, 16 bytes per lane, one wave-instruction = 16 rows
-  // x 64 B = 1 KiB of the (lane-linear, unpadded) stage image.  ds_read_b128 fragment reads of an unpadded 64-byte-row image
-  // would be 4-way bank conflicts (rows 4 apart share their 16-byte slots), so the four 16-byte pieces of row r are stored
-  // rotated by (r >> 2) & 3 -- applied on the SOURCE address here and in frag_B (rule: same involution on both sides).
-  constexpr int PRE_WL = B_PRE ? (3 * BN / 16) / NW : 1;   // wave-instructions per wave per tile
-  static_assert(!B_PRE || PRE_WL * NW * 16 == 3 * BN, "pre-split B: tile rows / wave count mismatch");
-  const unsigned short* pre_src[PRE_WL];
-  int pre_dst[PRE_WL];   // byte offset of this wave-instruction's 1 KiB piece inside a B stage
-  if (B_PRE) {
-#pragma unroll
-    for (int t = 0; t < PRE_WL; ++t) {
-      const int q = wave * PRE_WL + t;              // (wave is wave-uniform: the LDS base below is too)
-      const int pl = q / (BN / 16), rb = q % (BN / 16);
-      const int r = rb * 16 + (lane >> 2);
-      const int jl = (lane & 3) ^ ((r >> 2) & 3);
-      pre_src[t] = reinterpret_cast<const unsigned short*>(p.B) + (long)pl * p.bpl + (long)min(n0 + r, p.N - 1) * p.ldb + jl * 8;
-      pre_dst[t] = pl * BN * 64 + rb * 1024;
-    }
+  // PREC 3 ("h2"): power-of-two operand scales (gemm_params.h): from the bit pattern of the tensor's largest magnitude -- or of an
+  // UPPER BOUND of it -- in device memory, or from the host; the epilogue takes them out again (exact: powers of two)
+  float h2a = 1.f, h2b = 1.f;
+  if constexpr (PREC == 3) {
+    h2a = p.h2_amaxA ? h2_scale_from_bits(h2_amax_of(p.h2_amaxA, lane)) : (p.h2_sA != 0.f ? p.h2_sA : 1.f);
+    h2b = p.h2_amaxB ? h2_scale_from_bits(h2_amax_of(p.h2_amaxB, lane)) : (p.h2_sB != 0.f ? p.h2_sB : 1.f);
   }
-  auto dma_B = [&](float* Bd, int k0) {
-#pragma unroll
-    for (int t = 0; t < PRE_WL; ++t)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_src[t] + k0),
-                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(Bd) + pre_dst[t]), 16, 0, 0);
-  };
-
+  const float h2inv = 1.0f / (h2a * h2b);
+  auto splitA = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2a); else return split4(v); };
+  auto splitB = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2b); else return split4(v); };
   // ---- direct 3x3: window geometry (see the head of the kernel) -------------------------------------------------------------
   constexpr int HP = HALO ? (HS * 4 + NTHR - 1) / NTHR : 1;   // 16-byte pieces (4 channels of one slot) per thread per chunk
   int h_pitch = 0, h_b = 0, h_y0 = 0, h_x0 = 0;
@@ -318,13 +296,13 @@ void gemm_fast_kernel(GemmParams p) {
           v.z = fmaxf((v.z - h_mu.z) * h_sc.z + h_be.z, 0.f);
           v.w = fmaxf((v.w - h_mu.w) * h_sc.w + h_be.w, 0.f);
         }
-        const Split4 sp = split4(v);
+        const Split4 sp = splitA(v);
         // image [plane][channel half kh][slot][8 ch]: a fragment read is 16 lanes x 16 contiguous bytes (conflict-free without
         // padding); the four 8-byte pieces of a slot go to two 64-byte windows HS*16 bytes apart (HS % 8 == 4: disjoint banks)
         char* d = reinterpret_cast<char*>(Ad) + (j >> 2) * 16 + ((j >> 1) & 1) * (HS * 16) + (j & 1) * 8;
         *reinterpret_cast<uint2*>(d) = sp.hi;
         *reinterpret_cast<uint2*>(d + HS * 32) = sp.mid;
-        *reinterpret_cast<uint2*>(d + 2 * HS * 32) = sp.lo;
+        if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * HS * 32) = sp.lo;
       }
     }
   };
@@ -409,15 +387,6 @@ void gemm_fast_kernel(GemmParams p) {
     }
   };
 
-  // PREC 3 ("h2"): power-of-two operand scales (gemm_params.h); the epilogue takes them out again
-  float h2a = 1.f, h2b = 1.f;
-  if constexpr (PREC == 3) {
-    h2a = p.h2_amaxA ? h2_scale_from_bits(h2_amax_of(p.h2_amaxA, lane)) : (p.h2_sA != 0.f ? p.h2_sA : 1.f);
-    h2b = p.h2_amaxB ? h2_scale_from_bits(h2_amax_of(p.h2_amaxB, lane)) : (p.h2_sB != 0.f ? p.h2_sB : 1.f);
-  }
-  const float h2inv = 1.0f / (h2a * h2b);
-  auto splitA = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2a); else return split4(v); };
-  auto splitB = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2b); else return split4(v); };
   // ---- LDS stores: one 16-byte piece (chunk) of a tile at a time, so that the pipelined loop can spread them -----------
   auto store_A = [&](float* Ad, const float4& v, int q) {
     if (A_TR) {
@@ -446,14 +415,7 @@ void gemm_fast_kernel(GemmParams p) {
       *reinterpret_cast<uint2*>(d + FBK * B_KS) = sp.mid;
       if (NPLN == 3) *reinterpret_cast<uint2*>(d + 2 * FBK * B_KS) = sp.lo;
     } else if (B_PL) {
-#ifdef TRIS_EXP_NOBSPLIT   // experiment: what a pre-split (weight) operand would save -- raw bits instead of the split
-      Split4 sp;
-      sp.hi = make_uint2(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y));
-      sp.mid = make_uint2(__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
-      sp.lo = sp.hi;
-#else
       const Split4 sp = splitB(v);
-#endif
       char* d = reinterpret_cast<char*>(Bd) + (trow + q * RPASS) * PLB + (tid % KL) * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
       *reinterpret_cast<uint2*>(d + BN * PLB) = sp.mid;
@@ -465,12 +427,18 @@ void gemm_fast_kernel(GemmParams p) {
     }
   };
   f32x16 acc[FM][FN];
+  // h2: a second accumulator set for the two cross products (hi x lo', lo' x hi), whose lo' pieces carry a factor 2^11 (x3_split.h)
+  constexpr bool H2 = (PREC == 3);
+  f32x16 acx[H2 ? FM : 1][H2 ? FN : 1];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (H2) acx[i][j][r] = 0.f;
+      }
 
   const int li = lane & 31, kh = lane >> 5;
 
@@ -501,11 +469,6 @@ void gemm_fast_kernel(GemmParams p) {
       s.hi = tr_frag8(pl0, B_KS, g * 16 + 8 * kh, n16, lane);
       s.mid = tr_frag8(pl0 + FBK * B_KS, B_KS, g * 16 + 8 * kh, n16, lane);
       if (NPLN == 3) s.lo = tr_frag8(pl0 + 2 * FBK * B_KS, B_KS, g * 16 + 8 * kh, n16, lane);
-    } else if (B_PRE) {
-      const char* s0 = reinterpret_cast<const char*>(Bc) + col * 64 + (((g * 2 + kh) ^ ((col >> 2) & 3)) * 16);
-      s.hi = *reinterpret_cast<const bf16x8*>(s0);
-      s.mid = *reinterpret_cast<const bf16x8*>(s0 + BN * 64);
-      s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * BN * 64);
     } else {
       const char* s0 = reinterpret_cast<const char*>(Bc) + col * PLB + g * 32 + kh * 16;
       s.hi = *reinterpret_cast<const bf16x8*>(s0);
@@ -514,23 +477,23 @@ void gemm_fast_kernel(GemmParams p) {
     }
     return s;
   };
-  auto mfma_x = [&](const Split8& a, const Split8& b, f32x16& c) {  // smallest terms first
-    if constexpr (PREC == 3) {   // two fp16 pieces: lo x hi, hi x lo, hi x hi
+  auto mfma_x = [&](const Split8& a, const Split8& b, int i, int j) {
+    f32x16& c = acc[i][j];
+    if constexpr (H2) {   // two fp16 pieces: hi x hi into acc, the two cross products (x 2^11) into acx -- independent chains
+      f32x16& cx = acx[i][j];
       const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.mid);
       const f16x8 bh = __builtin_bit_cast(f16x8, b.hi), bl = __builtin_bit_cast(f16x8, b.mid);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cx, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-      return;
-    }
-    if (NPLN == 3) {
+      cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cx, 0, 0, 0);
+    } else {              // three bf16 pieces, smallest terms first
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
     }
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
   };
 
   if constexpr (HALO) {
@@ -542,7 +505,7 @@ void gemm_fast_kernel(GemmParams p) {
       const char* s0 = reinterpret_cast<const char*>(As) + (h_rowslot[i] + tapoff) * 16 + kh * (HS * 16);
       s.hi = *reinterpret_cast<const bf16x8*>(s0);
       s.mid = *reinterpret_cast<const bf16x8*>(s0 + HS * 32);
-      s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * HS * 32);
+      if (NPLN == 3) s.lo = *reinterpret_cast<const bf16x8*>(s0 + 2 * HS * 32);
       return s;
     };
     // (chunk, tap) past the end are clamped to the last tile: surplus tiles go to a stage that is never read
@@ -563,7 +526,7 @@ void gemm_fast_kernel(GemmParams p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          mfma_x(sa[i], sb[j], acc[i][j]);
+          mfma_x(sa[i], sb[j], i, j);
           const int want = ((i * FN + j + 1) * PB) / (FM * FN);
 #pragma unroll
           for (int c = 0; c < PB; ++c)
@@ -629,7 +592,7 @@ void gemm_fast_kernel(GemmParams p) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
-            mfma_x(sa[i], sb[j], acc[i][j]);
+            mfma_x(sa[i], sb[j], i, j);
             const int t = (g * FM + i) * FN + j + 1;  // products issued so far
             const int want = (t * NCH) / NPR;
             if (do_store) {
@@ -677,48 +640,6 @@ void gemm_fast_kernel(GemmParams p) {
       step(As, Bs, As1, Bs1, ra1, rb1, false);
       __syncthreads();
     }
-  } else if constexpr (B_PRE) {
-    // ---- pre-split B: A as in the classic loop (registers -> split -> one LDS buffer), B by LDS-DMA into two stages ---------------
-    // per K tile: request A(k+1) into registers and DMA B(k+1) into the idle stage, MFMAs on A | B(k), barrier, split + store
-    // A(k+1), barrier (the DMA has had the whole compute phase to land; the barrier's vmcnt(0) covers it).
-    float4 ra[PA];
-    auto compute = [&](const float* Bc) {
-#pragma unroll
-      for (int g = 0; g < FBK / 16; ++g) {
-        Split8 sa[FM], sb[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) sa[i] = frag_A(As, g, i);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) sb[j] = frag_B(Bc, g, j);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) mfma_x(sa[i], sb[j], acc[i][j]);
-      }
-    };
-    auto step = [&](const float* Bc, float* Bn, int k0) {
-      const bool more = (k0 + FBK) < kend;  // uniform
-      if (more) {
-        load_A(ra, k0 + FBK);
-        dma_B(Bn, k0 + FBK);
-      }
-      compute(Bc);
-      __syncthreads();
-      if (more) {
-#pragma unroll
-        for (int q = 0; q < PA; ++q) store_A(As, ra[q], q);
-        __syncthreads();
-      }
-    };
-    load_A(ra, kbeg);
-    dma_B(Bs, kbeg);
-#pragma unroll
-    for (int q = 0; q < PA; ++q) store_A(As, ra[q], q);
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += 2 * FBK) {
-      step(Bs, Bs1, k0);
-      if (k0 + FBK < kend) step(Bs1, Bs, k0 + FBK);
-    }
   } else {
     // ---- classic loop: one LDS buffer, two barriers per K tile ----------------------------------------------------------------
     float4 ra[PA], rb[PB];
@@ -734,12 +655,10 @@ void gemm_fast_kernel(GemmParams p) {
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += FBK) {
       const bool more = (k0 + FBK) < kend;  // uniform
-#ifndef TRIS_EXP_NOLOAD
       if (more) {
         load_A(ra, k0 + FBK);
         load_B(rb, k0 + FBK);
       }
-#endif
       if constexpr (PREC == 0) {
 #pragma unroll
         for (int g = 0; g < FBK; g += 8) {
@@ -785,21 +704,27 @@ void gemm_fast_kernel(GemmParams p) {
 #pragma unroll
           for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) mfma_x(sa[i], sb[j], acc[i][j]);
+            for (int j = 0; j < FN; ++j) mfma_x(sa[i], sb[j], i, j);
         }
       }
       __syncthreads();
-#ifndef TRIS_EXP_NOSTORE
       if (more) {
         store_lds();
         __syncthreads();
       }
-#endif
     }
   }
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ---------------------
   // (both loops end on a barrier: the staging buffers are free)
+  if constexpr (H2) {   // the cross products join at their weight 2^-11 (exact scaling, one rounding)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]);
+  }
   const float alpha_e = (PREC == 3) ? p.alpha * h2inv : p.alpha;   // (h2: the operand scales leave with alpha; slabs likewise)
   float st_s[FN], st_q[FN];  // fused BatchNorm statistics: per-column sum / sum of squares of this block's rows
 #pragma unroll
@@ -810,8 +735,8 @@ void gemm_fast_kernel(GemmParams p) {
   // kernel.  Each wave instead turns its block around in the idle staging LDS (32 x 36 floats, wave-private: program order
   // + a wave fence) and handles rows: 8 lanes x 16 bytes per row, 8 rows per instruction -- 4 loads/stores per block.
   constexpr int ELD = 36;
-  // waves whose 32 x 36 turn-around block fits an array (B_PRE: everything lives in As)
-  constexpr int EW_A = AS_ALL / (32 * ELD), EW_B = B_PRE ? 0 : B_SZ / (32 * ELD);
+  // waves whose 32 x 36 turn-around block fits an array
+  constexpr int EW_A = AS_ALL / (32 * ELD), EW_B = B_SZ / (32 * ELD);
   constexpr int EW_A1 = (NSTG == 2 && !HALO) ? EW_A : 0, EW_B1 = NSTG == 2 ? EW_B : 0;
   constexpr bool EPI_LDS = EW_A + EW_B + EW_A1 + EW_B1 >= NW;
   float4 vs_s[FN], vs_q[FN];

@@ -1,9 +1,9 @@
-// Shared by the GEMM / convolution translation units (gemm_conv.hip, conv_direct.hip): operand kinds, the launch parameter
-// block and the 16-byte load.  Included INSIDE each unit's anonymous namespace.
+// Shared by the GEMM / convolution translation units (gemm_conv.hip, gemm_inst.hip, conv_direct.hip): operand kinds, the launch
+// parameter block, a launch configuration and the 16-byte load.  Included INSIDE each unit's anonymous namespace.
 #pragma once
 
 enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2, A_HALO = 3 };  // A_HALO: direct 3x3 convolution (gemm_fast.h)
-enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3, B_NK_PRE = 4 };  // B_NK_PRE: pre-split bf16 planes (fast x3 kernel only)
+enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3 };
 enum { EPI_STD = 0, EPI_SLAB = 1 };
 
 struct GemmParams {
@@ -30,7 +30,6 @@ struct GemmParams {
   int xcd_remap;    // fast kernel: place all tiles of one split-K slice on one XCD (see gemm_fast.h)
   int gB;           // images in the gathered tensor (B_KN_IM2COL: bounds the running pixel coordinates of surplus prefetches)
   int wCin, wCout;  // weight geometry for B_KN_DGRAD: W[co][tap][ci]
-  long bpl;         // B_NK_PRE: elements between the bf16 planes of B
   int hmode;        // A_HALO: window shape, 1 = BM consecutive pixels in padded coordinates, 2 = (BM/16) x 16 patches
   // A_HALO, optional: the gathered tensor is the raw input x of a BatchNorm + ReLU; the kernel forms relu(bn(x)) in its window
   const float *in_mean, *in_invstd, *in_gamma, *in_beta;
@@ -42,11 +41,18 @@ struct GemmParams {
   // col_partial_kernel<1> computes in a pass of its own.
   const float *bnb_x, *bnb_y, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
   // PREC 3 ("h2": two fp16 pieces per operand, three f16 MFMAs per product): per-operand power-of-two scales, either derived in
-  // the kernel from the bit pattern of the tensor's largest magnitude in device memory (h2_amaxA / h2_amaxB, written by
-  // tris_amax_bits_f32) or, where that pointer is NULL, given by the host (h2_sA / h2_sB; 0 = 1.0)
+  // the kernel from the bit pattern of the tensor's largest magnitude -- or of an upper bound of it -- in device memory (h2_amaxA /
+  // h2_amaxB: amax words, include/tris_hip.h) or, where that pointer is NULL, given by the host (h2_sA / h2_sB; 0 = 1.0)
   const unsigned *h2_amaxA, *h2_amaxB;
   float h2_sA, h2_sB;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// one launch configuration of the family: tile, split-K slices, pipe = 1: the pipelined loop of gemm_fast.h (x3 only: two 16-deep
+// LDS stages, one barrier per K tile; 256 x 128 tiles exist in that form only).  conv3_dispatch / the direct weight gradient
+// store the id of a direct kernel in bm.
+struct Cfg { int bm, bn, splitk, pipe; };
+// do the operands meet the preconditions of gemm_fast_kernel?
+inline bool gemm_fast_ok(const GemmParams& p) { return p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4; }

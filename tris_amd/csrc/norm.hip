@@ -873,6 +873,23 @@ extern "C" int tris_bn_bwd_apply_pool_f32(const float* dYp, const float* X, cons
 
 // largest magnitude of a tensor as a bit pattern (positive floats order like unsigned integers): atomicMax into *out, which the
 // caller zeroes beforehand -- the operand scale of an "h2" product is derived from it inside the GEMM kernel (x3_split.h)
+// upper bound of |bn(x)| over the whole tensor from the affine parameters alone (include/tris_hip.h tris_bn_out_bound_f32): the
+// operand scale of an h2 product whose input relu(bn(x)) is formed inside the consuming kernel and never exists in memory
+__global__ __launch_bounds__(256) void bn_out_bound_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                           float xhat_max, unsigned* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(gamma[c]) * xhat_max + fabsf(beta[c]));
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0) out[0] = __builtin_bit_cast(unsigned, m);   // (one of the word's 128 lines; the others stay zero)
+}
+extern "C" int tris_bn_out_bound_f32(const float* gamma, const float* beta, int C, float xhat_max, unsigned* out, void* stream) {
+  if (C <= 0 || out == nullptr) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_out_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gamma, beta, C, xhat_max, out);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;

@@ -36,12 +36,6 @@ __device__ __forceinline__ Split8 split8(const float4 u, const float4 w) {
 struct Split4 { uint2 hi, mid, lo; };
 __device__ __forceinline__ Split4 split4(const float4 u) {
   Split4 o;
-#ifdef TRIS_EXP_NOSPLIT
-  o.hi.x = __builtin_bit_cast(unsigned, u.x); o.hi.y = __builtin_bit_cast(unsigned, u.y);
-  o.mid.x = __builtin_bit_cast(unsigned, u.z); o.mid.y = __builtin_bit_cast(unsigned, u.w);
-  o.lo = o.hi;
-  return o;
-#endif
   o.hi.x = pk_bf16(u.x, u.y);
   o.hi.y = pk_bf16(u.z, u.w);
   const float r0 = u.x - __builtin_bit_cast(float, o.hi.x << 16), r1 = u.y - __builtin_bit_cast(float, o.hi.x & 0xffff0000u);
@@ -54,9 +48,14 @@ __device__ __forceinline__ Split4 split4(const float4 u) {
 }
 
 
-// ---- two-piece fp16 split ("h2"): x * scale = hi + lo with hi, lo fp16 (11 + 11 significand bits), both round-to-nearest.  The
-// caller's scale is a power of two that brings the tensor's largest magnitude to [2^13, 2^14): hi cannot overflow, the lo piece
-// of everything within 2^-16 of the maximum stays a normal number.  The pieces travel in the same 16-bit planes as the bf16 ones.
+// ---- two-piece fp16 split ("h2"): x * scale = hi + lo' * 2^-11 with hi, lo' fp16 (11 + 11 significand bits + the sign of the
+// residual), both round-to-nearest.  The caller's scale is a power of two that brings the tensor's largest magnitude -- or any
+// upper bound of it -- to [2^13, 2^14), so hi cannot overflow.  The residual is stored PRE-SCALED by 2^11 (lo' = (x - hi) * 2^11,
+// |lo'| <= |hi|): it stays a normal fp16 number for as long as hi does, i.e. an element keeps all 22 bits down to 2^-27 of the
+// tensor's maximum (an unscaled residual would go subnormal 2^-16 below it).  Below that the representation error is ABSOLUTE,
+// <= 2^-36 in scaled units = 2^-49 of the maximum -- the whole scheme is fp32-class relative accuracy plus a fixed-point floor 49
+// bits under the tensor's largest magnitude.  The products hi x lo' and lo' x hi are accumulated apart from hi x hi and join it
+// with the factor 2^-11 in the epilogue (gemm_fast.h).  The pieces travel in the same 16-bit planes as the bf16 ones.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {
@@ -73,8 +72,8 @@ __device__ __forceinline__ Split4 split4h(const float4 u, const float s) {
   o.hi.x = pk_f16(x0, x1);
   o.hi.y = pk_f16(x2, x3);
   const f32x2 h0 = unpk_f16(o.hi.x), h1 = unpk_f16(o.hi.y);
-  o.mid.x = pk_f16(x0 - h0[0], x1 - h0[1]);
-  o.mid.y = pk_f16(x2 - h1[0], x3 - h1[1]);
+  o.mid.x = pk_f16((x0 - h0[0]) * 2048.f, (x1 - h0[1]) * 2048.f);   // (the differences are exact in fp32)
+  o.mid.y = pk_f16((x2 - h1[0]) * 2048.f, (x3 - h1[1]) * 2048.f);
   o.lo = o.mid;
   return o;
 }

@@ -29,7 +29,7 @@
 // 8 + 29 us of a 75 us launch).  Placement-independent.  The epoch that tags the flags lives in device memory (sync[0]) and is
 // advanced by the last workgroup to finish, so a captured launch replays correctly; spins are bounded (sync[2] != 0 afterwards:
 // a peer never published, the outputs of that launch are undefined).  All B * 8 workgroups must be co-resident: the entry point
-// declines (TRIS_WP_UNSUPPORTED) when B * 8 exceeds CUs x workgroups per CU.
+// declines (TRIS_DECLINED) when B * 8 exceeds CUs x workgroups per CU.
 //
 // Measured at B = 48 (tools/xattn_fused_trace.py, s_memtime stamps, median workgroup, us): logits 9.3 | publish 1.7 | wait 2.4 |
 // reduce 2.3 | soft-max 1.1 | publish 1.9 | wait 0.7 | gather 1.7 | new_vis 3.4 | new_lan 5.2 = 31 us per workgroup, 42 us per
@@ -619,7 +619,7 @@ extern "C" int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const 
   // supported: split-bf16 arithmetic, C = 512 | 1024, 8 <= P <= 104 (<= 13 pixel rows per workgroup x 8), N <= 64
   if (tris_get_gemm_mode() < 1 || !(C == 512 || C == 1024) || P < XF_SLOTS || P > 104 || N < 1 || N > 64 || B < 1 ||
       ws == nullptr || sync == nullptr || ws_bytes < xf_plan(B, N, C).total || xf_lds_bytes(P, (N + 15) / 16) > 160 * 1024)
-    return TRIS_WP_UNSUPPORTED;
+    return TRIS_DECLINED;
   {   // every workgroup must be resident at once (they wait for each other)
     static int cus = 0;
     if (cus == 0) {
@@ -629,7 +629,7 @@ extern "C" int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const 
       cus = n;
     }
     const long per_cu = (160L * 1024) / xf_lds_bytes(P, (N + 15) / 16);
-    if ((long)B * XF_SLOTS > (long)cus * (per_cu > 2 ? 2 : per_cu)) return TRIS_WP_UNSUPPORTED;
+    if ((long)B * XF_SLOTS > (long)cus * (per_cu > 2 ? 2 : per_cu)) return TRIS_DECLINED;
   }
   hipStream_t st = (hipStream_t)stream;
   char* w = reinterpret_cast<char*>(ws);

@@ -7,7 +7,7 @@
 Inputs are copied into static buffers; outputs are static buffers owned by the graphs (consume or clone them before
 the next replay).  Capture uses torch's stream-capture plumbing (torch.cuda.graph); every captured node is one of
 this repo's HIP kernels launched through the C ABI on the capturing stream."""
-import os
+
 
 import torch
 
@@ -22,6 +22,9 @@ class GraphedStage1Eval:
         self.s_ids[:, 0] = 49406
         self.s_ids[:, 1] = 49407
         H = img_shape[2]
+        from . import ops
+        # (h2 arithmetic: each graph owns the amax words its launches write and read, cleared inside the graph -- ops.h2_private_pool)
+        self.h2_vis, self.h2_txt = ops.h2_private_pool(), ops.h2_private_pool()
         with torch.no_grad():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -31,10 +34,12 @@ class GraphedStage1Eval:
                     net.forward_cached(v, self.s_ids, H)
             torch.cuda.current_stream().wait_stream(side)
             self.g_vis = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_vis):
+            with self.h2_vis, torch.cuda.graph(self.g_vis):
+                self.h2_vis.reset()
                 self.vis = net.encode_visual(self.s_img)
             self.g_txt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_txt):
+            with self.h2_txt, torch.cuda.graph(self.g_txt):
+                self.h2_txt.reset()
                 self.out = net.forward_cached(self.vis, self.s_ids, H)
 
     def visual(self, img):
@@ -56,14 +61,14 @@ class GraphedFrozenText:
 
     def __init__(self, clip_model, n, L, warmup=2):
         dev = next(clip_model.parameters()).device
-        self.key = (n, L, clip_model.token_embedding.weight.data_ptr())
         self.s_ids = torch.zeros(n, L, device=dev, dtype=torch.int64)
         self.s_ids[:, 0] = 49406
         self.s_ids[:, 1] = 49407
         from . import ops
-        # (h2 products tag their operands with words of a PER-STEP amax pool: a graph that outlives the step must not hold
-        # such pointers -- this tower is captured, and therefore always runs, in the x3 default: ops.h2_paused)
-        with torch.no_grad(), ops.h2_paused():
+        # (h2 products tag their operands with words of a PER-STEP amax pool: a graph that outlives the step must not hold such
+        # pointers -- this tower owns its words, cleared inside the graph; its frozen weights have constant words)
+        self.h2 = ops.h2_private_pool()
+        with torch.no_grad(), self.h2:
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cap):
@@ -74,6 +79,7 @@ class GraphedFrozenText:
             # thread_local: other threads of the process (the collective backend's watchdog, the autograd engine of a previous
             # step) may touch the device while this stream is capturing
             with torch.cuda.graph(self.g, capture_error_mode="thread_local"):
+                self.h2.reset()
                 self.out = clip_model.encode_text(self.s_ids)[1]
 
     def __call__(self, ids):
@@ -251,7 +257,6 @@ class SegmentedTrainStep:
         pool_c, pool_t, pool_w = (torch.cuda.graph_pool_handle() for _ in range(3))
         G = torch.cuda.CUDAGraph
         self.cuts, self.deferred, self.inline, self.cutting, keep = [], [], False, False, []
-        self.fine = os.environ.get("TRIS_SEG_FINE", "0") == "1"   # cuts inside the Bottlenecks too (ops.cut_fine)
         B = self.s_img.shape[0]
         K = self.s_neg.shape[1] if (self.s_neg is not None and args.negative_samples > 0) else 0
 
@@ -275,7 +280,8 @@ class SegmentedTrainStep:
                 self.inline = False
             return out[0], out[1], [sk for _, _, sk in fns]
 
-        self.h2_pool = ops.h2_begin_step()   # (TRIS_LINEAR_MODE=h2: the amax pool the captured launches write; zeroed per replay)
+        self.h2_pool = ops.h2_begin_step()   # (h2 arithmetic: the amax pool the captured launches write; zeroed per replay)
+        self.h2_aux = ops.h2_private_pool()  # (the frozen aux text tower's own words: its graph clears them itself)
         self.h2_arenas = list(ops._H2.get("arenas", [])) if self.h2_pool is not None else []
         ops._SEG = self
         try:
@@ -293,10 +299,10 @@ class SegmentedTrainStep:
             hidden = _capture(self.g_ftext, self.text, pool_t, lambda: net.backbone.encode_text(self.s_ids)[1])
             self.inline = False
             self.g_faux = G()
-            with torch.no_grad(), ops.h2_paused():
+            with torch.no_grad(), self.h2_aux:
                 ids_all, f_all = _capture(self.g_faux, self.text, pool_t,
-                                          lambda: (lambda i: (i, clip_model.encode_text(i)[1]))(ids_all_()))
-            at = os.environ.get("TRIS_SEG_TEXT_AT", "layer2")
+                                          lambda: (self.h2_aux.reset(), (lambda i: (i, clip_model.encode_text(i)[1]))(ids_all_()))[1])
+            at = "layer2"   # the TRIS text encoder starts behind this trunk stage (measured best of stem / layer1..3)
             fwd = _Chain(self.cap, pool_c)
             marks = {}
 
@@ -335,8 +341,8 @@ class SegmentedTrainStep:
             self.g_btext = G()
             _capture(self.g_btext, self.text, pool_t, lambda: torch.autograd.backward(hidden, h.grad))
             self.inline = False
-            n_late = min(int(os.environ.get("TRIS_SEG_LATE", "6")), len(trunk_cuts))
-            split = os.environ.get("TRIS_SEG_SPLIT", "1") != "0"
+            n_late = min(6, len(trunk_cuts))   # segments whose weight gradients are split over the weight-gradient and the text stream
+            split = True
             late_sinks = []
             for k, (x, leaf) in enumerate(reversed(trunk_cuts)):
                 late = k >= len(trunk_cuts) - n_late
@@ -350,7 +356,7 @@ class SegmentedTrainStep:
             # ---- AdamW.  The update is element-wise, so it can be cut where the gradients become final: everything outside the
             # arena span the LATE segments' weight-gradient launches write is complete once the early ones are, and is updated
             # on the compute stream while those last launches still run; the span itself follows the final join.
-            spans = self._late_spans(optimizer, late_sinks) if n_late and os.environ.get("TRIS_SEG_EARLY_OPT", "1") != "0" else None
+            spans = self._late_spans(optimizer, late_sinks) if n_late else None
             self.g_opt_early = None
             if spans:
                 early = []
@@ -427,7 +433,7 @@ class SegmentedTrainStep:
                 e.record(stream)
                 tm.append((name, e))
         mark("start")
-        if self.h2_pool is not None:    # TRIS_LINEAR_MODE=h2: a fresh amax pool, the weights' amaxes (the captured launches
+        if self.h2_pool is not None:    # h2 arithmetic: a fresh amax pool, the weights' amaxes (the captured launches
             self.h2_pool.zero_()        # write / read the same words every replay)
             ops.h2_weights_amax(self.h2_arenas)
         self.s_img.copy_(img, non_blocking=True)
@@ -506,15 +512,14 @@ class SegmentedTrainStep:
 
 
 def frozen_text(clip_model, ids):
-    """encode_text(ids)[1] of a frozen tower through a cached hipGraph (TRIS_HIPGRAPH=0: eager)"""
-    import os
-    if os.environ.get("TRIS_HIPGRAPH", "1") == "0" or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
-        from . import ops
-        with ops.h2_paused():
-            return clip_model.encode_text(ids)[1]
+    """encode_text(ids)[1] of a frozen tower through a cached hipGraph (cfg.hipgraph = False: eager)"""
+    from . import ops
+    from .config import cfg
+    if not cfg.hipgraph or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
+        return clip_model.encode_text(ids)[1]
     n, L = ids.shape
     cache = clip_model.__dict__.setdefault("_tris_text_graphs", {})
-    key = (n, L, clip_model.token_embedding.weight.data_ptr())
+    key = (n, L, clip_model.token_embedding.weight.data_ptr(), ops.get_gemm_mode())
     g = cache.get(key)
     if g is None:
         if len(cache) >= 4:

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..config import cfg
 from ..CLIP import clip
 from ..CLIP.clip.model import Conv2d, Linear
 from .attn import bilateral_prompt
@@ -19,8 +20,7 @@ _SIDE = {}
 
 
 def _overlap_enabled():
-    import os
-    return os.environ.get("TRIS_TEXT_STREAM", "1") != "0" and ops.streams_allowed()
+    return cfg.text_stream and ops.streams_allowed()
 
 
 def _side_stream(device):
@@ -29,8 +29,7 @@ def _side_stream(device):
 
 def _text_issue_point():
     """start | stem | layer1 | layer2 | layer3 | layer4: after which trunk stage the text encoder is issued (TRIS_TEXT_AT)"""
-    import os
-    at = os.environ.get("TRIS_TEXT_AT", "layer4")
+    at = cfg.text_at
     return at if at in ("start", "stem", "layer1", "layer2", "layer3", "layer4") else "layer4"
 
 

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 from ._lib import CONSTS, call, query
+from .config import cfg
 
 EW = CONSTS
 
@@ -67,24 +68,37 @@ def workspace(nbytes):
     return cur
 
 
+# ---- arithmetic of the dense products --------------------------------------------------------------------------------------
+# 'x3' (default): split-bf16 -- three bf16 pieces per fp32 operand, six bf16 MFMAs per product, fp32 accumulate: fp32-class
+#   accuracy at ~2.6x the f32-MFMA rate.
+# 'h2': two fp16 pieces per operand (the residual pre-scaled by 2^11), three f16 MFMAs per product, one power-of-two scale per
+#   TENSOR formed on the device from its largest magnitude: fp32-class accuracy over a 2^27 dynamic range inside a tensor, half the
+#   matrix work of x3 (csrc/x3_split.h, "h2 products" below).  A product whose operands have no amax runs in x3.
+# 'f32': the f32-input MFMA (bit-equal to an fmaf chain).
+_ARITH = "x3"
+
+
 def set_gemm_mode(mode):
-    """'f32' = f32-input MFMA (bit-equal to an fmaf chain); 'x3' = split-bf16 (three bf16 pieces per fp32 operand, six
-    bf16 MFMAs per product, fp32 accumulate): fp32-class accuracy at ~2.6x the f32-MFMA rate; 'x2' = two pieces, three
-    MFMAs: 16-bit significands (relative product error <= 2^-15, between fp32 and TF32) -- a throughput mode, NOT the default."""
-    call("tris_set_gemm_mode", {"f32": 0, "x3": 1, "x2": 2, "h2": 3}[mode])
+    """'x3' | 'h2' | 'f32' (env TRIS_GEMM_MODE at import).  h2 is per product on top of x3: the library's own default
+    arithmetic (tris_set_gemm_mode) stays x3 for whatever cannot run in h2."""
+    global _ARITH
+    assert mode in ("f32", "x3", "h2"), mode
+    call("tris_set_gemm_mode", 0 if mode == "f32" else 1)
+    _ARITH = mode
 
 
-_BWD_MODE = None
+def get_gemm_mode():
+    return _ARITH
 
 
 _TLS = __import__("threading").local()
 
 
 def _set_thread_mode(mode):
-    """per-thread arithmetic override of the dense products (None = none); returns the previous override"""
+    """per-thread arithmetic override of the dense products (None = none; 'f32' | 'x3'); returns the previous override"""
     prev = getattr(_TLS, "mode", None)
     _TLS.mode = mode
-    call("tris_set_gemm_mode_thread", -1 if mode is None else {"f32": 0, "x3": 1, "x2": 2, "h2": 3}[mode])
+    call("tris_set_gemm_mode_thread", -1 if mode is None else {"f32": 0, "x3": 1}[mode])
     return prev
 
 
@@ -92,83 +106,33 @@ def _thread_mode_is_set():
     return getattr(_TLS, "mode", None) is not None
 
 
-def set_backward_gemm_mode(mode):
-    """Arithmetic of the dense products launched from backward (data and weight gradients): None = same as forward,
-    or 'x2' / 'x3' / 'f32'.  Forward results (response maps, losses -- the parity bar) do not depend on it.  Env:
-    TRIS_BWD_GEMM_MODE."""
-    global _BWD_MODE
-    assert mode in (None, "f32", "x3", "x2")
-    _BWD_MODE = mode
-
-
-_WGRAD_MODE = None
-
-
-def set_wgrad_gemm_mode(mode):
-    """Arithmetic of the WEIGHT-gradient products only (Linear / 1x1 / 3x3 conv): None = same as the rest, or 'x2'.
-    A weight gradient is a leaf of the backward graph -- its rounding error is not propagated or amplified any further --
-    and a long reduction (>= B*L or B*H*W terms) in which per-term errors average down.  Env: TRIS_WGRAD_GEMM_MODE."""
-    global _WGRAD_MODE
-    assert mode in (None, "f32", "x3", "x2")
-    _WGRAD_MODE = mode
-
-
-def _wgrad_arith(fn):
-    """run a weight-gradient launch (a callable) under the configured weight-gradient arithmetic"""
-    if _WGRAD_MODE is None:
-        return fn()
-    prev = get_gemm_mode()
-    if prev == _WGRAD_MODE or prev == "f32":
-        return fn()
-    outer = _set_thread_mode(_WGRAD_MODE)   # per-thread override: launches of other threads keep their arithmetic
-    try:
-        return fn()
-    finally:
-        _set_thread_mode(outer)
-
-
-def _bwd_arith(fn):
-    """decorator for the backward of GEMM-bearing Functions: run it under the configured backward arithmetic"""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapper(ctx, *grads):
-        if _BWD_MODE is None:
-            return fn(ctx, *grads)
-        prev = get_gemm_mode()
-        if prev == _BWD_MODE or prev == "f32":
-            return fn(ctx, *grads)
-        outer = _set_thread_mode(_BWD_MODE)   # host-side, this thread only, read at launch time: the launches issued below
-        try:
-            return fn(ctx, *grads)
-        finally:
-            _set_thread_mode(outer)
-    return wrapper
-
-
-def _init_mode_from_env():
-    import os
-    m = os.environ.get("TRIS_GEMM_MODE")
-    if m:
-        set_gemm_mode(m)
-    b = os.environ.get("TRIS_BWD_GEMM_MODE")
-    if b:
-        set_backward_gemm_mode(b)
-    w = os.environ.get("TRIS_WGRAD_GEMM_MODE")
-    if w:
-        set_wgrad_gemm_mode(w)
-
-
 def set_autotune(on):
     """per-shape (tile, split-K) autotuning of the GEMM core on/off (include/tris_hip.h: tris_set_autotune)"""
     call("tris_set_autotune", int(bool(on)))
 
 
-def get_gemm_mode():
-    return ("f32", "x3", "x2", "h2")[_lib.load().tris_get_gemm_mode()]
+def set_option(name, value):
+    """developer option of the kernel library (include/tris_hip.h tris_set_option): FORCE_TILE, FORCE_PIPE, CONV_DIRECT,
+    WGRAD_DIRECT, BN_FOLD, TUNE_LOG, ...; value None restores the default"""
+    call("tris_set_option", name.encode(), None if value is None else str(value).encode())
 
 
-_init_mode_from_env()
+class option:
+    """`with ops.option("CONV_DIRECT", 0): ...` -- a library option for a scope (tests)"""
+
+    def __init__(self, name, value, restore=None):
+        self.name, self.value, self.restore = name, value, restore
+
+    def __enter__(self):
+        set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.restore)
+        return False
+
+
+if os.environ.get("TRIS_GEMM_MODE"):
+    set_gemm_mode(os.environ["TRIS_GEMM_MODE"])
 
 
 def cl_weight(w):
@@ -210,18 +174,10 @@ def cut(x):
     return _SEG.cut(x)
 
 
-def cut_fine(x):
-    """a second class of segment boundaries (inside the Bottlenecks): only where the capture asks for them"""
-    if _SEG is None or not getattr(_SEG, "fine", False):
-        return x
-    return cut(x)
-
-
 def _wgrad_enabled():
-    import os
     if _SEG is not None:
         return True
-    return os.environ.get("TRIS_WGRAD_STREAM", "1") != "0" and streams_allowed()
+    return cfg.wgrad_stream and streams_allowed()
 
 
 # ---- side streams on their own hardware queues ------------------------------------------------------------------------------
@@ -243,7 +199,7 @@ def _calibrated_streams(dev):
     if torch.cuda.is_current_stream_capturing():
         return []               # (no probing under stream capture; not remembered)
     picked = []
-    if os.environ.get("TRIS_STREAM_PROBE", "1") != "0" and hasattr(torch.cuda, "_sleep"):
+    if cfg.stream_probe and hasattr(torch.cuda, "_sleep"):
         main = torch.cuda.current_stream(dev)
         scratch = torch.zeros(64, device=f"cuda:{dev}")
 
@@ -287,7 +243,7 @@ def place_streams(group=None):
     Returns the stream the caller should make current (torch.cuda.set_stream) for all further work, or None to stay."""
     import torch.distributed as dist
     dev = torch.cuda.current_device()
-    if os.environ.get("TRIS_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
+    if not cfg.stream_probe or not hasattr(torch.cuda, "_sleep"):
         return None
     null = torch.cuda.current_stream(dev)
     scratch = torch.zeros(64, device=f"cuda:{dev}")
@@ -336,7 +292,7 @@ def place_streams(group=None):
             dist.barrier(group=group)       # ranks start each probe together: a late peer must not look like a shared queue
             if not probe(r, issue, coll) and backend_cls is None and k < len(reps):
                 backend_cls = k
-    if os.environ.get("TRIS_STREAM_PROBE_LOG") == "1":
+    if cfg.stream_probe_log:
         print(f"[place_streams] queue classes of the candidates {cls}, collective backend on class {backend_cls}", flush=True)
     free = [k for k in range(len(reps)) if k != backend_cls]
     if len(free) < 3:                       # fewer queues than roles: leave everything as the runtime handed it out
@@ -450,22 +406,23 @@ def profile_begin():
 
 
 def profile_end():
-    """-> list of (kind, flops, milliseconds)"""
+    """-> list of (kind, flops, milliseconds, algorithmic bytes)"""
     global _PROF
     rec, _PROF = _PROF, None
     torch.cuda.synchronize()
-    return [(k, f, a.elapsed_time(b)) for k, f, a, b in rec]
+    return [(k, f, a.elapsed_time(b), nb) for k, f, a, b, nb in rec]
 
 
-def _timed(kind, flops, fn, tag=None):
+def _timed(kind, flops, fn, tag=None, nbytes=0):
+    """nbytes: ALGORITHMIC HBM bytes of the launch -- every operand read once, every output written once"""
     if _PROF is None:
         return fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     r = fn()
     b.record()
-    if r is not False:   # (False = a *_wp entry point declined the shape: nothing was launched)
-        _PROF.append((kind if tag is None else f"{kind}:{tag}", flops, a, b))
+    if r is not False:   # (False = the entry point declined the shape: nothing was launched)
+        _PROF.append((kind if tag is None else f"{kind}:{tag}", flops, a, b, nbytes))
     return r
 
 
@@ -483,18 +440,14 @@ class batch_invariant:
         global _BATCH_INVARIANT
         _BATCH_INVARIANT += 1
         if _BATCH_INVARIANT == 1:
-            self._prev = os.environ.get("TRIS_CONV_DIRECT")
-            os.environ["TRIS_CONV_DIRECT"] = "0"      # (read per call by the convolution dispatch)
+            call("tris_set_conv_direct_thread", 0)     # this thread's products only; nothing process-wide is touched
         return self
 
     def __exit__(self, *exc):
         global _BATCH_INVARIANT
         _BATCH_INVARIANT -= 1
         if _BATCH_INVARIANT == 0:
-            if self._prev is None:
-                os.environ.pop("TRIS_CONV_DIRECT", None)
-            else:
-                os.environ["TRIS_CONV_DIRECT"] = self._prev
+            call("tris_set_conv_direct_thread", -1)
         return False
 
 
@@ -516,12 +469,14 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
         C.reshape(M, N).copy_(C4[:M])
         return C
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
-    if _H2["live"] and batch == 1:
+    if batch == 1:
         h2_arm(A, B)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
-        tag=(f"{'T' if tA else 'N'}{'T' if tB else 'N'} M{M} N{N} K{K} b{batch}" if _PROF_SHAPES else None))
+        tag=(f"{'T' if tA else 'N'}{'T' if tB else 'N'} M{M} N{N} K{K} b{batch}" if _PROF_SHAPES else None),
+        nbytes=4.0 * ((M * K if (sA == 0 and batch > 1) else batch * M * K) + batch * K * N
+                      + batch * M * N * (2 if resid is not None else 1)))
     return C
 
 
@@ -563,19 +518,14 @@ def _launch_with_stats(y, M, N, launch):
         y._bn_part = (part, rows.value)
 
 
-def _wp_call(name, *args):
-    """call a *_wp entry point: True if it ran, False if the planes cannot serve this shape (caller falls back)"""
+def _declinable(name, *args):
+    """call an entry point that may decline a shape: True if it ran, False if it returned TRIS_DECLINED (caller falls back)"""
     err = getattr(_lib.load(), name)(*args)
-    if err == -2:   # TRIS_WP_UNSUPPORTED
+    if err == -2:   # TRIS_DECLINED
         return False
     if err != 0:
         raise _lib.TrisHipError(f"{name} failed with hipError_t {err}")
     return True
-
-
-def _planes(w):
-    from . import planes
-    return planes.lookup(w)
 
 
 class GradBox:
@@ -603,40 +553,56 @@ class GradBox:
 
 
 # ----------------------------------------------------------------------------------------------- Linear / 1x1 conv
-# ---- "h2" products (opt-in: TRIS_LINEAR_MODE=h2) -----------------------------------------------------------
-# Linear / 1x1-convolution products of the TRAINING STEP with two fp16 pieces per operand and three f16 MFMAs (half the matrix
-# work of x3).  fp16 holds 11 significand bits per piece but only 5 exponent bits, so every operand is scaled by a power of two
-# derived -- inside the GEMM kernel -- from the tensor's largest magnitude.  That amax is a word in a per-step pool, written
-# either by the pass that PRODUCES the tensor (BatchNorm apply / backward apply: h2_mark_next, no extra traffic) or, for tensors
-# up to 64 MB, by a small pre-pass (tris_amax_bits_f32).  A product whose operands have no amax this step runs in x3 as usual.
-# Measured on the real operands of a step: error indistinguishable from a plain fp32 product (tools/h2_study.py).
-_H2 = {"live": False, "pool": None, "next": 0, "step": 0}
+# ---- "h2" products (ops.set_gemm_mode("h2") / TRIS_GEMM_MODE=h2) -------------------------------------------
+# Every product of the GEMM / convolution family with two fp16 pieces per operand and three f16 MFMAs (half the matrix work of
+# x3).  fp16 holds 11 significand bits per piece but only 5 exponent bits, so every operand is scaled by a power of two derived --
+# inside the kernel -- from the largest magnitude of its tensor; the residual piece is stored pre-scaled by 2^11, which keeps the
+# representation fp32-class over a 2^27 range inside a tensor (csrc/x3_split.h).  The amax is a word in a pool, written
+#   * by the pass that PRODUCES the tensor (BatchNorm apply / backward apply, LayerNorm, elementwise: h2_mark_next, no extra traffic),
+#   * for all parameters of an optimiser arena by ONE launch per step; for other parameters (a frozen model) once, into a pool of
+#     constants, until the parameter is written to,
+#   * for a BatchNorm + ReLU folded into its consuming convolution -- a tensor that never exists -- as an upper bound from the affine
+#     parameters (h2_bound_next),
+#   * otherwise by a small pre-pass (tensors up to 128 MB).
+# A product whose operands have no amax runs in x3.  A "step" is the life of the pool's words: h2_begin_step() clears the pool
+# (train_step calls it; any other entry -- an evaluation forward, a lone op in a test -- starts one on first use or when the pool
+# is full).
+_H2 = {"pool": None, "next": 0, "step": 0, "paused": 0, "arenas": [], "const": None, "const_next": 0, "const_tags": {}}
+_H2_STEP_IDS = [0]       # step ids are unique across the main pool and private pools: a tag never matches another pool's step
 H2_SLOTS = 2048          # amax words per step; a word is H2_SUB unsigned words (csrc/norm.hip amax_raise)
 H2_SUB = 2048
+H2_CONST_SLOTS = 1024
 H2_PREPASS_MAX = 1 << 25
 
 
-def h2_wanted():
-    return os.environ.get("TRIS_LINEAR_MODE", "") == "h2" and get_gemm_mode() == "x3"
+def h2_on():
+    return _ARITH == "h2" and not _H2["paused"] and not _thread_mode_is_set()
 
 
 _H2_ARENAS = []   # weak references to the optimiser arenas whose parameters get their amax from ONE launch per step
 
 
 def h2_register_arena(arena):
-    """an optimiser arena (tris_amd.optim.Arena: .p flat parameter buffer, .params, .offsets)"""
+    """an optimiser arena (tris_amd.optim.Arena: .p flat parameter buffer, .params, .offsets).  Its parameters are updated in
+    place by kernels that do not bump torch's version counters, so they never get a CONSTANT amax word (_h2_const_slot)."""
     import weakref
-    _H2_ARENAS.append(weakref.ref(arena))
+    r = weakref.ref(arena)
+    _H2_ARENAS.append(r)
+    for p in arena.params:
+        p._tris_arena = r       # (the LATEST arena a parameter was put into: an optimiser built later supersedes an earlier one)
 
 
 def _h2_live_arenas():
-    out = []
-    for r in list(_H2_ARENAS):
+    """the registered arenas that still own their parameters (an optimiser object that was superseded by a newer one over the same
+    parameters, or is only kept alive by a reference cycle, is not one), newest first, as many as fit half the pool"""
+    out, words = [], 0
+    for r in reversed(list(_H2_ARENAS)):
         a = r()
-        if a is None:
+        if a is None or not a.params or getattr(a.params[0], "_tris_arena", None) is not r:
             _H2_ARENAS.remove(r)
-        elif _H2["pool"] is not None and a.p.device == _H2["pool"].device:
+        elif _H2["pool"] is not None and a.p.device == _H2["pool"].device and words + len(a.params) <= H2_SLOTS // 2:
             out.append(a)
+            words += len(a.params)
     return out
 
 
@@ -654,20 +620,26 @@ def h2_weights_amax(arenas=None):
     return base
 
 
+def _h2_new_step_id():
+    _H2_STEP_IDS[0] += 1
+    return _H2_STEP_IDS[0]
+
+
 def h2_begin_step():
-    """start of a training step: a fresh amax pool (one memset) + the weights' amaxes (one launch per optimiser arena).
-    Returns the pool (or None when h2 is off)"""
-    if not h2_wanted():
-        _H2["live"] = False
+    """A fresh amax pool (one memset) + the weights' amaxes (one launch per optimiser arena).  Returns the pool (None when the
+    arithmetic is not h2).  Whatever was issued earlier on a side stream may still read the words about to be cleared: the
+    current stream first waits for the side streams."""
+    if _ARITH != "h2":
         return None
-    if _H2["pool"] is None or _H2["pool"].device != torch.device("cuda", torch.cuda.current_device()):
-        _H2["pool"] = torch.zeros(H2_SLOTS * H2_SUB, device="cuda", dtype=torch.int32)
+    wgrad_join()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if _H2["pool"] is None or _H2["pool"].device != dev:
+        _H2["pool"] = torch.zeros(H2_SLOTS * H2_SUB, device=dev, dtype=torch.int32)
     else:
         _H2["pool"].zero_()
-    _H2["step"] += 1
-    _H2["live"] = True
+    _H2["step"] = _h2_new_step_id()
     base = 0
-    arenas = _h2_live_arenas()
+    arenas = _h2_live_arenas() if not _H2.get("private") else []
     for a in arenas:
         for i, p in enumerate(a.params):
             p._h2 = (_H2["step"], _H2["pool"].data_ptr() + 4 * H2_SUB * (base + i), p._version)
@@ -679,71 +651,143 @@ def h2_begin_step():
 
 
 def h2_end_step():
-    _H2["live"] = False
+    """(kept for symmetry with h2_begin_step: the words stay valid until the next begin)"""
 
 
-def h2_arm_conv(A, B, cin, cout, kind):
-    """3x3 convolutions: armed, a product runs as the implicit GEMM in h2 -- against the x3 DIRECT kernels that pays from 128
-    channels up (fwd / dgrad / wgrad +24 ... +40 %), at 64 channels for the forward only, never for the stem
-    (profiles/r3_ab_same_box.txt); TRIS_H2_CONV=0 keeps every 3x3 in x3"""
-    if not _H2["live"] or os.environ.get("TRIS_H2_CONV", "1") == "0":
+class h2_private_pool:
+    """Products launched inside take their per-step amax words from a pool of their own, cleared on entry: a region that is
+    captured into a hipGraph of its own and replayed outside the steps it was recorded in (the frozen aux text tower) must not
+    hold words of the per-step pool.  Parameters inside get constant words (they must not be arena parameters of a live step)."""
+
+    def __init__(self, slots=512):
+        self.slots, self.pool = slots, None
+
+    def __enter__(self):
+        self.active = _ARITH == "h2"
+        if not self.active:
+            return self
+        self.saved = {k: _H2.get(k) for k in ("pool", "next", "step", "arenas", "private", "limit")}
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if self.pool is None or self.pool.device != dev:
+            self.pool = torch.zeros(self.slots * H2_SUB, device=dev, dtype=torch.int32)
+        _H2.update(pool=self.pool, arenas=[], private=True, limit=self.slots)
+        self.reset()
+        return self
+
+    def reset(self):
+        """clear the words and hand them out from the first again (call it as the first thing INSIDE a capture of the region: the
+        memset is then part of the graph, and the words are handed out in the same order at every recording)"""
+        if self.active:
+            self.pool.zero_()
+            _H2.update(next=0, step=_h2_new_step_id())
+
+    def __exit__(self, *exc):
+        if self.active:
+            _H2.update(self.saved)
         return False
-    c = min(cin, cout)
-    if not (c >= 128 or (c >= 64 and kind == "fwd")):
-        return False
-    return h2_arm(A, B)
 
 
 class h2_paused:
-    """products launched inside run in the default arithmetic (the frozen aux text tower: in the eager step it is replayed from a
-    cached hipGraph, which must not hold pointers into a per-step amax pool -- so it is x3 in every form of the step)"""
+    """products launched inside run in x3"""
 
     def __enter__(self):
-        self.was, _H2["live"] = _H2["live"], False
+        _H2["paused"] += 1
 
     def __exit__(self, *a):
-        _H2["live"] = self.was
+        _H2["paused"] -= 1
 
 
 def _h2_slot():
+    limit = _H2.get("limit") or H2_SLOTS
+    if _H2["pool"] is None or (_H2["next"] >= limit and not _H2.get("private")):
+        h2_begin_step()          # first use outside a training step, or the pool is full: a new step
     i = _H2["next"]
-    if i >= H2_SLOTS:
-        raise RuntimeError("h2: amax pool exhausted (more than H2_SLOTS tagged tensors in one step)")
+    if i >= limit:
+        return None              # (a private pool is never restarted: its region would lose words it still reads)
     _H2["next"] = i + 1
     return _H2["pool"].data_ptr() + 4 * H2_SUB * i
 
 
 def h2_mark_next(t):
-    """call right BEFORE the BatchNorm apply-type launch that writes `t`: that launch also leaves t's amax in a pool word"""
-    if not _H2["live"] or os.environ.get("TRIS_H2_PRODUCER", "1") == "0":   # (0: developer A/B, every amax from a pre-pass)
+    """call right BEFORE the launch that writes `t` (BatchNorm apply-type passes, LayerNorm, elementwise): that launch also
+    leaves t's amax in a pool word"""
+    if t is None or not h2_on():
         return
     slot = _h2_slot()
+    if slot is None:
+        return
     call("tris_amax_next", slot)
     t._h2 = (_H2["step"], slot, t._version)
 
 
-def _h2_amax(t):
+def h2_bound_word(gamma, beta, C, xhat_max):
+    """amax word holding an upper bound of |relu(bn(x))| for a train-mode BatchNorm whose output is never written (None: not h2)"""
+    if not h2_on():
+        return None
+    slot = _h2_slot()
+    if slot is not None:
+        call("tris_bn_out_bound_f32", P(gamma), P(beta), C, float(xhat_max), slot, _stream())
+    return slot
+
+
+def _h2_tag_slot(t):
     tag = getattr(t, "_h2", None)
     if tag is not None and tag[0] == _H2["step"] and tag[2] == t._version:
         return tag[1]
-    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
-    if t.numel() <= H2_PREPASS_MAX and dense and t.data_ptr() % 16 == 0 and t.numel() > 0:
-        slot = _h2_slot()
-        call("tris_amax_bits_f32", P(t), t.numel(), slot, _stream())
-        try:
-            t._h2 = (_H2["step"], slot, t._version)
-        except AttributeError:
-            pass
-        return slot
     return None
 
 
-def h2_arm(A, B):
-    """before a dense product of A and B: run it in h2 if both operands have an amax this step (one shot, this thread)"""
-    if not _H2["live"] or _thread_mode_is_set():
+def _h2_const_slot(t):
+    """amax word of a parameter outside the optimiser arenas (a frozen model's): computed once, valid until it is written to"""
+    key = id(t)
+    tag = _H2["const_tags"].get(key)
+    if tag is not None and tag[0] == t._version and tag[1] == t.data_ptr() and tag[3]() is t:
+        return tag[2]
+    if _H2["const"] is None or _H2["const"].device != t.device:
+        _H2["const"] = torch.zeros(H2_CONST_SLOTS * H2_SUB, device=t.device, dtype=torch.int32)
+        _H2["const_next"] = 0
+        _H2["const_tags"].clear()
+    if _H2["const_next"] >= H2_CONST_SLOTS:
+        return None
+    import weakref
+    slot = _H2["const"].data_ptr() + 4 * H2_SUB * _H2["const_next"]
+    _H2["const_next"] += 1
+    call("tris_amax_bits_f32", P(t), t.numel(), slot, _stream())
+    _H2["const_tags"][key] = (t._version, t.data_ptr(), slot, weakref.ref(t))
+    return slot
+
+
+def _h2_amax(t):
+    slot = _h2_tag_slot(t)
+    if slot is not None:
+        return slot
+    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    if not (t.numel() <= H2_PREPASS_MAX and dense and t.data_ptr() % 16 == 0 and t.numel() > 0):
+        return None
+    if isinstance(t, torch.nn.Parameter) and not getattr(t, "_tris_arena", False):
+        slot = _h2_const_slot(t)
+        if slot is not None:
+            return slot
+    slot = _h2_slot()
+    if slot is None:
+        return None
+    call("tris_amax_bits_f32", P(t), t.numel(), slot, _stream())
+    try:
+        t._h2 = (_H2["step"], slot, t._version)
+    except AttributeError:
+        pass
+    return slot
+
+
+def h2_arm(A, B, a_slot=None, b_slot=None):
+    """before a dense product of A and B: run it in h2 if both operands have an amax (one shot, this thread).  a_slot / b_slot: the
+    operand's amax word where the tensor itself is not at hand (a BatchNorm folded into the consuming convolution)"""
+    if not h2_on():
         return False
-    a = _h2_amax(A)
-    b = _h2_amax(B) if a is not None else None
+    a = a_slot if a_slot is not None else (_h2_amax(A) if A is not None else None)
+    b = None
+    if a is not None:
+        b = b_slot if b_slot is not None else (_h2_amax(B) if B is not None else None)
     if a is None or b is None:
         return False
     call("tris_h2_next", a, b, 0.0, 0.0)
@@ -788,13 +832,7 @@ class _BnBwdLink:
 
 
 def _bn_bwd_fuse_enabled():
-    return os.environ.get("TRIS_BN_BWD_FUSE", "1") != "0"
-
-
-def _bn_bwd_fuse_rows(M):
-    """fuse for this many rows?  The fused product cannot split K (its epilogue needs complete sums): below a few thousand rows
-    -- the 10 x 10 stage -- a split-K data gradient + the separate reduction pass is the faster pair (TRIS_BN_BWD_FUSE_MIN_M)"""
-    return M >= int(os.environ.get("TRIS_BN_BWD_FUSE_MIN_M", "0"))
+    return cfg.bn_bwd_fuse
 
 
 class LinearFn(torch.autograd.Function):
@@ -812,28 +850,12 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
         if resid is not None:
             resid = resid.contiguous()
-        wp = _planes(w)
         want_stats = stats and b is None and resid is None and act == 0
-        done = False
-        if wp is not None:   # weights pre-split into bf16 planes (tris_amd.planes)
-            if want_stats:
-                def launch(part, rows):
-                    nonlocal done
-                    done = _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
-                        "tris_gemm_wp_f32", P(x), wp[0], wp[1], P(y), M, N, K, None, None, 0, None, 0, part.data_ptr(),
-                        rows, _stream()))
-                _launch_with_stats(y, M, N, launch)
-            else:
-                ws = workspace(0)
-                done = _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
-                    "tris_gemm_wp_f32", P(x), wp[0], wp[1], P(y), M, N, K, P(b), P(resid), act, P(ws), ws.numel() * 4,
-                    None, None, _stream()))
-        if done:
-            pass
-        elif want_stats:
+        if want_stats:
             _launch_with_stats(y, M, N, lambda part, rows: _timed(
                 "gemm", 2.0 * M * N * K, lambda: (h2_arm(x, w), call("tris_gemm_bnstat_f32", P(x), P(w), P(y), M, N, K,
-                                                                     part.data_ptr(), rows, _stream()))[1]))
+                                                                     part.data_ptr(), rows, _stream()))[1],
+                nbytes=4.0 * (M * K + K * N + M * N)))
         else:
             gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid,
                  ldr=N, act=act)
@@ -844,7 +866,6 @@ class LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @_bwd_arith
     def backward(ctx, dy):
         if ctx.act == 2:
             raise RuntimeError("fused QuickGELU epilogue is forward-only; use QGeluFn when gradients are needed")
@@ -872,10 +893,8 @@ class LinearFn(torch.autograd.Function):
                 extra, box.value = box.value, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wp = _planes(pw)
-            ws = workspace(0)
             link, fused = ctx.bn_link, False
-            if link is not None and wp is None and _bn_bwd_fuse_rows(M):
+            if link is not None:
                 # x is the output of a BatchNorm(+ReLU) that has no other consumer: mask dx and reduce it for that BatchNorm's
                 # backward in this product's epilogue (_BnBwdLink)
                 import ctypes
@@ -884,15 +903,12 @@ class LinearFn(torch.autograd.Function):
                 _timed("gemm_bnbwd", 2.0 * M * N * K, lambda: (h2_arm(dy, w), call(
                     "tris_gemm_bnbwd_f32", P(dy), P(w), P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
                     P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()),
-                    rows.value > 0)[2])     # (False: the entry point declined the shape, nothing was launched)
+                    rows.value > 0)[2],     # (False: the entry point declined the shape, nothing was launched)
+                    nbytes=4.0 * (M * N + N * K + M * K * (2 + int(link.from_y) + int(extra is not None))))
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
-            if fused:
-                pass
-            elif wp is None or not _timed("gemm", 2.0 * M * N * K, lambda: _wp_call(
-                    "tris_gemm_wp_f32", P(dy), wp[2], wp[3], P(dx), M, K, N, None, P(extra), 0, P(ws), ws.numel() * 4, None,
-                    None, _stream())):
+            if not fused:
                 gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K)
         elif extra is not None:
             raise RuntimeError("a residual gradient was handed to a layer whose input needs no gradient")
@@ -901,10 +917,9 @@ class LinearFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if _sink(pw) is not None:   # into the gradient arena, on the weight-gradient stream
-                on_wgrad_stream(lambda: _wgrad_arith(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False)), dy, x,
-                                sink=_sink(pw))
+                on_wgrad_stream(lambda: gemm(dy, x, _sink(pw), N, K, M, N, K, K, True, False), dy, x, sink=_sink(pw))
             else:
-                dw = _emit(pw, lambda o: _wgrad_arith(lambda: gemm(dy, x, o, N, K, M, N, K, K, True, False)), True)
+                dw = _emit(pw, lambda o: gemm(dy, x, o, N, K, M, N, K, K, True, False), True)
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
@@ -936,7 +951,6 @@ class MatmulFn(torch.autograd.Function):
         return C
 
     @staticmethod
-    @_bwd_arith
     def backward(ctx, dC):
         A, B = ctx.saved_tensors
         M, N, K = ctx.dims
@@ -979,7 +993,6 @@ class BmmFn(torch.autograd.Function):
         return C
 
     @staticmethod
-    @_bwd_arith
     def backward(ctx, dC):
         A, B = ctx.saved_tensors
         tB, alpha, shared, Bt, M, N, K = ctx.cfg
@@ -1020,7 +1033,8 @@ class Conv3x3Fn(torch.autograd.Function):
         BatchNorm's backward sums in its epilogue.
         lazy = (x_raw, mean, invstd, gamma, beta): `x` is the NOT-YET-WRITTEN output buffer of a BatchNorm + ReLU over x_raw
         (batch_norm(..., lazy=True)); the direct kernels normalise x_raw while they stage it and `x` is never written -- or, when
-        they cannot serve the shape after all, it is written here first and everything proceeds as usual."""
+        they cannot serve the shape after all, it is written here first and everything proceeds as usual.  (h2: the unwritten
+        buffer carries the amax word of an upper bound of its would-be contents, BatchNormFn.forward.)"""
         _chk(x, w)
         ctx.bn_link = bn_link if (bn_link is not None and stride == 1 and not bn_link.from_y and x.is_contiguous()
                                   and bn_link.x.shape == x.shape) else None
@@ -1028,59 +1042,47 @@ class Conv3x3Fn(torch.autograd.Function):
         ctx.params = (w,)
         w = cl_weight(w)
         B, H, W, Cin = x.shape
+        Cout = w.shape[0]
         ctx.lazy = None
+        ctx.stride = stride
         if lazy is not None:
-            xr, mean, invstd, gamma, beta = lazy
-            if stride == 1 and _planes(ctx.params[0]) is None and conv3x3_bnin_ok(x.shape, w.shape[0]):
-                Cout = w.shape[0]
+            xr, mean, invstd, gamma, beta, bound = lazy
+            if stride == 1 and conv3x3_bnin_ok(x.shape, Cout):
                 y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
                 fl = 2.0 * B * H * W * Cout * 9 * Cin
+                nb = 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout)
+                ctx.h2_in = bound      # (None outside h2)
+
+                def launch(part, rows):
+                    return _timed("conv3x3_fwd", fl, lambda: (bound is not None and h2_arm(None, ctx.params[0], a_slot=bound), call(
+                        "tris_conv3x3_fwd_bnin_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta), P(w), P(y), B, H, W, Cin, Cout,
+                        None if part is None else part.data_ptr(), rows, _stream()))[1], nbytes=nb)
                 if stats:
-                    _launch_with_stats(y, B * H * W, Cout, lambda part, rows: _timed(
-                        "conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnin_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta),
-                                                        P(w), P(y), B, H, W, Cin, Cout, part.data_ptr(), rows, _stream())))
+                    _launch_with_stats(y, B * H * W, Cout, launch)
                 else:
-                    _timed("conv3x3_fwd", fl, lambda: call("tris_conv3x3_fwd_bnin_f32", P(xr), P(mean), P(invstd), P(gamma),
-                                                           P(beta), P(w), P(y), B, H, W, Cin, Cout, None, None, _stream()))
-                ctx.stride = stride
+                    launch(None, None)
                 ctx.lazy = True
                 ctx.save_for_backward(xr, w, mean, invstd, gamma, beta)
                 return y
+            h2_mark_next(x)
             call("tris_bn_apply_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta), None, P(x), B * H * W, Cin, 1, _stream())
-        Cout = w.shape[0]
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
         fl = 2.0 * B * Ho * Wo * Cout * 9 * Cin
-        wp = _planes(ctx.params[0])
-        done = False
-        if wp is not None:
-            if stats:
-                def launch(part, rows):
-                    nonlocal done
-                    done = _timed("conv3x3_fwd", fl, lambda: _wp_call(
-                        "tris_conv3x3_wp_fwd_f32", P(x), wp[0], wp[1], P(y), B, H, W, Cin, Cout, stride, part.data_ptr(),
-                        rows, _stream()))
-                _launch_with_stats(y, B * Ho * Wo, Cout, launch)
-            else:
-                done = _timed("conv3x3_fwd", fl, lambda: _wp_call(
-                    "tris_conv3x3_wp_fwd_f32", P(x), wp[0], wp[1], P(y), B, H, W, Cin, Cout, stride, None, None, _stream()))
-        if done:
-            pass
-        elif stats:
+        nb = 4.0 * (B * H * W * Cin + B * Ho * Wo * Cout + 9 * Cin * Cout)
+        if stats:
             _launch_with_stats(y, B * Ho * Wo, Cout, lambda part, rows: _timed(
-                "conv3x3_fwd", fl, lambda: (h2_arm_conv(x, ctx.params[0], Cin, Cout, "fwd"),
+                "conv3x3_fwd", fl, lambda: (h2_arm(x, ctx.params[0]),
                                             call("tris_conv3x3_fwd_bnstat_f32", P(x), P(w), P(y), B, H, W, Cin, Cout,
-                                                 stride, part.data_ptr(), rows, _stream()))[1]))
+                                                 stride, part.data_ptr(), rows, _stream()))[1], nbytes=nb))
         else:
             _timed("conv3x3_fwd", fl,
-                   lambda: (h2_arm_conv(x, ctx.params[0], Cin, Cout, "fwd"),
-                            call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))[1])
-        ctx.stride = stride
+                   lambda: (h2_arm(x, ctx.params[0]),
+                            call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))[1], nbytes=nb)
         ctx.save_for_backward(x, w)
         return y
 
     @staticmethod
-    @_bwd_arith
     def backward(ctx, dy):
         if ctx.lazy:
             x, w, mean, invstd, gamma, beta = ctx.saved_tensors   # x = the BatchNorm's raw input
@@ -1094,44 +1096,41 @@ class Conv3x3Fn(torch.autograd.Function):
             if ctx.stride != 1:
                 raise NotImplementedError("dgrad of the strided stem conv is never needed (its input is the image)")
             dx = torch.empty_like(x)
-            wp = _planes(ctx.params[0])
             fl = 2.0 * B * H * W * Cout * 9 * Cin
             link, fused = ctx.bn_link, False
-            if link is not None and wp is None and _bn_bwd_fuse_rows(B * H * W):   # (see LinearFn.backward)
+            if link is not None:   # (see LinearFn.backward)
                 import ctypes
                 part = torch.empty(((B * H * W + 127) // 128) * 2 * Cin, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("conv3x3_dgrad_bnbwd", fl, lambda: (h2_arm_conv(dy, ctx.params[0], Cin, Cout, "dgrad"), call(
+                _timed("conv3x3_dgrad_bnbwd", fl, lambda: (h2_arm(dy, ctx.params[0]), call(
                     "tris_conv3x3_dgrad_bnbwd_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
-                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()), rows.value > 0)[2])
+                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()), rows.value > 0)[2],
+                    nbytes=4.0 * (B * H * W * (Cout + 2 * Cin) + 9 * Cin * Cout))
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
-            # with the transposed, tap-mirrored planes the data gradient is a plain 3x3 convolution of dY
-            if fused:
-                pass
-            elif wp is None or not _timed("conv3x3_dgrad", fl, lambda: _wp_call(
-                    "tris_conv3x3_wp_fwd_f32", P(dy), wp[2], wp[3], P(dx), B, H, W, Cout, Cin, 1, None, None, _stream())):
+            if not fused:
                 _timed("conv3x3_dgrad", fl,
-                       lambda: (h2_arm_conv(dy, ctx.params[0], Cin, Cout, "dgrad"),
-                                call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))[1])
+                       lambda: (h2_arm(dy, ctx.params[0]),
+                                call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))[1],
+                       nbytes=4.0 * (B * H * W * (Cout + Cin) + 9 * Cin * Cout))
 
         def wgrad(o):
             ws = workspace(0)
             fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * 9 * Cin
-
-            def run():
-                xin = x
-                if ctx.lazy:
-                    if conv3x3_bnin_ok(x.shape, Cout):   # (asked again: the weight gradients may run in another arithmetic)
-                        return _timed("conv3x3_wgrad", fl, lambda: call(
-                            "tris_conv3x3_wgrad_bnin_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(dy), P(o), B, H, W, Cin,
-                            Cout, P(ws), ws.numel() * 4, _stream()))
-                    xin = torch.empty_like(x)   # materialise relu(bn(x)) after all
-                    call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
-                return _timed("conv3x3_wgrad", fl, lambda: (h2_arm_conv(dy, xin, Cin, Cout, "wgrad"), call(
-                    "tris_conv3x3_wgrad_f32", P(xin), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))[1])
-            _wgrad_arith(run)
+            nb = 4.0 * (B * H * W * Cin + dy.numel() + 9 * Cin * Cout)
+            xin = x
+            if ctx.lazy:
+                if conv3x3_bnin_ok(x.shape, Cout):
+                    return _timed("conv3x3_wgrad", fl, lambda: (ctx.h2_in is not None and h2_arm(dy, None, b_slot=ctx.h2_in), call(
+                        "tris_conv3x3_wgrad_bnin_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(dy), P(o), B, H, W, Cin,
+                        Cout, P(ws), ws.numel() * 4, _stream()))[1], nbytes=nb)
+                xin = torch.empty_like(x)   # materialise relu(bn(x)) after all
+                h2_mark_next(xin)
+                call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
+            return _timed("conv3x3_wgrad", fl, lambda: (h2_arm(dy, xin), call(
+                "tris_conv3x3_wgrad_f32", P(xin), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))[1],
+                nbytes=nb)
         dw = None
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
@@ -1145,13 +1144,12 @@ class Conv3x3Fn(torch.autograd.Function):
 def conv3x3_bnin_ok(xshape, Cout):
     """can conv3x3(relu(bn(x))) run with the BatchNorm folded into the direct kernels (forward AND weight gradient)?"""
     B, H, W, Cin = xshape
-    return os.environ.get("TRIS_WEIGHT_PLANES", "0") != "1" and bool(query("tris_conv3x3_bnin_ok", B, H, W, Cin, Cout))
+    return bool(query("tris_conv3x3_bnin_ok", B, H, W, Cin, Cout))
 
 
 def conv3x3(x, w, stride=1, stats=False):
     link = getattr(x, "_bn_link", None)
-    if link is not None and not (torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled()
-                                 and os.environ.get("TRIS_BN_BWD_FUSE") != "lin"):   # ("lin": developer A/B, 1x1 consumers only)
+    if link is not None and not (torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled()):
         link = None
     return Conv3x3Fn.apply(x, w, stride, stats, getattr(x, "_bn_lazy", None), link)
 
@@ -1210,7 +1208,7 @@ class BatchNormFn(torch.autograd.Function):
             mean = rmean
             invstd = torch.rsqrt(rvar + eps)
         # lazy: y stays UNWRITTEN -- its only consumer (a 3x3 convolution with direct kernels) normalises x while staging it
-        lazy = bool(lazy and training and relu and resid is None and os.environ.get("TRIS_BN_MASK_X", "1") != "0")
+        lazy = bool(lazy and training and relu and resid is None)
         if pool:
             h2_mark_next(y)
             call("tris_bn_apply_pool_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), x.shape[0], x.shape[1], x.shape[2], C,
@@ -1220,7 +1218,9 @@ class BatchNormFn(torch.autograd.Function):
             call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), P(y), M, C, int(relu),
                  _stream())
         if lazy:   # the hand-off to ops.conv3x3 rides on the (unwritten) output tensor itself
-            y._bn_lazy = (x, mean, invstd, gamma, beta)
+            # h2: the consuming convolution needs an operand scale for a tensor that never exists -- an upper bound of |y| from the
+            # affine parameters alone (Samuelson: |xhat| <= sqrt(n - 1)), as an amax word that travels with the hand-off
+            y._bn_lazy = (x, mean, invstd, gamma, beta, h2_bound_word(gamma, beta, C, math.sqrt(max(count - 1, 1))))
         ctx.cfg = (M, C, bool(relu), resid is not None, count, group)
         ctx.grad_box = grad_box
         ctx.params = (gamma, beta)
@@ -1228,7 +1228,7 @@ class BatchNormFn(torch.autograd.Function):
         ctx.link = None
         ctx.pool = pool
         if training:
-            keep_y = relu and not pool and (resid is not None or os.environ.get("TRIS_BN_MASK_X", "1") == "0")   # (env: developer A/B knob)
+            keep_y = relu and not pool and resid is not None
             ctx.save_for_backward(x, gamma, beta, mean, invstd, y if keep_y else None)
             if bwd_link and relu and not pool:
                 # the consumer (ops.linear) may reduce this BatchNorm's backward sums in its data-gradient epilogue: _BnBwdLink
@@ -1272,8 +1272,7 @@ class BatchNormFn(torch.autograd.Function):
             Bn, H, W = x.shape[0], x.shape[1], x.shape[2]
             call("tris_bn_bwd_reduce_pool_f32", P(dy), P(x), P(mean), P(invstd), Bn, H, W, C, p_dz, p_dzx, P(ws), P(gamma), P(beta),
                  _stream())
-        dz_first = (got is None and not ctx.pool and want_dz and relu and y is not None
-                    and os.environ.get("TRIS_BN_DZ_FIRST", "1") != "0")   # (env: developer A/B knob)
+        dz_first = got is None and not ctx.pool and want_dz and relu and y is not None
         if dz_first:
             d_res = torch.empty_like(x)
         if got is not None:
@@ -1334,7 +1333,7 @@ def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=Tru
     part = getattr(x, "_bn_part", None) if training else None
     bwd_link = bool(bwd_link and training and torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled())
     if pool and not (training and relu and resid is None and not lazy and x.dim() == 4 and x.shape[1] % 2 == 0
-                     and x.shape[2] % 2 == 0 and os.environ.get("TRIS_BN_POOL", "1") != "0"):
+                     and x.shape[2] % 2 == 0 and cfg.bn_pool):
         # eval mode / shapes the fused op does not take: the two ops one after the other
         return avgpool2(BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box,
                                           lazy, bwd_link, False))
@@ -1480,7 +1479,7 @@ def _mha_impl(L):
     of the packed QKV and the single-launch backward of the LDS-resident kernel wins (654 vs 806 us at N = 3840), from
     L = 50 (aux ViT) on the MFMA kernel does (fwd 47 vs 53 us, bwd 126 vs 159 us; L = 401: 73 / 84 TFLOP/s)."""
     import os
-    mode = os.environ.get("TRIS_MHA", "auto")
+    mode = cfg.mha
     if L > 64 or mode == "mfma":
         return "mfma"
     if mode == "valu":
@@ -1708,11 +1707,11 @@ class XAttnFn(torch.autograd.Function):
         done = False
         # ONE persistent launch (csrc/xattn_fused.hip) where its domain covers the shape and all B * 8 workgroups are co-resident
         # (45 vs 57 us for the two-launch pair at B = 48; TRIS_XATTN_FUSED=0 forces the pair)
-        ws_bytes = query("tris_xattn_fused_ws_bytes", B, N, C) if os.environ.get("TRIS_XATTN_FUSED", "1") != "0" else 0
+        ws_bytes = query("tris_xattn_fused_ws_bytes", B, N, C) if cfg.xattn_fused else 0
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
             sync = _xattn_sync(dev, B)
-            done = _timed("xattn_fwd_fused", 8.0 * B * Pp * N * C, lambda: _wp_call(
+            done = _timed("xattn_fwd_fused", 8.0 * B * Pp * N * C, lambda: _declinable(
                 "tris_xattn_fused_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B, Pp,
                 N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
         if not done:
@@ -1724,7 +1723,6 @@ class XAttnFn(torch.autograd.Function):
         return new_vis, new_lan
 
     @staticmethod
-    @_bwd_arith
     def backward(ctx, d_vis, d_lan):
         Qv, Kv, Vv, Qt, Kt, Vt, probs = ctx.saved_tensors
         B, Pp, N, C = ctx.dims

@@ -16,12 +16,13 @@ TRIS_TEXT_AT, default behind layer4) decides where its backward runs relative to
 ride on a trunk boundary.  They have their own boundaries on the text path (behind blocks 7 and 3 and behind the
 embedding), and the embedding tables, whose gradient is written after the last of them, are released by `finish()`.
 """
-import os
+
 
 import torch
 import torch.distributed as dist
 
 from . import comm
+from .config import cfg
 from .CLIP.clip.model import BatchNorm2d
 
 
@@ -64,14 +65,14 @@ class GradReducer:
         self.done = set()
         self.launch_log = []    # keys in launch order of the current / last step (tests)
         self.active = self.world > 1 or force
-        self.check = (os.environ.get("TRIS_DDP_CHECK") == "1") if check is None else check
+        self.check = cfg.ddp_check if check is None else check
         # NCCL/RCCL averages in the collective; gloo has no AVG: sum, then scale in finish()
         self.avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         # Sparse exchange of the token-embedding gradient (TRIS_DDP_SPARSE_EMBED=0 switches back to the dense all-reduce): the
         # table is [49408, 512] fp32 = 101 MB, of which a rank touches <= B*L rows per step.  `sparse_exclude` lists the arena
         # ranges left out of the dense segments; take_embedding_rows() does the exchange.
-        self.sparse_embed = os.environ.get("TRIS_DDP_SPARSE_EMBED", "1") != "0"
+        self.sparse_embed = cfg.ddp_sparse_embed
         self.sparse_exclude = {}   # id(param) -> (flat index, start, end)
         self.sparse_log = []       # (rows gathered, bytes on the wire per rank) of the current / last step (tests, dist_check)
         self.exposed = None        # (event before, event after) the compute stream's wait in finish(): exposed communication

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .config import cfg
 from .loss.clip_loss import clip_forward  # noqa: F401  (same import surface as the reference module)
 
 CLIP_INPUT = 224
@@ -41,17 +42,12 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
         K = neg_word_ids.shape[1]
         ids_all = torch.cat([ids_all, neg_word_ids.long().reshape(B * K, -1)], 0)
     main = side = ready = None
-    early = os.environ.get("TRIS_AUX_TEXT_AT", "after") == "start"   # developer A/B knob (round-1 order: before the trunk)
     if _overlap_enabled():
         main, side = torch.cuda.current_stream(), _side_stream(img.device)
         ready = torch.cuda.Event()
         ready.record(main)           # ids_all is complete here
-        if early:
-            side.wait_event(ready)
-            with torch.cuda.stream(side), torch.no_grad():
-                f_all = frozen_text(clip_model, ids_all)
     cls, _, _, sig_out, _ = model(img, word_ids)
-    if side is not None and not early:
+    if side is not None:
         # The frozen aux text tower has no backward and its output is needed only by the loss: it is ISSUED here, behind the
         # TRIS forward (whose own text encoder is needed sooner and shares the side stream), so that the host starts the
         # trunk at once instead of issuing ~130 small launches first; it executes under the rest of the forward.
@@ -82,8 +78,7 @@ def stage1_loss_block(clip_model, img, cls, sig_out, f_all, ids_all, K, args):
     f_i = vit.forward_patches(ops.fg_patches(cam, im, vit.patch_size))
     with torch.no_grad():
         if f_all is None:
-            with ops.h2_paused():
-                f_all = clip_model.encode_text(ids_all)[1]
+            f_all = clip_model.encode_text(ids_all)[1]
         elif callable(f_all):
             f_all = f_all()
         f_t = f_all[:B].contiguous()
@@ -91,39 +86,16 @@ def stage1_loss_block(clip_model, img, cls, sig_out, f_all, ids_all, K, args):
     return ops.stage1_loss(cls, f_i, f_t, f_neg, float(args.w1), float(args.w4), float(args.w5))
 
 
-def _weight_planes(module, frozen):
-    """pre-split bf16 planes of a module's weight matrices (tris_amd.planes), built on first use.  Opt-in
-    (TRIS_WEIGHT_PLANES=1): correct and tested, but measured slower than the in-kernel split with the current GEMM core."""
-    from .planes import WeightPlanes
-    if os.environ.get("TRIS_WEIGHT_PLANES", "0") != "1" or ops.get_gemm_mode() != "x3":
-        return None
-    net = module.module if hasattr(module, "module") else module
-    wp = getattr(net, "_tris_weight_planes", None)
-    if wp is None:
-        wp = WeightPlanes(list(net.named_parameters()), frozen=frozen)
-        net._tris_weight_planes = wp
-    return wp
-
-
 def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, reducer, device_hyper=False,
                optimizer_step=True):
     """forward -> losses -> backward -> [all-reduce] -> AdamW: the part of a step that is kernel launches only (what
     tris_amd.graphs.GraphedTrainStep captures).  device_hyper: the optimiser reads lr / bias corrections from device memory."""
-    import contextlib
-    from .planes import WeightPlanes
-    ops.h2_begin_step()   # (TRIS_LINEAR_MODE=h2: a fresh amax pool; no-op otherwise)
-    wp = _weight_planes(model, frozen=False)
-    wa = _weight_planes(clip_model, frozen=True)
-    if wp is not None:
-        wp.refresh()          # trainable set: every step (the weights are constant from here to the end of backward)
-    if wa is not None:
-        wa.ensure()           # frozen set: once, or again if its storage moved / a parameter was written to
-    with (WeightPlanes.active() if (wp is not None or wa is not None) else contextlib.nullcontext()):
-        losses, _, _ = stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args)
-        optimizer.zero_grad()
-        if reducer is not None:
-            reducer.begin_step()
-        losses[0].backward()
+    ops.h2_begin_step()   # (h2 arithmetic: a fresh amax pool + the weights' amaxes; no-op otherwise)
+    losses, _, _ = stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args)
+    optimizer.zero_grad()
+    if reducer is not None:
+        reducer.begin_step()
+    losses[0].backward()
     if reducer is not None:
         reducer.reduce()
     if optimizer_step:
@@ -136,13 +108,9 @@ def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
     return losses.detach()
 
 
-def _env_key():
-    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("TRIS_")))
-
-
 def _graphable(model, optimizer, img, reducer):
     """may this step be replayed from a hipGraph?  Opt-in (TRIS_STEP_GRAPH=1): see train_step"""
-    if os.environ.get("TRIS_STEP_GRAPH", "0") not in ("1", "seg") or reducer is not None or ops._PROF is not None:
+    if cfg.step_graph not in ("1", "seg") or reducer is not None or ops._PROF is not None:
         return False
     if not img.is_cuda or not hasattr(optimizer, "enable_device_hyper") or torch.cuda.is_current_stream_capturing():
         return False
@@ -150,7 +118,7 @@ def _graphable(model, optimizer, img, reducer):
     net = model.module if hasattr(model, "module") else model
     if not net.training or any(m.process_group is not None for m in net.modules() if isinstance(m, BatchNorm2d)):
         return False
-    return os.environ.get("TRIS_WEIGHT_PLANES", "0") != "1"
+    return True
 
 
 def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, lr_scheduler=None, reducer=None):
@@ -167,11 +135,11 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
         net = model.module if hasattr(model, "module") else model
         key = (tuple(img.shape), tuple(word_ids.shape), None if neg_word_ids is None else tuple(neg_word_ids.shape),
                img.dtype, word_ids.dtype, id(clip_model), id(optimizer), id(lr_scheduler), ops.get_gemm_mode(),
-               ops._BWD_MODE, ops._WGRAD_MODE, _env_key())
+               cfg.key())
         slot = net.__dict__.get("_tris_step_graph")
         if slot is None:
             from .graphs import GraphedTrainStep, SegmentedTrainStep
-            cls = SegmentedTrainStep if os.environ.get("TRIS_STEP_GRAPH") == "seg" else GraphedTrainStep
+            cls = SegmentedTrainStep if cfg.step_graph == "seg" else GraphedTrainStep
             g = cls(model, clip_model, optimizer, args, (img, word_ids, neg_word_ids), lr_scheduler)
             slot = net.__dict__["_tris_step_graph"] = (key, g)
         if slot[0] == key:
@@ -268,7 +236,7 @@ def build_loader(args, dataset, batch_size, shuffle, distributed):
             # equal shard sizes on every rank (DistributedSampler pads), which SyncBatchNorm's count = M * world relies on
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(dataset, shuffle=shuffle)
-    if os.environ.get("TRIS_HBM_LOADER", "1") != "0":
+    if cfg.hbm_loader:
         from .dataset.hbm import HbmLoader, HbmReferCache
         return HbmLoader(HbmReferCache(dataset, args.size), batch_size=batch_size, sampler=sampler,
                          shuffle=shuffle and sampler is None)

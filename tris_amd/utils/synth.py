@@ -47,6 +47,32 @@ def seed_fill(sd, seed=1234):
     return sd
 
 
+def heavy_tail_fill(sd, seed=1234, span=2.0, outlier=16.0, frac=0.01):
+    """seed_fill, then statistics that look like released CLIP weights rather than iid noise: every weight MATRIX gets a
+    log-uniform gain 2^U(-span, span) per output channel, `frac` of its channels a further factor `outlier`; every norm scale
+    (1-D `.weight`) a gain 2^U(-span/2, span/2) per channel, `frac` of them x sqrt(outlier).  Deterministic (one generator,
+    sorted keys, after the plain fill).  Used by the parity tests to stress per-tensor operand scaling (heavy tails, outlier
+    channels); the oracle receives the SAME state dict."""
+    seed_fill(sd, seed)
+    g = torch.Generator(device="cpu").manual_seed(seed + 977)
+    for k in sorted(sd.keys()):
+        t = sd[k]
+        if not t.is_floating_point() or k.endswith(("running_mean", "running_var", "logit_scale")) or t.dim() == 0:
+            continue
+        n = t.shape[0]
+        if t.dim() == 1 and k.endswith(".weight"):
+            gain = torch.exp2((torch.rand(n, generator=g) * 2 - 1) * (span / 2))
+            gain[torch.rand(n, generator=g) < frac] *= outlier ** 0.5
+        elif t.dim() >= 2 and k.endswith(("weight", "in_proj_weight", "text_projection", "proj")):
+            gain = torch.exp2((torch.rand(n, generator=g) * 2 - 1) * span)
+            gain[torch.rand(n, generator=g) < frac] *= outlier
+        else:
+            continue
+        with torch.no_grad():
+            t.mul_(gain.view(-1, *([1] * (t.dim() - 1))).to(t.device, t.dtype))
+    return sd
+
+
 def synthetic_ids(n, L=20, rng=None):
     """`n` token rows of length L; EOT is the arg-max id so the pooled token is well defined."""
     rng = rng if rng is not None else np.random.RandomState(0)

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .config import cfg
 from .utils.util import AverageMeter
 
 
@@ -30,7 +31,7 @@ def _host(x):
 
 def _graphed(net, img, L, cache):
     """hipGraph replay of the two halves of the eval forward, one capture per input shape (TRIS_HIPGRAPH=0 disables)."""
-    if os.environ.get("TRIS_HIPGRAPH", "1") == "0":
+    if not cfg.hipgraph:
         return None
     key = (tuple(img.shape), int(L))
     if key not in cache:
@@ -76,7 +77,7 @@ def validate(args, data_loader, model, local_rank=0, visualize=False, logger=Non
     st = {"I": 0, "U": 0, "n_sent": 0, "hit": 0}
     cam_out_name = []
     graphs = {}
-    group = max(1, int(os.environ.get("TRIS_EVAL_GROUP", "16")))
+    group = max(1, int(cfg.eval_group))
     end = time.time()
 
     def account(idx, j, img_id, bbox, I, U, am, cam, n_img):
