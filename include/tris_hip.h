@@ -366,8 +366,10 @@ int tris_gather_rows(const void* table, const long* index, long rows, long row_b
  * contents -- tris_mbox_bn_combine_f32 likewise writes NaN statistics and leaves the running statistics alone), then mode 0:
  * out[world][n] = the gathered
  * blocks in rank order; mode 1: out[n] = their sum in rank order (bit-identical on every rank).  `boxes` is a DEVICE array of
- * the `world` mailbox pointers as mapped in this process (own mailbox at index `rank`).  `seq` must be 1, 2, 3, ... in the
- * same order on every rank (flags are zero-initialised).  World size <= TRIS_MBOX_MAX_WORLD. */
+ * the `world` mailbox pointers as mapped in this process (own mailbox at index `rank`).  `seq` points at ONE caller-owned DEVICE
+ * word, zeroed once: the number of the exchange is read from it and advanced in it by the kernel itself (exchanges of a rank run
+ * on one stream; every rank issues the same sequence, so the counters agree) -- nothing about an exchange depends on host state,
+ * the launches can be captured into a hipGraph and replayed.  World size <= TRIS_MBOX_MAX_WORLD. */
 #define TRIS_MBOX_MAX_WORLD 16
 long tris_mbox_bytes(int cap_floats);
 int tris_mbox_alloc(void** ptr, int cap_floats);
@@ -376,14 +378,14 @@ int tris_mbox_ipc_handle(void* ptr, void* handle64);
 int tris_mbox_ipc_open(const void* handle64, void** ptr);
 int tris_mbox_ipc_close(void* ptr);
 int tris_mbox_exchange_f32(const float* src0, int n0, const float* src1, int n1, float* out, void* const* boxes, int world,
-                           int rank, int seq, int cap_floats, int mode, long spin_limit, int* err, void* stream);
+                           int rank, unsigned* seq, int cap_floats, int mode, long spin_limit, int* err, void* stream);
 /* SyncBatchNorm forward in ONE launch: exchange the [mean | invstd | biased var] block (3 C floats, what tris_bn_finalize_f32 /
  * tris_bn_stats_f32 write) and combine the `world` blocks into the global statistics stats[3C] + running statistics -- the
  * arithmetic of tris_bn_sync_combine_f32.  Every rank contributes count_per_rank rows: the SAME number on every rank (the global
  * count is count_per_rank * world, as with torch's DistributedSampler, which pads the shards to equal length; ranks with
  * unequal per-step batches are not representable here -- nor in tris_bn_sync_combine_f32 -- and must use equal shards). */
 int tris_mbox_bn_combine_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum, float* stats,
-                             float* running_mean, float* running_var, void* const* boxes, int world, int rank, int seq,
+                             float* running_mean, float* running_var, void* const* boxes, int world, int rank, unsigned* seq,
                              int cap_floats, long spin_limit, int* err, void* stream);
 
 #ifdef __cplusplus

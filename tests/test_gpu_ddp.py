@@ -27,9 +27,10 @@ PER_RANK = 2
 WORLD = 2
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, issue, arith):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRIS_AUTOTUNE="0", TRIS_RANDOM_INIT="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRIS_AUTOTUNE="0", TRIS_RANDOM_INIT="1",
+                      TRIS_STEP_GRAPH=issue, TRIS_GEMM_MODE=arith)
     import warnings
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -64,6 +65,7 @@ def _worker(rank, world, port, tmp):
         losses = train_step(model, aux, opt, full["img"][sl].cuda(), full["word_ids"][sl].cuda(),
                             full["neg_word_ids"][sl].cuda(), args, reducer=red)
         torch.cuda.synchronize()
+        assert ("_tris_step_graph" in net.__dict__) == (issue == "seg")      # the step really was (not) replayed from graphs
         out = {"losses": losses.cpu(), "launch_log": list(red.launch_log),
                "params": [a.p.detach().cpu() for a in opt.arenas]}
         if rank == 0:
@@ -92,14 +94,17 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path):
+@pytest.mark.parametrize("issue,arith", [("0", "x3"), ("seg", "h2")], ids=["eager-x3", "replayed-h2"])
+def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path, issue, arith):
+    """issue = "seg": the step is replayed from the segmented hipGraphs (SyncBatchNorm exchanges captured, collectives issued
+    between graph replays); arith: arithmetic of the dense products.  Same oracle, same tolerances."""
     import torch.multiprocessing as mp
     from oracle import tris_oracle as O
     from tris_amd.utils.shapes import aux_state_dict_spec, empty_state_dict, tris_state_dict_spec
     from tris_amd.utils.synth import seed_fill, synthetic_batch
     ctx = mp.get_context("spawn")
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path))) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), issue, arith)) for r in range(WORLD)]
     for p in procs:
         p.start()
     # the oracle runs on the host cores while the ranks run on the GPU
@@ -160,6 +165,24 @@ def test_two_ranks_match_the_concatenated_batch_oracle(tmp_path):
         assert diff <= 1e-6 * max(scale, 1e-12) + 1e-12, r["sparse_vs_dense"]
         assert r["sparse_log"] == [(WORLD * PER_RANK * 20, PER_RANK * 20 * (512 * 4 + 8))], r["sparse_log"]
     assert torch.equal(r0["tok_grad"], r1["tok_grad"])
+
+
+@pytest.mark.parametrize("issue,arith", [("0", "h2"), ("seg", "h2"), ("seg", "x3")])
+def test_dist_check_preflight_one_rank_with_real_rccl(issue, arith):
+    """tools/dist_check.py --single: the data-parallel code path at ONE rank with real RCCL calls (nccl process group of size 1),
+    SyncBatchNorm over the mailbox transport, the order check of the reducer on, the sparse embedding exchange -- eager and
+    through the segmented hipGraph replay.  The N > 1 run of the same script is the preflight of a scaling bench."""
+    import json
+    import subprocess
+    env = dict(os.environ, TRIS_STEP_GRAPH=issue, TRIS_GEMM_MODE=arith, TRIS_AUTOTUNE="0", TRIS_RANDOM_INIT="1",
+               MASTER_PORT=str(29700 + os.getpid() % 200))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--single", "--batch", "4", "--steps", "3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dist_check"] == "ok" and out["sync_bn_transport"] == "mailbox" and out["gemm_mode"] == arith
+    assert out["replayed"] == (issue == "seg")
 
 
 def test_optimizer_checkpoint_is_torch_adamw_layout():

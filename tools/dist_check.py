@@ -11,7 +11,8 @@ with the order check on (NaN-poisoned gradient arenas) and asserts:
   * parameters AND optimiser moments are bit-identical on all ranks after the last step;
   * losses are finite and no mailbox exchange timed out on any rank (comm.check_errors(collective=True)).
 Prints one JSON line on rank 0 with the transport, the exposed communication time and the step time.
-`--single` runs the same checks in ONE process with the collectives forced (TRIS_FORCE_DIST semantics: code-path check)."""
+`--single` runs the same checks in ONE process with the collectives forced (code-path check).  TRIS_STEP_GRAPH=seg runs the steps
+through the segmented hipGraph replay (collectives issued between graph replays), TRIS_GEMM_MODE=h2 in the h2 arithmetic."""
 import argparse
 import json
 import os
@@ -82,7 +83,8 @@ def main():
             assert len(red.sparse_log) == 1 and red.sparse_log[0][0] == world * a.batch * 20, (rank, s, red.sparse_log)
     comm.check_errors(collective=True)
     transport = "mailbox" if any(m is not None for m in comm.Mailbox._by_group.values()) else "torch.distributed"
-    if os.environ.get("TRIS_SYNCBN_COMM", "mailbox") == "mailbox":
+    from tris_amd.config import cfg
+    if cfg.syncbn_comm == "mailbox":
         assert transport == "mailbox", f"rank {rank}: SyncBatchNorm fell back to {transport}"
     # replicas: parameters and both Adam moments bit-identical everywhere (compared through an exact integer checksum)
     sig = []
@@ -97,6 +99,7 @@ def main():
     exposed = red.exposed_ms()
     if rank == 0:
         print(json.dumps({"dist_check": "ok", "world": world, "forced_single": force, "per_rank_batch": a.batch, "steps": a.steps,
+                          "step_issue": cfg.step_graph, "replayed": "_tris_step_graph" in net.__dict__, "gemm_mode": ops.get_gemm_mode(),
                           "sync_bn_transport": transport, "sparse_embed_rows": red.sparse_log[0] if red.sparse_log else None,
                           "comm_exposed_ms_last_step": None if exposed is None else round(exposed, 3),
                           "ms_last_step": round(t_step * 1e3, 2), "losses_last_step": [round(v, 5) for v in losses.tolist()]}))

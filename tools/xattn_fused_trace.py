@@ -48,3 +48,34 @@ for i in range(len(names) - 1):
     print(f"{names[i]:13s} -> {names[i + 1]:13s}  min {col.min():7.2f}  median {col.median():7.2f}  max {col.max():7.2f} us")
 tot = (tr[:, -1] - tr[:, 0]) / clk * 1e6
 print(f"workgroup lifetime  min {tot.min():.2f}  median {tot.median():.2f}  max {tot.max():.2f} us")
+# ---- where the time between the median workgroup and the whole launch goes -------------------------------
+# s_memtime counters are per XCD (not aligned across XCDs); consecutive workgroups go to consecutive XCDs, so workgroup g runs on
+# XCD g % 8.  Per XCD: launch ramp = last start - first start, span = last end - first start; the kernel's duration is the
+# largest span plus the launch / drain latency outside the workgroups.
+xcd = torch.arange(B * 8) % 8
+start, end = tr[:, 0], tr[:, -1]
+ramp, span, lifemax = [], [], []
+for x in range(8):
+    m = xcd == x
+    ramp.append(float((start[m].max() - start[m].min()) / clk * 1e6))
+    span.append(float((end[m].max() - start[m].min()) / clk * 1e6))
+    lifemax.append(float(tot[m].max()))
+print("per XCD: launch ramp (last start - first start) us:", " ".join(f"{v:5.1f}" for v in ramp))
+print("per XCD: span (last end - first start) us:         ", " ".join(f"{v:5.1f}" for v in span))
+print("per XCD: longest workgroup lifetime us:             ", " ".join(f"{v:5.1f}" for v in lifemax))
+# the slowest workgroup's own timeline, and the late starters (second workgroup of a doubly loaded CU starts when? -- with 384
+# workgroups on 256 CUs all are co-resident, so a late start is dispatch latency, not queueing)
+w = int(tot.argmax())
+print(f"slowest workgroup {w} (image {w // 8}, slice {w % 8}, XCD {w % 8}): " + " | ".join(f"{names[i + 1]} {float(d[w, i]):.1f}" for i in range(len(names) - 1)))
+late = ((start - torch.stack([start[xcd == x].min() for x in range(8)])[xcd]) / clk * 1e6)
+print(f"start offset inside the XCD: median {float(late.median()):.2f}  p90 {float(late.kthvalue(int(0.9 * late.numel())).values):.2f}  max {float(late.max()):.2f} us")
+# waits: time spent polling flags = the skew between the eight workgroups of an image
+print(f"wait phases (stage-1 flags + stage-2 flags): median {float((d[:, 2] + d[:, 6]).median()):.2f}  max {float((d[:, 2] + d[:, 6]).max()):.2f} us")
+# bytes a workgroup moves per phase (P = 100, N = 48, C = 1024, 8 slices) and the per-CU rate they imply
+KB = 1024.0
+phases = [("logits (Qv, Kv slices: 2 x P x C/8 x 4 B)", 2 * P * C / 8 * 4 / KB, 0), ("publish partial logits (write-through)", 43.0, 1),
+          ("reduce 1/8 of the rows (sc1 loads)", 46.0, 3), ("publish probabilities", 5.0, 5), ("gather At, Av", 50.0, 7),
+          ("new_vis (Vt planes from L2, store P x C/8)", P * C / 8 * 4 / KB, 8), ("new_lan (Vv slice read + N x C/8 store)", (P + N) * C / 8 * 4 / KB, 9)]
+for name, kb, i in phases:
+    us = float(d[:, i].median())
+    print(f"  {name:52s} {kb:6.1f} KB  median {us:5.2f} us  -> {kb * KB / (us * 1e-6) / 1e9:6.1f} GB/s per workgroup")

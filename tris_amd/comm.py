@@ -124,7 +124,9 @@ class Mailbox:
             ptrs.append(p.value)
         self.boxes = torch.tensor(ptrs, dtype=torch.int64, device="cuda")
         self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
-        self.seq = 0
+        # the exchange counter lives on the device and is advanced by the kernels themselves: an exchange depends on no host
+        # state, so SyncBatchNorm layers can be captured into the step's hipGraphs (tris_amd.graphs.SegmentedTrainStep)
+        self.seq = torch.zeros(1, dtype=torch.int32, device="cuda")
 
     @staticmethod
     def _chk(rc, what):
@@ -133,20 +135,18 @@ class Mailbox:
 
     def exchange(self, src, out, mode, src1=None):
         """block = [src | src1]; mode 0: out[world][n] gathered, mode 1: out[n] = sum over ranks"""
-        self.seq += 1
         self._chk(self.lib.tris_mbox_exchange_f32(src.data_ptr(), src.numel(), None if src1 is None else src1.data_ptr(),
                                                   0 if src1 is None else src1.numel(), out.data_ptr(), self.boxes.data_ptr(),
-                                                  self.world, self.rank, self.seq, self.CAP, mode, self.SPIN_LIMIT,
+                                                  self.world, self.rank, self.seq.data_ptr(), self.CAP, mode, self.SPIN_LIMIT,
                                                   self.err.data_ptr(), torch.cuda.current_stream().cuda_stream),
                   "tris_mbox_exchange_f32")
 
     def bn_combine(self, local_stats, C, count_per_rank, eps, momentum, stats, running_mean, running_var):
         """SyncBN forward exchange + combine in one launch (include/tris_hip.h: tris_mbox_bn_combine_f32)"""
-        self.seq += 1
         self._chk(self.lib.tris_mbox_bn_combine_f32(local_stats.data_ptr(), C, count_per_rank, eps, momentum, stats.data_ptr(),
                                                     None if running_mean is None else running_mean.data_ptr(),
                                                     None if running_var is None else running_var.data_ptr(),
-                                                    self.boxes.data_ptr(), self.world, self.rank, self.seq, self.CAP,
+                                                    self.boxes.data_ptr(), self.world, self.rank, self.seq.data_ptr(), self.CAP,
                                                     self.SPIN_LIMIT, self.err.data_ptr(),
                                                     torch.cuda.current_stream().cuda_stream), "tris_mbox_bn_combine_f32")
 

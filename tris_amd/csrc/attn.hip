@@ -177,39 +177,59 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __re
 // identical order on every rank -> bit-identical token-embedding gradients on every rank).  dtok must be zero-filled.
 __global__ __launch_bounds__(128) void embed_rows_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ rows,
                                                              float* __restrict__ dtok, int R, int W, float scale) {
-  constexpr int MAXW = 512;            // bitmap words: R <= 16384 list positions
-  __shared__ unsigned bm[MAXW];        // bit u: ids[u] == ids[t]   (u > t)
+  // The list is walked in chunks of CH positions (an LDS bitmap of the repeats per chunk), so R is not bounded by the bitmap:
+  // 16 ranks x 64 sentences x 20 tokens = 20480 positions must work.  W <= 4 * 128 * MAXC.
+  constexpr int MAXW = 512, CH = MAXW * 32, MAXC = 4;
+  __shared__ unsigned bm[MAXW];        // bit u - base: ids[u] == ids[t]   (u > t)
   __shared__ int s_first, s_any;
   const int t = blockIdx.x;
   const long id = ids[t];
-  const int nw = (R + 31) >> 5;
-  for (int w = threadIdx.x; w < nw; w += blockDim.x) bm[w] = 0u;
-  if (threadIdx.x == 0) { s_first = 1; s_any = 0; }
-  __syncthreads();
-  for (int u = threadIdx.x; u < R; u += blockDim.x) {
-    if (u != t && ids[u] == id) {
-      if (u < t) s_first = 0;          // (benign race: every writer stores the same value)
-      else { atomicOr(&bm[u >> 5], 1u << (u & 31)); s_any = 1; }
-    }
+  float4 acc[MAXC];
+#pragma unroll
+  for (int ci = 0; ci < MAXC; ++ci) {
+    const int c = (threadIdx.x + ci * blockDim.x) * 4;
+    acc[ci] = c < W ? *reinterpret_cast<const float4*>(rows + (long)t * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
-  if (!s_first) return;                // a later position of an id already summed by its first occurrence
-  const bool any = s_any != 0;
-  for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
-    float4 a = *reinterpret_cast<const float4*>(rows + (long)t * W + c);
-    if (any) {
-      for (int w = t >> 5; w < nw; ++w) {        // ascending list order: the sum is the same on every rank and every run
-        unsigned m = bm[w];
-        while (m) {
-          const int u = (w << 5) + __builtin_ctz(m);
-          m &= m - 1;
-          const float4 v = *reinterpret_cast<const float4*>(rows + (long)u * W + c);
-          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  if (threadIdx.x == 0) s_first = 1;
+  for (int base = 0; base < R; base += CH) {
+    const int n = min(CH, R - base), nw = (n + 31) >> 5;
+    __syncthreads();                   // (the previous chunk's bitmap has been consumed)
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) bm[w] = 0u;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    for (int u = base + threadIdx.x; u < base + n; u += blockDim.x) {
+      if (u != t && ids[u] == id) {
+        if (u < t) s_first = 0;        // (benign race: every writer stores the same value)
+        else { atomicOr(&bm[(u - base) >> 5], 1u << ((u - base) & 31)); s_any = 1; }
+      }
+    }
+    __syncthreads();
+    if (!s_first) return;              // a later position of an id already summed by its first occurrence (uniform)
+    if (s_any) {
+#pragma unroll
+      for (int ci = 0; ci < MAXC; ++ci) {
+        const int c = (threadIdx.x + ci * blockDim.x) * 4;
+        if (c >= W) continue;
+        for (int w = max(0, (t - base) >> 5); w < nw; ++w) {   // ascending list order: the same sum on every rank and every run
+          unsigned m = bm[w];
+          while (m) {
+            const int u = base + (w << 5) + __builtin_ctz(m);
+            m &= m - 1;
+            const float4 v = *reinterpret_cast<const float4*>(rows + (long)u * W + c);
+            acc[ci].x += v.x; acc[ci].y += v.y; acc[ci].z += v.z; acc[ci].w += v.w;
+          }
         }
       }
     }
-    a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
-    *reinterpret_cast<float4*>(dtok + id * W + c) = a;
+  }
+#pragma unroll
+  for (int ci = 0; ci < MAXC; ++ci) {
+    const int c = (threadIdx.x + ci * blockDim.x) * 4;
+    if (c < W) {
+      float4 a = acc[ci];
+      a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+      *reinterpret_cast<float4*>(dtok + id * W + c) = a;
+    }
   }
 }
 
@@ -288,7 +308,7 @@ extern "C" int tris_embed_bwd_f32(const long* ids, const float* dout, float* dto
 
 extern "C" int tris_embed_rows_bwd_f32(const long* ids, const float* rows, float* dtok, int R, int W, float scale,
                                        void* stream) {
-  if (R < 1 || R > 16384 || W % 4 != 0) return (int)hipErrorInvalidValue;
+  if (R < 1 || W % 4 != 0 || W > 2048) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(R), dim3(128), 0, (hipStream_t)stream, ids, rows, dtok, R, W, scale);
   TRIS_LAUNCH_CHECK();
   return 0;

@@ -15,6 +15,10 @@
 //   Two parities suffice: a rank can start exchange k+2 (which overwrites parity k) only after it has seen every peer's
 //   flag k+1, and a peer posts flag k+1 only after its own exchange k has completed (stream order).
 //
+// The exchange counter `seq` lives in DEVICE memory (one word per mailbox owner, advanced by the kernel itself): nothing about an
+// exchange depends on host state, so the launches can be captured into a hipGraph and replayed -- every rank runs the same
+// sequence of exchanges on one stream, so the counters advance in lockstep.
+//
 // A flag that does not arrive within the spin bound sets *err (checked by the host on EVERY rank, tris_amd.comm.check_errors)
 // and the kernel does NOT consume the stale slots: its outputs are filled with NaN and the running statistics are left
 // untouched, so the losses of that step are NaN on the rank that gave up -- the step fails loudly instead of hanging the GPU or
@@ -37,12 +41,21 @@ __device__ __forceinline__ float* slot_of(void* box, int parity, int sender, int
 
 // send my block [src0[n0] | src1[n1]] to every mailbox, publish, wait for the world's flags in my mailbox (one workgroup)
 // returns false (uniformly) when a sender's flag did not arrive within the spin bound
+// *seq_out = the number of this exchange (read from / advanced in *seq_dev: launches on one stream run in order)
 __device__ __forceinline__ bool mbox_send_wait(const float* src0, int n0, const float* src1, int n1,
-                                               void* const* __restrict__ boxes, int world, int rank, unsigned seq, int cap,
-                                               long spin_limit, int* __restrict__ err) {
+                                               void* const* __restrict__ boxes, int world, int rank, unsigned* seq_dev, int cap,
+                                               long spin_limit, int* __restrict__ err, unsigned* seq_out) {
   __shared__ int s_fail;
+  __shared__ unsigned s_seq;
   const int tid = threadIdx.x;
-  if (tid == 0) s_fail = 0;
+  if (tid == 0) {
+    s_fail = 0;
+    s_seq = *seq_dev + 1u;
+    *seq_dev = s_seq;
+  }
+  __syncthreads();
+  const unsigned seq = s_seq;
+  *seq_out = seq;
   const int par = seq & 1u;
   for (int w = 0; w < world; ++w) {
     float* dst = slot_of(boxes[w], par, rank, cap);
@@ -79,9 +92,10 @@ __device__ __forceinline__ bool mbox_send_wait(const float* src0, int n0, const 
 // every source element is stored to the mailboxes before the first element of `out` is written)
 __global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* src0, int n0, const float* src1,
                                                             int n1, float* out, void* const* __restrict__ boxes,
-                                                            int world, int rank, unsigned seq, int cap, int mode, long spin_limit,
+                                                            int world, int rank, unsigned* seq_dev, int cap, int mode, long spin_limit,
                                                             int* __restrict__ err) {
-  const bool ok = mbox_send_wait(src0, n0, src1, n1, boxes, world, rank, seq, cap, spin_limit, err);
+  unsigned seq;
+  const bool ok = mbox_send_wait(src0, n0, src1, n1, boxes, world, rank, seq_dev, cap, spin_limit, err, &seq);
   const int tid = threadIdx.x, par = seq & 1u, n = n0 + n1;
   if (!ok) {   // a peer never posted: do not read the stale slots
     const int tot = mode == 0 ? world * n : n;
@@ -108,8 +122,9 @@ __global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* src0, i
 __global__ __launch_bounds__(256) void mbox_bn_combine_kernel(const float* __restrict__ local, int C, float count, float eps,
                                                               float momentum, float* __restrict__ stats, float* running_mean,
                                                               float* running_var, void* const* __restrict__ boxes, int world,
-                                                              int rank, unsigned seq, int cap, long spin_limit, int* __restrict__ err) {
-  const bool ok = mbox_send_wait(local, 3 * C, nullptr, 0, boxes, world, rank, seq, cap, spin_limit, err);
+                                                              int rank, unsigned* seq_dev, int cap, long spin_limit, int* __restrict__ err) {
+  unsigned seq;
+  const bool ok = mbox_send_wait(local, 3 * C, nullptr, 0, boxes, world, rank, seq_dev, cap, spin_limit, err, &seq);
   const int par = seq & 1u;
   if (!ok) {   // a peer never posted: NaN statistics (the step's losses turn NaN), running statistics untouched
     for (int c = threadIdx.x; c < 3 * C; c += 256) stats[c] = __builtin_nanf("");
@@ -168,24 +183,24 @@ extern "C" int tris_mbox_ipc_open(const void* handle64, void** ptr) {
 extern "C" int tris_mbox_ipc_close(void* ptr) { return (int)hipIpcCloseMemHandle(ptr); }
 
 extern "C" int tris_mbox_exchange_f32(const float* src0, int n0, const float* src1, int n1, float* out, void* const* boxes,
-                                      int world, int rank, int seq, int cap_floats, int mode, long spin_limit, int* err,
+                                      int world, int rank, unsigned* seq, int cap_floats, int mode, long spin_limit, int* err,
                                       void* stream) {
   if (n0 <= 0 || n1 < 0 || n0 + n1 > cap_floats || world < 1 || world > TRIS_MBOX_MAX_WORLD || rank < 0 || rank >= world ||
-      seq <= 0)
+      seq == nullptr)
     return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mbox_exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src0, n0, src1, n1, out, boxes, world, rank,
-                     (unsigned)seq, cap_floats, mode, spin_limit, err);
+                     seq, cap_floats, mode, spin_limit, err);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int tris_mbox_bn_combine_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum,
                                         float* stats, float* running_mean, float* running_var, void* const* boxes, int world,
-                                        int rank, int seq, int cap_floats, long spin_limit, int* err, void* stream) {
-  if (C <= 0 || 3 * C > cap_floats || world < 1 || world > TRIS_MBOX_MAX_WORLD || rank < 0 || rank >= world || seq <= 0)
+                                        int rank, unsigned* seq, int cap_floats, long spin_limit, int* err, void* stream) {
+  if (C <= 0 || 3 * C > cap_floats || world < 1 || world > TRIS_MBOX_MAX_WORLD || rank < 0 || rank >= world || seq == nullptr)
     return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mbox_bn_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, local_stats, C, (float)count_per_rank, eps,
-                     momentum, stats, running_mean, running_var, boxes, world, rank, (unsigned)seq, cap_floats, spin_limit, err);
+                     momentum, stats, running_mean, running_var, boxes, world, rank, seq, cap_floats, spin_limit, err);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -385,12 +385,15 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
 #define TRIS_WG_GO(...)                                                                                                          \
   hipLaunchKernelGGL((wgrad3x3_direct_kernel<__VA_ARGS__, PREC>), grid, dim3(256), 0, st, X, dY, ws, H, W, Ci, Co, nci, upb, units, \
                      bn.mean, bn.invstd, bn.gamma, bn.beta, amax_dy, amax_x)
+  // blocks per CU the kernel is compiled for: two in x3; h2 holds the tap accumulators PLUS a transient set and the fragments of
+  // all its k groups -- more than 256 registers -- and runs one block per CU
+  constexpr int OCC = PREC == 3 ? 1 : 2;
   switch (id) {
-    case 1: TRIS_WG_GO(32, 32, 1, 1, 4, 4, 2, 16); break;
-    case 2: TRIS_WG_GO(64, 32, 2, 1, 2, 4, 2, 16); break;
-    case 3: TRIS_WG_GO(64, 64, 2, 2, 1, 2, 2, 16); break;
+    case 1: TRIS_WG_GO(32, 32, 1, 1, 4, 4, OCC, 16); break;
+    case 2: TRIS_WG_GO(64, 32, 2, 1, 2, 4, OCC, 16); break;
+    case 3: TRIS_WG_GO(64, 64, 2, 2, 1, 2, OCC, 16); break;
     case 4: TRIS_WG_GO(64, 64, 2, 2, 1, 4, 1, 16); break;
-    case 5: TRIS_WG_GO(64, 32, 2, 1, 2, 8, 2, 8); break;
+    case 5: TRIS_WG_GO(64, 32, 2, 1, 2, 8, OCC, 8); break;
     default: return (int)hipErrorInvalidValue;
   }
 #undef TRIS_WG_GO

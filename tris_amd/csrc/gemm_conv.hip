@@ -120,7 +120,7 @@ struct H2Guard {
   ~H2Guard() { if (on) g_mode_thread = saved; }
 };
 
-static bool pipe_ok(const GemmParams& p) { return g_gemm_mode == 1 && gemm_fast_ok(p); }
+static bool pipe_ok(const GemmParams& p) { return (g_gemm_mode == 1 || g_gemm_mode == 3) && gemm_fast_ok(p); }
 // static choice of the loop structure (the autotuner times both)
 static int default_pipe(const GemmParams& p, int bm, int bn, int splitk) {
   if (!pipe_ok(p) || bn == 32) return 0;
@@ -129,6 +129,7 @@ static int default_pipe(const GemmParams& p, int bm, int bn, int splitk) {
   // 3-13 % (fwd 40x40x256: 165 -> 175, 20x20x512: 136 -> 154, wgrad 20x20x512: 154 -> 174 TFLOP/s); the short-K 1x1
   // products and the transformer GEMMs are on par or a few % slower -> static default by kind, the autotuner times both
   if (g_opt.pipe_default >= 0) return g_opt.pipe_default;
+  if (g_gemm_mode == 3) return 0;   // (h2: the classic loop unless the tuner finds the pipelined one faster for the shape)
   return p.gC >= 128 ? 1 : 0;
 }
 
@@ -598,6 +599,78 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// Direct weight-gradient kernel (wgrad3x3_direct_kernel, configuration ids 1..5) or the implicit GEMM: every usable candidate is
+// timed once per (shape, arithmetic, plain | BatchNorm-folded) on first sight and the winner cached, like the tile choice.  Option
+// WGRAD_DIRECT=0 keeps the GEMM, =1..5 forces a configuration where it applies (tests).  gemm: null for the BatchNorm-folded form
+// (only the direct kernels can normalise their input while staging it).
+namespace {
+template <class Direct, class Gemm>
+int wgrad_pick(int B, int H, int W, int Cin, int Cout, long ws_bytes, bool bnin, hipStream_t st, Direct direct, Gemm gemm) {
+  const int forced = g_opt.wgrad_direct;
+  auto usable = [&](int id) { return wg_ok(id, H, W, Cin, Cout) && wg_slices(id, B, H, W, Cin, Cout, ws_bytes, g_opt.wg_blocks) >= 1; };
+  int first = 0;   // static choice: the measured winners (DESIGN.md); the autotuner times every usable configuration
+  for (int id : {1, 2, 5})
+    if (!first && usable(id)) first = id;
+  if (g_gemm_mode == 3 && usable(4)) first = 4;   // (h2: the 64 x 64 single-wave-per-quadrant tile folds its cross products least often)
+  if (forced == 0 && !bnin) return gemm();
+  if (forced > 0) return (forced < kWgN && usable(forced)) ? direct(forced) : (bnin ? (first ? direct(first) : (int)hipErrorInvalidValue) : gemm());
+  if (!first) return bnin ? (int)hipErrorInvalidValue : gemm();
+  const TuneKey key = {A_HALO, 64 + B_KN_IM2COL + (bnin ? 128 : 0), Cout, 9 * Cin, B * H * W, H * 4096 + W, g_gemm_mode};
+  int cached = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) cached = it->second.bm;
+  }
+  if (cached >= 0) return cached ? direct(cached) : gemm();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (!autotune_enabled() || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return direct(first);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return direct(first);
+  if (!bnin) {
+    const int rc = gemm();   // (tunes the GEMM's own tile / split-K on first sight)
+    if (rc != 0) return rc;
+  }
+  (void)hipDeviceSynchronize();
+  auto timed = [&](int id) -> float {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      (void)hipEventRecord(e0, st);
+      if ((id ? direct(id) : gemm()) != 0) return 1e30f;
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+      float ms = 1e30f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    return best;
+  };
+  const float t_gemm = bnin ? 1e30f : timed(0);
+  float best_ms = t_gemm;
+  int best_id = 0;
+  for (int id = 1; id < kWgN; ++id) {
+    if (!usable(id)) continue;
+    const float ms = timed(id);
+    if (ms < best_ms) { best_ms = ms; best_id = id; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = Cfg{best_id, 0, 1, 0};
+    if (g_opt.tune_log[0]) {
+      if (FILE* f = fopen(g_opt.tune_log, "a")) {
+        fprintf(f, "wgrad3x3 Cout=%d Cin=%d pixels=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)%s\n", Cout, Cin,
+                B * H * W, H, W, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f,
+                2.0 * Cout * 9.0 * Cin * B * H * W / (best_ms * 1e-3) * 1e-12, bnin ? 0.f : t_gemm * 1e3f, bnin ? " bn-folded" : "");
+        fclose(f);
+      }
+    }
+  }
+  return best_id ? direct(best_id) : gemm();
+}
+}  // namespace
+
 // dW[Cout][3][3][Cin] = sum over output pixels of dY (x) gathered X.  Split-K over pixels through `workspace`.
 extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin,
                                       int Cout, int stride, float* workspace, long ws_bytes, void* stream) {
@@ -630,74 +703,14 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   hipStream_t st = (hipStream_t)stream;
   H2Guard h2(p, h2n);   // (armed: A = dY, B = X)
   auto gemm = [&]() { return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, st); };
-  // direct kernel (wgrad3x3_direct_kernel) or the implicit GEMM: timed once per shape.  Option WGRAD_DIRECT=0 keeps the GEMM,
-  // =1..5 forces a direct configuration where it applies (tests).
-  const int forced = g_opt.wgrad_direct;
   const bool shape_ok = (g_gemm_mode == 1 || g_gemm_mode == 3) && stride == 1 && workspace != nullptr && al16(X) && al16(dY) && al16(dW) && al16(workspace) &&
                         (long)B * H * W * std::max(Cin, Cout) < (1L << 31);
   auto direct = [&](int id) {
     return run_wgrad_direct(id, X, dY, dW, B, H, W, Cin, Cout, workspace, ws_bytes, st, BnIn{nullptr, nullptr, nullptr, nullptr},
                             p.h2_amaxA, p.h2_amaxB);
   };
-  auto usable = [&](int id) { return wg_ok(id, H, W, Cin, Cout) && wg_slices(id, B, H, W, Cin, Cout, ws_bytes, g_opt.wg_blocks) >= 1; };
-  if (forced == 0 || !shape_ok) return gemm();
-  if (forced > 0) return (forced < kWgN && usable(forced)) ? direct(forced) : gemm();
-  int first = 0;   // static choice: the measured winners (DESIGN.md); the autotuner times every usable configuration
-  if (usable(1)) first = 1;
-  else if (usable(2)) first = 2;
-  else if (usable(5)) first = 5;
-  if (!first) return gemm();
-  const TuneKey key = {A_HALO, 64 + B_KN_IM2COL, p.M, p.N, p.K, H * 4096 + W, g_gemm_mode};
-  int cached = -1;
-  {
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    auto it = g_tuned.find(key);
-    if (it != g_tuned.end()) cached = it->second.bm;
-  }
-  if (cached >= 0) return cached ? direct(cached) : gemm();
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (!autotune_enabled() || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return direct(first);
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return direct(first);
-  int rc = gemm();   // (tunes the GEMM's own tile / split-K on first sight)
-  if (rc != 0) return rc;
-  (void)hipDeviceSynchronize();
-  auto timed = [&](int id) -> float {
-    float best = 1e30f;
-    for (int rep = 0; rep < 3; ++rep) {
-      (void)hipEventRecord(e0, st);
-      if ((id ? direct(id) : gemm()) != 0) return 1e30f;
-      (void)hipEventRecord(e1, st);
-      if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
-      float ms = 1e30f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
-      best = ms < best ? ms : best;
-    }
-    return best;
-  };
-  const float t_gemm = timed(0);
-  float best_ms = t_gemm;
-  int best_id = 0;
-  for (int id = 1; id < kWgN; ++id) {
-    if (!usable(id)) continue;
-    const float ms = timed(id);
-    if (ms < best_ms) { best_ms = ms; best_id = id; }
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  {
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    g_tuned[key] = Cfg{best_id, 0, 1, 0};
-    if (g_opt.tune_log[0]) {
-      if (FILE* f = fopen(g_opt.tune_log, "a")) {
-        fprintf(f, "wgrad3x3 Cout=%d Cin=%d pixels=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)\n", Cout, Cin, p.K, H,
-                W, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f, 2.0 * p.M * p.N * p.K / (best_ms * 1e-3) * 1e-12,
-                t_gemm * 1e3f);
-        fclose(f);
-      }
-    }
-  }
-  return best_id ? direct(best_id) : gemm();
+  if (!shape_ok) return gemm();
+  return wgrad_pick(B, H, W, Cin, Cout, ws_bytes, false, st, direct, gemm);
 }
 
 // Conv / 1x1-conv (GEMM) forward with the BatchNorm batch statistics of the OUTPUT fused into the epilogue.
@@ -833,16 +846,11 @@ extern "C" int tris_conv3x3_wgrad_bnin_f32(const float* X, const float* mean, co
   if (!bnin_enabled() || workspace == nullptr || !al16(X) || !al16(dY) || !al16(dW) || !al16(workspace) || !al16(mean) ||
       !al16(invstd) || !al16(gamma) || !al16(beta))
     return (int)hipErrorInvalidValue;
-  int id = wg_static_choice(B, H, W, Cin, Cout, ws_bytes);
-  if (id == 0) return (int)hipErrorInvalidValue;
-  {  // the configuration the plain weight gradient timed as fastest for this shape, if it is a direct one
-    const TuneKey key = {A_HALO, 64 + B_KN_IM2COL, Cout, 9 * Cin, B * H * W, H * 4096 + W, g_gemm_mode};
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    auto it = g_tuned.find(key);
-    if (it != g_tuned.end() && it->second.bm > 0) id = it->second.bm;
-  }
-  return run_wgrad_direct(id, X, dY, dW, B, H, W, Cin, Cout, workspace, ws_bytes, (hipStream_t)stream,
-                          BnIn{mean, invstd, gamma, beta}, pq.h2_amaxA, pq.h2_amaxB);
+  auto direct = [&](int id) {
+    return run_wgrad_direct(id, X, dY, dW, B, H, W, Cin, Cout, workspace, ws_bytes, (hipStream_t)stream, BnIn{mean, invstd, gamma, beta},
+                            pq.h2_amaxA, pq.h2_amaxB);
+  };
+  return wgrad_pick(B, H, W, Cin, Cout, ws_bytes, true, (hipStream_t)stream, direct, []() { return (int)hipErrorInvalidValue; });
 }
 
 extern "C" int tris_set_gemm_mode(int mode) {

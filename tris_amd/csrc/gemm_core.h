@@ -384,7 +384,7 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   int bm = cfg.bm, bn = cfg.bn, splitk = cfg.splitk;
   const bool fast = gemm_fast_ok(p);
   if (bn == 32 && !fast) bm = bn = 64;  // the 128x32 tile exists in the fast kernel only
-  const bool pipe = cfg.pipe && mode == 1 && fast && bn != 32;   // (the pipelined loop exists in x3 arithmetic)
+  const bool pipe = cfg.pipe && (mode == 1 || mode == 3) && fast && bn != 32;   // (the pipelined loop: x3 and h2)
   if (bm == 256 && !pipe) bm = 128;     // the 256-row tile exists in the pipelined form only
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
@@ -430,14 +430,21 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
       }                                                                                            \
     }                                                                                              \
   } while (0)
-#define TRIS_PIPE_GO(BM_, BN_, NW_, NWM_)                                                                                  \
-  do {                                                                                                                     \
-    if (splitk > 1) {                                                                                                      \
-      p.C = ws;                                                                                                            \
-      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 1, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p); \
-    } else {                                                                                                               \
-      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 1, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p);  \
-    }                                                                                                                      \
+#define TRIS_PIPE_ONE(BM_, BN_, NW_, NWM_, EPI_)                                                                                   \
+  do {                                                                                                                             \
+    if (mode == 3)                                                                                                                 \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, 3, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p);      \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, 1, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p);      \
+  } while (0)
+#define TRIS_PIPE_GO(BM_, BN_, NW_, NWM_)                        \
+  do {                                                           \
+    if (splitk > 1) {                                            \
+      p.C = ws;                                                  \
+      TRIS_PIPE_ONE(BM_, BN_, NW_, NWM_, EPI_SLAB);              \
+    } else {                                                     \
+      TRIS_PIPE_ONE(BM_, BN_, NW_, NWM_, EPI_STD);               \
+    }                                                            \
   } while (0)
   if (pipe) {
     if (bm == 256 && bn == 128) TRIS_PIPE_GO(256, 128, 8, 4);
@@ -450,6 +457,7 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   else TRIS_GO(64, 64, true);
 #undef TRIS_GO
 #undef TRIS_PIPE_GO
+#undef TRIS_PIPE_ONE
 #undef TRIS_FAST_EPI
 #undef TRIS_FAST
 #undef TRIS_NW

@@ -58,9 +58,14 @@ constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, i
   if (NSTG == 1) return (NW == 8 || (PREC == 3 && NW == 4 && BM * BN <= 128 * 64)) ? 4 : 2;
   const int lds = HS > 0 ? 4 * (gf_halo_floats(HS, PREC) + NSTG * gf_stage_floats(BN, FBK, PREC, b_rm))
                          : 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
-  const int blocks = lds * 2 <= 160 * 1024 ? 2 : 1;
+  // (h2, 256-row tiles: 128 accumulator registers per wave -- one block per CU whatever the LDS would allow)
+  const int blocks = (lds * 2 <= 160 * 1024 && !(PREC == 3 && BM == 256)) ? 2 : 1;
   const int w = blocks * NW / 4;
-  if (HS > 0) return w > 2 ? 2 : (w < 1 ? 1 : w);   // (direct 3x3: the window registers need more than 128 VGPRs)
+  if (HS > 0) {   // (direct 3x3: the window registers need more than 128 VGPRs; h2 with four 32 x 32 blocks per wave -- eight
+    // accumulator blocks -- more than 256: one wave per SIMD)
+    if (PREC == 3 && NW == 4 && BM * BN >= 128 * 128) return 1;
+    return w > 2 ? 2 : (w < 1 ? 1 : w);
+  }
   return w < 1 ? 1 : w;
 }
 

@@ -12,6 +12,10 @@ this repo's HIP kernels launched through the C ABI on the capturing stream."""
 import torch
 
 
+class NotCapturable(RuntimeError):
+    """the step cannot be replayed from hipGraphs in this configuration (train_step then runs it eagerly)"""
+
+
 class GraphedStage1Eval:
     def __init__(self, net, img_shape, query_len, warmup=2):
         assert not net.training, "capture the eval path (model.eval())"
@@ -153,13 +157,14 @@ class GraphedTrainStep:
         return self.losses
 
 
-def _prime(model, clip_model, optimizer, bns, batch, args, priming):
+def _prime(model, clip_model, optimizer, bns, batch, args, priming, reducer=None):
     """eager forward + backward passes WITHOUT an optimiser step, BatchNorm running statistics put back afterwards: first-
-    encounter autotuning, workspaces and allocator pools settle before anything is captured"""
+    encounter autotuning, workspaces and allocator pools settle before anything is captured (data parallel: every rank primes,
+    SyncBatchNorm exchanges and gradient collectives included -- the gradients are discarded)"""
     from .train_stage1 import _step_body
     keep = [(m.running_mean.clone(), m.running_var.clone(), m._nbt_pending) for m in bns]
     for _ in range(priming):
-        _step_body(model, clip_model, optimizer, batch[0], batch[1], batch[2], args, None, optimizer_step=False)
+        _step_body(model, clip_model, optimizer, batch[0], batch[1], batch[2], args, reducer, optimizer_step=False)
     torch.cuda.synchronize()
     with torch.no_grad():
         for m, (rm, rv, nbt) in zip(bns, keep):
@@ -234,11 +239,17 @@ class SegmentedTrainStep:
     deferred launch reads stays referenced until all captures are done, so no later segment's capture can be handed its memory.
     The three streams capture into three private pools (graphs that may run concurrently must not share one).
 
-    Same restrictions and the same bookkeeping (static inputs, device-side optimiser scalars, BatchNorm step counters) as
-    GraphedTrainStep; same kernels in the same arithmetic as the eager step, so step k of a replayed run equals step k of an
-    eager run bit for bit."""
+    Same bookkeeping (static inputs, device-side optimiser scalars, BatchNorm step counters) as GraphedTrainStep; same kernels
+    in the same arithmetic as the eager step, so step k of a replayed run equals step k of an eager run bit for bit.
 
-    def __init__(self, model, clip_model, optimizer, args, example, lr_scheduler=None, priming=2):
+    Data parallel (reducer given): SyncBatchNorm's mailbox exchanges are ordinary single-workgroup kernels whose exchange
+    counter lives on the device (csrc/comm.hip) -- they are captured like everything else.  Collectives are NOT: while the
+    backward graphs are recorded the reducer's boundary nodes only note behind which graph their segment becomes final
+    (release()), and the replay issues those all-reduces -- and the sparse embedding exchange -- eagerly from the reducer's
+    stream between two graph replays; finish() + ONE AdamW graph close the step (the early part of AdamW would update
+    parameters whose gradients are still on the wire)."""
+
+    def __init__(self, model, clip_model, optimizer, args, example, lr_scheduler=None, priming=2, reducer=None):
         from . import ops
         from .CLIP.clip.model import BatchNorm2d
         from .train_stage1 import stage1_loss_block
@@ -250,7 +261,15 @@ class SegmentedTrainStep:
         net = model.module if hasattr(model, "module") else model
         self.bns = [m for m in net.modules() if isinstance(m, BatchNorm2d)]
         optimizer.enable_device_hyper()
-        _prime(model, clip_model, optimizer, self.bns, (self.s_img, self.s_ids, self.s_neg), args, priming)
+        self.reducer = reducer if (reducer is not None and reducer.active) else None
+        self.released, self.embed_rows = [], None
+        _prime(model, clip_model, optimizer, self.bns, (self.s_img, self.s_ids, self.s_neg), args, priming, self.reducer)
+        if any(m.process_group is not None for m in self.bns):
+            # SyncBatchNorm is capturable through the mailbox transport only (its exchanges are plain kernels); priming has set
+            # the transport up -- collectively, so every rank takes the same decision here
+            from . import comm
+            if any(m is None for m in comm.Mailbox._by_group.values()) or not comm.Mailbox._by_group:
+                raise NotCapturable("SyncBatchNorm fell back to torch.distributed collectives: the step runs eagerly")
         nbt = [m._nbt_pending for m in self.bns]
         self.text, self.wg = ops.side_stream("text"), ops._wgrad_stream()
         self.cap = torch.cuda.Stream()           # all compute-stream pieces are captured on this one stream
@@ -278,7 +297,7 @@ class SegmentedTrainStep:
                     out.append(g)
             finally:
                 self.inline = False
-            return out[0], out[1], [sk for _, _, sk in fns]
+            return out[0], out[1], [sk for _, _, sk in fns] + [t for _, ts, _ in fns for t in ts if t is not None]
 
         self.h2_pool = ops.h2_begin_step()   # (h2 arithmetic: the amax pool the captured launches write; zeroed per replay)
         self.h2_aux = ops.h2_private_pool()  # (the frozen aux text tower's own words: its graph clears them itself)
@@ -331,16 +350,19 @@ class SegmentedTrainStep:
             self.fwd, self.fwd_marks = fwd.graphs, marks
 
             # ---- backward, segment by segment (compute stream), each followed by its weight gradients (their stream)
-            def b_heads():
-                optimizer.zero_grad()
+            def b_heads():      # (optimizer.zero_grad() is issued eagerly by the replay, in front of the reducer's order check)
                 self.losses[0].backward()
+            def take_released():
+                keys, self.released = self.released, []
+                return keys
             g = G()
             _capture(g, self.cap, pool_c, b_heads)
-            self.back = [(g,) + wgrad_graphs()[:2]]
+            self.back = [(g,) + wgrad_graphs()[:2] + (take_released(),)]
             self.inline = True
             self.g_btext = G()
             _capture(self.g_btext, self.text, pool_t, lambda: torch.autograd.backward(hidden, h.grad))
             self.inline = False
+            self.text_released = take_released()
             n_late = min(6, len(trunk_cuts))   # segments whose weight gradients are split over the weight-gradient and the text stream
             split = True
             late_sinks = []
@@ -349,14 +371,14 @@ class SegmentedTrainStep:
                 g = G()
                 _capture(g, self.cap, pool_c, lambda: torch.autograd.backward(x, leaf.grad))
                 gw, gt, sinks = wgrad_graphs(split=late and split)
-                self.back.append((g, gw, gt))
+                self.back.append((g, gw, gt, take_released()))
                 if late:
                     late_sinks += sinks
             self.first_late = len(self.back) - n_late
             # ---- AdamW.  The update is element-wise, so it can be cut where the gradients become final: everything outside the
             # arena span the LATE segments' weight-gradient launches write is complete once the early ones are, and is updated
             # on the compute stream while those last launches still run; the span itself follows the final join.
-            spans = self._late_spans(optimizer, late_sinks) if n_late else None
+            spans = self._late_spans(optimizer, late_sinks) if (n_late and self.reducer is None) else None
             self.g_opt_early = None
             if spans:
                 early = []
@@ -382,21 +404,27 @@ class SegmentedTrainStep:
         self._marks = None
 
     @staticmethod
-    def _late_spans(optimizer, sinks):
-        """{group index: (lo, hi)}: per arena, the element range that covers every gradient view in `sinks`; None if a view lies
-        in no arena"""
+    def _late_spans(optimizer, touched):
+        """{group index: (lo, hi)}: per arena, the element range that covers every arena-resident tensor in `touched` -- the
+        gradient views the late weight-gradient launches WRITE and the parameters they READ (a BatchNorm folded into a direct
+        convolution re-normalises its input with gamma / beta: the early AdamW must not have updated them yet).  Tensors that
+        live in no arena (activations) do not constrain anything; None if a gradient view lies in no arena."""
         spans = {}
-        for sk in sinks:
+        for t in touched:
             for gi, a in enumerate(optimizer.arenas):
-                off = (sk.data_ptr() - a.g.data_ptr()) // 4
-                if 0 <= off < a.numel:
-                    lo, hi = spans.get(gi, (off, off))
-                    end = (off + sk.numel() + 63) // 64 * 64
-                    spans[gi] = (min(lo, off // 64 * 64), max(hi, min(end, a.numel)))
-                    break
-            else:
-                return None
-        return spans
+                for base in (a.g, getattr(a, "p", None)):
+                    if base is None:
+                        continue
+                    off = (t.data_ptr() - base.data_ptr()) // 4
+                    if 0 <= off < a.numel and t.device == base.device:
+                        lo, hi = spans.get(gi, (off, off))
+                        end = (off + t.numel() + 63) // 64 * 64
+                        spans[gi] = (min(lo, off // 64 * 64), max(hi, min(end, a.numel)))
+                        break
+                else:
+                    continue
+                break
+        return spans or None
 
     def marks(self):
         """[(name, ms since the start of the step)] of the last replay made with .trace = True (synchronises)"""
@@ -415,6 +443,10 @@ class SegmentedTrainStep:
                 setattr(leaf, attr, v)
         self.cuts.append((x, leaf))
         return leaf
+
+    def release(self, key):
+        """(GradReducer._launch while capturing) segment `key` is final behind the backward graph being recorded"""
+        self.released.append(key)
 
     def defer(self, fn, tensors, sink):
         if self.inline:
@@ -469,7 +501,11 @@ class SegmentedTrainStep:
             g.replay()
         mark("heads_fwd_done")
         wg.wait_event(ev[0])
-        for i, (gb, gw, gt) in enumerate(self.back):
+        red = self.reducer
+        opt.zero_grad()
+        if red is not None:
+            red.begin_step()
+        for i, (gb, gw, gt, keys) in enumerate(self.back):
             gb.replay()
             e = ev[6 + i]
             e.record(main)
@@ -480,6 +516,11 @@ class SegmentedTrainStep:
                     self.g_btext.replay()
                     ev[2].record(text)
                     mark("text_bwd_done", text)
+                    if red is not None:      # the text encoder's segments + the sparse embedding exchange: behind its backward
+                        if self.embed_rows is not None:
+                            red.exchange_rows(*self.embed_rows)
+                        for k in self.text_released:
+                            red._launch_now(k)
             if gw is not None:
                 wg.wait_event(e)
                 with torch.cuda.stream(wg):
@@ -490,6 +531,9 @@ class SegmentedTrainStep:
                 with torch.cuda.stream(text):
                     gt.replay()
                     mark(f"w{i}t_done", text)
+            if red is not None:              # segments that became final with this piece of backward (their last weight
+                for k in keys:               # gradients were just queued on the side streams: the reducer's stream waits for them)
+                    red._launch_now(k)
             if i == self.first_late - 1:
                 ev[4].record(wg)        # every weight gradient outside the late span is behind this
         if self.g_opt_early is not None:
@@ -502,6 +546,8 @@ class SegmentedTrainStep:
         main.wait_event(ev[3])
         main.wait_event(ev[5])
         mark("joined")
+        if red is not None:
+            red.finish()                     # what is left (embedding, stem), then the compute stream waits for the collectives
         self.g_opt.replay()
         mark("opt_done")
         for m in self.bns:

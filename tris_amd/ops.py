@@ -820,14 +820,15 @@ class _BnBwdLink:
         self.dz, self.part, self.rows = (dz.data_ptr(), dz._version, tuple(dz.shape)), part, rows
 
     def take(self, dy):
-        """(part, rows) if dy is the masked gradient this link's GEMM produced; None if no GEMM filled the link; one use"""
+        """(part, rows) if dy IS the masked gradient this link's product left (same storage, version and shape); None if no product
+        filled the link -- or if what arrives is something else: a second consumer's gradient was added to it by autograd (a
+        down-sampling block whose shortcut backward ran late, a model that uses the BatchNorm output twice).  The caller then runs
+        the usual two passes on whatever arrived, which is correct for any sum of gradients (the ReLU mask is idempotent: masking
+        an already-masked term again changes nothing).  One use."""
         dz, part, rows = self.dz, self.part, self.rows
         self.dz = self.part = None
-        if dz is None:
+        if dz is None or (dy.data_ptr(), dy._version, tuple(dy.shape)) != dz:
             return None
-        if (dy.data_ptr(), dy._version, tuple(dy.shape)) != dz:
-            raise RuntimeError("a BatchNorm output marked bwd_link=True has a second autograd consumer: the masked gradient "
-                               "its 1x1 convolution produced was replaced or modified before it reached the BatchNorm backward")
         return part, rows
 
 
@@ -894,9 +895,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             link, fused = ctx.bn_link, False
-            if link is not None:
+            if link is not None and (box is None or extra is not None):
                 # x is the output of a BatchNorm(+ReLU) that has no other consumer: mask dx and reduce it for that BatchNorm's
-                # backward in this product's epilogue (_BnBwdLink)
+                # backward in this product's epilogue (_BnBwdLink).  With a gradient box whose value has NOT arrived yet (the
+                # other consumer's backward is still to run and will hand its term to autograd) the sums would miss that term:
+                # the plain data gradient runs and the BatchNorm backward does its own reduction
                 import ctypes
                 part = torch.empty(((M + 127) // 128) * 2 * K, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
@@ -1135,7 +1138,9 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
             if sk is not None:
-                on_wgrad_stream(lambda: wgrad(sk), dy, x, *((mean, invstd) if ctx.lazy else ()), sink=sk)
+                # (every tensor the deferred launch READS is named: a segmented capture keeps them alive and keeps the early part
+                # of AdamW away from the parameters among them -- the folded BatchNorm's gamma / beta)
+                on_wgrad_stream(lambda: wgrad(sk), dy, x, *((mean, invstd, gamma, beta) if ctx.lazy else ()), sink=sk)
             else:
                 dw = _emit(ctx.params[0], wgrad, True)
         return dx, dw, None, None, None, None
@@ -1544,9 +1549,9 @@ class EmbedFn(torch.autograd.Function):
         dpos.zero_()
         call("tris_embed_bwd_f32", P(ids), P(dout), None, P(dpos), N, L, W, _stream())     # positional part
         red = ctx.reducer
-        if red is not None and st[0] is not None and W % 4 == 0 and red.take_embedding_rows(ctx.params[0], ids.view(-1), dout.view(N * L, W), dtok):
+        if red is not None and st[0] is not None and W % 4 == 0 and W <= 2048 and red.take_embedding_rows(ctx.params[0], ids.view(-1), dout.view(N * L, W), dtok):
             pass     # the reducer gathers every rank's rows and scatters them (scale 1 / world) into dtok
-        elif W % 4 == 0:
+        elif W % 4 == 0 and W <= 2048:
             call("tris_embed_rows_bwd_f32", P(ids), P(dout), P(dtok), N * L, W, 1.0, _stream())
         else:
             call("tris_embed_bwd_f32", P(ids), P(dout), P(dtok), None, N, L, W, _stream())

@@ -129,6 +129,17 @@ class GradReducer:
 
     # ---- runtime -----------------------------------------------------------------------------------------------------
     def _launch(self, key):
+        """called by the boundary nodes from inside backward.  While a segmented capture of the step is being recorded
+        (tris_amd.graphs.SegmentedTrainStep) nothing is launched: the capture notes WHERE the segment was released and the
+        replay issues the collectives there, between two graph replays -- collectives are never part of a graph."""
+        from . import ops
+        if ops._SEG is not None:
+            if self.active:
+                ops._SEG.release(key)
+            return
+        self._launch_now(key)
+
+    def _launch_now(self, key):
         if key in self.done or not self.active:
             return
         self.done.add(key)
@@ -181,6 +192,14 @@ class GradReducer:
         if not (self.active and self.sparse_embed and id(param) in self.sparse_exclude):
             return False
         from . import ops
+        if ops._SEG is not None:      # segmented capture: the exchange is issued by the replay, behind the text backward graph
+            ops._SEG.embed_rows = (ids, rows, dtok)
+            return True
+        self.exchange_rows(ids, rows, dtok)
+        return True
+
+    def exchange_rows(self, ids, rows, dtok):
+        from . import ops
         R, W = rows.shape
         world = max(self.world, 1)
         # (backends without AVG -- gloo -- scale the whole arenas by 1 / world in finish(): the table must not be scaled twice)
@@ -210,7 +229,6 @@ class GradReducer:
                 dtok.index_add_(0, ids, rows)
         self.sparse_log.append((world * R, R * (W * 4 + 8)))
         self.last_rows = (ids, rows)
-        return True
 
     def boundary(self, x, key):
         if not self.active or not torch.is_grad_enabled() or not x.requires_grad:
@@ -226,7 +244,7 @@ class GradReducer:
         if self.active:
             if self.segments:
                 for k in self.segments:
-                    self._launch(k)
+                    self._launch_now(k)
             else:  # no plan: whole arenas
                 from . import ops
                 ops.wgrad_join()

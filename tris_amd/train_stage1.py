@@ -110,14 +110,21 @@ def _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
 
 def _graphable(model, optimizer, img, reducer):
     """may this step be replayed from a hipGraph?  Opt-in (TRIS_STEP_GRAPH=1): see train_step"""
-    if cfg.step_graph not in ("1", "seg") or reducer is not None or ops._PROF is not None:
+    if cfg.step_graph not in ("1", "seg") or ops._PROF is not None:
         return False
     if not img.is_cuda or not hasattr(optimizer, "enable_device_hyper") or torch.cuda.is_current_stream_capturing():
         return False
     from .CLIP.clip.model import BatchNorm2d
     net = model.module if hasattr(model, "module") else model
-    if not net.training or any(m.process_group is not None for m in net.modules() if isinstance(m, BatchNorm2d)):
+    if not net.training:
         return False
+    sync_bn = any(m.process_group is not None for m in net.modules() if isinstance(m, BatchNorm2d))
+    if cfg.step_graph == "1":      # ONE graph: single-process steps only (collectives are never captured)
+        return reducer is None and not sync_bn
+    if sync_bn:                    # segmented replay: SyncBatchNorm through the mailbox transport only (device-side counter)
+        from . import comm
+        if any(m is None for m in comm.Mailbox._by_group.values()) or cfg.syncbn_comm != "mailbox":
+            return False
     return True
 
 
@@ -134,15 +141,21 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
     if _graphable(model, optimizer, img, reducer):
         net = model.module if hasattr(model, "module") else model
         key = (tuple(img.shape), tuple(word_ids.shape), None if neg_word_ids is None else tuple(neg_word_ids.shape),
-               img.dtype, word_ids.dtype, id(clip_model), id(optimizer), id(lr_scheduler), ops.get_gemm_mode(),
+               img.dtype, word_ids.dtype, id(clip_model), id(optimizer), id(lr_scheduler), id(reducer), ops.get_gemm_mode(),
                cfg.key())
         slot = net.__dict__.get("_tris_step_graph")
         if slot is None:
-            from .graphs import GraphedTrainStep, SegmentedTrainStep
+            from .graphs import GraphedTrainStep, NotCapturable, SegmentedTrainStep
             cls = SegmentedTrainStep if cfg.step_graph == "seg" else GraphedTrainStep
-            g = cls(model, clip_model, optimizer, args, (img, word_ids, neg_word_ids), lr_scheduler)
+            kw = {"reducer": reducer} if cls is SegmentedTrainStep else {}
+            try:
+                g = cls(model, clip_model, optimizer, args, (img, word_ids, neg_word_ids), lr_scheduler, **kw)
+            except NotCapturable as e:
+                import warnings
+                warnings.warn(str(e))
+                g = None
             slot = net.__dict__["_tris_step_graph"] = (key, g)
-        if slot[0] == key:
+        if slot[0] == key and slot[1] is not None:
             return slot[1](img, word_ids, neg_word_ids)
     losses = _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, reducer)
     if lr_scheduler is not None:
@@ -320,6 +333,10 @@ def main(args, tokenizer=None):
                                     lr_scheduler=scheduler, reducer=reducer, logger=log)
         torch.cuda.synchronize()
         train_time += time.time() - t0
+        if args.distributed:
+            # a SyncBatchNorm exchange that timed out poisoned its outputs: stop on every rank BEFORE validating / checkpointing
+            from . import comm
+            comm.check_errors(collective=True)
         res = evaluate()
         oIoU, val_acc, hit = res[0]
         if float(val_acc) > best["val_acc"] and local_rank == 0:
