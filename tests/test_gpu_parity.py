@@ -171,6 +171,11 @@ def test_g5_g6_train_step(model, aux, batch, golden):
     # Gradient probes.  Element-wise agreement between two *correct* fp32 implementations is limited by round-off
     # amplified through ~50 train-mode BatchNorms at batch 2 (the fp32 CPU oracle itself is 1-5 % off an fp64 run
     # element-wise on early-layer gradients; see test_gradients_vs_fp64_noise_floor for the calibrated check).
+    # Calibrated bound (tests/golden/g6_noise_floor.npz, oracle/gen_noise_floor.py): the probes' fp64 values, and how far the fp32
+    # CPU run is from them -- 1e-6 ... 1e-3 of the norm depending on the layer.  The HIP path is another correct fp32-class
+    # implementation: it must sit within a small multiple of that floor (norm: 8x, never tighter than 2e-4; head elements: 3x the
+    # fp32 run's largest element error in the tensor, never tighter than 5e-4 of the largest gradient element).
+    nf = golden("g6_noise_floor.npz")
     for k in [n[len("grad_norm."):] for n in g.files if n.startswith("grad_norm.")]:
         p = named[k]
         assert p.grad is not None, k
@@ -179,6 +184,13 @@ def test_g5_g6_train_step(model, aux, batch, golden):
         head = p.grad.reshape(-1)[:16]
         href = g["grad_head." + k]
         assert err(head, href) <= 0.1 * np.abs(href).max() + 1e-2 * gn / np.sqrt(p.numel()) + 1e-7, k
+        n64 = float(nf["norm64." + k])
+        tol_n = max(8.0 * float(nf["f32_normdev." + k]), 2e-4 * n64)
+        dev_n = abs(float(p.grad.double().norm()) - n64)
+        assert dev_n <= tol_n, (k, "norm", dev_n / n64, float(nf["f32_normdev." + k]) / n64)
+        tol_h = max(3.0 * float(nf["f32_maxdev." + k]), 5e-4 * float(nf["absmax64." + k]))
+        dev_h = float(np.abs(head.detach().double().cpu().numpy() - nf["head64." + k]).max())
+        assert dev_h <= tol_h, (k, "head", dev_h, tol_h, float(nf["f32_headdev." + k]))
         if k != "logit_scale":
             # first AdamW step moves every element by ~lr*sign(g): a near-zero gradient element whose sign differs
             # (round-off) shows up as exactly 2*lr; allow at most 2 such elements out of the 16 probed

@@ -1,10 +1,11 @@
-# closing run of a round (on the GPU box: gpurun -- bash tools/closing_run.sh): full GPU test suite, smoke, bench (with CPU baseline), then the profile set of tools/closing_profiles.sh; outputs under gpurun_out/, copied to profiles/ by hand
+# closing run of a round (on the GPU box: gpurun -- bash tools/closing_run.sh): full GPU test suite, smoke, bench (with CPU baseline and every side leg; autotuner log per arithmetic), the cross-attention phase table, then the profile sets of tools/closing_profiles.sh for h2 and x3; outputs under gpurun_out/, copied to profiles/ by hand
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-export TAG=${TAG:-r3z}
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_gputests.log 2>&1 < /dev/null; echo "tests rc=$?"; grep -E "passed|failed" gpurun_out/${TAG}_gputests.log | tail -2
+export TAG=${TAG:-r4}
+timeout 1800 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/${TAG}_gputests.log 2>&1 < /dev/null; echo "tests rc=$?"; grep -E "passed|failed" gpurun_out/${TAG}_gputests.log | tail -2
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1 < /dev/null; tail -1 gpurun_out/${TAG}_smoke.log
-TRIS_TUNE_LOG=gpurun_out/${TAG}_tune.txt timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1 < /dev/null; grep "^{" gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; cut -c1-300 gpurun_out/${TAG}_bench.json
-timeout 400 python bench.py --backbone clip-ViT-B/16 --no-cpu-baseline --no-pipeline > gpurun_out/${TAG}_bench_vit.log 2>&1 < /dev/null; grep "^{" gpurun_out/${TAG}_bench_vit.log > gpurun_out/${TAG}_bench_vit.json; cut -c1-200 gpurun_out/${TAG}_bench_vit.json
-timeout 300 python tools/gemm_wp_bench.py > gpurun_out/${TAG}_gemm_weight_planes.txt 2>&1 < /dev/null; tail -3 gpurun_out/${TAG}_gemm_weight_planes.txt | cut -c1-160
+TRIS_TUNE_LOG=gpurun_out/${TAG}_autotune_log_all.txt timeout 1200 python bench.py > gpurun_out/${TAG}_bench.log 2>&1 < /dev/null; grep "^{" gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; cut -c1-300 gpurun_out/${TAG}_bench.json
+grep "mode=3" gpurun_out/${TAG}_autotune_log_all.txt > gpurun_out/${TAG}_autotune_log_h2.txt; grep "mode=1" gpurun_out/${TAG}_autotune_log_all.txt > gpurun_out/${TAG}_autotune_log_x3.txt; wc -l gpurun_out/${TAG}_autotune_log_*.txt | tail -3
+timeout 300 python tools/xattn_fused_trace.py > gpurun_out/${TAG}_xattn_phase_trace.txt 2>&1 < /dev/null; tail -12 gpurun_out/${TAG}_xattn_phase_trace.txt | cut -c1-200
 timeout 300 python tools/step_graph_marks.py > gpurun_out/${TAG}_step_graph_marks.txt 2>&1 < /dev/null; tail -2 gpurun_out/${TAG}_step_graph_marks.txt
-bash tools/closing_profiles.sh
+MODE=h2 bash tools/closing_profiles.sh
+MODE=x3 bash tools/closing_profiles.sh

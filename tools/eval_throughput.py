@@ -1,5 +1,5 @@
 """Evaluation throughput of BASELINE configs[1] (validate.py's loop): refs per second of the one-ref-at-a-time loop (trunk and
-sentence halves replayed from hipGraphs) against the batched evaluation (TRIS_EVAL_GROUP refs per pass), on a synthetic loader of
+sentence halves replayed from hipGraphs) against the batched evaluation (cfg.eval_group refs per pass), on a synthetic loader of
 RefCOCOg-shaped refs (320 px images, 2 sentences each, 427 x 640 masks) -- same (oIoU, mIoU, hit) from both, asserted here.
 Used by bench.py (`eval` object) and runnable on its own:  python tools/eval_throughput.py"""
 import json
@@ -43,16 +43,14 @@ def measure(n_refs=64, sentences=2, groups=(1, 16, 32), model=None):
     out, first = {}, None
     quiet = SimpleNamespace(info=lambda *a, **k: None)
     for g in groups:
-        os.environ["TRIS_EVAL_GROUP"] = str(g)
-        try:
+        from tris_amd.config import cfg
+        with cfg.override(eval_group=int(g)):
             validate(args, loader[:max(g, 4)], model, 0, logger=quiet)          # graphs / autotune / allocator warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res = validate(args, loader, model, 0, logger=quiet)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        finally:
-            os.environ.pop("TRIS_EVAL_GROUP")
         res = (res[0], float(res[1]), res[2])
         first = res if first is None else first
         assert res == first, ("batched evaluation changed the metrics", g, res, first)

@@ -412,9 +412,9 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_on
     g_tuned[key] = Cfg{best_id, 0, 1, 0};
     if (g_opt.tune_log[0]) {
       if (FILE* f = fopen(g_opt.tune_log, "a")) {
-        fprintf(f, "conv3x3 bkind=%d M=%d N=%d K=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)\n", key.bk, p.M, p.N,
-                p.K, p.gH, p.gW, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f,
-                2.0 * p.M * p.N * p.K / (best_ms * 1e-3) * 1e-12, t_im2col * 1e3f);
+        fprintf(f, "conv3x3 bkind=%d M=%d N=%d K=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us) mode=%d\n", key.bk,
+                p.M, p.N, p.K, p.gH, p.gW, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f,
+                2.0 * p.M * p.N * p.K / (best_ms * 1e-3) * 1e-12, t_im2col * 1e3f, g_gemm_mode);
         fclose(f);
       }
     }
@@ -660,9 +660,10 @@ int wgrad_pick(int B, int H, int W, int Cin, int Cout, long ws_bytes, bool bnin,
     g_tuned[key] = Cfg{best_id, 0, 1, 0};
     if (g_opt.tune_log[0]) {
       if (FILE* f = fopen(g_opt.tune_log, "a")) {
-        fprintf(f, "wgrad3x3 Cout=%d Cin=%d pixels=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)%s\n", Cout, Cin,
-                B * H * W, H, W, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f,
-                2.0 * Cout * 9.0 * Cin * B * H * W / (best_ms * 1e-3) * 1e-12, bnin ? 0.f : t_gemm * 1e3f, bnin ? " bn-folded" : "");
+        fprintf(f, "wgrad3x3 Cout=%d Cin=%d pixels=%d HxW=%dx%d -> %s %d  %.1f us  %.1f TFLOP/s  (implicit GEMM %.1f us)%s mode=%d\n", Cout,
+                Cin, B * H * W, H, W, best_id ? "direct" : "implicit", best_id, best_ms * 1e3f,
+                2.0 * Cout * 9.0 * Cin * B * H * W / (best_ms * 1e-3) * 1e-12, bnin ? 0.f : t_gemm * 1e3f, bnin ? " bn-folded" : "",
+                g_gemm_mode);
         fclose(f);
       }
     }
