@@ -166,7 +166,7 @@ def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
         p.grad = None
         p.register_post_accumulate_grad_hook(lambda q: written.add(name_of[id(q)]))
     launches = []
-    orig = red._launch
+    orig = red._launch_now      # (boundary nodes call _launch, which defers to _launch_now outside a graph capture; finish() calls it directly)
 
     def checked(key):
         if key not in red.done:
@@ -174,7 +174,7 @@ def test_no_segment_is_reduced_before_its_last_gradient(monkeypatch, overlap):
             assert not missing, f"segment {key!r} released before {missing[:3]} (+{len(missing)}) had a gradient"
             launches.append(key)
         orig(key)
-    red._launch = checked
+    red._launch_now = checked
 
     B = 2
     img = torch.randn(B, 3, 64, 64)
@@ -227,7 +227,7 @@ def test_round1_plan_would_have_been_caught(monkeypatch):
         p.grad = None
         p.register_post_accumulate_grad_hook(lambda q: written.add(name_of[id(q)]))
     bad = {}
-    orig = red._launch
+    orig = red._launch_now      # (boundary nodes call _launch, which defers to _launch_now outside a graph capture; finish() calls it directly)
 
     def spy(key):
         if key not in red.done:
