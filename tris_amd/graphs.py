@@ -302,6 +302,13 @@ class SegmentedTrainStep:
         self.h2_pool = ops.h2_begin_step()   # (h2 arithmetic: the amax pool the captured launches write; zeroed per replay)
         self.h2_aux = ops.h2_private_pool()  # (the frozen aux text tower's own words: its graph clears them itself)
         self.h2_arenas = list(ops._H2.get("arenas", [])) if self.h2_pool is not None else []
+        # No garbage collection while streams are capturing: a collection that runs in the middle (any thread -- the autograd engine
+        # executes Python too) may destroy hipGraphs / free pool memory of an earlier captured step, which is illegal on a capturing
+        # thread and aborts the process.  Collect first, then keep the collector off until the last capture has ended.
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         ops._SEG = self
         try:
             # ---- forward.  Where the two text towers START relative to the trunk is chosen as in the eager step (model_stage1.
@@ -396,6 +403,8 @@ class SegmentedTrainStep:
             ops._SEG = None
             ops.h2_end_step()
             self.cuts, self.deferred = [], []
+            if gc_was:
+                gc.enable()
         del keep, trunk_cuts, h, hidden, vis, late_sinks, fwd
         for m, n in zip(self.bns, nbt):          # (capture launched nothing: the forward's host-side count is taken back)
             m._nbt_pending = n
