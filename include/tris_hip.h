@@ -159,8 +159,10 @@ int tris_amax_bits_f32(const float* x, long n, unsigned* out, void* stream);
 /* the same for nseg tensors base + offs[i] (sizes[i] floats; device arrays) in one launch -> slots[i]: the weights of an arena */
 int tris_amax_segments_f32(const float* base, const long* offs, const long* sizes, int nseg, unsigned* slots, void* stream);
 /* one shot, calling thread: the next tris_bn_apply_f32 / tris_bn_apply_pool_f32 / tris_bn_bwd_apply_f32 /
- * tris_bn_bwd_apply_pool_f32 / tris_layernorm_fwd_f32 / tris_layernorm_bwd_f32 (dX) / tris_elementwise_f32 also maxes the magnitude bits of what it WRITES into *out (zeroed by the caller): the amax of an
- * h2 operand as a by-product of the pass that produces the tensor, instead of a pass of its own */
+ * tris_bn_bwd_apply_pool_f32 / tris_layernorm_fwd_f32 / tris_layernorm_bwd_f32 (dX) / tris_elementwise_f32 / tris_gemm_f32 (C) /
+ * tris_mha_fwd_f32 / tris_mha_mfma_fwd_f32 (out) / tris_mha_bwd_f32 / tris_mha_mfma_bwd_f32 (dqkv) also maxes the magnitude bits of
+ * what it WRITES into *out (zeroed by the caller): the amax of an h2 operand as a by-product of the pass that produces the tensor,
+ * instead of a pass of its own.  Each of these entry points TAKES the arming first thing, whether or not it then launches anything. */
 int tris_amax_next(unsigned* out);
 int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB);
 /* *out (an amax word, zeroed by the caller) <- bits of max over c of |gamma[c]| * xhat_max + |beta[c]|: an upper bound of

@@ -49,20 +49,9 @@ for i in range(len(names) - 1):
 tot = (tr[:, -1] - tr[:, 0]) / clk * 1e6
 print(f"workgroup lifetime  min {tot.min():.2f}  median {tot.median():.2f}  max {tot.max():.2f} us")
 # ---- where the time between the median workgroup and the whole launch goes -------------------------------
-# s_memtime counters are per XCD (not aligned across XCDs); consecutive workgroups go to consecutive XCDs, so workgroup g runs on
-# XCD g % 8.  Per XCD: launch ramp = last start - first start, span = last end - first start; the kernel's duration is the
-# largest span plus the launch / drain latency outside the workgroups.
-xcd = torch.arange(B * 8) % 8
-start, end = tr[:, 0], tr[:, -1]
-ramp, span, lifemax = [], [], []
-for x in range(8):
-    m = xcd == x
-    ramp.append(float((start[m].max() - start[m].min()) / clk * 1e6))
-    span.append(float((end[m].max() - start[m].min()) / clk * 1e6))
-    lifemax.append(float(tot[m].max()))
-print("per XCD: launch ramp (last start - first start) us:", " ".join(f"{v:5.1f}" for v in ramp))
-print("per XCD: span (last end - first start) us:         ", " ".join(f"{v:5.1f}" for v in span))
-print("per XCD: longest workgroup lifetime us:             ", " ".join(f"{v:5.1f}" for v in lifemax))
+# (s_memtime counters are not aligned across the chip -- neither per XCD nor in a way a start stamp reveals --, so only
+# per-workgroup DELTAS are meaningful: the launch ramp and the drain are the difference between the longest workgroup lifetime
+# and the event-timed duration of the call printed at the top)
 # the slowest workgroup's own timeline, and the late starters (second workgroup of a doubly loaded CU starts when? -- with 384
 # workgroups on 256 CUs all are co-resident, so a late start is dispatch latency, not queueing)
 w = int(tot.argmax())

@@ -7,7 +7,12 @@
 #include "common.h"
 #include "tris_hip.h"
 
+// (one-shot arming of an amax by-product, csrc/norm.hip tris_amax_next)
+extern "C" __attribute__((visibility("hidden"))) unsigned* tris_internal_take_amax_next();
+
 namespace {
+
+#include "amax.h"
 
 constexpr int HD = 64;       // head dim
 constexpr int HP = HD + 4;   // padded LDS row: 68 floats = 17 sixteen-byte slots -> ds_read_b128 of 16 consecutive rows is
@@ -22,7 +27,7 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4 v) {
 // qkv: [N, L, 3W] packed (q | k | v), out: [N, L, W].  All LDS traffic is 16-byte wide: scores read q/k rows as float4,
 // the output phase gives each thread 4 consecutive channels of one row.
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L,
-                                                      int W, int causal, float scale) {
+                                                      int W, int causal, float scale, unsigned* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* q = sm;
   float* k = q + L * HP;
@@ -61,17 +66,21 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   float* ob = out + (long)n * L * W + h * HD;
+  unsigned am = 0u;
   for (int idx = tid; idx < L * (HD / 4); idx += 256) {
     const int i = idx >> 4, d = (idx & 15) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < L; ++j) fma4(acc, s[i * LP + j], lds4(&v[j * HP + d]));
     *reinterpret_cast<float4*>(&ob[(long)i * W + d]) = acc;
+    am = max(am, abits4(acc));
   }
+  if (amax != nullptr) amax_commit_block(am, amax);   // (the amax word of `out`: operand scale of the h2 product that consumes it)
 }
 
 // dqkv: [N, L, 3W]; recomputes P from q,k.
 __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                      float* __restrict__ dqkv, int L, int W, int causal, float scale) {
+                                                      float* __restrict__ dqkv, int L, int W, int causal, float scale,
+                                                      unsigned* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* q = sm;
   float* k = q + L * HP;
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   float* ob = dqkv + (long)n * L * 3 * W + h * HD;
+  unsigned am = 0u;
   for (int idx = tid; idx < L * (HD / 4); idx += 256) {
     const int i = idx >> 4, d = (idx & 15) * 4;
     float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dk = dq, dv = dq;
@@ -136,7 +146,9 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(r) = dq;
     *reinterpret_cast<float4*>(r + W) = dk;
     *reinterpret_cast<float4*>(r + 2 * W) = dv;
+    am = max(am, max(abits4(dq), max(abits4(dk), abits4(dv))));
   }
+  if (amax != nullptr) amax_commit_block(am, amax);
 }
 
 __global__ void embed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ tok,
@@ -271,7 +283,7 @@ extern "C" int tris_mha_fwd_f32(const float* qkv, float* out, int N, int L, int 
   size_t lds = (size_t)(3 * L * HP + L * (L + 1)) * sizeof(float);
   if (int e = mha_init()) return e;
   hipLaunchKernelGGL(mha_fwd_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, qkv, out, L, W, causal,
-                     0.125f);
+                     0.125f, tris_internal_take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -282,7 +294,7 @@ extern "C" int tris_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv
   size_t lds = (size_t)(4 * L * HP + 2 * L * (L + 1)) * sizeof(float);
   if (int e = mha_init()) return e;
   hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, qkv, dout, dqkv, L, W, causal,
-                     0.125f);
+                     0.125f, tris_internal_take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -16,7 +16,12 @@
 #include "common.h"
 #include "tris_hip.h"
 
+// (one-shot arming of an amax by-product, csrc/norm.hip tris_amax_next)
+extern "C" __attribute__((visibility("hidden"))) unsigned* tris_internal_take_amax_next();
+
 namespace {
+
+#include "amax.h"
 
 constexpr int HD = 64;
 constexpr int LDT = HD + 4;  // LDS row stride (floats): 16-byte aligned, conflict-free for 16-row b128 fragment reads
@@ -74,7 +79,7 @@ __device__ __forceinline__ void stage64(float* dst, const float* base, long row_
 // ------------------------------------------------------------------------------------------------------------- forward
 __global__ __launch_bounds__(256) void mha_mfma_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            float* __restrict__ lse, int L, int W, int causal,
-                                                           float scale) {
+                                                           float scale, unsigned* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * LDT];
   __shared__ __attribute__((aligned(16))) float Vs[64 * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void mha_mfma_fwd_kernel(const float* __restri
       }
     }
   }
+  unsigned am = 0u;
   if (q0 < L) {
     const float linv = 1.f / l;
     float* ob = out + (long)n * L * W + h * HD;
@@ -137,18 +143,23 @@ __global__ __launch_bounds__(256) void mha_mfma_fwd_kernel(const float* __restri
       const int q = q0 + 4 * kg + t;
       if (q < L) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ob[(long)q * W + 16 * j + r] = acc[j][t] * li;
+        for (int j = 0; j < 4; ++j) {
+          const float o = acc[j][t] * li;
+          ob[(long)q * W + 16 * j + r] = o;
+          am = max(am, __builtin_bit_cast(unsigned, o) & 0x7fffffffu);
+        }
       }
     }
     if (kg == 0 && q0 + r < L) lse[((long)n * H + h) * L + q0 + r] = m + __logf(l);
   }
+  if (amax != nullptr) amax_commit(am, amax);   // (per wave: q0 < L is wave-uniform; the amax word of `out`)
 }
 
 // ---------------------------------------------------------------------------------------------------------- backward dQ
 __global__ __launch_bounds__(256) void mha_mfma_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                           const float* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, float* __restrict__ dqkv, int L,
-                                                          int W, int causal, float scale) {
+                                                          int W, int causal, float scale, unsigned* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * LDT];
   __shared__ __attribute__((aligned(16))) float Vs[64 * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
@@ -197,6 +208,7 @@ __global__ __launch_bounds__(256) void mha_mfma_dq_kernel(const float* __restric
       }
     }
   }
+  unsigned am = 0u;
   if (q0 < L) {
     float* ob = dqkv + (long)n * L * 3 * W + h * HD;
 #pragma unroll
@@ -204,17 +216,21 @@ __global__ __launch_bounds__(256) void mha_mfma_dq_kernel(const float* __restric
       const int q = q0 + 4 * kg + t;
       if (q < L) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ob[(long)q * 3 * W + 16 * j + r] = acc[j][t];
+        for (int j = 0; j < 4; ++j) {
+          ob[(long)q * 3 * W + 16 * j + r] = acc[j][t];
+          am = max(am, __builtin_bit_cast(unsigned, acc[j][t]) & 0x7fffffffu);
+        }
       }
     }
   }
+  if (amax != nullptr) amax_commit(am, amax);   // (dqkv's amax word: this launch's dQ part, the dK / dV launch adds its own)
 }
 
 // ------------------------------------------------------------------------------------------------------ backward dK, dV
 __global__ __launch_bounds__(256) void mha_mfma_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dqkv, int L, int W, int causal,
-                                                           float scale) {
+                                                           float scale, unsigned* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float Qs[64 * LDT];
   __shared__ __attribute__((aligned(16))) float Gs[64 * LDT];
   __shared__ float Ls[64], Ds[64];
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(256) void mha_mfma_dkv_kernel(const float* __restri
       }
     }
   }
+  unsigned am = 0u;
   if (k0 < L) {
     float* ob = dqkv + (long)n * L * 3 * W + h * HD;
 #pragma unroll
@@ -270,10 +287,12 @@ __global__ __launch_bounds__(256) void mha_mfma_dkv_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) {
           ob[(long)k * 3 * W + W + 16 * j + r] = dk[j][t];
           ob[(long)k * 3 * W + 2 * W + 16 * j + r] = dv[j][t];
+          am = max(am, max(__builtin_bit_cast(unsigned, dk[j][t]) & 0x7fffffffu, __builtin_bit_cast(unsigned, dv[j][t]) & 0x7fffffffu));
         }
       }
     }
   }
+  if (amax != nullptr) amax_commit(am, amax);
 }
 
 }  // namespace
@@ -282,7 +301,7 @@ extern "C" int tris_mha_mfma_fwd_f32(const float* qkv, float* out, float* lse, i
                                      void* stream) {
   if (W != heads * HD || L < 1 || N < 1 || (((uintptr_t)qkv) & 15)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mha_mfma_fwd_kernel, dim3(cdiv(L, 64), heads, N), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, L,
-                     W, causal, 1.0f / sqrtf((float)HD));
+                     W, causal, 1.0f / sqrtf((float)HD), tris_internal_take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -293,11 +312,12 @@ extern "C" int tris_mha_mfma_bwd_f32(const float* qkv, const float* out, const f
   if (W != heads * HD || L < 1 || N < 1) return (int)hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)HD);
   const dim3 grid(cdiv(L, 64), heads, N);
+  unsigned* amax = tris_internal_take_amax_next();   // (dqkv's amax word: both launches max into it)
   hipLaunchKernelGGL(mha_mfma_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, dout, lse, delta, dqkv, L, W,
-                     causal, scale);
+                     causal, scale, amax);
   TRIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(mha_mfma_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, dout, lse, delta, dqkv, L, W,
-                     causal, scale);
+                     causal, scale, amax);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -76,6 +76,7 @@ static thread_local int g_mode_thread = -1;
 
 }  // namespace
 // one configuration of one operand-kind pair: gemm_inst.hip (hidden symbols of the same shared object)
+extern "C" __attribute__((visibility("hidden"))) unsigned* tris_internal_take_amax_next();   // (csrc/norm.hip)
 #define TRIS_RUN_DECL(AK_, BK_)                                                                                                   \
   extern "C" __attribute__((visibility("hidden"))) int tris_internal_run_cfg_##AK_##BK_(const void* params, int batch, float* ws, \
                                                                                          void* stream, const void* cfg, int mode);
@@ -433,9 +434,11 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
                              const float* bias, int bias_mode, const float* resid, long ldr, long sR, int act,
                              float alpha, float* workspace, long ws_bytes, void* stream) {
   const H2Next h2n = h2_take();
+  unsigned* amax_out = tris_internal_take_amax_next();   // (one-shot by-product: the amax word of C, tris_amax_next)
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0) return (int)hipErrorInvalidValue;
   GemmParams p = {};
+  p.amax_out = amax_out;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;
   p.bias = bias; p.bias_mode = bias ? bias_mode : 0;

@@ -14,6 +14,7 @@
 namespace {
 
 #include "gemm_params.h"
+#include "amax.h"
 
 constexpr int BK = 16;
 constexpr int PAD = 4;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --------------
   const int li = lane & 31, kh = lane >> 5;
+  unsigned g_am = 0u;
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -324,10 +326,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
             if (p.resid) v += p.resid[(long)zb * p.sR + (long)row * p.ldr + col];
             p.C[(long)zb * p.sC + (long)row * p.ldc + col] = v;
+            g_am = max(g_am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu);
           }
         }
       }
     }
+  if (EPI == EPI_STD && p.amax_out != nullptr) amax_commit(g_am, p.amax_out);
 }
 
 // Sum split-K slabs (ws[s][M][N]) and apply the standard epilogue.  VEC = 4: one thread owns 4 consecutive columns of a
@@ -336,7 +340,10 @@ template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmParams p) {
   const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   const long total = (long)p.M * p.N;
-  if (idx >= total) return;
+  if (idx >= total) {
+    if (p.amax_out != nullptr) amax_commit(0u, p.amax_out);   // (all lanes of the wave take part in the shuffles)
+    return;
+  }
   float v[VEC];
 #pragma unroll
   for (int t = 0; t < VEC; ++t) v[t] = 0.f;
@@ -374,6 +381,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   else
 #pragma unroll
     for (int t = 0; t < VEC; ++t) p.C[(long)row * p.ldc + col0 + t] = v[t];
+  if (p.amax_out != nullptr) {
+    unsigned am = 0u;
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) am = max(am, __builtin_bit_cast(unsigned, v[t]) & 0x7fffffffu);
+    amax_commit(am, p.amax_out);
+  }
 }
 
 #include "gemm_fast.h"

@@ -31,6 +31,7 @@
 // (8 x 8 bits) and is accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Result: fp32-class accuracy at 6 bf16 MFMAs per
 // 16-deep step (6 x 32 cycles) instead of 8 f32 MFMAs (8 x 64 cycles).
 #include "x3_split.h"
+#include "amax.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -745,6 +746,7 @@ void gemm_fast_kernel(GemmParams p) {
   constexpr int EW_A1 = (NSTG == 2 && !HALO) ? EW_A : 0, EW_B1 = NSTG == 2 ? EW_B : 0;
   constexpr bool EPI_LDS = EW_A + EW_B + EW_A1 + EW_B1 >= NW;
   float4 vs_s[FN], vs_q[FN];
+  unsigned e_am = 0u;   // largest magnitude stored (bits): by-product for p.amax_out
 #pragma unroll
   for (int j = 0; j < FN; ++j) vs_s[j] = vs_q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool vec_epi = EPI_LDS && p.vecC;  // uniform
@@ -822,6 +824,7 @@ void gemm_fast_kernel(GemmParams p) {
                 vs_q[j].z += v.z * ((xx.z - nmu.z) * nis.z); vs_q[j].w += v.w * ((xx.w - nmu.w) * nis.w);
               } else {
               *reinterpret_cast<float4*>(p.C + (long)zb * p.sC + (long)row * p.ldc + col) = v;
+              e_am = max(e_am, abits4(v));
               vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
               vs_q[j].x += v.x * v.x; vs_q[j].y += v.y * v.y; vs_q[j].z += v.z * v.z; vs_q[j].w += v.w * v.w;
               }
@@ -862,6 +865,7 @@ void gemm_fast_kernel(GemmParams p) {
               st_q[j] += v * ((xx - mu1) * is1);
             } else {
             p.C[(long)zb * p.sC + (long)row * p.ldc + col] = v;
+            e_am = max(e_am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu);
             st_s[j] += v;
             st_q[j] += v * v;
             }
@@ -870,6 +874,7 @@ void gemm_fast_kernel(GemmParams p) {
       }
     }
   }
+  if (EPI == EPI_STD && p.amax_out != nullptr) amax_commit(e_am, p.amax_out);   // (per wave, uniform)
   if (EPI == EPI_STD && p.stat_part != nullptr) {
     // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the NWM waves along M:
     // shuffle, then LDS, then one fp64 partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)

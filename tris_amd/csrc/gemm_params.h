@@ -45,6 +45,9 @@ struct GemmParams {
   // h2_amaxB: amax words, include/tris_hip.h) or, where that pointer is NULL, given by the host (h2_sA / h2_sB; 0 = 1.0)
   const unsigned *h2_amaxA, *h2_amaxB;
   float h2_sA, h2_sB;
+  // optional by-product (tris_gemm_f32 after tris_amax_next): the largest magnitude of the values written to C, maxed into this
+  // amax word -- the operand scale of an h2 product that consumes C directly (amax.h); split-K products leave it in the reduce
+  unsigned* amax_out;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

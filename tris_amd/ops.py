@@ -471,6 +471,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
     if batch == 1:
         h2_arm(A, B)
+    h2_mark_next(C)      # (h2: the product also leaves the amax of what it writes -- another product may consume C directly)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
@@ -1435,6 +1436,7 @@ class MhaFn(torch.autograd.Function):
         N, L, W3 = qkv.shape
         W = W3 // 3
         out = torch.empty(N, L, W, device=qkv.device, dtype=torch.float32)
+        h2_mark_next(out)
         call("tris_mha_fwd_f32", P(qkv), P(out), N, L, W, heads, int(causal), _stream())
         ctx.cfg = (N, L, W, heads, int(causal))
         ctx.save_for_backward(qkv)
@@ -1446,6 +1448,7 @@ class MhaFn(torch.autograd.Function):
         N, L, W, heads, causal = ctx.cfg
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
+        h2_mark_next(dqkv)
         call("tris_mha_bwd_f32", P(qkv), P(do), P(dqkv), N, L, W, heads, causal, _stream())
         return dqkv, None, None
 
@@ -1461,6 +1464,7 @@ class MhaMfmaFn(torch.autograd.Function):
         W = W3 // 3
         out = torch.empty(N, L, W, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(N, heads, L, device=qkv.device, dtype=torch.float32)
+        h2_mark_next(out)
         _timed("mha_fwd", 4.0 * N * heads * L * L * 64 * (0.5 if causal else 1.0),
                lambda: call("tris_mha_mfma_fwd_f32", P(qkv), P(out), P(lse), N, L, W, heads, int(causal), _stream()))
         ctx.cfg = (N, L, W, heads, int(causal))
@@ -1474,6 +1478,7 @@ class MhaMfmaFn(torch.autograd.Function):
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
+        h2_mark_next(dqkv)
         call("tris_mha_mfma_bwd_f32", P(qkv), P(out), P(do), P(lse), P(delta), P(dqkv), N, L, W, heads, causal, _stream())
         return dqkv, None, None
 
