@@ -570,7 +570,7 @@ class GradBox:
 # is full).
 _H2 = {"pool": None, "next": 0, "step": 0, "paused": 0, "arenas": [], "const": None, "const_next": 0, "const_tags": {}}
 _H2_STEP_IDS = [0]       # step ids are unique across the main pool and private pools: a tag never matches another pool's step
-H2_SLOTS = 2048          # amax words per step; a word is H2_SUB unsigned words (csrc/norm.hip amax_raise)
+H2_SLOTS = 4096          # amax words per step; a word is H2_SUB unsigned words (csrc/amax.h amax_raise)
 H2_SUB = 2048
 H2_CONST_SLOTS = 1024
 H2_PREPASS_MAX = 1 << 25
