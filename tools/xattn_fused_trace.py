@@ -56,8 +56,6 @@ print(f"workgroup lifetime  min {tot.min():.2f}  median {tot.median():.2f}  max 
 # workgroups on 256 CUs all are co-resident, so a late start is dispatch latency, not queueing)
 w = int(tot.argmax())
 print(f"slowest workgroup {w} (image {w // 8}, slice {w % 8}, XCD {w % 8}): " + " | ".join(f"{names[i + 1]} {float(d[w, i]):.1f}" for i in range(len(names) - 1)))
-late = ((start - torch.stack([start[xcd == x].min() for x in range(8)])[xcd]) / clk * 1e6)
-print(f"start offset inside the XCD: median {float(late.median()):.2f}  p90 {float(late.kthvalue(int(0.9 * late.numel())).values):.2f}  max {float(late.max()):.2f} us")
 # waits: time spent polling flags = the skew between the eight workgroups of an image
 print(f"wait phases (stage-1 flags + stage-2 flags): median {float((d[:, 2] + d[:, 6]).median()):.2f}  max {float((d[:, 2] + d[:, 6]).max()):.2f} us")
 # bytes a workgroup moves per phase (P = 100, N = 48, C = 1024, 8 slices) and the per-CU rate they imply
