@@ -50,7 +50,8 @@ int tris_set_gemm_mode(int mode);
 int tris_set_gemm_mode_thread(int mode);
 /* Developer options (tests, tools): name = FORCE_TILE (128x128|128x64|64x64|128x32|256x128), FORCE_PIPE (0|1), PIPE (0|1),
  * CONV_DIRECT (0 = implicit GEMM only, 1..6 = that direct configuration where it applies), WGRAD_DIRECT (0, 1..5), BN_FOLD (0|1),
- * STEM_CONV1 (0|1), WG_BLOCKS (n), TUNE_LOG (file); a leading "TRIS_" is accepted; value NULL or "" restores the default.  Initial
+ * STEM_CONV1 (0|1), WG_BLOCKS (n), STREAM_FORM (0|1: streaming form of the element-wise passes over more than the memory-side cache), COL_BLOCKS (n),
+ * TUNE_LOG (file); a leading "TRIS_" is accepted; value NULL or "" restores the default.  Initial
  * values come from the environment variables TRIS_<name>, read once when the library is loaded -- nothing reads the environment
  * per call.  tris_set_conv_direct_thread: CONV_DIRECT for the products of the calling thread only (-1 = none): batch-invariant
  * evaluation pins the implicit 3x3 kernels this way. */

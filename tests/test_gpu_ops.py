@@ -326,6 +326,49 @@ def test_batchnorm_train(ops, shape, res, relu):
         close(ops.batch_norm(gx, gg, gb, grm, grv, None, False, False), ye, name="eval")
 
 
+@pytest.mark.parametrize("M,C", [(76800, 512), (300001, 128)])
+def test_batchnorm_streaming_form_equals_the_default_form(ops, M, C):
+    """Launches whose streams exceed the 256 MB memory-side cache take the nontemporal one-piece-per-block form of bn_apply /
+    bn_bwd_apply (csrc/norm.hip, STREAM_FORM): same arithmetic per element, so bit-identical to the grid-stride form -- with and
+    without the residual / ReLU, the three mask sources of the backward, the optional masked-gradient output, a ragged tail
+    (300001 rows: the last block is partial) and the amax by-product."""
+    import tris_amd.ops as o
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, r, dy = rnd(M, C) * 2 + 1, rnd(M, C), rnd(M, C)
+    mean, invstd, gamma, beta = rnd(C), rnd(C).abs() + 0.5, rnd(C), rnd(C)
+    sdz, sdzx = rnd(C) * 100, rnd(C) * 100
+    assert 3 * x.numel() * 4 > 256 << 20
+    P, st = o.P, o._stream()
+
+    def fwd(resid, relu):
+        y = torch.empty_like(x)
+        am = torch.zeros(2048, dtype=torch.int32, device="cuda")
+        o.call("tris_amax_next", P(am))
+        o.call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(r) if resid else None, P(y), M, C, int(relu), st)
+        return y, int(am.max())
+
+    def bwd(mask, want_dz):
+        y = torch.relu((x - mean) * (invstd * gamma) + beta + r) if mask == "y" else None
+        dx, dz = torch.empty_like(x), (torch.empty_like(x) if want_dz else None)
+        o.call("tris_bn_bwd_apply_f32", P(dy), P(y), P(x), P(mean), P(invstd), P(gamma), P(sdz), P(sdzx), 1.0 / M, P(dx), P(dz), M, C,
+               P(beta) if mask == "beta" else None, st)
+        return dx, dz
+
+    cases = [lambda: fwd(True, True), lambda: fwd(False, True), lambda: fwd(True, False),
+             lambda: bwd("y", True), lambda: bwd("beta", False), lambda: bwd(None, False)]
+    for k, run in enumerate(cases):
+        with o.option("STREAM_FORM", 0):
+            ref = run()
+        got = run()
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            if torch.is_tensor(a):
+                assert torch.equal(a, b), k
+            else:
+                assert a == b, (k, a, b)
+
+
 @pytest.mark.parametrize("res", [False, True])
 @pytest.mark.parametrize("shape,N", [((3, 20, 20, 64), 256), ((2, 9, 9, 128), 32), ((2, 40, 40, 32), 64), ((1, 10, 10, 256), 64)])
 def test_batchnorm_backward_reduced_in_the_consuming_1x1_convolution(ops, shape, N, res, monkeypatch):

@@ -18,9 +18,23 @@
 #include "common.h"
 #include "tris_hip.h"
 
+extern "C" {
+// options that live in norm.hip's translation unit (set through tris_set_option below)
+extern __attribute__((visibility("hidden"))) int tris_internal_stream_form;
+extern __attribute__((visibility("hidden"))) int tris_internal_col_blocks;
+}
+
 namespace {
 
 #include "gemm_params.h"
+
+// Epilogue streams (C, residual, the BatchNorm-backward operands) of a launch that together exceed the 256 MB memory-side cache
+// travel with the nontemporal policy -- norm.hip "BIG form" has the measurement; split-K slabs are re-read at once and stay cached.
+static int stream_nt(const GemmParams& p, int batch) {
+  if (!tris_internal_stream_form) return 0;
+  const long streams = 1 + (p.resid ? 1 : 0) + (p.bnb_x ? 1 : 0) + (p.bnb_y ? 1 : 0);
+  return (long)p.M * p.N * 4 * batch * streams > (256L << 20) ? 1 : 0;
+}
 
 // ---- developer options ------------------------------------------------------------------------------------------------------
 // Read from the environment ONCE, when the library is loaded; tests and tools change them through tris_set_option() (name =
@@ -34,6 +48,8 @@ struct Options {
   int bn_fold = 1;        // BN_FOLD=0: BatchNorm + ReLU never folded into the direct convolutions
   int stem_conv1 = 1;     // STEM_CONV1=0: the stem's first convolution through the generic kernels
   int wg_blocks = 512;    // WG_BLOCKS: blocks the direct weight gradient aims for (two per CU)
+  // (STREAM_FORM=0: element-wise passes never take the nontemporal one-piece-per-block form; COL_BLOCKS: blocks a column
+  //  reduction aims for -- both live in norm.hip's translation unit: tris_internal_stream_form / tris_internal_col_blocks)
   char tune_log[256] = {0};  // TUNE_LOG=<file>: one line per tuned shape
 };
 static int parse_tile(const char* e) {
@@ -50,13 +66,15 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "BN_FOLD")) o.bn_fold = unset ? 1 : (v[0] != '0');
   else if (!strcmp(name, "STEM_CONV1")) o.stem_conv1 = unset ? 1 : (v[0] != '0');
   else if (!strcmp(name, "WG_BLOCKS")) o.wg_blocks = unset ? 512 : std::max(1, atoi(v));
+  else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 1 : (v[0] != '0');
+  else if (!strcmp(name, "COL_BLOCKS")) tris_internal_col_blocks = unset ? 512 : std::max(1, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
   else return false;
   return true;
 }
 static Options init_options() {
   Options o;
-  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "TUNE_LOG"}) {
+  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "TUNE_LOG"}) {
     char env[64];
     snprintf(env, sizeof(env), "TRIS_%s", n);
     if (const char* v = getenv(env)) set_option(o, n, v);
@@ -84,8 +102,10 @@ TRIS_RUN_DECL(0, 0) TRIS_RUN_DECL(0, 1) TRIS_RUN_DECL(1, 0) TRIS_RUN_DECL(1, 1) 
 #undef TRIS_RUN_DECL
 namespace {
 template <int AK, int BKIND>
-int run_cfg(const GemmParams& p, int batch, float* ws, hipStream_t st, const Cfg& cfg) {
+int run_cfg(const GemmParams& p0, int batch, float* ws, hipStream_t st, const Cfg& cfg) {
   const int mode = g_gemm_mode;
+  GemmParams p = p0;
+  p.nt = stream_nt(p, batch);
   if (AK == A_ROWK && BKIND == B_NK) return tris_internal_run_cfg_00(&p, batch, ws, st, &cfg, mode);
   if (AK == A_ROWK && BKIND == B_KN) return tris_internal_run_cfg_01(&p, batch, ws, st, &cfg, mode);
   if (AK == A_COLK && BKIND == B_NK) return tris_internal_run_cfg_10(&p, batch, ws, st, &cfg, mode);
@@ -308,8 +328,10 @@ extern "C" __attribute__((visibility("hidden"))) int tris_internal_stem_conv1(co
     int Cin, int Cout, int stride, double* stat_part, void* stream);
 namespace {
 template <int BKIND>
-int run_halo(const GemmParams& p, int id, hipStream_t st) {
+int run_halo(const GemmParams& p0, int id, hipStream_t st) {
   const int dg = BKIND == B_KN_DGRAD ? 1 : 0;
+  GemmParams p = p0;
+  p.nt = stream_nt(p, 1);
   const int rc = g_gemm_mode == 3 ? tris_internal_run_halo_p3(&p, id, dg, st) : tris_internal_run_halo_p1(&p, id, dg, st);
   if (rc == 0) ++g_direct_launches[0];
   return rc;

@@ -750,6 +750,7 @@ void gemm_fast_kernel(GemmParams p) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) vs_s[j] = vs_q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool vec_epi = EPI_LDS && p.vecC;  // uniform
+  const bool nt_e = EPI == EPI_STD && p.nt != 0;   // uniform: epilogue streams larger than the memory-side cache (gemm_conv.hip stream_nt)
   if (vec_epi) {
     float* stg;
     {
@@ -800,14 +801,14 @@ void gemm_fast_kernel(GemmParams p) {
                 v.z = v.z / (1.0f + expf(-1.702f * v.z)); v.w = v.w / (1.0f + expf(-1.702f * v.w));
               }
               if (p.resid) {
-                const float4 rr = ld4(p.resid + (long)zb * p.sR + (long)row * p.ldr + col);
+                const float4 rr = ld4s(p.resid + (long)zb * p.sR + (long)row * p.ldr + col, nt_e);
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
               }
               if (p.bnb_x != nullptr) {
                 const long o = (long)row * p.ldc + col;
-                const float4 xx = ld4(p.bnb_x + o);
+                const float4 xx = ld4s(p.bnb_x + o, nt_e);
                 if (p.bnb_y != nullptr) {
-                  const float4 yy = ld4(p.bnb_y + o);
+                  const float4 yy = ld4s(p.bnb_y + o, nt_e);
                   if (!(yy.x > 0.f)) v.x = 0.f;
                   if (!(yy.y > 0.f)) v.y = 0.f;
                   if (!(yy.z > 0.f)) v.z = 0.f;
@@ -818,12 +819,12 @@ void gemm_fast_kernel(GemmParams p) {
                   if (!((xx.z - nmu.z) * nsc.z + nbe.z > 0.f)) v.z = 0.f;
                   if (!((xx.w - nmu.w) * nsc.w + nbe.w > 0.f)) v.w = 0.f;
                 }
-                *reinterpret_cast<float4*>(p.C + o) = v;
+                st4s(p.C + o, v, nt_e);
                 vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
                 vs_q[j].x += v.x * ((xx.x - nmu.x) * nis.x); vs_q[j].y += v.y * ((xx.y - nmu.y) * nis.y);
                 vs_q[j].z += v.z * ((xx.z - nmu.z) * nis.z); vs_q[j].w += v.w * ((xx.w - nmu.w) * nis.w);
               } else {
-              *reinterpret_cast<float4*>(p.C + (long)zb * p.sC + (long)row * p.ldc + col) = v;
+              st4s(p.C + (long)zb * p.sC + (long)row * p.ldc + col, v, nt_e);
               e_am = max(e_am, abits4(v));
               vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
               vs_q[j].x += v.x * v.x; vs_q[j].y += v.y * v.y; vs_q[j].z += v.z * v.z; vs_q[j].w += v.w * v.w;

@@ -48,9 +48,19 @@ struct GemmParams {
   // optional by-product (tris_gemm_f32 after tris_amax_next): the largest magnitude of the values written to C, maxed into this
   // amax word -- the operand scale of an h2 product that consumes C directly (amax.h); split-K products leave it in the reduce
   unsigned* amax_out;
+  int nt;   // EPI_STD vector epilogue: C stores and the residual / bnb_x / bnb_y loads are nontemporal (set per launch: stream_nt)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+typedef float gp_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4s(const float* p, bool nt) {   // (nt uniform)
+  if (nt) { const gp_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gp_f32x4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+  return ld4(p);
+}
+__device__ __forceinline__ void st4s(float* p, float4 v, bool nt) {
+  if (nt) { const gp_f32x4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<gp_f32x4*>(p)); }
+  else *reinterpret_cast<float4*>(p) = v;
+}
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // one launch configuration of the family: tile, split-K slices, pipe = 1: the pipelined loop of gemm_fast.h (x3 only: two 16-deep

@@ -6,12 +6,39 @@
 #include "common.h"
 #include "tris_hip.h"
 
+extern "C" {
+// options (tris_set_option, gemm_conv.hip): 1 = element-wise passes over more than the memory-side cache take the streaming form
+__attribute__((visibility("hidden"))) int tris_internal_stream_form = 1;
+__attribute__((visibility("hidden"))) int tris_internal_col_blocks = 512;   // blocks a column reduction aims for
+}
+
 namespace {
 
 #include "amax.h"
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Streaming ("BIG") form of the element-wise passes.  Measured on an idle MI355X (tools/probes/stream_forms.hip ->
+// profiles/r4_stream_forms.txt; y = relu(bn(x) + r), M = 307200, C = 256: three tensors of 315 MB): the grid-stride walk below
+// with the default cache policy moves 4.7-5.0 TB/s; ONE contiguous piece of 1024 vectors per block with four nontemporal loads
+// per stream in flight and nontemporal stores moves 6.9-7.2 TB/s (either change alone: 5.3-5.7).  Tensors that fit the 256 MB
+// memory-side cache together (3 x 79 MB) run at 6.5-7.0 TB/s in the default form, are no faster in this one -- and their
+// consumer finds them in that cache -- so the launchers pick this form only when the streams of a launch exceed 256 MB.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4nt(const float* p) {
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4nt(float* p, float4 v) {
+  const f32x4_t w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<f32x4_t*>(p));
+}
+constexpr int BIG_U = 4;                       // vectors per thread and stream
+constexpr long BIG_PIECE = 256L * BIG_U;       // vectors per block
+constexpr long BIG_BYTES = 256L << 20;         // the memory-side cache
+// (a thread of the BIG form sees ONE channel vector for its BIG_U vectors iff 256 * 4 floats is a multiple of C)
+inline bool big_form(long n4, int C, int streams) { return tris_internal_stream_form && C >= 4 && 1024 % C == 0 && n4 * 16 * streams > BIG_BYTES && n4 >= 4 * BIG_PIECE; }
+inline int big_grid(long n4) { return (int)((n4 + BIG_PIECE - 1) / BIG_PIECE); }
 
 // ------------------------------------------------------------------------------------------------------
 // Column (per-channel) partial reductions.  Block = 256 threads covering CVB = min(C/4,256) channel-vectors
@@ -255,13 +282,14 @@ __global__ void bn_sync_combine_kernel(const float* __restrict__ gathered, int W
 // y = (x - mean) * invstd * gamma + beta (+ resid) (relu)
 // The launch keeps gridDim*blockDim a multiple of C/4, so a thread sees ONE channel vector for its whole grid-stride walk:
 // the per-channel constants are folded to (scale, shift) once and the loop is a pure 16-byte stream, two vectors per trip.
+template <bool BIG>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ resid,
                                                        float* __restrict__ Y, long n4, int C, int relu,
                                                        unsigned* __restrict__ amax = nullptr) {
   const long stride = (long)gridDim.x * blockDim.x;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long i = BIG ? (long)blockIdx.x * BIG_PIECE + threadIdx.x : (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)((i * 4) % C);
   const float4 mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
   const float4 sc = make_float4(is.x * g.x, is.y * g.y, is.z * g.z, is.w * g.w);
@@ -277,13 +305,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     return y;
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
-  for (; i + stride < n4; i += 2 * stride) {
-    const float4 x0 = ld4(X + i * 4), x1 = ld4(X + (i + stride) * 4);
-    const float4 r0 = resid ? ld4(resid + i * 4) : z4, r1 = resid ? ld4(resid + (i + stride) * 4) : z4;
-    st4(Y + i * 4, one(x0, r0));
-    st4(Y + (i + stride) * 4, one(x1, r1));
+  if (BIG) {
+    float4 x[BIG_U], r[BIG_U];
+#pragma unroll
+    for (int u = 0; u < BIG_U; ++u) {
+      const long j = i + u * 256;
+      x[u] = j < n4 ? ld4nt(X + j * 4) : z4;
+      r[u] = (resid && j < n4) ? ld4nt(resid + j * 4) : z4;
+    }
+#pragma unroll
+    for (int u = 0; u < BIG_U; ++u) {
+      const long j = i + u * 256;
+      if (j < n4) st4nt(Y + j * 4, one(x[u], r[u]));
+    }
+  } else {
+    for (; i + stride < n4; i += 2 * stride) {
+      const float4 x0 = ld4(X + i * 4), x1 = ld4(X + (i + stride) * 4);
+      const float4 r0 = resid ? ld4(resid + i * 4) : z4, r1 = resid ? ld4(resid + (i + stride) * 4) : z4;
+      st4(Y + i * 4, one(x0, r0));
+      st4(Y + (i + stride) * 4, one(x1, r1));
+    }
+    if (i < n4) st4(Y + i * 4, one(ld4(X + i * 4), resid ? ld4(resid + i * 4) : z4));
   }
-  if (i < n4) st4(Y + i * 4, one(ld4(X + i * 4), resid ? ld4(resid + i * 4) : z4));
   if (amax != nullptr) amax_commit_block(am, amax);
 }
 
@@ -322,7 +365,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
 
 // dx = gamma * invstd * (dz - sum_dz/cnt - xhat * sum_dzxhat/cnt),  dz = dY * (Y>0 if Y); optional dZ <- dz
 // POOL: dY is the pooled gradient (see col_partial_kernel), pool_h / pool_w the full-size map.
-template <bool POOL>
+template <bool POOL, bool BIG = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                            const float* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -334,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int pool_w = 0, unsigned* __restrict__ amax = nullptr) {
   unsigned am = 0u;
   const long stride = (long)gridDim.x * blockDim.x;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long i = BIG ? (long)blockIdx.x * BIG_PIECE + threadIdx.x : (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)((i * 4) % C);
   const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), a = ld4(sum_dz + c), b = ld4(sum_dzx + c);
   // beta_mask != NULL: ReLU mask recomputed from X (bn_apply_kernel's expression) instead of read from Y
@@ -343,41 +386,63 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float4 k1 = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
   const float4 k2 = make_float4(a.x * inv_cnt, a.y * inv_cnt, a.z * inv_cnt, a.w * inv_cnt);
   const float4 k3 = make_float4(is.x * b.x * inv_cnt, is.y * b.y * inv_cnt, is.z * b.z * inv_cnt, is.w * b.w * inv_cnt);
-  auto one = [&](long j) {
+  const bool use_y = !beta_mask && Y != nullptr;
+  auto load_g = [&](long j) {
     float4 g;
     if (POOL) {
       g = ld4(dY + pooled_row(j * 4 / C, pool_h, pool_w) * C + c);
       g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
     } else {
-      g = ld4(dY + j * 4);
+      g = BIG ? ld4nt(dY + j * 4) : ld4(dY + j * 4);
     }
-    const float4 x = ld4(X + j * 4);
+    return g;
+  };
+  // (x, g, y) of vector j -> masked g stored to dZ (if asked), dx stored
+  auto finish = [&](long j, float4 g, const float4 x, const float4 y) {
     if (beta_mask) {
       if (!((x.x - mu.x) * k1.x + be.x > 0.f)) g.x = 0.f;   // k1 = invstd * gamma = the forward's scale
       if (!((x.y - mu.y) * k1.y + be.y > 0.f)) g.y = 0.f;
       if (!((x.z - mu.z) * k1.z + be.z > 0.f)) g.z = 0.f;
       if (!((x.w - mu.w) * k1.w + be.w > 0.f)) g.w = 0.f;
-    } else if (Y) {
-      const float4 y = ld4(Y + j * 4);
+    } else if (use_y) {
       if (!(y.x > 0.f)) g.x = 0.f;
       if (!(y.y > 0.f)) g.y = 0.f;
       if (!(y.z > 0.f)) g.z = 0.f;
       if (!(y.w > 0.f)) g.w = 0.f;
     }
-    if (dZ) st4(dZ + j * 4, g);  // masked upstream gradient = gradient of the residual branch
+    if (dZ) { if (BIG) st4nt(dZ + j * 4, g); else st4(dZ + j * 4, g); }  // masked upstream gradient = gradient of the residual branch
     float4 o;
     o.x = k1.x * (g.x - k2.x - (x.x - mu.x) * k3.x);
     o.y = k1.y * (g.y - k2.y - (x.y - mu.y) * k3.y);
     o.z = k1.z * (g.z - k2.z - (x.z - mu.z) * k3.z);
     o.w = k1.w * (g.w - k2.w - (x.w - mu.w) * k3.w);
-    st4(dX + j * 4, o);
+    if (BIG) st4nt(dX + j * 4, o); else st4(dX + j * 4, o);
     am = max(am, abits4(o));
   };
-  for (; i + stride < n4; i += 2 * stride) {
-    one(i);
-    one(i + stride);
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  if (BIG) {
+    float4 g[BIG_U], x[BIG_U], y[BIG_U];
+#pragma unroll
+    for (int u = 0; u < BIG_U; ++u) {
+      const long j = i + u * 256;
+      const bool ok = j < n4;
+      g[u] = ok ? load_g(j) : z4;
+      x[u] = ok ? ld4nt(X + j * 4) : z4;
+      y[u] = (ok && use_y) ? ld4nt(Y + j * 4) : z4;
+    }
+#pragma unroll
+    for (int u = 0; u < BIG_U; ++u) {
+      const long j = i + u * 256;
+      if (j < n4) finish(j, g[u], x[u], y[u]);
+    }
+  } else {
+    auto one = [&](long j) { finish(j, load_g(j), ld4(X + j * 4), use_y ? ld4(Y + j * 4) : z4); };
+    for (; i + stride < n4; i += 2 * stride) {
+      one(i);
+      one(i + stride);
+    }
+    if (i < n4) one(i);
   }
-  if (i < n4) one(i);
   if (amax != nullptr) amax_commit_block(am, amax);
 }
 
@@ -711,7 +776,7 @@ inline int bn_grid(long n4, int C) {
 struct ColPlan { int nb; long rpb; };
 inline ColPlan col_plan(long M, int C) {
   int CV = C / 4, CVB = CV < 256 ? CV : 256, RS = 256 / CVB;
-  static const int target = getenv("TRIS_COL_BLOCKS") ? atoi(getenv("TRIS_COL_BLOCKS")) : 512;   // developer knob
+  const int target = tris_internal_col_blocks;
   long rpb = (M + target - 1) / target;
   long minr = (long)RS * 8;
   if (rpb < minr) rpb = minr;
@@ -779,8 +844,12 @@ extern "C" int tris_bn_apply_f32(const float* X, const float* mean, const float*
                                  void* stream) {
   if (C % 4) return (int)hipErrorInvalidValue;
   long n4 = M * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma,
-                     beta, resid, Y, n4, C, relu, take_amax_next());
+  if (big_form(n4, C, resid ? 3 : 2))
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(big_grid(n4)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta,
+                       resid, Y, n4, C, relu, take_amax_next());
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma,
+                       beta, resid, Y, n4, C, relu, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -918,8 +987,13 @@ extern "C" int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const floa
                                      float inv_count, float* dX, float* dZ, long M, int C, const float* beta_mask,
                                      void* stream) {
   long n4 = M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean, invstd,
-                     gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask, 0, 0, take_amax_next());
+  const int streams = 3 + ((Y && !beta_mask) ? 1 : 0) + (dZ ? 1 : 0);
+  if (big_form(n4, C, streams))
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(big_grid(n4)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean,
+                       invstd, gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask, 0, 0, take_amax_next());
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), dim3(bn_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, dY, Y, X, mean,
+                       invstd, gamma, sum_dz, sum_dzx, inv_count, dX, dZ, n4, C, beta_mask, 0, 0, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
