@@ -33,7 +33,7 @@ namespace {
 static int stream_nt(const GemmParams& p, int batch) {
   if (!tris_internal_stream_form) return 0;
   const long streams = 1 + (p.resid ? 1 : 0) + (p.bnb_x ? 1 : 0) + (p.bnb_y ? 1 : 0);
-  return (long)p.M * p.N * 4 * batch * streams > (256L << 20) ? 1 : 0;
+  return (long)p.M * p.N * 4 * batch * streams > ((long)tris_internal_stream_form << 20) ? 1 : 0;
 }
 
 // ---- developer options ------------------------------------------------------------------------------------------------------
@@ -48,7 +48,7 @@ struct Options {
   int bn_fold = 1;        // BN_FOLD=0: BatchNorm + ReLU never folded into the direct convolutions
   int stem_conv1 = 1;     // STEM_CONV1=0: the stem's first convolution through the generic kernels
   int wg_blocks = 512;    // WG_BLOCKS: blocks the direct weight gradient aims for (two per CU)
-  // (STREAM_FORM=0: element-wise passes never take the nontemporal one-piece-per-block form; COL_BLOCKS: blocks a column
+  // (STREAM_FORM=0: element-wise passes never take the nontemporal one-piece-per-block form, n > 1: they do above n MB (1 = default = 256); COL_BLOCKS: blocks a column
   //  reduction aims for -- both live in norm.hip's translation unit: tris_internal_stream_form / tris_internal_col_blocks)
   char tune_log[256] = {0};  // TUNE_LOG=<file>: one line per tuned shape
 };
@@ -66,7 +66,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "BN_FOLD")) o.bn_fold = unset ? 1 : (v[0] != '0');
   else if (!strcmp(name, "STEM_CONV1")) o.stem_conv1 = unset ? 1 : (v[0] != '0');
   else if (!strcmp(name, "WG_BLOCKS")) o.wg_blocks = unset ? 512 : std::max(1, atoi(v));
-  else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 1 : (v[0] != '0');
+  else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 256 : (atoi(v) == 1 ? 256 : std::max(0, atoi(v)));
   else if (!strcmp(name, "COL_BLOCKS")) tris_internal_col_blocks = unset ? 512 : std::max(1, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
   else return false;

@@ -8,7 +8,7 @@
 
 extern "C" {
 // options (tris_set_option, gemm_conv.hip): 1 = element-wise passes over more than the memory-side cache take the streaming form
-__attribute__((visibility("hidden"))) int tris_internal_stream_form = 1;
+__attribute__((visibility("hidden"))) int tris_internal_stream_form = 256;   // MB; 0 = never
 __attribute__((visibility("hidden"))) int tris_internal_col_blocks = 512;   // blocks a column reduction aims for
 }
 
@@ -35,9 +35,8 @@ __device__ __forceinline__ void st4nt(float* p, float4 v) {
 }
 constexpr int BIG_U = 4;                       // vectors per thread and stream
 constexpr long BIG_PIECE = 256L * BIG_U;       // vectors per block
-constexpr long BIG_BYTES = 256L << 20;         // the memory-side cache
 // (a thread of the BIG form sees ONE channel vector for its BIG_U vectors iff 256 * 4 floats is a multiple of C)
-inline bool big_form(long n4, int C, int streams) { return tris_internal_stream_form && C >= 4 && 1024 % C == 0 && n4 * 16 * streams > BIG_BYTES && n4 >= 4 * BIG_PIECE; }
+inline bool big_form(long n4, int C, int streams) { return tris_internal_stream_form && C >= 4 && 1024 % C == 0 && n4 * 16 * streams > ((long)tris_internal_stream_form << 20) && n4 >= 4 * BIG_PIECE; }
 inline int big_grid(long n4) { return (int)((n4 + BIG_PIECE - 1) / BIG_PIECE); }
 
 // ------------------------------------------------------------------------------------------------------
