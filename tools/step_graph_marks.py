@@ -1,7 +1,7 @@
 """Per-piece time stamps of the segmented captured step (TRIS_STEP_GRAPH=seg): where the graphs of the three streams start and end
 within a step (HIP events behind every graph launch; averages over 5 steps).  usage: python tools/step_graph_marks.py"""
 import os, sys, warnings
-os.environ.setdefault("TRIS_RANDOM_INIT", "1"); os.environ["TRIS_STEP_GRAPH"] = "seg"   # (read once, at import of tris_amd.config)
+os.environ.setdefault("TRIS_RANDOM_INIT", "1"); os.environ.setdefault("TRIS_GEMM_MODE", "h2"); os.environ["TRIS_STEP_GRAPH"] = "seg"   # (read once, at import of tris_amd.config)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tris_amd.args import get_parser
