@@ -217,6 +217,16 @@ int tris_avgpool2_bwd_f32(const float* dY, float* dX, int B, int H, int W, int C
 #define TRIS_EW_SCALE 6     /* O = s * A */
 #define TRIS_EW_RELU 7      /* O = max(A, 0) */
 int tris_elementwise_f32(int op, const float* A, const float* B, float* O, long n, float s, void* stream);
+/* the same with B broadcast: B has nb elements and is read modulo nb (A, O: [n / nb, nb]; n % nb == 0, nb % 4 == 0).
+ * model_stage1.py:74: the sentence features of the step against every image's attended ones (0.1 * new_lan + norm_lan) */
+int tris_elementwise_bcast_f32(int op, const float* A, const float* B, float* O, long n, long nb, float s, void* stream);
+/* O = X * exp(ls[0]), e_out[0] = exp(ls[0])  (model_stage1.py:77-78: score * logit_scale.exp(), ls a device scalar).
+ * bwd: dX = dO * exp(ls[0]) (dX may be NULL), dls[0] = sum(dO * O) (written; deterministic two-stage sum);
+ * workspace: tris_scale_exp_workspace_bytes() */
+int tris_scale_exp_fwd_f32(const float* X, const float* ls, float* O, float* e_out, long n, void* stream);
+long tris_scale_exp_workspace_bytes(void);
+int tris_scale_exp_bwd_f32(const float* dO, const float* O, const float* ls, float* dX, float* dls, float* workspace, long n,
+                           void* stream);
 int tris_nchw_to_nhwc_f32(const float* X, float* Y, int B, int C, int H, int W, void* stream);
 
 /* ---- text / ViT transformer pieces --------------------------------------------------------------------------------- */
@@ -242,7 +252,9 @@ int tris_embed_bwd_f32(const long* ids, const float* dout, float* dtok, float* d
  * rank with scale = 1 / world: <= world * B * L rows of W floats travel instead of the dense [vocab, W] table (101 MB at
  * 49408 x 512; reference: DistributedDataParallel all-reduces it densely, train_stage1.py:70). */
 int tris_embed_rows_bwd_f32(const long* ids, const float* rows, float* dtok, int R, int W, float scale, void* stream);
-/* x[arange(N), ids.argmax(-1)]  (model.py:562) */
+/* out = [a; b]: int64 rows of two lists in one (positive + negative queries of a step, train_stage1.py:342-347: batched here) */
+int tris_concat_i64(const long* a, long na, const long* b, long nb, long* out, void* stream);
+/* x[arange(N), ids.argmax(-1)]  (model.py:562); ids NULL: x[:, 0] -- the ViT class token (model.py:443) */
 int tris_eot_gather_fwd_f32(const long* ids, const float* x, float* out, int N, int L, int W, void* stream);
 int tris_eot_gather_bwd_f32(const long* ids, const float* dout, float* dx, int N, int L, int W, void* stream);
 
@@ -314,12 +326,12 @@ int tris_vit_assemble_bwd_f32(const float* dx, float* demb, int B, int T, int W,
 /* The whole loss block: fg_loss = MaxLoss(clip_forward) (train_stage1.py:263-284,340), cbs_loss (:342-353),
  * cls_loss = multilabel_soft_margin_loss(cls, eye) (:354), loss = w1*l1 + w4*l4 + w5*l5 (:364).
  * per_img: scratch [B,3]; rowloss: scratch [B]; losses[4] = {total, l1, l4, l5}.  fneg may be NULL when K == 0.
- * bwd: g3 = device {dL/dl1, dL/dl5, dL/dl4}. */
+ * bwd: g = device gradient of losses[4]; the kernels form dL/dl1 = g[0]*w1 + g[1], dL/dl4 = g[0]*w4 + g[2], dL/dl5 = g[0]*w5 + g[3]. */
 int tris_stage1_loss_fwd_f32(const float* cls, const float* fi, const float* ft, const float* fneg, int B, int N, int E,
                              int K, float w1, float w4, float w5, float* per_img, float* rowloss, float* losses,
                              void* stream);
-int tris_stage1_loss_bwd_f32(const float* cls, const float* fi, const float* ft, const float* fneg, const float* g3,
-                             int B, int N, int E, int K, float* dcls, float* dfi, void* stream);
+int tris_stage1_loss_bwd_f32(const float* cls, const float* fi, const float* ft, const float* fneg, const float* g,
+                             float w1, float w4, float w5, int B, int N, int E, int K, float* dcls, float* dfi, void* stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------------------- */
 /* torch.optim.AdamW step over a flat arena (train_stage1.py:135-139, 370); step_count is the 1-based t */

@@ -88,7 +88,8 @@ def _install_standins(mp):
                          batch_norm=batch_norm,
                          avgpool2=avgpool2, embed=embed, layer_norm=layer_norm, mha=mha, eot_gather=eot_gather,
                          matmul=matmul, bmm=bmm, l2norm=l2norm, instance_norm=instance_norm, xattn=xattn,
-                         score_heads=score_heads, quick_gelu=torch.sigmoid, axpy=lambda a, b, s: s * a + b).items():
+                         score_heads=score_heads, quick_gelu=torch.sigmoid, axpy=lambda a, b, s, grad_box_b=None: s * a + b,
+                         axpy_bcast=lambda a, b, s, grad_box_b=None: s * a + b, scale_exp=lambda x, ls: (x * ls.exp(), ls.exp())).items():
         mp.setattr(ops, name, fn)
 
 

@@ -755,6 +755,68 @@ def test_stage1_loss(ops, K):
     close(out, torch.stack([loss, l1, l4, l5]), name="losses")
     close(gc.grad, cls.grad, name="dcls")
     close(gi.grad, fi.grad, name="dfi")
+    # a general upstream gradient of (total, l1, l4, l5): the kernels fold the loss weights into it themselves
+    up = torch.tensor([0.7, -1.3, 0.25, 2.0])
+    cls.grad = fi.grad = None
+    a2, c2 = fi.detach().clone().requires_grad_(True), cls.detach().clone().requires_grad_(True)
+    an = a2 / a2.norm(dim=-1, keepdim=True)
+    r1 = -(torch.log((an * t.detach()).sum(-1).clamp(0.0001, 0.9999))).mean()
+    r5 = (-(torch.log(1 - (an[:, None] * n.detach()).sum(-1)))).mean(1).mean() if K else torch.zeros(())
+    r4 = F.multilabel_soft_margin_loss(c2, torch.eye(B))
+    (torch.stack([r1 + 5 * r4 + 2 * r5, r1, r4, r5]) * up).sum().backward()
+    gc2, gi2 = gpu_leaf(cls), gpu_leaf(fi)
+    out2 = ops.stage1_loss(gc2, gi2, ft.detach().cuda(), fneg.detach().cuda() if K else None, 1.0, 5.0, 2.0)
+    (out2 * up.cuda()).sum().backward()
+    close(gc2.grad, c2.grad, name="dcls (general upstream gradient)")
+    close(gi2.grad, a2.grad, name="dfi (general upstream gradient)")
+
+
+def test_axpy_broadcast_scale_exp_concat_token0(ops):
+    """the small ops that replaced torch element-wise launches on the training path (model_stage1.py:74, 77-78; train_stage1.py:342;
+    CLIP/clip/model.py:443), forward and backward against torch"""
+    B, N, C = 5, 7, 64
+    a, b = leaf(B, N, C), leaf(N, C, seed=3)
+    ref = 0.1 * a + b.unsqueeze(0)
+    w = leaf(B, N, C, seed=9).detach()
+    (ref * w).sum().backward()
+    ga, gb = gpu_leaf(a), gpu_leaf(b)
+    out = ops.axpy_bcast(ga, gb, 0.1)
+    (out * w.cuda()).sum().backward()
+    close(out, ref, name="axpy_bcast")
+    close(ga.grad, a.grad, name="da")
+    close(gb.grad, b.grad, name="db (summed over the broadcast dimension)")
+    # score * exp(logit_scale)
+    x, ls = leaf(3, 50, 11), torch.tensor(2.659, requires_grad=True)
+    e = ls.exp()
+    y = x * e
+    wy = leaf(3, 50, 11, seed=4).detach()
+    (y * wy).sum().backward()
+    gx, gls = gpu_leaf(x), gpu_leaf(ls)
+    gy, ge = ops.scale_exp(gx, gls)
+    (gy * wy.cuda()).sum().backward()
+    close(gy, y, name="scale_exp")
+    close(ge, e, name="exp(logit_scale)")
+    close(gx.grad, x.grad, name="dx")
+    close(gls.grad, ls.grad, 1e-5 * float(ls.grad.abs()) + 1e-6, name="dlogit_scale")
+    # gradient through the returned scale as well
+    gls2 = gpu_leaf(ls)
+    gy2, ge2 = ops.scale_exp(gx.detach(), gls2)
+    (gy2.sum() + 3.0 * ge2).backward()
+    ls2 = ls.detach().clone().requires_grad_(True)
+    ((x.detach() * ls2.exp()).sum() + 3.0 * ls2.exp()).backward()
+    close(gls2.grad, ls2.grad, 1e-5 * float(ls2.grad.abs()) + 1e-6, name="dlogit_scale (both outputs)")
+    # int64 concat
+    i1, i2 = torch.randint(0, 49408, (4, 20)), torch.randint(0, 49408, (12, 20))
+    assert torch.equal(ops.concat_i64(i1.cuda(), i2.cuda()).cpu(), torch.cat([i1, i2], 0))
+    # class token
+    t = leaf(4, 50, 96)
+    wt = leaf(4, 96, seed=2).detach()
+    (t[:, 0, :] * wt).sum().backward()
+    gt = gpu_leaf(t)
+    o0 = ops.token0(gt)
+    (o0 * wt.cuda()).sum().backward()
+    close(o0, t[:, 0, :], name="token0")
+    close(gt.grad, t.grad, name="dtoken0")
 
 
 def test_adamw_matches_torch(ops):
@@ -930,3 +992,41 @@ def test_side_streams_are_probed_onto_their_own_hardware_queues():
         assert overlap(main, a), f"picked stream {i} shares the compute stream's hardware queue"
         for b in picked[i + 1:]:
             assert overlap(a, b)
+
+
+def test_fusion_gradient_boxes_equal_autograd_sums(ops):
+    """norm_vis / norm_lan feed three projections of the cross-modal fusion and the 0.1 residual mix: with gradient boxes each
+    projection's data-gradient product adds the running sum in its epilogue (model/attn.py forward_cl, model_stage1.py
+    forward_cached); with TRIS_GRAD_BOX=0 autograd sums the four terms with element-wise passes.  Same gradients either way."""
+    import tris_amd.ops as o
+    from tris_amd.model.attn import bilateral_prompt
+    from tris_amd.utils.synth import seed_fill
+    B, Pp, N, C = 3, 100, 5, 128
+    fuse = bilateral_prompt(C, lan_chans=C).cuda().train()
+    seed_fill(fuse.state_dict(), 77)
+    g = torch.Generator().manual_seed(5)
+    vis0, lan0 = torch.randn(B, Pp, C, generator=g), torch.randn(N, C, generator=g)
+    wv, wl = torch.randn(B, Pp, C, generator=g).cuda(), torch.randn(B, N, C, generator=g).cuda()
+
+    def run(boxes):
+        with CFG.override(grad_box=boxes):
+            vis, lan = vis0.clone().cuda().requires_grad_(True), lan0.clone().cuda().requires_grad_(True)
+            nv, nl = o.l2norm(vis), o.l2norm(lan)
+            grad = boxes
+            bv = o.GradBox() if grad else None
+            bl = o.GradBox() if grad else None
+            new_vis, new_lan = fuse.forward_cl(nv, nl, box_vis=bv, box_lan=bl)
+            ov = o.axpy(new_vis, nv, 0.1, grad_box_b=bv)
+            ol = o.axpy_bcast(new_lan, nl, 0.1, grad_box_b=bl)
+            for p_ in fuse.parameters():
+                p_.grad = None
+            ((ov * wv).sum() + (ol * wl).sum()).backward()
+            torch.cuda.synchronize()
+            if boxes:   # every box was filled and consumed: no gradient fell back to autograd's own sum
+                assert bv.value is None and bl.value is None
+            return vis.grad.clone(), lan.grad.clone(), [p_.grad.clone() for p_ in fuse.parameters()]
+    a, b = run(True), run(False)
+    close(a[0], b[0], 2e-6 * float(b[0].abs().max()) + 1e-9, name="d vis")
+    close(a[1], b[1], 2e-6 * float(b[1].abs().max()) + 1e-9, name="d lan")
+    for x, y in zip(a[2], b[2]):
+        close(x, y, 2e-6 * float(y.abs().max()) + 1e-9, name="d parameter")

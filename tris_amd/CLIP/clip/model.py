@@ -334,7 +334,7 @@ class VisionTransformer(nn.Module):
         x = ops.vit_assemble(emb, self.class_embedding, self.positional_embedding)
         x = self.ln_pre(x)
         x = self.transformer(x)
-        cls = self.ln_post(x[:, 0, :].contiguous())
+        cls = self.ln_post(ops.token0(x))
         return ops.matmul(cls, self.proj)
 
     def forward_spatial(self, x):

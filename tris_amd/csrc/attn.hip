@@ -4,6 +4,8 @@
 // One workgroup per (head, sequence): Q/K/V tiles of the packed QKV activation are staged in LDS (row pad 1 ->
 // conflict-free column walks), scores and probabilities live in LDS, the row softmax is a 64-lane wavefront
 // shuffle reduction.  The FLOPs here are ~1% of the step, so this is VALU f32, not MFMA.
+#include <algorithm>
+
 #include "common.h"
 #include "tris_hip.h"
 
@@ -250,10 +252,12 @@ __global__ void eot_gather_kernel(const long* __restrict__ ids, const float* __r
                                   float* __restrict__ dx, const float* __restrict__ dout, int L, int W) {
   const int n = blockIdx.x;
   int best = 0;
-  long bv = ids[(long)n * L];
-  for (int l = 1; l < L; ++l) {
-    long vv = ids[(long)n * L + l];
-    if (vv > bv) { bv = vv; best = l; }
+  if (ids != nullptr) {   // (ids == NULL: row 0 of every sequence -- the ViT class token)
+    long bv = ids[(long)n * L];
+    for (int l = 1; l < L; ++l) {
+      long vv = ids[(long)n * L + l];
+      if (vv > bv) { bv = vv; best = l; }
+    }
   }
   if (out) {
     for (int c = threadIdx.x; c < W; c += blockDim.x) out[(long)n * W + c] = x[((long)n * L + best) * W + c];
@@ -322,6 +326,21 @@ extern "C" int tris_embed_rows_bwd_f32(const long* ids, const float* rows, float
                                        void* stream) {
   if (R < 1 || W % 4 != 0 || W > 2048) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(R), dim3(128), 0, (hipStream_t)stream, ids, rows, dtok, R, W, scale);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+// out = [a; b]  (int64 token rows: the positive and the negative queries of a step in one list, train_stage1.py:342-347: batched here)
+namespace {
+__global__ void concat_i64_kernel(const long* __restrict__ a, long na, const long* __restrict__ b, long nb, long* __restrict__ out) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) out[i] = i < na ? a[i] : b[i - na];
+}
+}  // namespace
+extern "C" int tris_concat_i64(const long* a, long na, const long* b, long nb, long* out, void* stream) {
+  const long n = na + nb;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(concat_i64_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, out);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -417,16 +417,16 @@ __global__ __launch_bounds__(256) void clip_loss_fwd_kernel(const float* __restr
     out[b * 3 + 2] = K > 0 ? cbs / (float)K : 0.f;
   }
 }
-// d fi given upstream scalars g1 (dL/dl1), g5 (dL/dl5) held in device memory (gl[0], gl[1]).
+// d fi given the upstream gradient g[4] of (total, l1, l4, l5) in device memory: dL/dl1 = g[0]*w1 + g[1], dL/dl5 = g[0]*w5 + g[3]
 __global__ __launch_bounds__(256) void clip_loss_bwd_kernel(const float* __restrict__ fi, const float* __restrict__ ft,
-                                                            const float* __restrict__ fneg, const float* __restrict__ gl,
-                                                            float* __restrict__ dfi, int B, int E, int K) {
+                                                            const float* __restrict__ fneg, const float* __restrict__ g,
+                                                            float w1, float w5, float* __restrict__ dfi, int B, int E, int K) {
   extern __shared__ float sm[];  // dhat[E]
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* a = fi + (long)b * E;
   const float* t = ft + (long)b * E;
-  const float g1 = gl[0], g5 = gl[1];
+  const float g1 = __fadd_rn(__fmul_rn(g[0], w1), g[1]), g5 = __fadd_rn(__fmul_rn(g[0], w5), g[3]);
   float saa = 0.f, stt = 0.f, sat = 0.f;
   for (int c = tid; c < E; c += 256) { float x = a[c], y = t[c]; saa += x * x; stt += y * y; sat += x * y; }
   saa = block_sum_256(saa, red);
@@ -465,13 +465,14 @@ __global__ void msm_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
   }
   rowloss[b] = -s / (float)N;
 }
-__global__ void msm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx, int B,
-                               int N) {
+__global__ void msm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float w4, float* __restrict__ dx,
+                               int B, int N) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * N) return;
   int b = i / N, j = i - b * N;
   float sg = 1.0f / (1.0f + expf(-x[i]));
-  dx[i] = g[0] * (sg - (j == b ? 1.0f : 0.f)) / ((float)B * (float)N);
+  const float g4 = __fadd_rn(__fmul_rn(g[0], w4), g[2]);   // dL/dl4
+  dx[i] = g4 * (sg - (j == b ? 1.0f : 0.f)) / ((float)B * (float)N);
 }
 // losses[0..3] = total, l1, l4, l5 from per-image partials (fixed order => deterministic)
 __global__ void loss_finalize_kernel(const float* __restrict__ per_img, const float* __restrict__ rowloss, int B,
@@ -618,15 +619,15 @@ extern "C" int tris_stage1_loss_fwd_f32(const float* cls, const float* fi, const
   TRIS_LAUNCH_CHECK();
   return 0;
 }
-// g3 = device pointer to {dL/dl1, dL/dl5, dL/dl4} as produced by the host wrapper (upstream grad x weights)
+// g = device pointer to the upstream gradient of losses[4] = (total, l1, l4, l5); the loss weights fold it into dL/dl1, dL/dl4, dL/dl5
 extern "C" int tris_stage1_loss_bwd_f32(const float* cls, const float* fi, const float* ft, const float* fneg,
-                                        const float* g3, int B, int N, int E, int K, float* dcls, float* dfi,
-                                        void* stream) {
+                                        const float* g, float w1, float w4, float w5, int B, int N, int E, int K,
+                                        float* dcls, float* dfi, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(clip_loss_bwd_kernel, dim3(B), dim3(256), (size_t)E * sizeof(float), st, fi, ft, fneg, g3, dfi, B,
+  hipLaunchKernelGGL(clip_loss_bwd_kernel, dim3(B), dim3(256), (size_t)E * sizeof(float), st, fi, ft, fneg, g, w1, w5, dfi, B,
                      E, K);
   TRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(msm_bwd_kernel, dim3(cdiv((long)B * N, 256)), dim3(256), 0, st, cls, g3 + 2, dcls, B, N);
+  hipLaunchKernelGGL(msm_bwd_kernel, dim3(cdiv((long)B * N, 256)), dim3(256), 0, st, cls, g, w4, dcls, B, N);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

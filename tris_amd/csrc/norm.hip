@@ -708,14 +708,15 @@ __device__ __forceinline__ float ew1(int op, float a, float b, float s) {
     default: return a;
   }
 }
+// nb > 0: B has nb elements and is read modulo nb (a [rows, nb] operand against one broadcast row; n % 4 == nb % 4 == 0)
 __global__ void ew_kernel(int op, const float* __restrict__ A, const float* __restrict__ Bp, float* __restrict__ O,
-                          long n, float s, unsigned* __restrict__ amax = nullptr) {
+                          long n, float s, unsigned* __restrict__ amax = nullptr, long nb = 0) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
   unsigned am = 0u;
   for (long j = i; j < n4; j += stride) {
-    float4 a = ld4(A + j * 4), b = Bp ? ld4(Bp + j * 4) : make_float4(0, 0, 0, 0);
+    float4 a = ld4(A + j * 4), b = Bp ? ld4(Bp + (nb > 0 ? (j * 4) % nb : j * 4)) : make_float4(0, 0, 0, 0);
     const float4 o = make_float4(ew1(op, a.x, b.x, s), ew1(op, a.y, b.y, s), ew1(op, a.z, b.z, s), ew1(op, a.w, b.w, s));
     st4(O + j * 4, o);
     am = max(am, abits4(o));
@@ -1085,6 +1086,68 @@ extern "C" int tris_avgpool2_bwd_f32(const float* dY, float* dX, int B, int H, i
 extern "C" int tris_elementwise_f32(int op, const float* A, const float* B, float* O, long n, float s, void* stream) {
   hipLaunchKernelGGL(ew_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, op, A, B, O, n, s,
                      take_amax_next());
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_elementwise_bcast_f32(int op, const float* A, const float* B, float* O, long n, long nb, float s,
+                                          void* stream) {
+  if (B == nullptr || nb < 4 || (nb & 3) || (n & 3) || n % nb) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, op, A, B, O, n, s, take_amax_next(), nb);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+// O = X * exp(ls[0]); e_out[0] = exp(ls[0])   (model_stage1.py:77-78: score * logit_scale.exp())
+namespace {
+__global__ __launch_bounds__(256) void scale_exp_fwd_kernel(const float* __restrict__ X, const float* __restrict__ ls,
+                                                            float* __restrict__ O, float* __restrict__ e_out, long n) {
+  const float e = expf(ls[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) e_out[0] = e;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) O[i] = X[i] * e;
+}
+// dX = dO * e; part[block] = sum(dO * O) over the block's elements (fp64 from the block reduction on)
+__global__ __launch_bounds__(256) void scale_exp_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                            const float* __restrict__ ls, float* __restrict__ dX,
+                                                            double* __restrict__ part, long n) {
+  __shared__ double red[256];
+  const float e = expf(ls[0]);
+  const long stride = (long)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float g = dO[i];
+    if (dX) dX[i] = g * e;
+    acc += g * O[i];
+  }
+  red[threadIdx.x] = (double)acc;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void scale_exp_bwd_finish_kernel(const double* __restrict__ part, int nb, float* __restrict__ dls) {
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += part[i];   // fixed order
+  dls[0] = (float)s;
+}
+constexpr int SE_BLOCKS = 128;
+}  // namespace
+extern "C" int tris_scale_exp_fwd_f32(const float* X, const float* ls, float* O, float* e_out, long n, void* stream) {
+  hipLaunchKernelGGL(scale_exp_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, X, ls, O, e_out, n);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" long tris_scale_exp_workspace_bytes() { return (long)SE_BLOCKS * sizeof(double); }
+// dls[0] = d/d ls = sum(dO * O) (written, not accumulated); dX may be NULL
+extern "C" int tris_scale_exp_bwd_f32(const float* dO, const float* O, const float* ls, float* dX, float* dls,
+                                      float* workspace, long n, void* stream) {
+  double* part = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(scale_exp_bwd_kernel, dim3(SE_BLOCKS), dim3(256), 0, (hipStream_t)stream, dO, O, ls, dX, part, n);
+  TRIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scale_exp_bwd_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, part, SE_BLOCKS, dls);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

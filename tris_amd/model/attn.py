@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..config import cfg
 from ..CLIP.clip.model import Conv2d, Linear
 
 
@@ -34,9 +35,9 @@ class ReLU(nn.Module):
     pass
 
 
-def _vbranch(seq, x, relu):
+def _vbranch(seq, x, relu, grad_box=None, grad_box_out=None):
     """Sequential(Conv2d 1x1 + bias, InstanceNorm2d, [ReLU]) on channels-last [B,P,C]"""
-    y = ops.linear(x, seq[0].weight, seq[0].bias)
+    y = ops.linear(x, seq[0].weight, seq[0].bias, grad_box=grad_box, grad_box_out=grad_box_out)
     return ops.instance_norm(y, seq[1].weight, seq[1].bias, relu, seq[1].eps)
 
 
@@ -51,12 +52,29 @@ class bilateral_prompt(nn.Module):
         self.v_output = nn.Sequential(Conv2d(m, vis_chans, 1, bias=True), InstanceNorm2d(vis_chans))
         self.t_output = nn.Sequential(Linear(m, lan_chans))
 
-    def forward_cl(self, vis, lan):
-        """vis [B,P,C] channels-last pixels, lan [N,C] sentences -> (new_vis [B,P,C], new_lan [B,N,C])"""
+    def forward_cl(self, vis, lan, box_vis=None, box_lan=None):
+        """vis [B,P,C] channels-last pixels, lan [N,C] sentences -> (new_vis [B,P,C], new_lan [B,N,C]).
+        vis and lan each feed three projections (and, in the caller, a residual mix): instead of autograd summing four gradients
+        with element-wise passes, each projection's data-gradient product adds the sum so far in its epilogue (ops.GradBox chain:
+        backward runs the projections in reverse creation order; a box that is not filled in time just falls back to autograd).
+        box_vis / box_lan: where the caller's later consumer of vis / lan leaves its gradient (or None)."""
         B, Pp, C = vis.shape
         scale = 1.0 / math.sqrt(lan.shape[-1])
-        Qv, Kv, Vv = (_vbranch(getattr(self, f"v_proj{i}"), vis, True) for i in (1, 2, 3))
-        Qt, Kt, Vt = (getattr(self, f"t_proj{i}")[0](lan, act=1) for i in (1, 2, 3))
+        chain = torch.is_grad_enabled() and cfg.grad_box
+
+        def boxes(x, last):
+            if not (chain and x.requires_grad):
+                return None, None, None
+            return ops.GradBox(), ops.GradBox(), last
+        v1, v2, v3 = boxes(vis, box_vis)
+        t1, t2, t3 = boxes(lan, box_lan)
+        Qv = _vbranch(self.v_proj1, vis, True, grad_box=v1)
+        Kv = _vbranch(self.v_proj2, vis, True, grad_box=v2, grad_box_out=v1)
+        Vv = _vbranch(self.v_proj3, vis, True, grad_box=v3, grad_box_out=v2)
+        tp = [getattr(self, f"t_proj{i}")[0] for i in (1, 2, 3)]
+        Qt = ops.linear(lan, tp[0].weight, tp[0].bias, None, 1, grad_box=t1)
+        Kt = ops.linear(lan, tp[1].weight, tp[1].bias, None, 1, grad_box=t2, grad_box_out=t1)
+        Vt = ops.linear(lan, tp[2].weight, tp[2].bias, None, 1, grad_box=t3, grad_box_out=t2)
         if Qt.shape[0] <= 64 and C % 64 == 0 and Pp <= 256:
             new_vis, new_lan = ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)   # fused cross attention (csrc/xattn.hip)
         else:  # composed from the GEMM core + row softmax (same math) for shapes outside the fused kernel's limits

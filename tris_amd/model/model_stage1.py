@@ -95,14 +95,18 @@ class TRIS(nn.Module):
             _, hidden = self.backbone.encode_text(word_id)             # [N,E]   (N = B sentences)
         norm_lan = ops.l2norm(self.lan_project(hidden))                 # [N,C]
         if self.args.attn_multi > 0:
-            new_vis, new_lan = self.attn_fusion.forward_cl(norm_vis, norm_lan)
-            norm_vis = ops.axpy(new_vis, norm_vis, 0.1)                 # hard-coded 0.1 (model_stage1.py:73-74)
-            lan_b = ops.axpy(new_lan, norm_lan.unsqueeze(0).expand(B, -1, -1).contiguous(), 0.1)   # [B,N,C]
+            # norm_vis / norm_lan feed the three projections of the fusion AND the residual mix below: the mix leaves its gradient
+            # in a box that the fusion's last projection adds in its data-gradient epilogue (attn.forward_cl)
+            grad = torch.is_grad_enabled() and cfg.grad_box
+            bv = ops.GradBox() if grad and norm_vis.requires_grad else None
+            bl = ops.GradBox() if grad and norm_lan.requires_grad else None
+            new_vis, new_lan = self.attn_fusion.forward_cl(norm_vis, norm_lan, box_vis=bv, box_lan=bl)
+            norm_vis = ops.axpy(new_vis, norm_vis, 0.1, grad_box_b=bv)  # hard-coded 0.1 (model_stage1.py:73-74)
+            lan_b = ops.axpy_bcast(new_lan, norm_lan, 0.1, grad_box_b=bl)   # [B,N,C]: 0.1 * new_lan + norm_lan per image
         else:
             lan_b = norm_lan.unsqueeze(0).expand(B, -1, -1).contiguous()
         score = ops.bmm(norm_vis, lan_b, tB=True)                       # [B,P,N]
-        logit_scale = self.logit_scale.exp()
-        score = score * logit_scale
+        score, logit_scale = ops.scale_exp(score, self.logit_scale)    # score * logit_scale.exp(), and the scale itself
         if self.training:
             cls_out, cls_fg, relu_map, sig_map = ops.score_heads(score, h_, w_, out_size, True,
                                                                  float(self.args.FOCAL_P),
@@ -129,7 +133,7 @@ class TRIS(nn.Module):
             lan_p = ops.axpy(new_lan, norm_lan.unsqueeze(1).contiguous(), 0.1)      # [S,1,C]
         else:
             lan_p = norm_lan.unsqueeze(1).contiguous()
-        score = ops.bmm(vis_p, lan_p, tB=True) * self.logit_scale.exp()            # [S,P,1]
+        score = ops.scale_exp(ops.bmm(vis_p, lan_p, tB=True), self.logit_scale)[0]   # [S,P,1]
         # the map kernels read score[i,:,i] (Stage-1's diagonal): lay the S single-sentence columns out on a diagonal
         full = torch.zeros(S, score.shape[1], S, device=score.device, dtype=torch.float32)
         ar = torch.arange(S, device=score.device)

@@ -1571,7 +1571,7 @@ class EotGatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ids, x):
         _chk(ids, x)
-        ids, x = ids.contiguous(), x.contiguous()
+        ids, x = (None if ids is None else ids.contiguous()), x.contiguous()
         N, L, W = x.shape
         out = torch.empty(N, W, device=x.device, dtype=torch.float32)
         call("tris_eot_gather_fwd_f32", P(ids), P(x), P(out), N, L, W, _stream())
@@ -1590,6 +1590,11 @@ class EotGatherFn(torch.autograd.Function):
 
 def eot_gather(ids, x):
     return EotGatherFn.apply(ids, x)
+
+
+def token0(x):
+    """x[:, 0, :] of [N, L, W] as a copy, with its own backward kernel (the ViT class token, CLIP/clip/model.py:443)"""
+    return EotGatherFn.apply(None, x)
 
 
 # ----------------------------------------------------------------------------------------------- heads
@@ -1767,22 +1772,100 @@ def xattn(Qv, Kv, Vv, Qt, Kt, Vt):
 
 
 class AxpyFn(torch.autograd.Function):
-    """s * a + b"""
+    """s * a + b.  grad_box_b: b's gradient (dy itself) is left in that GradBox for another consumer of b to add in its
+    data-gradient epilogue instead of being summed by autograd."""
 
     @staticmethod
-    def forward(ctx, a, b, s):
-        ctx.s = s
+    def forward(ctx, a, b, s, grad_box_b=None):
+        ctx.s, ctx.box = s, grad_box_b
         return ew("TRIS_EW_AXPY", a.contiguous(), b.contiguous(), s)
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
         da = ew("TRIS_EW_SCALE", dy, None, ctx.s) if ctx.needs_input_grad[0] else None
-        return da, (dy if ctx.needs_input_grad[1] else None), None
+        db = dy if ctx.needs_input_grad[1] else None
+        if db is not None and ctx.box is not None and ctx.box.deposit(db):
+            db = None
+        return da, db, None, None
 
 
-def axpy(a, b, s):
-    return AxpyFn.apply(a, b, s)
+def axpy(a, b, s, grad_box_b=None):
+    return AxpyFn.apply(a, b, s, grad_box_b)
+
+
+class AxpyBcastFn(torch.autograd.Function):
+    """s * a + b with b [n...] broadcast over the leading dimension of a [R, n...]  (model_stage1.py:74: the sentence features of
+    the step against every image's attended ones; the expanded copy of b is never made)"""
+
+    @staticmethod
+    def forward(ctx, a, b, s, grad_box_b=None):
+        _chk(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        assert a.shape[1:] == b.shape and b.numel() % 4 == 0, (a.shape, b.shape)
+        ctx.s, ctx.box = s, grad_box_b
+        out = torch.empty_like(a)
+        h2_mark_next(out)
+        call("tris_elementwise_bcast_f32", EW["TRIS_EW_AXPY"], P(a), P(b), P(out), a.numel(), b.numel(), float(s), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        da = ew("TRIS_EW_SCALE", dy, None, ctx.s) if ctx.needs_input_grad[0] else None
+        db = None
+        if ctx.needs_input_grad[1]:
+            R = dy.shape[0]
+            db = colsum(dy, R, dy.numel() // R, torch.empty(dy.shape[1:], device=dy.device, dtype=torch.float32))
+            if ctx.box is not None and ctx.box.deposit(db):
+                db = None
+        return da, db, None, None
+
+
+def axpy_bcast(a, b, s, grad_box_b=None):
+    return AxpyBcastFn.apply(a, b, s, grad_box_b)
+
+
+class ScaleExpFn(torch.autograd.Function):
+    """(x, ls) -> (x * exp(ls), exp(ls)) for a 0-dim device scalar ls  (model_stage1.py:77-78)"""
+
+    @staticmethod
+    def forward(ctx, x, ls):
+        _chk(x, ls)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        e = torch.empty((), device=x.device, dtype=torch.float32)
+        call("tris_scale_exp_fwd_f32", P(x), P(ls), P(out), P(e), x.numel(), _stream())
+        ctx.save_for_backward(out, ls, e)
+        ctx.set_materialize_grads(False)
+        return out, e
+
+    @staticmethod
+    def backward(ctx, dout, de):
+        out, ls, e = ctx.saved_tensors
+        dx = dls = None
+        if dout is not None:
+            dout = dout.contiguous()
+            dx = torch.empty_like(dout) if ctx.needs_input_grad[0] else None
+            dls = torch.empty((), device=out.device, dtype=torch.float32)
+            ws = workspace(query("tris_scale_exp_workspace_bytes"))
+            call("tris_scale_exp_bwd_f32", P(dout), P(out), P(ls), P(dx), P(dls), P(ws), out.numel(), _stream())
+        if de is not None:       # (nobody differentiates through the returned scale on this path; kept correct all the same)
+            dls = de * e if dls is None else dls + de * e
+        return dx, (dls if ctx.needs_input_grad[1] else None)
+
+
+def scale_exp(x, ls):
+    return ScaleExpFn.apply(x, ls)
+
+
+def concat_i64(a, b):
+    """[a; b] of two int64 row lists (no gradient)"""
+    a, b = a.contiguous(), b.contiguous()
+    assert a.dtype == b.dtype == torch.int64 and a.shape[1:] == b.shape[1:] and a.is_cuda and b.is_cuda
+    out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), device=a.device, dtype=torch.int64)
+    call("tris_concat_i64", a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), out.data_ptr(), _stream())
+    return out
 
 
 class MulFn(torch.autograd.Function):
@@ -1966,11 +2049,11 @@ class Stage1LossFn(torch.autograd.Function):
         cls, fi, ft, fneg = ctx.saved_tensors
         B, N, E, K, w1, w4, w5 = ctx.cfg
         g = g.contiguous()
-        # dL/dl1 = g[0]*w1 + g[1]; dL/dl5 = g[0]*w5 + g[3]; dL/dl4 = g[0]*w4 + g[2]
-        g3 = torch.stack([g[0] * w1 + g[1], g[0] * w5 + g[3], g[0] * w4 + g[2]]).contiguous()
+        # (the kernels fold the loss weights: dL/dl1 = g[0]*w1 + g[1]; dL/dl5 = g[0]*w5 + g[3]; dL/dl4 = g[0]*w4 + g[2])
         dcls = torch.empty_like(cls)
         dfi = torch.empty_like(fi)
-        call("tris_stage1_loss_bwd_f32", P(cls), P(fi), P(ft), P(fneg), P(g3), B, N, E, K, P(dcls), P(dfi), _stream())
+        call("tris_stage1_loss_bwd_f32", P(cls), P(fi), P(ft), P(fneg), P(g), float(w1), float(w4), float(w5), B, N, E, K, P(dcls),
+             P(dfi), _stream())
         return dcls, dfi, None, None, None, None, None
 
 

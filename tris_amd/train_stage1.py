@@ -40,7 +40,7 @@ def stage1_forward_losses(model, clip_model, img, word_ids, neg_word_ids, args):
     K = 0
     if neg_word_ids is not None and args.negative_samples > 0:
         K = neg_word_ids.shape[1]
-        ids_all = torch.cat([ids_all, neg_word_ids.long().reshape(B * K, -1)], 0)
+        ids_all = ops.concat_i64(ids_all, neg_word_ids.long().reshape(B * K, -1))
     main = side = ready = None
     if _overlap_enabled():
         main, side = torch.cuda.current_stream(), _side_stream(img.device)
