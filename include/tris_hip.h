@@ -38,6 +38,15 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                   int bias_mode, const float* resid, long ldr, long strideR, int act, float alpha, float* workspace,
                   long workspace_bytes, void* stream);
 
+/* One-shot: the NEXT tris_gemm_f32 launched from the calling thread (batch 1) also
+ *   - stores the value BEFORE the activation to pre_out (layout of C) -- with act = 2 one launch yields QuickGELU(x W^T + b) and the
+ *     pre-activation its backward needs (CLIP/clip/model.py:361-376, the transformer MLP);
+ *   - multiplies what it stores by quickgelu'(dact_x[m, n]) (layout of C; applied last) -- the data gradient of the Linear behind a
+ *     QuickGELU comes out as the gradient of the pre-activation.
+ * Either pointer may be NULL.  The armed product runs without split-K and returns TRIS_DECLINED (nothing launched, arming consumed)
+ * when the fast kernel does not serve its operands. */
+int tris_gemm_epilogue_next(float* pre_out, const float* dact_x);
+
 /* Arithmetic of the dense-product kernels.  tris_set_gemm_mode sets the process-wide DEFAULT; tris_set_gemm_mode_thread
  * sets an override for the calling thread only (-1 = none) -- e.g. the autograd thread running the weight-gradient
  * products in another mode -- so that concurrent launches from other threads are unaffected.  Both are host-side values

@@ -26,7 +26,7 @@ def _install_standins(mp):
     def conv3x3(x, w, stride=1, stats=False):
         return F.conv2d(x.permute(0, 3, 1, 2), w, stride=stride, padding=1).permute(0, 2, 3, 1).contiguous()
 
-    def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
+    def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None, act_link=False):
         y = x @ w.reshape(w.shape[0], -1).t()
         if b is not None:
             y = y + b
@@ -89,7 +89,8 @@ def _install_standins(mp):
                          avgpool2=avgpool2, embed=embed, layer_norm=layer_norm, mha=mha, eot_gather=eot_gather,
                          matmul=matmul, bmm=bmm, l2norm=l2norm, instance_norm=instance_norm, xattn=xattn,
                          score_heads=score_heads, quick_gelu=torch.sigmoid, axpy=lambda a, b, s, grad_box_b=None: s * a + b,
-                         axpy_bcast=lambda a, b, s, grad_box_b=None: s * a + b, scale_exp=lambda x, ls: (x * ls.exp(), ls.exp())).items():
+                         axpy_bcast=lambda a, b, s, grad_box_b=None: s * a + b, scale_exp=lambda x, ls: (x * ls.exp(), ls.exp()),
+                         linear_qgelu=lambda x, w, b=None: torch.sigmoid(linear(x, w, b))).items():
         mp.setattr(ops, name, fn)
 
 

@@ -1030,3 +1030,27 @@ def test_fusion_gradient_boxes_equal_autograd_sums(ops):
     close(a[1], b[1], 2e-6 * float(b[1].abs().max()) + 1e-9, name="d lan")
     for x, y in zip(a[2], b[2]):
         close(x, y, 2e-6 * float(y.abs().max()) + 1e-9, name="d parameter")
+
+
+@pytest.mark.parametrize("M,W", [(2400, 768), (37, 64), (50, 48)])
+def test_mlp_with_quickgelu_in_the_epilogues(ops, M, W):
+    """transformer MLP (CLIP/clip/model.py:361-376): c_fc + QuickGELU in one launch that also stores the pre-activation, the
+    QuickGELU backward in c_proj's data-gradient epilogue (tris_gemm_epilogue_next).  (50, 48): K % 32 != 0 -- the armed product
+    declines and the unfused passes run; same numbers."""
+    import tris_amd.ops as o
+    x, w1, b1 = leaf(M, W), leaf(4 * W, W, scale=0.05), leaf(4 * W, scale=0.1)
+    w2, b2 = leaf(W, 4 * W, scale=0.05, seed=1), leaf(W, scale=0.1, seed=1)
+    h = x @ w1.t() + b1
+    y = (h * torch.sigmoid(1.702 * h)) @ w2.t() + b2 + x
+    wy = leaf(M, W, seed=7).detach()
+    (y * wy).sum().backward()
+    g = [gpu_leaf(t) for t in (x, w1, b1, w2, b2)]
+    f = o.linear_qgelu(g[0], g[1], g[2])
+    link = f._act_link
+    gy = o.linear(f, g[3], g[4], g[0], 0, act_link=True)
+    (gy * wy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert link.applied == (W % 32 == 0)     # the fused backward ran exactly where the fast kernel serves the product
+    close(gy, y, name="y")
+    for a, b_, n in zip(g, (x, w1, b1, w2, b2), ("dx", "dw1", "db1", "dw2", "db2")):
+        close(a.grad, b_.grad, 2e-5 if M > 1000 else TOL, name=n)

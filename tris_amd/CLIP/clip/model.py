@@ -289,10 +289,14 @@ class ResidualAttentionBlock(nn.Module):
         a = ops.mha(qkv, self.attn.num_heads, self.causal)
         x = self.attn.out_proj(a, resid=x, grad_box_res=b1)
         h = self.ln_2(x, b2)
+        if torch.is_grad_enabled() and cfg.mlp_fuse:
+            # c_fc + QuickGELU in one launch (the epilogue also stores the pre-activation); the QuickGELU backward rides c_proj's
+            # data-gradient epilogue: f has no other consumer
+            f = ops.linear_qgelu(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias)
+            return ops.linear(f, self.mlp.c_proj.weight, self.mlp.c_proj.bias, x, 0, grad_box_res=b2, act_link=True)
         if torch.is_grad_enabled():
-            f = self.mlp.gelu(self.mlp.c_fc(h))
-        else:
-            f = self.mlp.c_fc(h, act=2)  # QuickGELU fused into the GEMM epilogue (inference / frozen aux text)
+            return self.mlp.c_proj(self.mlp.gelu(self.mlp.c_fc(h)), resid=x, grad_box_res=b2)
+        f = self.mlp.c_fc(h, act=2)  # QuickGELU fused into the GEMM epilogue (inference / frozen aux text)
         return self.mlp.c_proj(f, resid=x, grad_box_res=b2)
 
 

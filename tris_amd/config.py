@@ -16,6 +16,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   text_at            TRIS_TEXT_AT              where TRIS.forward issues its text encoder: "layer4" | "layer2" | "start"
   bn_bwd_fuse        TRIS_BN_BWD_FUSE          BatchNorm-backward reductions in the consuming product's epilogue
   bn_pool            TRIS_BN_POOL              BatchNorm + ReLU + AvgPool2d(2) as one op
+  mlp_fuse           TRIS_MLP_FUSE             QuickGELU forward / backward in the epilogues of the transformer MLP's two products
   grad_box           TRIS_GRAD_BOX             residual-branch gradients handed to the consuming product's epilogue
   mha                TRIS_MHA                  attention kernel: "auto" | "valu" | "mfma"
   xattn_fused        TRIS_XATTN_FUSED          cross attention as one persistent launch where it applies
@@ -49,6 +50,7 @@ class _Config:
         self.bn_bwd_fuse = _flag("TRIS_BN_BWD_FUSE", True)
         self.bn_pool = _flag("TRIS_BN_POOL", True)
         self.grad_box = _flag("TRIS_GRAD_BOX", True)
+        self.mlp_fuse = _flag("TRIS_MLP_FUSE", True)
         self.mha = e("TRIS_MHA", "auto")
         self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
         self.hbm_loader = _flag("TRIS_HBM_LOADER", True)

@@ -451,16 +451,27 @@ int conv3_dispatch(GemmParams& p, hipStream_t st, int* stat_rows, bool direct_on
 // may the fused-statistics epilogue of the fast kernel serve this product?
 static bool stats_eligible(const GemmParams& p) { return gemm_fast_ok(p) && p.M >= 128; }
 
+// One-shot arming of the NEXT tris_gemm_f32 of the calling thread with two epilogue extras (GemmParams::pre_out / dact_x)
+struct EpiNext { float* pre; const float* dact; bool armed; };
+static thread_local EpiNext g_epi_next = {nullptr, nullptr, false};
+extern "C" int tris_gemm_epilogue_next(float* pre_out, const float* dact_x) {
+  g_epi_next = {pre_out, dact_x, pre_out != nullptr || dact_x != nullptr};
+  return 0;
+}
+
 extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
                              long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
                              const float* bias, int bias_mode, const float* resid, long ldr, long sR, int act,
                              float alpha, float* workspace, long ws_bytes, void* stream) {
   const H2Next h2n = h2_take();
   unsigned* amax_out = tris_internal_take_amax_next();   // (one-shot by-product: the amax word of C, tris_amax_next)
+  const EpiNext epi = g_epi_next;
+  g_epi_next.armed = false;
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0) return (int)hipErrorInvalidValue;
   GemmParams p = {};
   p.amax_out = amax_out;
+  if (epi.armed) { p.pre_out = epi.pre; p.dact_x = epi.dact; }
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;
   p.bias = bias; p.bias_mode = bias ? bias_mode : 0;
@@ -470,6 +481,11 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.fastA = p.vecA && (!transA || M % 4 == 0);
   p.fastB = p.vecB && (transB || N % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  if (epi.armed) {   // the extras live in the fast kernel's one-pass epilogue only: no split-K, no generic kernel
+    if (batch != 1 || transA || !gemm_fast_ok(p)) return TRIS_DECLINED;
+    workspace = nullptr;
+    ws_bytes = 0;
+  }
   H2Guard h2(p, h2n);
   if (!transA && transB) return launch_cfg<A_ROWK, B_NK>(p, batch, workspace, ws_bytes, st);
   if (!transA && !transB) return launch_cfg<A_ROWK, B_KN>(p, batch, workspace, ws_bytes, st);

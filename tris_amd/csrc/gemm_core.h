@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
       }
     }
-  if (EPI == EPI_STD && p.amax_out != nullptr) amax_commit(g_am, p.amax_out);
+  if (EPI != EPI_SLAB && p.amax_out != nullptr) amax_commit(g_am, p.amax_out);
 }
 
 // Sum split-K slabs (ws[s][M][N]) and apply the standard epilogue.  VEC = 4: one thread owns 4 consecutive columns of a
@@ -394,10 +394,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // launch one configuration (+ split-K reduce).  mode: 0 = f32-input MFMA, 1 = split-bf16 x3, 3 = two-piece fp16 h2
 template <int AK, int BKIND>
 int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mode) {
-  int bm = cfg.bm, bn = cfg.bn, splitk = cfg.splitk;
+  int bm = cfg.bm, bn = cfg.bn, splitk = ws != nullptr ? cfg.splitk : 1;   // (a tuned split-K choice without a workspace: one slice)
   const bool fast = gemm_fast_ok(p);
   if (bn == 32 && !fast) bm = bn = 64;  // the 128x32 tile exists in the fast kernel only
-  const bool pipe = cfg.pipe && (mode == 1 || mode == 3) && fast && bn != 32;   // (the pipelined loop: x3 and h2)
+  const bool xtra = p.pre_out != nullptr || p.dact_x != nullptr;   // (tris_gemm_epilogue_next: classic loop, one slice, fast kernel)
+  const bool pipe = cfg.pipe && (mode == 1 || mode == 3) && fast && bn != 32 && !xtra;   // (the pipelined loop: x3 and h2)
   if (bm == 256 && !pipe) bm = 128;     // the 256-row tile exists in the pipelined form only
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
@@ -431,6 +432,9 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
       if (splitk > 1) {                                                                            \
         p.C = ws;                                                                                  \
         TRIS_FAST_EPI(BM_, BN_, EPI_SLAB);                                                         \
+      } else if (xtra) {                                                                           \
+        if constexpr (AK == A_ROWK && (BKIND == B_NK || BKIND == B_KN)) TRIS_FAST_EPI(BM_, BN_, EPI_XTRA); \
+        else return (int)hipErrorInvalidValue;                                                     \
       } else {                                                                                     \
         TRIS_FAST_EPI(BM_, BN_, EPI_STD);                                                          \
       }                                                                                            \

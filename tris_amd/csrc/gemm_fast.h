@@ -750,7 +750,7 @@ void gemm_fast_kernel(GemmParams p) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) vs_s[j] = vs_q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool vec_epi = EPI_LDS && p.vecC;  // uniform
-  const bool nt_e = EPI == EPI_STD && p.nt != 0;   // uniform: epilogue streams larger than the memory-side cache (gemm_conv.hip stream_nt)
+  const bool nt_e = EPI != EPI_SLAB && p.nt != 0;   // uniform: epilogue streams larger than the memory-side cache (gemm_conv.hip stream_nt)
   if (vec_epi) {
     float* stg;
     {
@@ -771,9 +771,9 @@ void gemm_fast_kernel(GemmParams p) {
         __builtin_amdgcn_wave_barrier();
         const int col = n0 + wn * WN + j * 32 + ec;
         float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == EPI_STD && p.bias_mode == 1 && col < p.N) bc = ld4(p.bias + col);
+        if (EPI != EPI_SLAB && p.bias_mode == 1 && col < p.N) bc = ld4(p.bias + col);
         float4 nmu = bc, nis = bc, nsc = bc, nbe = bc;   // fused BatchNorm-backward reduction: the columns' constants
-        if (EPI == EPI_STD && p.bnb_x != nullptr && col < p.N) {
+        if (EPI != EPI_SLAB && p.bnb_x != nullptr && col < p.N) {
           nmu = ld4(p.bnb_mean + col);
           nis = ld4(p.bnb_invstd + col);
           if (p.bnb_y == nullptr) {
@@ -794,6 +794,7 @@ void gemm_fast_kernel(GemmParams p) {
               v.x *= alpha_e; v.y *= alpha_e; v.z *= alpha_e; v.w *= alpha_e;
               if (p.bias_mode == 1) { v.x += bc.x; v.y += bc.y; v.z += bc.z; v.w += bc.w; }
               else if (p.bias_mode == 2) { const float bb = p.bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+              if (EPI == EPI_XTRA && p.pre_out != nullptr) *reinterpret_cast<float4*>(p.pre_out + (long)row * p.ldc + col) = v;
               if (p.act == 1) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
               } else if (p.act == 2) {
@@ -824,6 +825,10 @@ void gemm_fast_kernel(GemmParams p) {
                 vs_q[j].x += v.x * ((xx.x - nmu.x) * nis.x); vs_q[j].y += v.y * ((xx.y - nmu.y) * nis.y);
                 vs_q[j].z += v.z * ((xx.z - nmu.z) * nis.z); vs_q[j].w += v.w * ((xx.w - nmu.w) * nis.w);
               } else {
+              if (EPI == EPI_XTRA && p.dact_x != nullptr) {
+                const float4 xg = ld4(p.dact_x + (long)row * p.ldc + col);
+                v.x = v.x * qgelu_grad(xg.x); v.y = v.y * qgelu_grad(xg.y); v.z = v.z * qgelu_grad(xg.z); v.w = v.w * qgelu_grad(xg.w);
+              }
               st4s(p.C + (long)zb * p.sC + (long)row * p.ldc + col, v, nt_e);
               e_am = max(e_am, abits4(v));
               vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
@@ -852,9 +857,11 @@ void gemm_fast_kernel(GemmParams p) {
             v *= alpha_e;
             if (p.bias_mode == 1) v += p.bias[col];
             else if (p.bias_mode == 2) v += p.bias[row];
+            if (EPI == EPI_XTRA && p.pre_out != nullptr) p.pre_out[(long)row * p.ldc + col] = v;
             if (p.act == 1) v = fmaxf(v, 0.f);
             else if (p.act == 2) v = v / (1.0f + expf(-1.702f * v));
             if (p.resid) v += p.resid[(long)zb * p.sR + (long)row * p.ldr + col];
+            if (EPI == EPI_XTRA && p.dact_x != nullptr) v = v * qgelu_grad(p.dact_x[(long)row * p.ldc + col]);
             if (p.bnb_x != nullptr) {   // (fused BatchNorm-backward reduction, scalar form: see the vector epilogue)
               const long o = (long)row * p.ldc + col;
               const float xx = p.bnb_x[o], mu1 = p.bnb_mean[col], is1 = p.bnb_invstd[col];
@@ -875,8 +882,8 @@ void gemm_fast_kernel(GemmParams p) {
       }
     }
   }
-  if (EPI == EPI_STD && p.amax_out != nullptr) amax_commit(e_am, p.amax_out);   // (per wave, uniform)
-  if (EPI == EPI_STD && p.stat_part != nullptr) {
+  if (EPI != EPI_SLAB && p.amax_out != nullptr) amax_commit(e_am, p.amax_out);   // (per wave, uniform)
+  if (EPI != EPI_SLAB && p.stat_part != nullptr) {
     // rows of one column live in the 2 lane halves (kh) [vector epilogue: the 8 row groups er] and the NWM waves along M:
     // shuffle, then LDS, then one fp64 partial row per block: part[tile_m][2][N]  (finished by bn_finalize_kernel)
     static_assert(NWM * BN * 4 <= AS_ALL, "statistics scratch does not fit the staging buffer");

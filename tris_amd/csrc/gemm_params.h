@@ -4,7 +4,7 @@
 
 enum { A_ROWK = 0, A_COLK = 1, A_IM2COL = 2, A_HALO = 3 };  // A_HALO: direct 3x3 convolution (gemm_fast.h)
 enum { B_NK = 0, B_KN = 1, B_KN_DGRAD = 2, B_KN_IM2COL = 3 };
-enum { EPI_STD = 0, EPI_SLAB = 1 };
+enum { EPI_STD = 0, EPI_SLAB = 1, EPI_XTRA = 2 };   // EPI_XTRA: EPI_STD + the pre_out / dact_x extras (classic loop, row-major A)
 
 struct GemmParams {
   const float* A;
@@ -48,6 +48,11 @@ struct GemmParams {
   // optional by-product (tris_gemm_f32 after tris_amax_next): the largest magnitude of the values written to C, maxed into this
   // amax word -- the operand scale of an h2 product that consumes C directly (amax.h); split-K products leave it in the reduce
   unsigned* amax_out;
+  // optional (tris_gemm_epilogue_next, EPI_STD, no split-K; same layout as C): pre_out receives the value BEFORE the activation (what
+  // a fused QuickGELU's backward needs); dact_x: the stored value is multiplied by quickgelu'(dact_x[m, n]) last -- the data gradient
+  // of the Linear behind a QuickGELU comes out as the gradient of its pre-activation
+  float* pre_out;
+  const float* dact_x;
   int nt;   // EPI_STD vector epilogue: C stores and the residual / bnb_x / bnb_y loads are nontemporal (set per launch: stream_nt)
 };
 
@@ -66,6 +71,11 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // one launch configuration of the family: tile, split-K slices, pipe = 1: the pipelined loop of gemm_fast.h (x3 only: two 16-deep
 // LDS stages, one barrier per K tile; 256 x 128 tiles exist in that form only).  conv3_dispatch / the direct weight gradient
 // store the id of a direct kernel in bm.
+// d/dx [x * sigmoid(1.702 x)] with norm.hip's TRIS_EW_QGELU_BWD expression (bit-identical to the unfused pass)
+__device__ __forceinline__ float qgelu_grad(float b) {
+  const float sg = 1.0f / (1.0f + expf(-1.702f * b));
+  return sg + 1.702f * b * sg * (1.f - sg);
+}
 struct Cfg { int bm, bn, splitk, pipe; };
 // do the operands meet the preconditions of gemm_fast_kernel?
 inline bool gemm_fast_ok(const GemmParams& p) { return p.fastA && p.fastB && (p.K % 32 == 0) && p.M >= 4 && p.N >= 4; }

@@ -452,8 +452,20 @@ class batch_invariant:
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
-         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True):
+         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True, pre_out=None, dact=None):
+    """pre_out / dact (tris_gemm_epilogue_next): also store the pre-activation value / multiply the result by quickgelu'(dact);
+    the call then returns False -- nothing launched -- when the fast kernel does not serve the operands (caller falls back)."""
     _chk(A, B, C, bias, resid)
+    if pre_out is not None or dact is not None:
+        if _BATCH_INVARIANT or batch != 1:
+            return False
+        h2_arm(A, B)
+        h2_mark_next(C)
+        call("tris_gemm_epilogue_next", P(pre_out), P(dact))
+        return _timed("gemm", 2.0 * M * N * K, lambda: _declinable(
+            "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), 1, 0, 0, 0, P(bias), bias_mode, P(resid),
+            ldr, sR, act, float(alpha), None, 0, _stream()),
+            nbytes=4.0 * (M * K + K * N + M * N * (2 + int(resid is not None))))
     if _BATCH_INVARIANT and batch == 1 and not tA and M < 4 and lda == K and ldc == N and (resid is None or ldr == N) and bias_mode != 2:
         # products of fewer than four rows run a different (generic) kernel than larger ones: in batch-invariant mode they are
         # padded to four rows so that a sentence evaluated alone goes through the same arithmetic as one evaluated in a batch
@@ -841,9 +853,11 @@ class LinearFn(torch.autograd.Function):
     """y = act(x . W^T + b) + resid  with W [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv on channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None, bn_link=None):
+    def forward(ctx, x, w, b, resid, act, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None, bn_link=None,
+                act_link=None):
         _chk(x, w, b, resid)
         ctx.grad_box, ctx.grad_box_out, ctx.grad_box_res = grad_box, grad_box_out, grad_box_res
+        ctx.act_link = act_link
         ctx.bn_link = bn_link if (bn_link is not None and x.is_contiguous() and bn_link.x.shape == x.shape) else None
         x = x.contiguous()
         K = x.shape[-1]
@@ -912,6 +926,12 @@ class LinearFn(torch.autograd.Function):
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value)
+            alink = ctx.act_link
+            if not fused and alink is not None and extra is None:
+                # x = QuickGELU(pre) with this product as its only consumer (linear_qgelu): the data gradient comes out of the
+                # epilogue already multiplied by quickgelu'(pre); the producer's backward is told so
+                if gemm(dy, w, dx, M, K, N, N, K, K, False, False, dact=alink.pre) is not False:
+                    fused = alink.applied = True
             if not fused:
                 gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K)
         elif extra is not None:
@@ -927,14 +947,74 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_b:
             db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
-        return dx, dw, db, d_res, None, None, None, None, None, None
+        return dx, dw, db, d_res, None, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None):
+def linear(x, w, b=None, resid=None, act=0, stats=False, grad_box=None, grad_box_out=None, grad_box_res=None, act_link=False):
+    """act_link=True: x is the output of linear_qgelu and THIS product is its only consumer -- the QuickGELU backward rides this
+    product's data-gradient epilogue (the caller vouches for the single consumer)"""
     link = getattr(x, "_bn_link", None)
     if link is not None and not (torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled()):
         link = None
-    return LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res, link)
+    alink = getattr(x, "_act_link", None) if (act_link and torch.is_grad_enabled() and x.requires_grad) else None
+    return LinearFn.apply(x, w, b, resid, act, stats, grad_box, grad_box_out, grad_box_res, link, alink)
+
+
+class _ActLink:
+    """QuickGELU hand-off between linear_qgelu (producer: holds the pre-activation) and the Linear that consumes its output:
+    `applied` is set by the consumer's backward when its data gradient already carries quickgelu'(pre)."""
+    __slots__ = ("pre", "applied")
+
+    def __init__(self, pre):
+        self.pre, self.applied = pre, False
+
+
+class LinearQGeluFn(torch.autograd.Function):
+    """QuickGELU(x . W^T + b) in one launch (CLIP/clip/model.py:361-376: c_fc + gelu of the transformer MLP): the epilogue stores the
+    activated value AND the pre-activation its backward needs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk(x, w, b)
+        x = x.contiguous()
+        K = x.shape[-1]
+        N = w.numel() // K
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        pre = torch.empty_like(y)
+        if gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, act=2, pre_out=pre) is False:
+            gemm(x, w, pre, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0)
+            ew("TRIS_EW_QGELU", pre, out=y)
+        ctx.dims, ctx.has_b, ctx.params = (M, N, K), b is not None, (w, b)
+        ctx.link = y._act_link = _ActLink(pre)
+        ctx.save_for_backward(x, w, pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        pw, pb = ctx.params
+        M, N, K = ctx.dims
+        dy = dy.contiguous()
+        dpre = dy if ctx.link.applied else ew("TRIS_EW_QGELU_BWD", dy, pre)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dpre, w, dx, M, K, N, N, K, K, False, False)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if _sink(pw) is not None:
+                on_wgrad_stream(lambda: gemm(dpre, x, _sink(pw), N, K, M, N, K, K, True, False), dpre, x, sink=_sink(pw))
+            else:
+                dw = _emit(pw, lambda o: gemm(dpre, x, o, N, K, M, N, K, K, True, False), True)
+        db = None
+        if ctx.has_b:
+            db = _emit(pb, lambda o: colsum(dpre, M, N, o), ctx.needs_input_grad[2])
+        return dx, dw, db
+
+
+def linear_qgelu(x, w, b=None):
+    return LinearQGeluFn.apply(x, w, b)     # (the returned tensor carries `_act_link`, set inside forward)
 
 
 class MatmulFn(torch.autograd.Function):
