@@ -1054,3 +1054,24 @@ def test_mlp_with_quickgelu_in_the_epilogues(ops, M, W):
     close(gy, y, name="y")
     for a, b_, n in zip(g, (x, w1, b1, w2, b2), ("dx", "dw1", "db1", "dw2", "db2")):
         close(a.grad, b_.grad, 2e-5 if M > 1000 else TOL, name=n)
+
+
+def test_gemm_epilogue_streams_nontemporal_equals_default(ops):
+    """a product whose epilogue streams (C + residual) exceed the memory-side cache stores / loads them with the nontemporal
+    policy (gemm_conv.hip stream_nt, option STREAM_FORM): same values bit for bit"""
+    import tris_amd.ops as o
+    M, N, K = 307200, 256, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A, W = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) * 0.1
+    R = torch.randn(M, N, device="cuda", generator=g)
+    assert 2 * M * N * 4 > 256 << 20
+    outs = []
+    for sf in (0, None):
+        with o.option("STREAM_FORM", sf):
+            C = torch.empty(M, N, device="cuda")
+            o.gemm(A, W, C, M, N, K, K, K, N, False, True, resid=R, ldr=N)
+            outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = (A[:512].double() @ W.double().t() + R[:512].double()).float()
+    close(outs[1][:512], ref, 1e-4, name="rows vs fp64")
