@@ -293,8 +293,11 @@ def main():
     if xa:
         P_, N_, C_ = 100, a.batch, 1024
         xbytes = a.batch * (4 * P_ * C_ + N_ * C_) * 4 + 3 * N_ * C_ * 4
-        fused = [r for r in xa if r[0] == "xattn_fwd_fused"]
-        if fused and len(fused) == len(xa):
+        fused = [r for r in xa if r[0] in ("xattn_fwd_fused", "xattn_fwd_px")]
+        if fused and len(fused) == len(xa) and fused[0][0] == "xattn_fwd_px":
+            xname = ("xattn_px_kernel (ONE persistent launch cut by pixel rows, csrc/xattn_px.hip) + xattn_text_planes_kernel "
+                     "(sentence bf16 planes)")
+        elif fused and len(fused) == len(xa):
             xname = "xattn_fused_kernel (ONE persistent launch, csrc/xattn_fused.hip) + xattn_text_planes_kernel (sentence bf16 planes)"
         elif mode in ("x3", "h2"):
             xname = "xattn_scores_x3_kernel + xattn_out_x3_kernel"

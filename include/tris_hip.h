@@ -302,6 +302,17 @@ long tris_xattn_fused_sync_words(int B);
 int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                              const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
                              float* ws, long ws_bytes, unsigned* sync, void* stream);
+/* The same forward as ONE persistent launch cut by PIXEL ROWS (csrc/xattn_px.hip; split-bf16 arithmetic, C = 512 | 1024,
+ * P <= 104, N <= 64): S workgroups of 512 threads per image (S = min(8, CUs / B), one workgroup per CU), workgroup s owns pixels
+ * [s P / S, (s + 1) P / S).  The pixel -> sentence direction (model/attn.py:118-119, 124) never leaves the workgroup; the
+ * sentence -> pixel direction (attn.py:121-122, 127) needs ONE in-kernel hand-off of N x own-pixels logits, hidden behind the
+ * former, and is then finished per 32-channel unit.  Same arguments, scratch / sync conventions, probs planes (0 and 2) and
+ * TRIS_DECLINED behaviour as tris_xattn_fused_fwd_f32; the sync words may be the same buffer. */
+long tris_xattn_px_ws_bytes(int B, int N, int C);
+long tris_xattn_px_sync_words(int B);
+int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
+                          const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
+                          float* ws, long ws_bytes, unsigned* sync, void* stream);
 /* backward of a softmax taken over the P axis of [B,P,N]: dX = scale*Y*(dY - sum_p Y*dY)  (model/attn.py:122) */
 int tris_softmax_col_bwd_f32(const float* dY, const float* Y, float* dX, int B, int P, int N, float scale,
                              void* stream);

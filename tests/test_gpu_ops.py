@@ -854,11 +854,14 @@ def test_eval_post(ops):
 
 
 @pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 97, 64, 512), (5, 8, 3, 512),
-                                     (7, 104, 33, 1024)])
-def test_xattn_single_launch_kernel_matches_the_two_launch_pair(ops, monkeypatch, B, P, N, C):
-    """csrc/xattn_fused.hip (one persistent launch, eight workgroups per image, in-kernel all-reduce of the partial logits over
-    agent-scope release / acquire) against an fp64 reference and against the default two-launch pair, including the saved
-    probabilities the backward pass reads; five calls in a row exercise the device-side epoch; no wait may have timed out."""
+                                     (7, 104, 33, 1024), (40, 100, 33, 1024), (64, 100, 48, 512), (33, 57, 17, 1024),
+                                     (60, 103, 64, 1024)])
+def test_xattn_single_launch_kernels_match_the_two_launch_pair(ops, monkeypatch, B, P, N, C):
+    """The two persistent single-launch forms -- csrc/xattn_px.hip (cut by pixel rows, S <= 8 workgroups of 512 threads per image,
+    one in-kernel hand-off of the sentence -> pixel logits) and csrc/xattn_fused.hip (eight channel slices per image, reduce-scatter
+    + all-gather of the partial logits) -- against an fp64 reference and against the two-launch pair, including the saved
+    probabilities the backward pass reads; five calls in a row exercise the device-side epoch; no wait may have timed out.  The
+    shapes cover S = 4 .. 8, one and two pixel tiles per workgroup, uneven pixel / channel-unit ranges, N = 1 .. 64, C = 512 | 1024."""
     g = torch.Generator().manual_seed(B * 1000 + P + N)
     Qv, Kv, Vv = (torch.randn(B, P, C, generator=g).cuda() * 1.5 for _ in range(3))
     Qt, Kt, Vt = (torch.randn(N, C, generator=g).cuda() * 1.5 for _ in range(3))
@@ -867,20 +870,25 @@ def test_xattn_single_launch_kernel_matches_the_two_launch_pair(ops, monkeypatch
     At = torch.softmax(Qt.cpu().double() @ Kv.cpu().double().transpose(1, 2) * sc, dim=2)
     rv, rl = Av @ Vt.cpu().double(), At @ Vv.cpu().double()
     outs = {}
-    for fused in ("0", "1"):
-        monkeypatch.setattr(CFG, "xattn_fused", fused == "1")
-        before = ops.query("tris_xattn_fused_ws_bytes", B, N, C)
-        assert before > 0
+    for form in ("pair", "slices", "px"):
+        monkeypatch.setattr(CFG, "xattn_fused", form != "pair")
+        monkeypatch.setattr(CFG, "xattn_px", form == "px")
+        assert ops.query("tris_xattn_fused_ws_bytes", B, N, C) > 0 and ops.query("tris_xattn_px_ws_bytes", B, N, C) > 0
+        ops.profile_begin()
         for _ in range(5):
             q = [t.clone().requires_grad_(True) for t in (Qv, Kv, Vv, Qt, Kt, Vt)]
             nv, nl = ops.xattn(*q)
+        kinds = {r[0] for r in ops.profile_end() if r[0].startswith("xattn")}
+        if form == "px" and ops.get_gemm_mode() != "f32" and B * max((P + 31) // 32, C // 256) <= 256:   # inside the pixel-row form's domain: it must have run
+            assert kinds == {"xattn_fwd_px"}, kinds
         (nv.sum() + nl.sum()).backward()
-        outs[fused] = (nv.detach(), nl.detach(), [t.grad for t in q])
-        close(nv.detach().cpu(), rv.float(), 2e-5, name=f"new_vis fused={fused}")
-        close(nl.detach().cpu(), rl.float(), 2e-5, name=f"new_lan fused={fused}")
+        outs[form] = (nv.detach(), nl.detach(), [t.grad for t in q])
+        close(nv.detach().cpu(), rv.float(), 2e-5, name=f"new_vis {form}")
+        close(nl.detach().cpu(), rl.float(), 2e-5, name=f"new_lan {form}")
     assert not ops.xattn_timed_out()
-    for a, b in zip(outs["0"][2], outs["1"][2]):   # the backward reads Av / AtT saved by whichever forward ran
-        close(a, b, 2e-4, name="gradient through the saved probabilities")
+    for form in ("slices", "px"):
+        for a, b in zip(outs["pair"][2], outs[form][2]):   # the backward reads Av / AtT saved by whichever forward ran
+            close(a, b, 2e-4, name=f"gradient through the saved probabilities ({form})")
 
 
 @pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64)])

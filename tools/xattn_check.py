@@ -1,0 +1,30 @@
+"""Dev tool: the three cross-attention forward forms against fp64 at one shape, with timings (GPU box)."""
+import math, sys, torch
+sys.path.insert(0, ".")
+from tris_amd import ops
+from tris_amd.config import cfg
+B, P, N, C = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (48, 100, 48, 1024)
+g = torch.Generator().manual_seed(0)
+Qv, Kv, Vv = (torch.randn(B, P, C, generator=g).cuda() * 1.5 for _ in range(3))
+Qt, Kt, Vt = (torch.randn(N, C, generator=g).cuda() * 1.5 for _ in range(3))
+sc = 1.0 / math.sqrt(C)
+Av = torch.softmax(Qv.double() @ Kt.double().t() * sc, dim=2)
+At = torch.softmax(Qt.double() @ Kv.double().transpose(1, 2) * sc, dim=2)
+rv, rl = Av @ Vt.double(), At @ Vv.double()
+by = B * (4 * P * C + N * C) * 4 + 3 * N * C * 4
+for form in ("pair", "slices", "px"):
+    cfg.xattn_fused, cfg.xattn_px = form != "pair", form == "px"
+    with torch.no_grad():
+        ops.profile_begin()
+        for _ in range(3):
+            nv, nl = ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)
+        kinds = sorted({r[0] for r in ops.profile_end()})
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record()
+        for _ in range(50):
+            ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)
+        b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) / 50 * 1e3
+    ev = float((nv.double() - rv).abs().max() / rv.abs().max()); el = float((nl.double() - rl).abs().max() / rl.abs().max())
+    print(f"{form:7s} {kinds}  {us:6.1f} us  {by / us / 1e3:7.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}   rel err new_vis {ev:.2e} new_lan {el:.2e}"
+          f"  timed out: {ops.xattn_timed_out()}")

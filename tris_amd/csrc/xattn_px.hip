@@ -1,0 +1,618 @@
+// Bilateral image<->text cross attention (reference model/attn.py:117-128) as ONE persistent launch, cut by PIXELS
+// (gfx950, split-bf16 x3).
+//
+//   Av  = softmax_n(Qv Kt^T / sqrt(C))   [B,P,N]      new_vis = Av  Vt      [B,P,C]
+//   AtT = softmax_p(Kv Qt^T / sqrt(C))   [B,P,N]      new_lan = AtT^T Vv    [B,N,C]
+//
+// Why this cut.  The pair is an HBM stream (1.84 MB per image at P = 100, N = 48, C = 1024) and one CU fetches ~10 B/clk of it,
+// so an image has to be spread over several CUs -- the question is which axis is cut.  Channel slices (xattn_fused.hip) make
+// BOTH soft-maxes wait for a reduction over workgroups: three dependent hand-offs of 43 + 5 KB per workgroup, and eight slices
+// x 48 images do not fit 256 CUs once.  Pixel rows do: S workgroups per image (S = 5 at B = 48: 240 workgroups, one per CU), and
+// workgroup s owns pixels [s P / S, (s + 1) P / S).  Then
+//   * the pixel -> sentence direction never leaves the workgroup: Qv rows . Kt^T over ALL channels, the soft-max over the
+//     sentences of a row, new_vis rows = Av . Vt;
+//   * the sentence -> pixel direction needs ONE hand-off of N x (own pixels) floats (3.8 KB per workgroup, 19 KB per image):
+//     the logits Kv rows . Qt^T are complete per pixel; the soft-max over the pixels of the image needs everyone's columns.  Each
+//     workgroup publishes its columns as soon as they exist, runs the whole pixel -> sentence direction, and only then looks at
+//     the flags: the hand-off latency (~4 us on this part) hides behind ~5 us of independent work;
+//   * new_lan = At . Vv reduces over pixels, so it is cut by CHANNELS instead: workgroup s owns 32-channel units
+//     [s U / S, (s + 1) U / S), U = C / 32, reads Vv[b, :, own channels] (requested before the hand-off) and every workgroup of
+//     the image repeats the tiny soft-max over pixels (N x P values).
+// Every operand byte is read by exactly one workgroup; the sentence operands (3 x N x C, shared by all images) come pre-split into
+// bf16 planes in MFMA fragment order from L2 (xattn_planes.h).  HBM traffic = algorithmic + saved probabilities + 2 x 19 KB per
+// image of exchange.
+//
+// Workgroup = 512 threads.  Logits: waves 0-3 take Kv . Qt^T, waves 4-7 Qv . Kt^T, each over a quarter of the channels (pixel rows
+// read row-contiguous, 8 rows x 128 B per instruction, turned into MFMA fragments through wave-private LDS tiles; three k-steps of
+// loads in flight), partial blocks summed through LDS.  new_vis: wave w owns channel tiles w + 8 i (channels are the MFMA rows: a
+// lane stores four consecutive channels of a pixel).  new_lan: wave w owns unit w of the workgroup (<= 8): its Vv columns are
+// split once, staged k-major per 32-pixel step in a wave-private LDS buffer and gathered with ds_read_b64_tr_b16.
+//
+// Inter-workgroup protocol as in xattn_fused.hip (MI355X_MICROARCH "workgroup dispatch / visibility", recipe R1): write-through
+// (sc1) 16-byte stores, every storing wave drains vmcnt, barrier, one lane raises the (image, slot) flag relaxed at agent scope;
+// consumers poll relaxed from one wave, barrier, sc1 loads; no fences.  Epoch in device memory (sync[0], advanced by the last
+// workgroup to finish): a captured launch replays.  Spins are bounded (sync[2] != 0 afterwards: outputs undefined).  All B * S
+// workgroups must be co-resident (one per CU: ~140 KB of LDS); the entry point declines otherwise.
+#include "common.h"
+#include "tris_hip.h"
+#include "x3_split.h"
+#include "xattn_planes.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XP_MAXS = 8;         // workgroups per image (and 32-channel units per workgroup) at most
+constexpr int XP_SYNC_FLAGS = 16;  // sync[0] epoch, [1] finish ticket, [2] time-out flag, [16 + b * 8 + s] publish flags
+constexpr long XP_SPIN = 4000000;  // polls before a wait gives up (~seconds)
+constexpr int XP_TLD = 36;         // row stride (floats) of a wave-private 16 x 32 turn-around tile (conflict-free b128 fragment reads)
+constexpr int XP_AVS = 68;         // row stride (floats) of the Av rows [32][64]
+constexpr int XP_ATS = 132;        // row stride (floats) of the gathered At rows [NT * 16][128]
+constexpr int XP_KS = 80;          // bytes per pixel row of a k-major Vv plane (32 channels x 2 B + 16)
+constexpr int XP_PLANE = 32 * XP_KS;   // one plane of one 32-pixel step
+
+#ifdef TRIS_XP_TRACE
+#define XP_STAMP(i) do { if (tid == 0) xp_trace[(long)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XP_STAMP_V(i) do { if (tid == 256) xp_trace[(long)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XP_STAMP(i) do { } while (0)
+#define XP_STAMP_V(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() is a workgroup-scope release, i.e.
+// s_waitcnt vmcnt(0) as well -- every prefetch issued before it would be waited for (measured: 2.5 us per barrier behind the Vv request)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4_wt(__amdgpu_buffer_rsrc_t rs, long float_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(float_off * 4), 0, 16);
+}
+__device__ __forceinline__ float4 ld4_wt(__amdgpu_buffer_rsrc_t rs, long float_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(float_off * 4), 0, 16));
+}
+__device__ __forceinline__ bf16x8 ldf(const uint4* p) { return __builtin_bit_cast(bf16x8, *p); }
+
+// N independent accumulation chains issued piece by piece: consecutive MFMAs never depend on each other; smallest terms first
+template <int NCH>
+__device__ __forceinline__ void mfma6_n(const Split8 (&a)[NCH], const Split8 (&b)[NCH], f32x4v (&c)[NCH]) {
+#define XP_PIECE(PA, PB)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < NCH; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].PA, b[i].PB, c[i], 0, 0, 0);
+  XP_PIECE(lo, hi) XP_PIECE(hi, lo) XP_PIECE(mid, mid) XP_PIECE(mid, hi) XP_PIECE(hi, mid) XP_PIECE(hi, hi)
+#undef XP_PIECE
+}
+
+constexpr int xp_max(int a, int b) { return a > b ? a : b; }
+template <int NT, int NPT> struct XpLds {
+  static constexpr int turn = 8 * NPT * 16 * XP_TLD * 4;              // wave-private turn-around tiles (logits phase)
+  static constexpr int red = 8 * NPT * NT * 1024;                    // partial logit blocks of the eight waves
+  static constexpr int av = 32 * XP_AVS * 4;                         // Av rows, behind turn | red
+  static constexpr int planes = 8 * 3 * XP_PLANE;                    // wave-private Vv planes (new_lan phase), aliases turn | red
+  static constexpr int atf = NT * 4 * 3 * 1024;                      // At as bf16 piece planes in MFMA fragment order, behind the Vv planes
+  static constexpr int arena = xp_max(turn + red + av, planes + atf);
+  static constexpr int at = NT * 16 * XP_ATS * 4;                    // gathered logits / At rows (fp32)
+  static constexpr int total = arena + at + 16;
+};
+
+// grid B * S, block 512.  KQ = 32-channel steps per wave of the logits phase (C = 128 KQ).
+template <int NT, int NPT, int KQ>
+__global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restrict__ Qv, const float* __restrict__ Kv,
+                                                          const float* __restrict__ Vv, const uint4* __restrict__ QtF,
+                                                          const uint4* __restrict__ KtF, const uint4* __restrict__ VtF,
+                                                          float* __restrict__ new_vis, float* __restrict__ new_lan,
+                                                          float* __restrict__ probs, float* __restrict__ Sx, int sx_bytes,
+                                                          unsigned* __restrict__ sync, int B, int P, int N, int S, float scale) {
+  constexpr int C = 128 * KQ;
+  constexpr int KST = C / 32;
+  constexpr int KS2 = (NT + 1) / 2;      // 32-sentence steps of the new_vis product
+  constexpr int CT = C / 16;             // channel tiles
+  constexpr int U = C / 32;              // 32-channel units
+  using L = XpLds<NT, NPT>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* AvL = reinterpret_cast<float*>(lds + L::turn + L::red);
+  float* AtL = reinterpret_cast<float*>(lds + L::arena);
+  uint4* AtF = reinterpret_cast<uint4*>(lds + L::planes);
+  unsigned* s_epoch_p = reinterpret_cast<unsigned*>(lds + L::arena + L::at);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int b = blockIdx.x / S, slot = blockIdx.x - b * S;
+  const int p0 = (slot * P) / S, p1 = ((slot + 1) * P) / S, PW = p1 - p0;   // own pixels
+  const int u0 = (slot * U) / S, NU = ((slot + 1) * U) / S - u0;            // own 32-channel units (new_lan)
+  if (tid == 0) {
+    *s_epoch_p = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    s_epoch_p[1] = 0u; s_epoch_p[2] = 0u;   // arrival counters of the two halves
+  }
+  const __amdgpu_buffer_rsrc_t sxr = __builtin_amdgcn_make_buffer_rsrc(Sx, 0, sx_bytes, 0x00020000);
+#ifdef TRIS_XP_TRACE
+  unsigned long long* xp_trace = reinterpret_cast<unsigned long long*>(Sx + (long)B * XP_MAXS * NT * 16 * 32);
+#endif
+  XP_STAMP(0);
+
+  // ---- logits of the own pixels over all channels ---------------------------------------------------------------------------------
+  // waves 0-3: D_t[p][n] = sum_c Kv[p][c] Qt[n][c];  waves 4-7: D_v[p][n] = sum_c Qv[p][c] Kt[n][c];  wave (g, q): channels
+  // [q C / 4, (q + 1) C / 4).  The pixels are the MFMA rows: a lane ends up with four consecutive pixels of one sentence.
+  {
+    const int g = wave >> 2, q = wave & 3;
+    const float* X = g ? Qv : Kv;
+    const uint4* F = (g ? KtF : QtF) + ((long)(q * KQ) * 3) * 64 + lane;
+    float* tile = reinterpret_cast<float*>(lds) + wave * (NPT * 16 * XP_TLD);
+    const int lr = lane >> 3, lc = (lane & 7) * 4;   // loader coordinates: row within an 8-row half, float offset in the 128-B piece
+    const float* gp[NPT][2];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) gp[t][h] = X + ((long)b * P + min(p0 + t * 16 + lr + 8 * h, p1 - 1)) * C + q * (C / 4) + lc;
+    f32x4v acc[NPT * NT];
+#pragma unroll
+    for (int i = 0; i < NPT * NT; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    constexpr int AHEAD = KQ < 3 ? KQ : 3;           // k-steps of pixel rows in flight
+    float4 v[KQ][NPT][2];
+    Split8 fr[KQ][NT];
+    auto load_px = [&](int i) {
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) v[i][t][h] = ld4(gp[t][h] + i * 32);
+    };
+    auto load_fr = [&](int i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint4* f = F + ((long)(j * KST + i) * 3) * 64;
+        fr[i][j].hi = ldf(f); fr[i][j].mid = ldf(f + 64); fr[i][j].lo = ldf(f + 128);
+      }
+    };
+    constexpr int FAHEAD = (KQ < 2 || NT * NPT >= 8) ? 1 : 2;          // k-steps of sentence fragments in flight (throughput = bytes in flight / latency)
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) load_px(i);
+#pragma unroll
+    for (int i = 0; i < FAHEAD; ++i) load_fr(i);
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (i + AHEAD < KQ) load_px(i + AHEAD);
+      if (i + FAHEAD < KQ) load_fr(i + FAHEAD);
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(tile + t * (16 * XP_TLD) + (lr + 8 * h) * XP_TLD + lc) = v[i][t][h];
+      wave_lds_fence();
+      Split8 sp[NPT];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t) {
+        const float* f = tile + t * (16 * XP_TLD) + r16 * XP_TLD + kg * 8;
+        sp[t] = split8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
+      }
+      wave_lds_fence();
+      Split8 ca[NPT * NT], cb[NPT * NT];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { ca[t * NT + j] = sp[t]; cb[t * NT + j] = fr[i][j]; }
+      mfma6_n<NPT * NT>(ca, cb, acc);
+    }
+    XP_STAMP(1);
+    // partial blocks -> LDS  (red[wave][t * NT + j][lane] x 16 B; behind the turn-around tiles of all waves)
+    float* red = reinterpret_cast<float*>(lds + L::turn) + wave * (NPT * NT * 256);
+#pragma unroll
+    for (int i = 0; i < NPT * NT; ++i)
+      *reinterpret_cast<float4*>(red + i * 256 + lane * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  }
+  lds_barrier();
+  const unsigned epoch = *s_epoch_p;
+  constexpr int TILES = NPT * NT;
+  constexpr int VR = 13;   // 8 pixel rows per instruction: P <= 104
+  float4 vreg[VR];
+  auto load_vv = [&]() {   // the Vv columns of the own unit (wave w = unit w): they do not depend on anything
+    const int prow = lane >> 3, c4 = (lane & 7) * 4;
+    const int unit = u0 + min(wave, NU - 1);
+#pragma unroll
+    for (int i = 0; i < VR; ++i) vreg[i] = ld4(Vv + ((long)b * P + min(i * 8 + prow, P - 1)) * C + unit * 32 + c4);
+  };
+  // ---- the two directions run side by side, four waves each, and meet once before new_lan.  They share no data, so each half
+  // synchronises on its own LDS counter (group_sync) instead of the workgroup barrier: the latency chain of the hand-off
+  // (write-through drain ~2.5 us, flags ~2 us, gather ~3 us, soft-max over pixels) runs under the L2-bound new_vis product.
+  const int grp = wave >> 2, tg = tid & 255;
+  const int nks = (P + 31) >> 5;   // 32-pixel steps of the new_lan product, <= 4
+  unsigned* gctr = s_epoch_p + 1 + grp;      // arrivals of the own half (zeroed before the barrier above)
+  unsigned gtarget = 0;
+  auto group_sync = [&]() {
+    gtarget += 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(gctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gtarget) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+  };
+  if (grp == 1) {
+    // ---- pixel -> sentence direction, all inside the workgroup (waves 4-7) ------------------------------------------------------------
+    {
+      const float* red = reinterpret_cast<const float*>(lds + L::turn) + 4 * TILES * 256;   // the D_v quarters
+      for (int e = tg; e < TILES * 64; e += 256) {
+        const int tj = e >> 6, l = e & 63, t = tj / NT, j = tj - t * NT;
+        float4 a = *reinterpret_cast<const float4*>(red + tj * 256 + l * 4);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const float4 w = *reinterpret_cast<const float4*>(red + (q * TILES + tj) * 256 + l * 4);
+          a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
+        }
+        const int pl = t * 16 + 4 * (l >> 4), n = j * 16 + (l & 15);
+        AvL[(pl + 0) * XP_AVS + n] = a.x * scale; AvL[(pl + 1) * XP_AVS + n] = a.y * scale;
+        AvL[(pl + 2) * XP_AVS + n] = a.z * scale; AvL[(pl + 3) * XP_AVS + n] = a.w * scale;
+      }
+    }
+    group_sync();
+    // soft-max over the sentences: 16 threads per row, 4 sentences each (rows >= PW and columns >= N become zeros: they are k /
+    // column padding of the MFMA operands below)
+#pragma unroll
+    for (int pr = 0; pr < NPT; ++pr) {
+      const int px = pr * 16 + (tg >> 4), q = tg & 15;
+      float* row = AvL + px * XP_AVS;
+      float x[4];
+      float m = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { x[u] = (q + 16 * u < N) ? row[q + 16 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float sm = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { x[u] = (q + 16 * u < N) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float inv = px < PW ? 1.f / sm : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float y = x[u] * inv;
+        row[q + 16 * u] = y;
+        if (px < PW && q + 16 * u < N) probs[(((long)b * 4 + 0) * P + p0 + px) * N + q + 16 * u] = y;
+      }
+    }
+    group_sync();
+    XP_STAMP_V(3);
+    load_vv();
+    // new_vis[b, own pixels, :] = Av . Vt: wave w owns the channel tiles (w - 4) + 4 i; channels are the MFMA rows
+    Split8 sa[NPT][KS2];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const float* a = AvL + (t * 16 + r16) * XP_AVS + ks * 32 + kg * 8;
+        sa[t][ks] = split8(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4));
+      }
+    group_sync();   // (third arrival: this half is done with the partial blocks and the Av rows -- the other half may reuse their LDS)
+    // Vt^T fragments through a buffer resource: lanes whose eight sentences are all >= N ask for an out-of-range offset and get
+    // zeros without a byte moved (N = 48: a quarter of the second 32-sentence step) -- and without a branch around the load
+    const __amdgpu_buffer_rsrc_t vtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(VtF), 0, CT * KS2 * 3 * 1024, 0x00020000);
+    constexpr int NIT = CT / 4;
+    constexpr int VA = 3;                  // channel tiles of Vt^T fragments in flight per wave
+    Split8 vt[VA + 1][KS2];
+    auto load_vt = [&](int ct, Split8 (&d)[KS2]) {
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const int off = (ks * 32 + kg * 8 < N) ? (((ct * KS2 + ks) * 3) * 64 + lane) * 16 : 0x7fffffff;
+        d[ks].hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 0, 0));
+        d[ks].mid = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 1024, 0));
+        d[ks].lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 2048, 0));
+      }
+    };
+    const int wv = wave - 4;
+#pragma unroll
+    for (int it = 0; it < VA; ++it) load_vt(wv + 4 * it, vt[it]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ct = wv + 4 * it;
+      if (it + VA < NIT) load_vt(ct + 4 * VA, vt[(it + VA) % (VA + 1)]);
+      constexpr int NCH = NPT * KS2;
+      Split8 ca[NCH], cb[NCH];
+      f32x4v co[NCH];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          ca[t * KS2 + ks] = vt[it % (VA + 1)][ks];
+          cb[t * KS2 + ks] = sa[t][ks];
+          co[t * KS2 + ks] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+      mfma6_n<NCH>(ca, cb, co);        // D[c = 4 kg + r][p = r16]
+#pragma unroll
+      for (int t = 0; t < NPT; ++t) {
+        f32x4v o = co[t * KS2];
+#pragma unroll
+        for (int ks = 1; ks < KS2; ++ks) o += co[t * KS2 + ks];
+        if (t * 16 + r16 < PW)   // 4 consecutive channels of one pixel per lane: one 16-byte store
+          *reinterpret_cast<float4*>(new_vis + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg) =
+              make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    XP_STAMP_V(9);
+  } else {
+    // ---- sentence -> pixel direction up to At (waves 0-3): sum the quarters of D_t, publish the own columns, gather everyone's ----------
+    {
+      const float* red = reinterpret_cast<const float*>(lds + L::turn);   // the D_t quarters
+      for (int e = tg; e < TILES * 64; e += 256) {
+        const int tj = e >> 6, l = e & 63, t = tj / NT, j = tj - t * NT;
+        float4 a = *reinterpret_cast<const float4*>(red + tj * 256 + l * 4);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const float4 w = *reinterpret_cast<const float4*>(red + (q * TILES + tj) * 256 + l * 4);
+          a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
+        }
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+        st4_wt(sxr, (((long)b * S + slot) * (NT * 16) + j * 16 + (l & 15)) * 32 + t * 16 + 4 * (l >> 4), a);   // Sx[b][slot][n][32 local pixels]
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
+    group_sync();
+    if (tg == 0)                                        // ... then ONE lane raises the flag
+      __hip_atomic_store(&sync[XP_SYNC_FLAGS + b * XP_MAXS + slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    XP_STAMP(2);
+    load_vv();
+    {   // every wave looks at the flags itself (no barrier between the wait and the gather)
+      bool ok = true;
+      if (lane < S) {
+        const unsigned* f = &sync[XP_SYNC_FLAGS + b * XP_MAXS + lane];
+        long spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > XP_SPIN) { ok = false; break; }
+        }
+      }
+      if (!ok) atomicExch(&sync[2], epoch);
+      __builtin_amdgcn_wave_barrier();   // (no acquire fence: the payload is read with sc1 loads, which do not look at this CU's L1)
+    }
+    XP_STAMP(5);
+    // gather: rows (workgroup s2 of the image, sentence n) of PC 16-byte pieces; a thread keeps its (row-in-sweep, piece) and walks
+    // the rows; all its loads in flight at once (one round trip); idle threads ask out of range
+    {
+      const int PC = ((P + S - 1) / S + 3) >> 2, RPI = 256 / PC;      // pieces per row, rows per sweep of the 256 threads
+      const int lr = tg / PC, f4 = (tg - lr * PC) * 4;
+      const int tab = (min(lane, S) * P) / S;                         // lane i: first pixel of workgroup i (i = S: P)
+      const int rows = S * NT * 16;
+      constexpr int GB = 8;
+      for (int r0 = 0; r0 < rows; r0 += GB * RPI) {
+        float4 w[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int rw = r0 + u * RPI + lr;
+          const bool in = lr < RPI && rw < rows;
+          const int s2 = in ? rw / (NT * 16) : 0;
+          const int pw2 = __shfl(tab, s2 + 1, 64) - __shfl(tab, s2, 64);
+          const int off = (in && f4 < pw2) ? (int)((((long)b * S * (NT * 16) + rw) * 32 + f4) * 4) : 0x7fffffff;
+          w[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sxr, off, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int rw = r0 + u * RPI + lr;
+          const bool in = lr < RPI && rw < rows;
+          const int s2 = in ? rw / (NT * 16) : 0, n = rw - s2 * (NT * 16);
+          const int q0 = __shfl(tab, s2, 64), pw2 = __shfl(tab, s2 + 1, 64) - q0;
+          if (in && f4 < pw2) {
+            float* d = AtL + n * XP_ATS + q0 + f4;
+            d[0] = w[u].x;
+            if (f4 + 1 < pw2) d[1] = w[u].y;
+            if (f4 + 2 < pw2) d[2] = w[u].z;
+            if (f4 + 3 < pw2) d[3] = w[u].w;
+          }
+        }
+      }
+    }
+    group_sync();
+    XP_STAMP(6);
+    // soft-max over the pixels of each sentence row: 8 threads per row, 16 pixels each (columns >= P and rows >= N become zeros)
+    for (int n = tg >> 3; n < NT * 16; n += 32) {
+      const int q = tg & 7;
+      float* row = AtL + n * XP_ATS;
+      float x[16];
+      float m = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { x[u] = (q + 8 * u < P) ? row[q + 8 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float sm = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { x[u] = (q + 8 * u < P) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float inv = n < N ? 1.f / sm : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) row[q + 8 * u] = x[u] * inv;
+    }
+    group_sync();
+    XP_STAMP(7);
+    // At -> bf16 piece planes in MFMA fragment order (every new_lan wave reads all of them) -- their LDS was the other half's
+    // partial blocks and Av rows: wait for its third arrival (long past) --, and the AtT plane [P][N] of the own pixels that the
+    // backward pass reads
+    while (__hip_atomic_load(s_epoch_p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 12u) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+    for (int e = tg; e < NT * 4 * 64; e += 256) {
+      const int fk = e >> 6, l = e & 63, j = fk >> 2, ks = fk & 3;
+      if (ks < nks) {
+        const float* a = AtL + (j * 16 + (l & 15)) * XP_ATS + ks * 32 + (l >> 4) * 8;
+        const Split8 sp = split8(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4));
+        uint4* d = AtF + (fk * 3) * 64 + l;
+        d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid); d[128] = __builtin_bit_cast(uint4, sp.lo);
+      }
+    }
+    for (int e = tg; e < PW * N; e += 256) {
+      const int lp = e / N, n = e - lp * N;
+      probs[(((long)b * 4 + 2) * P + p0 + lp) * N + n] = AtL[n * XP_ATS + p0 + lp];
+    }
+    XP_STAMP(10);
+  }
+  // the Vv rows of the own unit as bf16 pieces (registers): only LDS traffic and MFMAs follow the barrier
+  Split4 vsp[VR];
+  {
+    const int prow = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < VR; ++i) vsp[i] = split4(i * 8 + prow < P ? vreg[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  lds_barrier();   // both directions meet
+  XP_STAMP(4);
+  // new_lan[b, :, unit] = At . Vv[b, :, unit]: wave w = unit w of the workgroup; per 32-pixel step the pieces of the Vv rows are
+  // stored k-major in the wave's own plane buffer and gathered as MFMA fragments by the transpose read
+  if (wave < NU) {
+    char* pl = lds + wave * (3 * XP_PLANE);
+    const int prow = lane >> 3, c8 = (lane & 7) * 8;
+    const int k0 = kg * 8 + (r16 >> 2);
+    const int tro0 = k0 * XP_KS + 8 * (r16 & 3), tro1 = (k0 + 4) * XP_KS + 8 * (r16 & 3);
+    auto trf = [&](const char* plane, int ct) {
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + tro0 + ct * 32));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + tro1 + ct * 32));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    f32x4v co[2 * NT];
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) co[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < nks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int vi = ks * 4 + i;
+          char* d = pl + (i * 8 + prow) * XP_KS + c8;
+          const uint2 z = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(d) = vi < VR ? vsp[vi < VR ? vi : 0].hi : z;
+          *reinterpret_cast<uint2*>(d + XP_PLANE) = vi < VR ? vsp[vi < VR ? vi : 0].mid : z;
+          *reinterpret_cast<uint2*>(d + 2 * XP_PLANE) = vi < VR ? vsp[vi < VR ? vi : 0].lo : z;
+        }
+        wave_lds_fence();
+        Split8 ca[2 * NT], cb[2 * NT];
+        Split8 va[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          va[ct].hi = trf(pl, ct); va[ct].mid = trf(pl + XP_PLANE, ct); va[ct].lo = trf(pl + 2 * XP_PLANE, ct);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const uint4* f = AtF + ((j * 4 + ks) * 3) * 64 + lane;
+          Split8 at;
+          at.hi = ldf(f); at.mid = ldf(f + 64); at.lo = ldf(f + 128);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) { ca[ct * NT + j] = va[ct]; cb[ct * NT + j] = at; }
+        }
+        mfma6_n<2 * NT>(ca, cb, co);      // D[c = 4 kg + r][n = r16]
+      }
+    }
+    const int c0 = (u0 + wave) * 32;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (j * 16 + r16 < N) {
+          const f32x4v o = co[ct * NT + j];
+          *reinterpret_cast<float4*>(new_lan + ((long)b * N + j * 16 + r16) * C + c0 + ct * 16 + 4 * kg) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+  }
+  XP_STAMP(8);
+  // ---- the last workgroup to finish advances the epoch ----------------------------------------------------------------------------------
+  if (tid == 0) {
+    const unsigned t = atomicAdd(&sync[1], 1u);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+struct XpPlan { long qtf, ktf, vtf, sx, total; int NT, KS2; };
+inline XpPlan xp_plan(int B, int N, int C) {
+  XpPlan p;
+  p.NT = (N + 15) / 16;
+  p.KS2 = (p.NT + 1) / 2;
+  const long a = (long)p.NT * (C / 32) * 3 * 64 * 16, v = (long)(C / 16) * p.KS2 * 3 * 64 * 16;
+  p.qtf = 0; p.ktf = a; p.vtf = 2 * a; p.sx = 2 * a + v;
+  p.total = p.sx + (long)B * XP_MAXS * p.NT * 16 * 32 * 4;
+#ifdef TRIS_XP_TRACE
+  p.total += (long)B * XP_MAXS * 16 * 8;
+#endif
+  return p;
+}
+
+// workgroups per image: as many as fit one per CU (<= 8), at least what 32 own pixels / 8 own units per workgroup need
+inline int xp_slots(int B, int P, int C, int cus) {
+  const int U = C / 32;
+  int smin = (P + 31) / 32;
+  if ((U + XP_MAXS - 1) / XP_MAXS > smin) smin = (U + XP_MAXS - 1) / XP_MAXS;
+  int smax = cus / B;
+  if (smax > XP_MAXS) smax = XP_MAXS;
+  if (smax > P) smax = P;
+  return smax >= smin ? smax : 0;
+}
+
+template <int NT, int NPT, int KQ>
+int launch_px(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt, const float* Vt,
+              float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C, int S, char* ws, unsigned* sync,
+              hipStream_t st) {
+  const XpPlan pl = xp_plan(B, N, C);
+  uint4* QtF = reinterpret_cast<uint4*>(ws + pl.qtf);
+  uint4* KtF = reinterpret_cast<uint4*>(ws + pl.ktf);
+  uint4* VtF = reinterpret_cast<uint4*>(ws + pl.vtf);
+  float* Sx = reinterpret_cast<float*>(ws + pl.sx);
+  const int slots = 2 * NT * (C / 32) * 64 + (C / 16) * pl.KS2 * 64;
+  hipLaunchKernelGGL(xattn_text_planes_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, st, Qt, Kt, Vt, QtF, KtF, VtF, N, C, NT,
+                     pl.KS2);
+  constexpr int lds = XpLds<NT, NPT>::total;
+  static bool attr_done = false;   // (one instantiation = one function-local flag)
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_px_kernel<NT, NPT, KQ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds > 65536 ? lds : 65536);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((xattn_px_kernel<NT, NPT, KQ>), dim3(B * S), dim3(512), (size_t)lds, st, Qv, Kv, Vv, QtF, KtF, VtF,
+                     new_vis, new_lan, probs, Sx, (int)(pl.total - pl.sx), sync, B, P, N, S, 1.0f / sqrtf((float)C));
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+int xp_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 1;
+    cus = n;
+  }
+  return cus;
+}
+
+}  // namespace
+
+extern "C" long tris_xattn_px_ws_bytes(int B, int N, int C) {
+  if (B < 1 || N < 1 || N > 64 || !(C == 512 || C == 1024)) return 0;
+  return xp_plan(B, N, C).total;
+}
+
+extern "C" long tris_xattn_px_sync_words(int B) { return XP_SYNC_FLAGS + (long)XP_MAXS * B; }
+
+extern "C" int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
+                                     const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N,
+                                     int C, float* ws, long ws_bytes, unsigned* sync, void* stream) {
+  // supported: split-bf16 arithmetic, C = 512 | 1024, P <= 104, N <= 64, B * S workgroups co-resident one per CU
+  if (tris_get_gemm_mode() < 1 || !(C == 512 || C == 1024) || P < 1 || P > 104 || N < 1 || N > 64 || B < 1 || ws == nullptr ||
+      sync == nullptr || ws_bytes < xp_plan(B, N, C).total)
+    return TRIS_DECLINED;
+  const int S = xp_slots(B, P, C, xp_cus());
+  if (S == 0) return TRIS_DECLINED;
+  const int npt = ((P + S - 1) / S + 15) / 16;   // pixel tiles of the largest own range
+  hipStream_t st = (hipStream_t)stream;
+  char* w = reinterpret_cast<char*>(ws);
+#define TRIS_XP3(NT_, NPT_)                                                                                                     \
+  (C == 1024 ? launch_px<NT_, NPT_, 8>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, S, w, sync, st)             \
+             : launch_px<NT_, NPT_, 4>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, S, w, sync, st))
+#define TRIS_XP(NT_) (npt == 1 ? TRIS_XP3(NT_, 1) : TRIS_XP3(NT_, 2))
+  switch ((N + 15) / 16) {
+    case 1: return TRIS_XP(1);
+    case 2: return TRIS_XP(2);
+    case 3: return TRIS_XP(3);
+    default: return TRIS_XP(4);
+  }
+#undef TRIS_XP
+#undef TRIS_XP3
+}

@@ -1770,7 +1770,7 @@ def _xattn_sync(dev, B):
     """the fused cross-attention kernel's device-side bookkeeping (launch epoch, finish ticket, time-out flag, publish flags):
     zeroed once, then owned by the kernel.  One buffer per (device, stream): launches on one stream are ordered."""
     key = (dev, torch.cuda.current_stream().cuda_stream)
-    n = int(query("tris_xattn_fused_sync_words", B))
+    n = max(int(query("tris_xattn_fused_sync_words", B)), int(query("tris_xattn_px_sync_words", B)))
     t = _XATTN_SYNC.get(key)
     if t is None or t.numel() < n:
         if torch.cuda.is_current_stream_capturing() and t is not None:
@@ -1800,15 +1800,17 @@ class XAttnFn(torch.autograd.Function):
         new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
         probs = torch.empty(B, 4, Pp, N, device=dev, dtype=torch.float32)
         done = False
-        # ONE persistent launch (csrc/xattn_fused.hip) where its domain covers the shape and all B * 8 workgroups are co-resident
-        # (45 vs 57 us for the two-launch pair at B = 48; TRIS_XATTN_FUSED=0 forces the pair)
-        ws_bytes = query("tris_xattn_fused_ws_bytes", B, N, C) if cfg.xattn_fused else 0
-        if ws_bytes > 0:
-            ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
-            sync = _xattn_sync(dev, B)
-            done = _timed("xattn_fwd_fused", 8.0 * B * Pp * N * C, lambda: _declinable(
-                "tris_xattn_fused_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B, Pp,
-                N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
+        # ONE persistent launch where a kernel's domain covers the shape and all its workgroups are co-resident: cut by pixel rows
+        # (csrc/xattn_px.hip, S <= 8 workgroups per image, one hand-off) or, failing that, by channel slices (csrc/xattn_fused.hip,
+        # eight per image, three hand-offs); TRIS_XATTN_FUSED=0 forces the two-launch pair
+        for kind, on in (("px", cfg.xattn_fused and cfg.xattn_px), ("fused", cfg.xattn_fused)):
+            ws_bytes = query(f"tris_xattn_{kind}_ws_bytes", B, N, C) if on and not done else 0
+            if ws_bytes > 0:
+                ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
+                sync = _xattn_sync(dev, B)
+                done = _timed(f"xattn_fwd_{kind}", 8.0 * B * Pp * N * C, lambda: _declinable(
+                    f"tris_xattn_{kind}_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B,
+                    Pp, N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
         if not done:
             _timed("xattn_fwd_pair", 8.0 * B * Pp * N * C,
                    lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
