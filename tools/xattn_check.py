@@ -12,6 +12,9 @@ Av = torch.softmax(Qv.double() @ Kt.double().t() * sc, dim=2)
 At = torch.softmax(Qt.double() @ Kv.double().transpose(1, 2) * sc, dim=2)
 rv, rl = Av @ Vt.double(), At @ Vv.double()
 by = B * (4 * P * C + N * C) * 4 + 3 * N * C * 4
+import os
+if os.environ.get("PX_SLOTS"):
+    ops.set_option("XATTN_PX_SLOTS", os.environ["PX_SLOTS"])
 for form in ("pair", "slices", "px"):
     cfg.xattn_fused, cfg.xattn_px = form != "pair", form == "px"
     with torch.no_grad():

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/libxp_trace.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTRIS_XP_TRACE",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTRIS_XP_TRACE", *[f"-D{x}" for x in os.environ.get("XP_DEFS", "").split()],
                        f"-I{ROOT}/include", f"-I{ROOT}/tris_amd/csrc", f"{ROOT}/tris_amd/csrc/xattn_px.hip", "-o", so,
                        f"-L{ROOT}/tris_amd", "-l:libtris_hip.so", f"-Wl,-rpath,{ROOT}/tris_amd"])
 from tris_amd import _lib
@@ -37,8 +37,8 @@ b.record(); torch.cuda.synchronize()
 print(f"prep + px launch (trace build): {a.elapsed_time(b) / 20 * 1e3:.1f} us per call; time-out word {int(sync[2])}")
 S = min(8, 256 // B, P)
 NT = (N + 15) // 16
-off = (wsb - B * 8 * 16 * 8) // 8
-raw = ws[:wsb // 4].view(torch.int64)[off:off + B * S * 16].view(B * S, 16).cpu().double()
+off = (wsb - B * 8 * 32 * 8) // 8
+raw = ws[:wsb // 4].view(torch.int64)[off:off + B * S * 32].view(B * S, 32).cpu().double()
 # stamp ids (thread 0 = first wave of the sentence->pixel half T, thread 256 = first wave of the pixel->sentence half V):
 # 0 start | 1 logits done (T) | 2 flag raised | 5 flags seen | 6 gathered | 7 At soft-max done | 10 At planes written |
 # V: 3 row soft-max done, 9 new_vis done | 4 both halves joined | 8 end
@@ -52,3 +52,8 @@ for name, i, j in rows:
     col = us(i, j)
     print(f"{name:56s} min {col.min():7.2f}  median {col.median():7.2f}  max {col.max():7.2f} us")
 print(f"({B * S} workgroups, S = {S})")
+ld = (raw[:, 16:24] - raw[:, 0:1]) / clk * 1e6      # per-wave end of the logits loop, from the workgroup's start stamp
+print("per-wave end of the logits loop (us from start), median over workgroups: " + " ".join(f"{float(ld[:, w].median()):.2f}" for w in range(8)))
+jn = (raw[:, 24:32] - raw[:, 0:1]) / clk * 1e6
+print("per-wave arrival at the join (us from start), median:                    " + " ".join(f"{float(jn[:, w].median()):.2f}" for w in range(8)))
+print(f"V: reduce done (after its first group sync) from T's logits-done stamp: median {float(us(1, 12).median()):.2f} us")

@@ -22,6 +22,8 @@ extern "C" {
 // options that live in norm.hip's translation unit (set through tris_set_option below)
 extern __attribute__((visibility("hidden"))) int tris_internal_stream_form;
 extern __attribute__((visibility("hidden"))) int tris_internal_col_blocks;
+// option that lives in xattn_px.hip's translation unit
+extern __attribute__((visibility("hidden"))) int tris_internal_xattn_px_slots;
 }
 
 namespace {
@@ -49,7 +51,8 @@ struct Options {
   int stem_conv1 = 1;     // STEM_CONV1=0: the stem's first convolution through the generic kernels
   int wg_blocks = 512;    // WG_BLOCKS: blocks the direct weight gradient aims for (two per CU)
   // (STREAM_FORM=0: element-wise passes never take the nontemporal one-piece-per-block form, n > 1: they do above n MB (1 = default = 256); COL_BLOCKS: blocks a column
-  //  reduction aims for -- both live in norm.hip's translation unit: tris_internal_stream_form / tris_internal_col_blocks)
+  //  reduction aims for -- both live in norm.hip's translation unit: tris_internal_stream_form / tris_internal_col_blocks;
+  //  XATTN_PX_SLOTS=n: workgroups per image of the pixel-row cross attention, 0 = as many as fit one per CU -- xattn_px.hip)
   char tune_log[256] = {0};  // TUNE_LOG=<file>: one line per tuned shape
 };
 static int parse_tile(const char* e) {
@@ -68,13 +71,14 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "WG_BLOCKS")) o.wg_blocks = unset ? 512 : std::max(1, atoi(v));
   else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 256 : (atoi(v) == 1 ? 256 : std::max(0, atoi(v)));
   else if (!strcmp(name, "COL_BLOCKS")) tris_internal_col_blocks = unset ? 512 : std::max(1, atoi(v));
+  else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
   else return false;
   return true;
 }
 static Options init_options() {
   Options o;
-  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "TUNE_LOG"}) {
+  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "TUNE_LOG"}) {
     char env[64];
     snprintf(env, sizeof(env), "TRIS_%s", n);
     if (const char* v = getenv(env)) set_option(o, n, v);

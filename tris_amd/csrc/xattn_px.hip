@@ -38,6 +38,9 @@
 #include "x3_split.h"
 #include "xattn_planes.h"
 
+// XATTN_PX_SLOTS option (tris_set_option): workgroups per image, 0 = as many as fit one per CU
+extern "C" { __attribute__((visibility("hidden"))) int tris_internal_xattn_px_slots = 0; }
+
 namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -55,9 +58,11 @@ constexpr int XP_KS = 80;          // bytes per pixel row of a k-major Vv plane 
 constexpr int XP_PLANE = 32 * XP_KS;   // one plane of one 32-pixel step
 
 #ifdef TRIS_XP_TRACE
-#define XP_STAMP(i) do { if (tid == 0) xp_trace[(long)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define XP_STAMP_V(i) do { if (tid == 256) xp_trace[(long)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XP_STAMP(i) do { if (tid == 0) xp_trace[(long)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XP_STAMP_V(i) do { if (tid == 256) xp_trace[(long)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XP_STAMP_W(i) do { if (lane == 0) xp_trace[(long)blockIdx.x * 32 + (i) + wave] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define XP_STAMP_W(i) do { } while (0)
 #define XP_STAMP(i) do { } while (0)
 #define XP_STAMP_V(i) do { } while (0)
 #endif
@@ -70,6 +75,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // s_waitcnt vmcnt(0) as well -- every prefetch issued before it would be waited for (measured: 2.5 us per barrier behind the Vv request)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// (nontemporal loads of the pixel rows / stores of the outputs were measured: 30.7 vs 27.7 us per workgroup -- the default policy stays)
+__device__ __forceinline__ float4 ld4_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4_nt(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4_wt(__amdgpu_buffer_rsrc_t rs, long float_off, float4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(float_off * 4), 0, 16);
 }
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
 #pragma unroll
       for (int t = 0; t < NPT; ++t)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) v[i][t][h] = ld4(gp[t][h] + i * 32);
+        for (int h = 0; h < 2; ++h) v[i][t][h] = ld4_nt(gp[t][h] + i * 32);
     };
     auto load_fr = [&](int i) {
 #pragma unroll
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       mfma6_n<NPT * NT>(ca, cb, acc);
     }
     XP_STAMP(1);
+    XP_STAMP_W(16);
     // partial blocks -> LDS  (red[wave][t * NT + j][lane] x 16 B; behind the turn-around tiles of all waves)
     float* red = reinterpret_cast<float*>(lds + L::turn) + wave * (NPT * NT * 256);
 #pragma unroll
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     const int prow = lane >> 3, c4 = (lane & 7) * 4;
     const int unit = u0 + min(wave, NU - 1);
 #pragma unroll
-    for (int i = 0; i < VR; ++i) vreg[i] = ld4(Vv + ((long)b * P + min(i * 8 + prow, P - 1)) * C + unit * 32 + c4);
+    for (int i = 0; i < VR; ++i) vreg[i] = ld4_nt(Vv + ((long)b * P + min(i * 8 + prow, P - 1)) * C + unit * 32 + c4);
   };
   // ---- the two directions run side by side, four waves each, and meet once before new_lan.  They share no data, so each half
   // synchronises on its own LDS counter (group_sync) instead of the workgroup barrier: the latency chain of the hand-off
@@ -245,49 +254,57 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       }
     }
     group_sync();
-    // soft-max over the sentences: 16 threads per row, 4 sentences each (rows >= PW and columns >= N become zeros: they are k /
-    // column padding of the MFMA operands below)
+    XP_STAMP_V(12);
+    // soft-max over the sentences: 4 threads per row, <= 16 sentences each, one pass (rows >= PW and columns >= N become zeros:
+    // they are k / column padding of the MFMA operands below)
+    {
+      const int px = tg >> 2, q = tg & 3;
+      if (px < NPT * 16) {
+        float* row = AvL + px * XP_AVS;
+        float x[16];
+        float m = -INFINITY;
 #pragma unroll
-    for (int pr = 0; pr < NPT; ++pr) {
-      const int px = pr * 16 + (tg >> 4), q = tg & 15;
-      float* row = AvL + px * XP_AVS;
-      float x[4];
-      float m = -INFINITY;
+        for (int u = 0; u < 16; ++u) { x[u] = (q + 4 * u < N) ? row[q + 4 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float sm = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { x[u] = (q + 16 * u < N) ? row[q + 16 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+        for (int u = 0; u < 16; ++u) { x[u] = (q + 4 * u < N) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
+        sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
+        const float inv = px < PW ? 1.f / sm : 0.f;
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      float sm = 0.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { x[u] = (q + 16 * u < N) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-      const float inv = px < PW ? 1.f / sm : 0.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float y = x[u] * inv;
-        row[q + 16 * u] = y;
-        if (px < PW && q + 16 * u < N) probs[(((long)b * 4 + 0) * P + p0 + px) * N + q + 16 * u] = y;
+        for (int u = 0; u < 16; ++u) {
+          const float y = x[u] * inv;
+          row[q + 4 * u] = y;
+          if (px < PW && q + 4 * u < N) probs[(((long)b * 4 + 0) * P + p0 + px) * N + q + 4 * u] = y;
+        }
       }
     }
     group_sync();
     XP_STAMP_V(3);
     load_vv();
-    // new_vis[b, own pixels, :] = Av . Vt: wave w owns the channel tiles (w - 4) + 4 i; channels are the MFMA rows
-    Split8 sa[NPT][KS2];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t)
-#pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) {
-        const float* a = AvL + (t * 16 + r16) * XP_AVS + ks * 32 + kg * 8;
-        sa[t][ks] = split8(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4));
-      }
+    // new_vis[b, own pixels, :] = Av . Vt: wave w owns the channel tiles (w - 4) + 4 i; channels are the MFMA rows.  Av goes to
+    // LDS as bf16 piece planes in fragment order once (AvF, in the space of the turn-around tiles: the other half left its own
+    // when it arrived at its first group barrier) and is re-read per channel tile: the registers hold Vt^T fragments in flight
+    // instead -- this product runs at (bytes in flight) / (L2 latency)
+    while (__hip_atomic_load(s_epoch_p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+    uint4* AvF = reinterpret_cast<uint4*>(lds);
+    for (int e = tg; e < NPT * KS2 * 64; e += 256) {
+      const int fk = e >> 6, l = e & 63, t = fk / KS2, ks = fk - t * KS2;
+      const float* a = AvL + (t * 16 + (l & 15)) * XP_AVS + ks * 32 + (l >> 4) * 8;
+      const Split8 sp = split8(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4));
+      uint4* d = AvF + (fk * 3) * 64 + l;
+      d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid); d[128] = __builtin_bit_cast(uint4, sp.lo);
+    }
     group_sync();   // (third arrival: this half is done with the partial blocks and the Av rows -- the other half may reuse their LDS)
     // Vt^T fragments through a buffer resource: lanes whose eight sentences are all >= N ask for an out-of-range offset and get
     // zeros without a byte moved (N = 48: a quarter of the second 32-sentence step) -- and without a branch around the load
     const __amdgpu_buffer_rsrc_t vtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(VtF), 0, CT * KS2 * 3 * 1024, 0x00020000);
     constexpr int NIT = CT / 4;
-    constexpr int VA = 3;                  // channel tiles of Vt^T fragments in flight per wave
+#ifndef XP_VA
+#define XP_VA (NPT == 2 ? 4 : 5)
+#endif
+    constexpr int VA = XP_VA;              // channel tiles of Vt^T fragments in flight per wave
     Split8 vt[VA + 1][KS2];
     auto load_vt = [&](int ct, Split8 (&d)[KS2]) {
 #pragma unroll
@@ -312,8 +329,9 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       for (int t = 0; t < NPT; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
+          const uint4* f = AvF + ((t * KS2 + ks) * 3) * 64 + lane;
           ca[t * KS2 + ks] = vt[it % (VA + 1)][ks];
-          cb[t * KS2 + ks] = sa[t][ks];
+          cb[t * KS2 + ks].hi = ldf(f); cb[t * KS2 + ks].mid = ldf(f + 64); cb[t * KS2 + ks].lo = ldf(f + 128);
           co[t * KS2 + ks] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         }
       mfma6_n<NCH>(ca, cb, co);        // D[c = 4 kg + r][p = r16]
@@ -323,8 +341,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
 #pragma unroll
         for (int ks = 1; ks < KS2; ++ks) o += co[t * KS2 + ks];
         if (t * 16 + r16 < PW)   // 4 consecutive channels of one pixel per lane: one 16-byte store
-          *reinterpret_cast<float4*>(new_vis + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg) =
-              make_float4(o[0], o[1], o[2], o[3]);
+          st4_nt(new_vis + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
       }
     }
     XP_STAMP_V(9);
@@ -401,30 +418,30 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     }
     group_sync();
     XP_STAMP(6);
-    // soft-max over the pixels of each sentence row: 8 threads per row, 16 pixels each (columns >= P and rows >= N become zeros)
-    for (int n = tg >> 3; n < NT * 16; n += 32) {
-      const int q = tg & 7;
-      float* row = AtL + n * XP_ATS;
-      float x[16];
-      float m = -INFINITY;
+    // soft-max over the pixels of each sentence row: 4 threads per row, 32 pixels each, one pass (columns >= P and rows >= N
+    // become zeros)
+    {
+      const int n = tg >> 2, q = tg & 3;
+      if (n < NT * 16) {
+        float* row = AtL + n * XP_ATS;
+        float x[32];
+        float m = -INFINITY;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { x[u] = (q + 8 * u < P) ? row[q + 8 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+        for (int u = 0; u < 32; ++u) { x[u] = (q + 4 * u < P) ? row[q + 4 * u] : -INFINITY; m = fmaxf(m, x[u]); }
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float sm = 0.f;
 #pragma unroll
-      for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      float sm = 0.f;
+        for (int u = 0; u < 32; ++u) { x[u] = (q + 4 * u < P) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
+        sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
+        const float inv = n < N ? 1.f / sm : 0.f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { x[u] = (q + 8 * u < P) ? __expf(x[u] - m) : 0.f; sm += x[u]; }
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-      const float inv = n < N ? 1.f / sm : 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) row[q + 8 * u] = x[u] * inv;
+        for (int u = 0; u < 32; ++u) row[q + 4 * u] = x[u] * inv;
+      }
     }
     group_sync();
     XP_STAMP(7);
     // At -> bf16 piece planes in MFMA fragment order (every new_lan wave reads all of them) -- their LDS was the other half's
-    // partial blocks and Av rows: wait for its third arrival (long past) --, and the AtT plane [P][N] of the own pixels that the
-    // backward pass reads
+    // partial blocks and Av rows: wait for its third arrival (long past)
     while (__hip_atomic_load(s_epoch_p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 12u) __builtin_amdgcn_s_sleep(0);
     asm volatile("" ::: "memory");
     for (int e = tg; e < NT * 4 * 64; e += 256) {
@@ -436,10 +453,6 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
         d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid); d[128] = __builtin_bit_cast(uint4, sp.lo);
       }
     }
-    for (int e = tg; e < PW * N; e += 256) {
-      const int lp = e / N, n = e - lp * N;
-      probs[(((long)b * 4 + 2) * P + p0 + lp) * N + n] = AtL[n * XP_ATS + p0 + lp];
-    }
     XP_STAMP(10);
   }
   // the Vv rows of the own unit as bf16 pieces (registers): only LDS traffic and MFMAs follow the barrier
@@ -449,8 +462,13 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < VR; ++i) vsp[i] = split4(i * 8 + prow < P ? vreg[i] : make_float4(0.f, 0.f, 0.f, 0.f));
   }
+  XP_STAMP_W(24);
   lds_barrier();   // both directions meet
   XP_STAMP(4);
+  for (int e = tid; e < PW * N; e += 512) {   // the AtT plane [P][N] of the own pixels that the backward pass reads
+    const int lp = e / N, n = e - lp * N;
+    probs[(((long)b * 4 + 2) * P + p0 + lp) * N + n] = AtL[n * XP_ATS + p0 + lp];
+  }
   // new_lan[b, :, unit] = At . Vv[b, :, unit]: wave w = unit w of the workgroup; per 32-pixel step the pieces of the Vv rows are
   // stored k-major in the wave's own plane buffer and gathered as MFMA fragments by the transpose read
   if (wave < NU) {
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       for (int j = 0; j < NT; ++j)
         if (j * 16 + r16 < N) {
           const f32x4v o = co[ct * NT + j];
-          *reinterpret_cast<float4*>(new_lan + ((long)b * N + j * 16 + r16) * C + c0 + ct * 16 + 4 * kg) = make_float4(o[0], o[1], o[2], o[3]);
+          st4_nt(new_lan + ((long)b * N + j * 16 + r16) * C + c0 + ct * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
         }
   }
   XP_STAMP(8);
@@ -529,7 +547,7 @@ inline XpPlan xp_plan(int B, int N, int C) {
   p.qtf = 0; p.ktf = a; p.vtf = 2 * a; p.sx = 2 * a + v;
   p.total = p.sx + (long)B * XP_MAXS * p.NT * 16 * 32 * 4;
 #ifdef TRIS_XP_TRACE
-  p.total += (long)B * XP_MAXS * 16 * 8;
+  p.total += (long)B * XP_MAXS * 32 * 8;
 #endif
   return p;
 }
@@ -542,6 +560,7 @@ inline int xp_slots(int B, int P, int C, int cus) {
   int smax = cus / B;
   if (smax > XP_MAXS) smax = XP_MAXS;
   if (smax > P) smax = P;
+  if (tris_internal_xattn_px_slots > 0 && tris_internal_xattn_px_slots < smax) smax = tris_internal_xattn_px_slots;
   return smax >= smin ? smax : 0;
 }
 
