@@ -5,7 +5,9 @@ timeout 1800 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_ou
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1 < /dev/null; tail -1 gpurun_out/${TAG}_smoke.log
 TRIS_TUNE_LOG=gpurun_out/${TAG}_autotune_log_all.txt timeout 1200 python bench.py > gpurun_out/${TAG}_bench.log 2>&1 < /dev/null; grep "^{" gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; cut -c1-300 gpurun_out/${TAG}_bench.json
 grep "mode=3" gpurun_out/${TAG}_autotune_log_all.txt > gpurun_out/${TAG}_autotune_log_h2.txt; grep "mode=1" gpurun_out/${TAG}_autotune_log_all.txt > gpurun_out/${TAG}_autotune_log_x3.txt; wc -l gpurun_out/${TAG}_autotune_log_*.txt | tail -3
-timeout 300 python tools/xattn_fused_trace.py > gpurun_out/${TAG}_xattn_phase_trace.txt 2>&1 < /dev/null; tail -12 gpurun_out/${TAG}_xattn_phase_trace.txt | cut -c1-200
+timeout 300 python tools/xattn_px_trace.py > gpurun_out/${TAG}_xattn_phase_trace.txt 2>&1 < /dev/null; tail -18 gpurun_out/${TAG}_xattn_phase_trace.txt | cut -c1-200
+timeout 300 python tools/xattn_check.py > gpurun_out/${TAG}_xattn_forms.txt 2>&1 < /dev/null; tail -3 gpurun_out/${TAG}_xattn_forms.txt | cut -c1-200
+bash tools/xattn_pmc.sh ${TAG} > /dev/null 2>&1 < /dev/null; cut -c1-160 gpurun_out/${TAG}_xattn_pmc.txt
 timeout 300 python tools/step_graph_marks.py > gpurun_out/${TAG}_step_graph_marks.txt 2>&1 < /dev/null; tail -2 gpurun_out/${TAG}_step_graph_marks.txt
 timeout 300 python tools/wait_probe.py 5 > gpurun_out/${TAG}_wait_probe.txt 2>&1 < /dev/null; grep -v 'stream2  wait' gpurun_out/${TAG}_wait_probe.txt | tail -8
 MODE=h2 bash tools/closing_profiles.sh
