@@ -306,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
 #endif
     constexpr int VA = XP_VA;              // channel tiles of Vt^T fragments in flight per wave
     Split8 vt[VA + 1][KS2];
+    const int wv = wave - 4;
     auto load_vt = [&](int ct, Split8 (&d)[KS2]) {
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
@@ -315,7 +316,6 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
         d[ks].lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 2048, 0));
       }
     };
-    const int wv = wave - 4;
 #pragma unroll
     for (int it = 0; it < VA; ++it) load_vt(wv + 4 * it, vt[it]);
 #pragma unroll
