@@ -891,6 +891,35 @@ def test_xattn_single_launch_kernels_match_the_two_launch_pair(ops, monkeypatch,
             close(a, b, 2e-4, name=f"gradient through the saved probabilities ({form})")
 
 
+def test_xattn_pixel_row_launch_replays_from_a_graph(ops):
+    """The persistent cross-attention launch keeps its epoch and flags in device memory: captured once, it must replay with NEW
+    operand values each time (the sentence planes are rebuilt by the captured preparation launch) and hand the same results as
+    the eager call; no wait may time out."""
+    if ops.get_gemm_mode() == "f32":
+        pytest.skip("the single-launch forms are split-bf16 kernels")
+    B, P, N, C = 48, 100, 48, 1024
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *sh: torch.randn(*sh, generator=g).cuda()
+    Qv, Kv, Vv, Qt, Kt, Vt = mk(B, P, C), mk(B, P, C), mk(B, P, C), mk(N, C), mk(N, C), mk(N, C)
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)     # (allocations, sync words of this stream)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            nv, nl = ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)
+        for it in range(3):
+            for t in (Qv, Kv, Vv, Qt, Kt, Vt):
+                t.copy_(torch.randn(t.shape, generator=g).cuda() * (1.0 + it))
+            graph.replay()
+            torch.cuda.synchronize()
+            ev, el = ops.xattn(Qv, Kv, Vv, Qt, Kt, Vt)
+            assert torch.equal(nv, ev) and torch.equal(nl, el), f"replay {it}"
+    assert not ops.xattn_timed_out()
+
+
 @pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64)])
 def test_xattn_fused(ops, B, P, N, C):
     Qv, Kv, Vv = leaf(B, P, C, seed=1), leaf(B, P, C, seed=2), leaf(B, P, C, seed=3)
