@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     f32x4v acc[NPT * NT];
 #pragma unroll
     for (int i = 0; i < NPT * NT; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    constexpr int AHEAD = KQ < 3 ? KQ : 3;           // k-steps of pixel rows in flight
+    constexpr int AHEAD = KQ < 3 ? KQ : 3;           // k-steps of pixel rows in flight (4: no faster, spills)
     float4 v[KQ][NPT][2];
     Split8 fr[KQ][NT];
     auto load_px = [&](int i) {
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     for (int i = 0; i < FAHEAD; ++i) load_fr(i);
 #pragma unroll
     for (int i = 0; i < KQ; ++i) {
+      if (i + FAHEAD < KQ) load_fr(i + FAHEAD);   // (L2 fragments before the HBM rows: the memory counter is in order)
       if (i + AHEAD < KQ) load_px(i + AHEAD);
-      if (i + FAHEAD < KQ) load_fr(i + FAHEAD);
 #pragma unroll
       for (int t = 0; t < NPT; ++t)
 #pragma unroll
