@@ -20,4 +20,17 @@ for (k, c), v in sorted(tot.items()):
 PY
   rm -rf $D $D.log
 done
+# kernel durations of the same script (idle device): rocprofv3 --kernel-trace --stats
+D=gpurun_out/_xp_stats
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o x -- python tools/xattn_check.py > $D.log 2>&1 < /dev/null
+F=$(ls $D/*/*kernel_stats.csv $D/*kernel_stats.csv 2>/dev/null | head -1)
+echo "kernel durations (rocprofv3 --kernel-trace --stats, ns): name, calls, average, min, max" >> $OUT
+python - "$F" >> $OUT <<'PY'
+import csv, re, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "xattn" in r["Name"]:
+        n = re.sub(r"\(anonymous namespace\)::|void |\(.*$", "", r["Name"])[:50]
+        print(f"  {n:52s} {r['Calls']:>5s} {float(r['AverageNs']):10.0f} {float(r['MinNs']):10.0f} {float(r['MaxNs']):10.0f}")
+PY
+rm -rf $D $D.log
 cat $OUT
