@@ -14,7 +14,7 @@
 //   * the sentence -> pixel direction needs ONE hand-off of N x (own pixels) floats (3.8 KB per workgroup, 19 KB per image):
 //     the logits Kv rows . Qt^T are complete per pixel; the soft-max over the pixels of the image needs everyone's columns.  Each
 //     workgroup publishes its columns as soon as they exist, runs the whole pixel -> sentence direction, and only then looks at
-//     the flags: the hand-off latency (~4 us on this part) hides behind ~5 us of independent work;
+//     the flags: the hand-off's latency chain (~8 us on this part) hides behind the other direction's products;
 //   * new_lan = At . Vv reduces over pixels, so it is cut by CHANNELS instead: workgroup s owns 32-channel units
 //     [s U / S, (s + 1) U / S), U = C / 32, reads Vv[b, :, own channels] (requested before the hand-off) and every workgroup of
 //     the image repeats the tiny soft-max over pixels (N x P values).
@@ -22,17 +22,25 @@
 // bf16 planes in MFMA fragment order from L2 (xattn_planes.h).  HBM traffic = algorithmic + saved probabilities + 2 x 19 KB per
 // image of exchange.
 //
-// Workgroup = 512 threads.  Logits: waves 0-3 take Kv . Qt^T, waves 4-7 Qv . Kt^T, each over a quarter of the channels (pixel rows
-// read row-contiguous, 8 rows x 128 B per instruction, turned into MFMA fragments through wave-private LDS tiles; three k-steps of
-// loads in flight), partial blocks summed through LDS.  new_vis: wave w owns channel tiles w + 8 i (channels are the MFMA rows: a
-// lane stores four consecutive channels of a pixel).  new_lan: wave w owns unit w of the workgroup (<= 8): its Vv columns are
-// split once, staged k-major per 32-pixel step in a wave-private LDS buffer and gathered with ds_read_b64_tr_b16.
+// Workgroup = 512 threads = two halves of four waves, one per direction, that share no data and therefore synchronise on LDS
+// counters of their own (group_sync) instead of s_barrier; they meet once, before new_lan.
+//   T (waves 0-3)  D_t = Kv rows . Qt^T, each wave over a quarter of the channels -> summed through LDS -> published (write-through,
+//                  drain, flag) -> wait for the S flags -> gather everyone's columns (one round trip) -> soft-max over pixels ->
+//                  At as bf16 piece planes in LDS.  A chain of latencies (~12 us) that runs under V's products.
+//   V (waves 4-7)  D_v = Qv rows . Kt^T likewise -> soft-max over sentences -> Av as piece planes in LDS -> new_vis, wave w owns the
+//                  channel tiles (w - 4) + 4 i (channels are the MFMA rows: a lane stores four consecutive channels of a pixel),
+//                  Vt^T fragments four tiles ahead.
+//   all            new_lan: wave w owns 32-channel unit w of the workgroup (<= 8): its Vv columns (requested early, split once) are
+//                  staged k-major per 32-pixel step in a wave-private LDS buffer and gathered with ds_read_b64_tr_b16.
+// Pixel rows are read row-contiguous (8 rows x 128 B per instruction) and turned into MFMA fragments through wave-private LDS
+// tiles.  Workgroup barriers are s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() is a workgroup-scope release, i.e. vmcnt(0),
+// and would wait for every prefetch in flight.  Measured per phase: profiles/r4_xattn_phase_table.txt (tools/xattn_px_trace.py).
 //
 // Inter-workgroup protocol as in xattn_fused.hip (MI355X_MICROARCH "workgroup dispatch / visibility", recipe R1): write-through
 // (sc1) 16-byte stores, every storing wave drains vmcnt, barrier, one lane raises the (image, slot) flag relaxed at agent scope;
-// consumers poll relaxed from one wave, barrier, sc1 loads; no fences.  Epoch in device memory (sync[0], advanced by the last
+// every consuming wave polls relaxed itself, then reads with sc1 loads; no fences.  Epoch in device memory (sync[0], advanced by the last
 // workgroup to finish): a captured launch replays.  Spins are bounded (sync[2] != 0 afterwards: outputs undefined).  All B * S
-// workgroups must be co-resident (one per CU: ~140 KB of LDS); the entry point declines otherwise.
+// workgroups must be co-resident (one per CU: 120-145 KB of LDS); the entry point declines otherwise.
 #include "common.h"
 #include "tris_hip.h"
 #include "x3_split.h"
