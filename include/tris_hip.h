@@ -310,6 +310,10 @@ int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const float* Vv, 
  * TRIS_DECLINED behaviour as tris_xattn_fused_fwd_f32; the sync words may be the same buffer. */
 long tris_xattn_px_ws_bytes(int B, int N, int C);
 long tris_xattn_px_sync_words(int B);
+/* host-side plan of the pixel-row launch: workgroups per image S on a device of `cus` compute units (0 = the call would decline:
+ * B * S workgroups must be resident one per CU, a workgroup owns <= 32 pixels and <= 8 of the C / 32 channel units).  Workgroup s
+ * owns pixels [s P / S, (s + 1) P / S) and units [s U / S, (s + 1) U / S), U = C / 32 (integer division). */
+long tris_xattn_px_slots(int B, int P, int C, int cus);
 int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                           const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C,
                           float* ws, long ws_bytes, unsigned* sync, void* stream);

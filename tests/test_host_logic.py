@@ -192,3 +192,32 @@ def test_gradient_box_protocol():
     assert not box.deposit(g2) and box.value is g1          # occupied: the second gradient stays with autograd
     box.value, box.consumed = None, True                     # what the consuming backward does
     assert not box.deposit(g2) and box.value is None         # too late: the consumer has already run
+
+
+def test_cross_attention_pixel_row_plan_covers_every_pixel_and_channel_unit_once():
+    """csrc/xattn_px.hip cuts an image into S pixel ranges and S ranges of 32-channel units by integer division; the host-side
+    plan (tris_xattn_px_slots, no GPU needed) must respect the kernel's limits -- B * S workgroups resident one per CU, <= 32
+    own pixels (two MFMA tiles), <= 8 own units (one per wave) -- and the ranges must tile [0, P) and [0, U) exactly."""
+    from tris_amd import _lib
+    lib = _lib.load()
+    seen_s = set()
+    for cus in (256, 304, 64):
+        for C in (512, 1024):
+            U = C // 32
+            for B in (1, 2, 3, 7, 16, 32, 40, 48, 51, 60, 64, 65, 100, 128, 300):
+                for P in (1, 5, 8, 31, 32, 33, 57, 97, 100, 103, 104):
+                    S = int(lib.tris_xattn_px_slots(B, P, C, cus))
+                    if S == 0:
+                        # declines only when no S in 1..8 satisfies all three limits
+                        assert not any(B * s <= cus and s <= P and -(-P // s) <= 32 and -(-U // s) <= 8 for s in range(1, 9)), (B, P, C, cus)
+                        continue
+                    seen_s.add(S)
+                    assert 1 <= S <= 8 and B * S <= cus and S <= P
+                    px = [((s * P) // S, ((s + 1) * P) // S) for s in range(S)]
+                    un = [((s * U) // S, ((s + 1) * U) // S) for s in range(S)]
+                    assert px[0][0] == 0 and px[-1][1] == P and all(a[1] == b[0] for a, b in zip(px, px[1:]))
+                    assert un[0][0] == 0 and un[-1][1] == U and all(a[1] == b[0] for a, b in zip(un, un[1:]))
+                    assert all(1 <= hi - lo <= 32 for lo, hi in px) and all(1 <= hi - lo <= 8 for lo, hi in un)
+    assert seen_s >= {4, 5, 6, 8}
+    assert lib.tris_xattn_px_slots(48, 100, 1024, 256) == 5      # the headline shape: 240 workgroups on 256 CUs
+    assert lib.tris_xattn_px_slots(48, 105, 1024, 256) == 0 and lib.tris_xattn_px_slots(48, 100, 768, 256) == 0

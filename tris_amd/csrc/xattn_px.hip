@@ -618,6 +618,11 @@ extern "C" long tris_xattn_px_ws_bytes(int B, int N, int C) {
 
 extern "C" long tris_xattn_px_sync_words(int B) { return XP_SYNC_FLAGS + (long)XP_MAXS * B; }
 
+extern "C" long tris_xattn_px_slots(int B, int P, int C, int cus) {
+  if (B < 1 || P < 1 || P > 104 || !(C == 512 || C == 1024) || cus < 1) return 0;
+  return xp_slots(B, P, C, cus);
+}
+
 extern "C" int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                                      const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N,
                                      int C, float* ws, long ws_bytes, unsigned* sync, void* stream) {
