@@ -309,6 +309,11 @@ def main():
                   "kernel": xname + " (fused bilateral cross attention, forward, all launches, HIP events around the call)",
                   "single_launch": bool(fused and len(fused) == len(xa)),
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
+                  "bound_note": ("pixel-row form: one hand-off, 240 workgroups on 256 CUs, traffic ~1.2 x algorithmic; every workgroup reads "
+                                 "the full sentence operands from L2 (0.86 MB of bf16 piece planes against 0.32 MB of its own HBM stream), "
+                                 "the phases are paced per CU by the in-order memory counter, not by bytes or MFMAs: "
+                                 "profiles/r4_xattn_phase_table.txt; 36.5 us on an idle device (0.30)")
+                  if fused and len(fused) == len(xa) and fused[0][0] == "xattn_fwd_px" else None,
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
         try:   # HBM bytes of the cross-attention launches from the same --pmc passes
             import csv as _csv
