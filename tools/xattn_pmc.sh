@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 TAG=${1:-r4}
 OUT=gpurun_out/${TAG}_xattn_pmc.txt; : > $OUT
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   D=gpurun_out/_xp_$(echo $C | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o x -- python tools/xattn_check.py > $D.log 2>&1 < /dev/null
   F=$(ls $D/*/*counter_collection.csv $D/*counter_collection.csv 2>/dev/null | head -1)
