@@ -189,6 +189,10 @@ def train_one_epoch(train_loader, model, optimizer, epoch, local_rank, args, ite
             # the loop on all ranks): a rank that gave up on an exchange has NaN statistics, and training must stop on all of them
             from . import comm
             comm.check_errors(collective=True)
+        if idx % args.print_freq == 0 and ops.xattn_timed_out():
+            # a wait inside a persistent cross-attention launch gave up (a peer workgroup never became resident): that launch's
+            # outputs are undefined -- stop instead of training on them (host sync: only where the loop prints)
+            raise RuntimeError("fused cross attention: an in-kernel wait timed out; rerun with TRIS_XATTN_FUSED=0 (the two-launch pair)")
         if idx % args.print_freq == 0 and local_rank == 0:
             v = last.tolist()  # the only host sync, every print_freq steps (the reference syncs every step, :374-387)
             msg = (f"Train:[{epoch:2d}/{args.epoch}][{idx:4d}/{num_steps}] | lr {optimizer.param_groups[0]['lr']:.6f} || "
