@@ -1041,10 +1041,20 @@ extern "C" int tris_layernorm_fwd_f32(const float* X, const float* gamma, const 
   return 0;
 }
 
+// rows per block of the LayerNorm backward: a wave walks its rows one after the other (two dependent wave reductions per row), so the
+// launch is a chain of row latencies -- at most 512 blocks (partial rows for the finalizer), at least 4 rows (one per wave).
+// LN_BWD_BLOCKS option: the block count aimed for (128 = rounds 1-3).
+extern "C" { __attribute__((visibility("hidden"))) int tris_internal_ln_bwd_blocks = 512; }
+static long ln_bwd_rpb(long rows) {
+  const long target = tris_internal_ln_bwd_blocks;
+  long rpb = (rows + target - 1) / target;
+  const long floor_ = target > 128 ? 4 : 8;
+  return rpb < floor_ ? floor_ : rpb;
+}
 extern "C" long tris_layernorm_bwd_workspace_bytes(long rows, int W) {
-  long rpb = (rows + 127) / 128;
-  if (rpb < 8) rpb = 8;
+  const long rpb = ln_bwd_rpb(rows);
   long nb = (rows + rpb - 1) / rpb;
+  if (nb < 512) nb = 512;   // (sized for either setting of the option)
   return nb * 2 * W * (long)sizeof(float);
 }
 
@@ -1053,8 +1063,7 @@ extern "C" int tris_layernorm_bwd_f32(const float* dY, const float* X, const flo
                                       float* workspace, const float* extra, void* stream) {
   if (W % 4 || W > 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  long rpb = (rows + 127) / 128;
-  if (rpb < 8) rpb = 8;
+  const long rpb = ln_bwd_rpb(rows);
   int nb = (int)((rows + rpb - 1) / rpb);
   float* part = dgamma ? workspace : nullptr;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dY, X, gamma, mean, rstd, dX, part, rows, W,
