@@ -23,8 +23,9 @@ extern "C" {
 extern __attribute__((visibility("hidden"))) int tris_internal_stream_form;
 extern __attribute__((visibility("hidden"))) int tris_internal_col_blocks;
 extern __attribute__((visibility("hidden"))) int tris_internal_ln_bwd_blocks;
-// REDUCE_WIDE=0: split-K slabs of small outputs are summed by the one-thread-per-four-columns kernel as well (gemm_core.h)
-__attribute__((visibility("hidden"))) int tris_internal_reduce_wide = 1;
+// REDUCE_WIDE=0: split-K slabs of small outputs are summed by the one-thread-per-four-columns kernel as well; 4 | 8 | 16: slab
+// groups (waves) per block of the wide kernel (gemm_core.h)
+__attribute__((visibility("hidden"))) int tris_internal_reduce_wide = 4;
 // option that lives in xattn_px.hip's translation unit
 extern __attribute__((visibility("hidden"))) int tris_internal_xattn_px_slots;
 }
@@ -75,7 +76,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 256 : (atoi(v) == 1 ? 256 : std::max(0, atoi(v)));
   else if (!strcmp(name, "COL_BLOCKS")) tris_internal_col_blocks = unset ? 512 : std::max(1, atoi(v));
   else if (!strcmp(name, "LN_BWD_BLOCKS")) tris_internal_ln_bwd_blocks = unset ? 512 : std::min(512, std::max(1, atoi(v)));
-  else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 1 : (v[0] != '0');
+  else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 4 : std::max(0, atoi(v));
   else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
   else return false;

@@ -392,10 +392,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_reduce_wide; }   // option REDUCE_WIDE (gemm_conv.hip)
 // The same sum for outputs too SMALL to fill the chip with one thread per four columns (a 64 x 64 weight gradient cut into 128
 // slabs is 4 blocks of the kernel above, each thread walking 128 slabs four at a time: ~30 us of latency for 2 MB): a block of
-// 1024 threads owns 64 float4 columns, its 16 waves take the slabs s = w, w + 16, ..., the partial sums meet in LDS in a fixed
-// order (deterministic; the order differs from the kernel above -- ((s0 + s16 + ..) + (s1 + s17 + ..)) + ..).
-__global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* __restrict__ ws, int S, GemmParams p) {
-  __shared__ float4 part[16][64];
+// G waves owns 64 float4 columns, wave w takes the slabs s = w, w + G, ..., the partial sums meet in LDS in a fixed order
+// (deterministic; the order differs from the kernel above -- ((s0 + sG + ..) + (s1 + s(G+1) + ..)) + ..).  G = 4 by default: a
+// 1024-thread block (G = 16) is faster on an idle device but waits for sixteen free wave slots of one CU inside the step (47 us
+// on average against ~5, measured); option REDUCE_WIDE = G.
+template <int G>   // slab groups = waves per block
+__global__ __launch_bounds__(64 * G) void splitk_reduce_wide_kernel(const float* __restrict__ ws, int S, GemmParams p) {
+  __shared__ float4 part[G][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long total = (long)p.M * p.N;
   const long idx = ((long)blockIdx.x * 64 + c) * 4;
@@ -403,13 +406,13 @@ __global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* _
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (in) {
     int s = g;
-    for (; s + 48 < S; s += 64) {
-      const float4 x0 = ld4(ws + (long)s * total + idx), x1 = ld4(ws + (long)(s + 16) * total + idx);
-      const float4 x2 = ld4(ws + (long)(s + 32) * total + idx), x3 = ld4(ws + (long)(s + 48) * total + idx);
+    for (; s + 3 * G < S; s += 4 * G) {
+      const float4 x0 = ld4(ws + (long)s * total + idx), x1 = ld4(ws + (long)(s + G) * total + idx);
+      const float4 x2 = ld4(ws + (long)(s + 2 * G) * total + idx), x3 = ld4(ws + (long)(s + 3 * G) * total + idx);
       a.x = (((a.x + x0.x) + x1.x) + x2.x) + x3.x; a.y = (((a.y + x0.y) + x1.y) + x2.y) + x3.y;
       a.z = (((a.z + x0.z) + x1.z) + x2.z) + x3.z; a.w = (((a.w + x0.w) + x1.w) + x2.w) + x3.w;
     }
-    for (; s < S; s += 16) {
+    for (; s < S; s += G) {
       const float4 x0 = ld4(ws + (long)s * total + idx);
       a.x += x0.x; a.y += x0.y; a.z += x0.z; a.w += x0.w;
     }
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* _
   if (g != 0) return;
   float v[4] = {part[0][c].x, part[0][c].y, part[0][c].z, part[0][c].w};
 #pragma unroll
-  for (int w = 1; w < 16; ++w) { v[0] += part[w][c].x; v[1] += part[w][c].y; v[2] += part[w][c].z; v[3] += part[w][c].w; }
+  for (int w = 1; w < G; ++w) { v[0] += part[w][c].x; v[1] += part[w][c].y; v[2] += part[w][c].z; v[3] += part[w][c].w; }
   unsigned am = 0u;
   if (in) {
     const int row = (int)(idx / p.N), col0 = (int)(idx - (long)row * p.N);
@@ -538,7 +541,14 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
     p.C = Cfinal;
     long total = (long)p.M * p.N;
     if ((p.N & 3) == 0 && al16(ws) && al16(p.C) && splitk >= 8 && total / 4 < 128 * 256 && tris_internal_reduce_wide)
-      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(cdiv(total / 4, 64)), dim3(1024), 0, st, ws, splitk, p);
+    {
+      if (tris_internal_reduce_wide >= 16)
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel<16>, dim3(cdiv(total / 4, 64)), dim3(1024), 0, st, ws, splitk, p);
+      else if (tris_internal_reduce_wide >= 8)
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel<8>, dim3(cdiv(total / 4, 64)), dim3(512), 0, st, ws, splitk, p);
+      else
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel<4>, dim3(cdiv(total / 4, 64)), dim3(256), 0, st, ws, splitk, p);
+    }
     else if ((p.N & 3) == 0 && al16(ws) && al16(p.C))
       hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, ws, splitk, p);
     else
