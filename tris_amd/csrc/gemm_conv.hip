@@ -23,6 +23,7 @@ extern "C" {
 extern __attribute__((visibility("hidden"))) int tris_internal_stream_form;
 extern __attribute__((visibility("hidden"))) int tris_internal_col_blocks;
 extern __attribute__((visibility("hidden"))) int tris_internal_ln_bwd_blocks;
+extern __attribute__((visibility("hidden"))) int tris_internal_fin_block;
 // REDUCE_WIDE=0: split-K slabs of small outputs are summed by the one-thread-per-four-columns kernel as well; 4 | 8 | 16: slab
 // groups (waves) per block of the wide kernel (gemm_core.h)
 __attribute__((visibility("hidden"))) int tris_internal_reduce_wide = 4;
@@ -76,6 +77,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 256 : (atoi(v) == 1 ? 256 : std::max(0, atoi(v)));
   else if (!strcmp(name, "COL_BLOCKS")) tris_internal_col_blocks = unset ? 512 : std::max(1, atoi(v));
   else if (!strcmp(name, "LN_BWD_BLOCKS")) tris_internal_ln_bwd_blocks = unset ? 512 : std::min(512, std::max(1, atoi(v)));
+  else if (!strcmp(name, "FIN_BLOCK")) tris_internal_fin_block = unset ? 256 : (atoi(v) >= 1024 ? 1024 : atoi(v) >= 512 ? 512 : 256);
   else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 4 : std::max(0, atoi(v));
   else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
@@ -84,7 +86,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
 }
 static Options init_options() {
   Options o;
-  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "REDUCE_WIDE", "TUNE_LOG"}) {
+  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "TUNE_LOG"}) {
     char env[64];
     snprintf(env, sizeof(env), "TRIS_%s", n);
     if (const char* v = getenv(env)) set_option(o, n, v);

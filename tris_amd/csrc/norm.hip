@@ -211,7 +211,11 @@ __device__ __forceinline__ void reduce_parts(const T* __restrict__ part, int nb,
   }
 }
 inline int fin_grid(int C, int nb) { (void)nb; return cdiv(C, FIN_CH); }
-inline int fin_block(int nb) { return nb > 2048 ? 1024 : 256; }
+// (FIN_BLOCK option: threads of a finalizer block for more than 2048 partial rows.  Rounds 1-3 used 1024 there -- more loads in flight on
+//  an idle device; but a block of sixteen waves has to find sixteen free wave slots on one CU, which takes time inside the step:
+//  256 everywhere is 0.2 ms per step faster, 39.30 -> 39.10 ms, A/B x3 on one box)
+extern "C" { __attribute__((visibility("hidden"))) int tris_internal_fin_block = 256; }
+inline int fin_block(int nb) { return nb > 2048 ? tris_internal_fin_block : 256; }
 
 // BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
