@@ -175,6 +175,52 @@ int tris_amax_segments_f32(const float* base, const long* offs, const long* size
  * instead of a pass of its own.  Each of these entry points TAKES the arming first thing, whether or not it then launches anything. */
 int tris_amax_next(unsigned* out);
 int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB);
+/* Operand planes ("P8", csrc/planes.h; DESIGN.md "operand planes"): a tensor in the byte geometry of its fp32 original whose every 8
+ * consecutive elements of the contiguous dimension are 16 bytes of fp16 hi pieces followed by 16 bytes of pre-scaled fp16 lo pieces,
+ * x s = hi + lo' 2^-11 with the power-of-two scale s that *word implies (an amax word holding the tensor's largest magnitude or an
+ * upper bound of it, final BEFORE the tensor is written).  tris_h2_planes_f32 / tris_h2_unplanes_f32 convert (n % 8 == 0);
+ * tris_h2_planes_segments_f32 converts nseg tensors base + offs[i] (sizes[i] floats, word slots + 2048 slot_index[i]; device arrays)
+ * of one flat buffer into out_base + offs[i] in one launch (the convolution weights of an optimiser arena, once per step).
+ * tris_h2_next_planes arms the calling thread like tris_h2_next, for a product whose operands A and B are BOTH such plane tensors
+ * (same pointers, shapes and leading dimensions as the fp32 form; contiguous dimensions multiples of 8): the kernels store the
+ * pieces as they arrive instead of splitting fp32 values, and the result is bit-identical to the h2 product of the fp32 originals at
+ * the same scales.  flags bit 0: the bn_y operand of tris_gemm_bnbwd_f32 is a plane tensor as well.  A product the fast kernels do not
+ * serve FAILS (hipErrorInvalidValue): there is no fp32 operand to fall back on; the *_bnin forms refuse planes. */
+int tris_h2_planes_f32(const float* x, float* planes_out, long n, const unsigned* word, void* stream);
+int tris_h2_planes_segments_f32(const float* base, const long* offs, const long* sizes, const long* slot_index, int nseg,
+                                const unsigned* slots, float* out_base, void* stream);
+int tris_h2_unplanes_f32(const float* planes, float* out, long n, const unsigned* word, void* stream);
+int tris_h2_next_planes(const unsigned* amaxA, const unsigned* amaxB, int flags);
+/* The RN50 trunk's element-wise passes with plane OUTPUT (csrc/planes.hip; reference: CLIP/clip/model.py:42-55 Bottleneck.forward,
+ * the BatchNorm2d / ReLU / AvgPool2d calls between its convolutions).  Same arithmetic as tris_bn_apply_f32 / tris_bn_apply_pool_f32 /
+ * tris_avgpool2_fwd_f32 / tris_bn_bwd_apply_f32 / tris_bn_bwd_apply_pool_f32 on groups of 8 channels (C % 8 == 0); the result is split
+ * with the scale of *out_word, which must hold an upper bound of the output's magnitude BEFORE the launch:
+ *   tris_bn_out_bound2_f32: *out <- bits of max_c(|gamma[c]| xhat_max + |beta[c]|) + (add_word ? value of *add_word : 0) -- Samuelson's
+ *     bound of a train-mode BatchNorm output (xhat_max = sqrt(rows - 1)) plus the bound of the residual it is added to;
+ *   tris_bn_bwd_bound_f32: *out <- bits of max_c |gamma invstd| (amax_dz + |sum_dz| inv_count + xhat_max |sum_dzx| inv_count), the
+ *     bound of dx = gamma invstd (dz - mean(dz) - xhat mean(dz xhat)); *dz_word: amax of the masked upstream gradient, left by the pass
+ *     that reduced it (tris_amax_next before tris_bn_bwd_reduce_f32 / _pool_f32 / tris_gemm_bnbwd_f32 / tris_conv3x3_dgrad_bnbwd_f32).
+ * resid_kind: 0 none, 1 fp32, 2 planes scaled by *resid_word.  Ypl of the backward: the BatchNorm's OUTPUT as planes (its ReLU mask is
+ * "a piece is non-zero"), or NULL with beta_mask (mask recomputed from X) or without (no ReLU).  tris_avgpool2_fwd_pl_f32: planes in,
+ * planes out at the SAME scale word (a mean never exceeds the bound of its terms). */
+int tris_bn_apply_pl_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         const float* resid, int resid_kind, const unsigned* resid_word, float* Ypl, const unsigned* out_word, long M,
+                         int C, int relu, void* stream);
+int tris_bn_bwd_reduce_pl_f32(const float* dY, const float* Ypl, const float* X, const float* mean, const float* invstd, long M, int C,
+                              float* sum_dz, float* sum_dzx, float* workspace, float* dz_out, void* stream);
+int tris_bn_apply_pool_pl_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              float* Ypl, const unsigned* out_word, int B, int H, int W, int C, void* stream);
+int tris_avgpool2_fwd_pl_f32(const float* Xpl, float* Ypl, const unsigned* word, int B, int H, int W, int C, void* stream);
+int tris_bn_bwd_apply_pl_f32(const float* dY, const float* Ypl, const float* X, const float* mean, const float* invstd,
+                             const float* gamma, const float* sum_dz, const float* sum_dzx, float inv_count, float* dXpl,
+                             const unsigned* out_word, float* dZ, long M, int C, const float* beta_mask, void* stream);
+int tris_bn_bwd_apply_pool_pl_f32(const float* dYp, const float* X, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, const float* sum_dz, const float* sum_dzx, float inv_count, float* dXpl,
+                                  const unsigned* out_word, int B, int H, int W, int C, void* stream);
+int tris_bn_out_bound2_f32(const float* gamma, const float* beta, int C, float xhat_max, const unsigned* add_word, unsigned* out,
+                           void* stream);
+int tris_bn_bwd_bound_f32(const float* gamma, const float* invstd, const float* sum_dz, const float* sum_dzx, int C, float inv_count,
+                          float xhat_max, const unsigned* dz_word, unsigned* out, void* stream);
 /* *out (an amax word, zeroed by the caller) <- bits of max over c of |gamma[c]| * xhat_max + |beta[c]|: an upper bound of
  * |bn(x)| (and of relu(bn(x))) for a train-mode BatchNorm over `count` rows when xhat_max = sqrt(count - 1) (Samuelson's inequality:
  * no element lies further than sqrt(n - 1) standard deviations from the mean) */

@@ -35,7 +35,7 @@ def _install_standins(mp):
         return y if resid is None else y + resid
 
     def batch_norm(x, g, b, rm, rv, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-                   grad_box=None, lazy=False, bwd_link=False, pool=False):
+                   grad_box=None, lazy=False, bwd_link=False, pool=False, planes=False, dx_planes=False):
         y = x * g + b          # (statistics are irrelevant for the order of the graph)
         if resid is not None:
             y = y + resid

@@ -1,0 +1,314 @@
+"""Operand planes of the h2 arithmetic (csrc/planes.h, DESIGN.md "operand planes"): tensors written ONCE as their two fp16 pieces by
+the pass that produces them, consumed by the dense products without a split (gemm_fast.h PREC 4).
+  * conversions round-trip to the h2 rounding of the fp32 tensor;
+  * every product kind on planes is BIT-IDENTICAL to the h2 product that splits the same fp32 operands in the kernel;
+  * the BatchNorm passes with plane output equal their fp32 forms up to that rounding, masks included;
+  * a Bottleneck stack and the whole B = 2 training step agree with the run without planes and with the oracle."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+WORD = 2048
+
+
+@pytest.fixture()
+def ops():
+    from tris_amd import ops as o
+    from tris_amd.config import cfg
+    prev, prev_pl = o.get_gemm_mode(), cfg.h2_planes
+    o.set_gemm_mode("h2")
+    cfg.h2_planes = True
+    yield o
+    cfg.h2_planes = prev_pl
+    o.set_gemm_mode(prev)
+
+
+def _word(ops, t=None, value=None):
+    w = torch.zeros(WORD, device="cuda", dtype=torch.int32)
+    if t is not None:
+        ops.call("tris_amax_bits_f32", ops.P(t), t.numel(), w.data_ptr(), ops._stream())
+    else:
+        w[0] = torch.tensor(value, dtype=torch.float32).view(torch.int32)
+    return w
+
+
+def _planes(ops, t, w):
+    o = torch.empty_like(t)
+    ops.call("tris_h2_planes_f32", ops.P(t), ops.P(o), t.numel(), w.data_ptr(), ops._stream())
+    return o
+
+
+def _unplanes(ops, p, w):
+    o = torch.empty_like(p)
+    ops.call("tris_h2_unplanes_f32", ops.P(p), ops.P(o), p.numel(), w.data_ptr(), ops._stream())
+    return o
+
+
+def _h2_round(x, amax):
+    """the value an h2 operand holds: hi + lo' 2^-11 with hi = fp16(x s), lo' = fp16((x s - hi) 2^11), s = 2^(13 - floor(log2 amax))"""
+    s = 2.0 ** (13 - math.floor(math.log2(amax)))
+    xs = x.double() * s
+    hi = xs.float().half()
+    lo = ((xs.float() - hi.float()) * 2048.0).half()
+    return ((hi.double() + lo.double() / 2048.0) / s).float()
+
+
+@pytest.mark.parametrize("bound_factor", [1.0, 700.0])
+def test_conversion_round_trip_is_the_h2_rounding(ops, bound_factor):
+    torch.manual_seed(0)
+    x = (torch.randn(1 << 16, device="cuda") * torch.logspace(-6, 2, 1 << 16, device="cuda")).contiguous()
+    amax = float(x.abs().max()) * bound_factor            # (a loose upper bound, as the Samuelson words are, works the same)
+    w = _word(ops, value=amax)
+    back = _unplanes(ops, _planes(ops, x, w), w)
+    torch.cuda.synchronize()
+    assert torch.equal(back, _h2_round(x.cpu(), amax).cuda())
+    rel = ((back - x).abs() / x.abs().clamp_min(1e-30))
+    big = x.abs() > amax * 2.0 ** -20
+    assert float(rel[big].max()) <= 2.0 ** -21            # 22 significand bits wherever the element is within 2^-20 of the bound
+
+
+def _arm(ops, wa, wb, planes, flags=0):
+    if planes:
+        ops.call("tris_h2_next_planes", wa.data_ptr(), wb.data_ptr(), flags)
+    else:
+        ops.call("tris_h2_next", wa.data_ptr(), wb.data_ptr(), 0.0, 0.0)
+
+
+@pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(640, 256, 512), (1000, 136, 96), (384, 64, 2048)])
+def test_gemm_on_planes_is_bit_identical_to_the_split_in_kernel(ops, tA, tB, M, N, K):
+    torch.manual_seed(M + N + K)
+    if tA:
+        M = M // 8 * 8
+    if not tB:
+        N = N // 8 * 8
+    A = torch.randn((K, M) if tA else (M, K), device="cuda") * 3
+    B = torch.randn((N, K) if tB else (K, N), device="cuda") * 0.02
+    wa, wb = _word(ops, A), _word(ops, B)
+    Ap, Bp = _planes(ops, A, wa), _planes(ops, B, wb)
+    ws = ops.workspace(0)
+    out = []
+    for planes in (False, True):
+        C = torch.empty(M, N, device="cuda")
+        a, b = (Ap, Bp) if planes else (A, B)
+        _arm(ops, wa, wb, planes)
+        ops.call("tris_gemm_f32", ops.P(a), ops.P(b), ops.P(C), M, N, K, a.shape[1], b.shape[1], N, int(tA), int(tB), 1, 0, 0, 0, None, 0,
+                 None, 0, 0, 0, 1.0, ops.P(ws), ws.numel() * 4, ops._stream())
+        out.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1])
+    ref = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double())
+    assert float((out[1].double() - ref).norm() / ref.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("direct", ["0", None])
+@pytest.mark.parametrize("B,H,C1,C2", [(2, 16, 32, 64), (2, 16, 64, 64), (3, 20, 128, 32), (2, 8, 256, 256)])
+def test_conv3x3_on_planes_is_bit_identical(ops, direct, B, H, C1, C2):
+    torch.manual_seed(B * H + C1)
+    ops.set_option("CONV_DIRECT", direct)
+    ops.set_option("WGRAD_DIRECT", direct)
+    x = torch.randn(B, H, H, C1, device="cuda")
+    w = torch.randn(C2, 3, 3, C1, device="cuda") * 0.05
+    dy = torch.randn(B, H, H, C2, device="cuda") * 1e-3
+    wx, ww, wd = _word(ops, x), _word(ops, w), _word(ops, dy)
+    xp, wp, dp = _planes(ops, x, wx), _planes(ops, w, ww), _planes(ops, dy, wd)
+    ws = ops.workspace(0)
+    res = {}
+    for planes in (False, True):
+        xx, wwt, dd = (xp, wp, dp) if planes else (x, w, dy)
+        y, dx, dw = torch.empty(B, H, H, C2, device="cuda"), torch.empty_like(x), torch.empty_like(w)
+        _arm(ops, wx, ww, planes)
+        ops.call("tris_conv3x3_fwd_f32", ops.P(xx), ops.P(wwt), ops.P(y), B, H, H, C1, C2, 1, ops._stream())
+        _arm(ops, wd, ww, planes)
+        ops.call("tris_conv3x3_dgrad_f32", ops.P(dd), ops.P(wwt), ops.P(dx), B, H, H, C1, C2, ops._stream())
+        _arm(ops, wd, wx, planes)
+        ops.call("tris_conv3x3_wgrad_f32", ops.P(xx), ops.P(dd), ops.P(dw), B, H, H, C1, C2, 1, ops.P(ws), ws.numel() * 4, ops._stream())
+        res[planes] = (y, dx, dw)
+    torch.cuda.synchronize()
+    for a, b, name in zip(res[False], res[True], ("forward", "dgrad", "wgrad")):
+        assert torch.equal(a, b), name
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    assert float((res[True][0].double() - ref).norm() / ref.norm()) < 2e-6
+
+
+def _bn_case(M, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3).cuda()
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).cuda(), (0.2 * torch.randn(C, generator=g)).cuda()
+    mean = x.mean(0).contiguous()
+    invstd = torch.rsqrt(x.var(0, unbiased=False) + 1e-5).contiguous()
+    return x, gamma, beta, mean, invstd
+
+
+@pytest.mark.parametrize("rk", [0, 1, 2])
+@pytest.mark.parametrize("M,C", [(600, 64), (4099, 256), (333, 2048)])
+def test_batchnorm_apply_with_plane_output(ops, rk, M, C):
+    """= tris_bn_apply_f32 rounded to the h2 operand at the scale of the Samuelson bound (+ the residual's bound)"""
+    x, gamma, beta, mean, invstd = _bn_case(M, C, M + C + rk)
+    resid = torch.relu(torch.randn(M, C, device="cuda")) * 3 if rk else None
+    rw = _word(ops, resid) if rk else None
+    rp = _planes(ops, resid, rw) if rk == 2 else resid
+    resid_seen = _unplanes(ops, rp, rw) if rk == 2 else resid     # (a plane residual is read as its h2 rounding)
+    want = torch.empty_like(x)
+    ops.call("tris_bn_apply_f32", ops.P(x), ops.P(mean), ops.P(invstd), ops.P(gamma), ops.P(beta), ops.P(resid_seen), ops.P(want), M, C, 1,
+             ops._stream())
+    word = torch.zeros(WORD, device="cuda", dtype=torch.int32)
+    ops.call("tris_bn_out_bound2_f32", ops.P(gamma), ops.P(beta), C, math.sqrt(M - 1), rw.data_ptr() if rk else None, word.data_ptr(),
+             ops._stream())
+    y = torch.empty_like(x)
+    ops.call("tris_bn_apply_pl_f32", ops.P(x), ops.P(mean), ops.P(invstd), ops.P(gamma), ops.P(beta), ops.P(rp), rk,
+             rw.data_ptr() if rk == 2 else None, ops.P(y), word.data_ptr(), M, C, 1, ops._stream())
+    torch.cuda.synchronize()
+    bound = float(word.max().view(torch.float32))
+    assert float(want.max()) <= bound
+    got = _unplanes(ops, y, word)
+    assert torch.equal(got, _h2_round(want.cpu(), bound).cuda())
+    assert float((got - want).abs().max()) <= bound * 2.0 ** -36 + float(want.abs().max()) * 2.0 ** -21
+
+
+def test_batchnorm_pool_and_avgpool_with_plane_output(ops):
+    B, H, W, C = 3, 8, 12, 64
+    x, gamma, beta, mean, invstd = _bn_case(B * H * W, C, 5)
+    want = torch.empty(B, H // 2, W // 2, C, device="cuda")
+    ops.call("tris_bn_apply_pool_f32", ops.P(x), ops.P(mean), ops.P(invstd), ops.P(gamma), ops.P(beta), ops.P(want), B, H, W, C, ops._stream())
+    word = torch.zeros(WORD, device="cuda", dtype=torch.int32)
+    ops.call("tris_bn_out_bound2_f32", ops.P(gamma), ops.P(beta), C, math.sqrt(B * H * W - 1), None, word.data_ptr(), ops._stream())
+    y = torch.empty_like(want)
+    ops.call("tris_bn_apply_pool_pl_f32", ops.P(x), ops.P(mean), ops.P(invstd), ops.P(gamma), ops.P(beta), ops.P(y), word.data_ptr(), B, H, W, C,
+             ops._stream())
+    torch.cuda.synchronize()
+    bound = float(word.max().view(torch.float32))
+    assert torch.equal(_unplanes(ops, y, word), _h2_round(want.cpu(), bound).cuda())
+    # average pool of a plane tensor: planes out at the same word
+    full = torch.relu(torch.randn(B, H, W, C, device="cuda"))
+    fw = _word(ops, full)
+    fp = _planes(ops, full, fw)
+    seen = _unplanes(ops, fp, fw)
+    want2 = torch.empty(B, H // 2, W // 2, C, device="cuda")
+    ops.call("tris_avgpool2_fwd_f32", ops.P(seen), ops.P(want2), B, H, W, C, ops._stream())
+    got2 = torch.empty_like(want2)
+    ops.call("tris_avgpool2_fwd_pl_f32", ops.P(fp), ops.P(got2), fw.data_ptr(), B, H, W, C, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(_unplanes(ops, got2, fw), _h2_round(want2.cpu(), float(full.max())).cuda())
+
+
+@pytest.mark.parametrize("mask", ["none", "x", "y"])
+@pytest.mark.parametrize("M,C", [(777, 64), (2500, 512)])
+def test_batchnorm_backward_apply_with_plane_output(ops, mask, M, C):
+    x, gamma, beta, mean, invstd = _bn_case(M, C, M + C)
+    dy = torch.randn(M, C, device="cuda") * 1e-3
+    y = torch.relu((x - mean) * invstd * gamma + beta + torch.randn(M, C, device="cuda"))
+    yw = _word(ops, y)
+    yp = _planes(ops, y, yw)
+    assert torch.equal(_unplanes(ops, yp, yw) > 0, y > 0)
+    sums = torch.empty(2 * C, device="cuda")
+    ws = ops.workspace(ops.query("tris_col_workspace_bytes", M, C))
+    dzw = torch.zeros(WORD, device="cuda", dtype=torch.int32)
+    ops.call("tris_amax_next", dzw.data_ptr())
+    if mask == "y":
+        ops.call("tris_bn_bwd_reduce_pl_f32", ops.P(dy), ops.P(yp), ops.P(x), ops.P(mean), ops.P(invstd), M, C, ops.P(sums), ops.P(sums, C),
+                 ops.P(ws), None, ops._stream())
+        ref_s = torch.empty(2 * C, device="cuda")
+        ops.call("tris_bn_bwd_reduce_f32", ops.P(dy), ops.P(y), ops.P(x), ops.P(mean), ops.P(invstd), M, C, ops.P(ref_s), ops.P(ref_s, C),
+                 ops.P(ws), None, None, None, ops._stream())
+        torch.cuda.synchronize()
+        assert torch.equal(sums, ref_s)          # the mask read from the planes is the mask read from y
+    else:
+        ops.call("tris_bn_bwd_reduce_f32", ops.P(dy), None, ops.P(x), ops.P(mean), ops.P(invstd), M, C, ops.P(sums), ops.P(sums, C), ops.P(ws),
+                 ops.P(gamma) if mask == "x" else None, ops.P(beta) if mask == "x" else None, None, ops._stream())
+    want, dz_want = torch.empty_like(x), torch.empty_like(x)
+    ops.call("tris_bn_bwd_apply_f32", ops.P(dy), ops.P(y) if mask == "y" else None, ops.P(x), ops.P(mean), ops.P(invstd), ops.P(gamma),
+             ops.P(sums), ops.P(sums, C), 1.0 / M, ops.P(want), ops.P(dz_want), M, C, ops.P(beta) if mask == "x" else None, ops._stream())
+    torch.cuda.synchronize()
+    assert float(dzw.max().view(torch.float32)) == float(dz_want.abs().max())     # the reduce pass left the amax of the masked gradient
+    word = torch.zeros(WORD, device="cuda", dtype=torch.int32)
+    ops.call("tris_bn_bwd_bound_f32", ops.P(gamma), ops.P(invstd), ops.P(sums), ops.P(sums, C), C, 1.0 / M, math.sqrt(M - 1), dzw.data_ptr(),
+             word.data_ptr(), ops._stream())
+    got, dz_got = torch.empty_like(x), torch.empty_like(x)
+    ops.call("tris_bn_bwd_apply_pl_f32", ops.P(dy), ops.P(yp) if mask == "y" else None, ops.P(x), ops.P(mean), ops.P(invstd), ops.P(gamma),
+             ops.P(sums), ops.P(sums, C), 1.0 / M, ops.P(got), word.data_ptr(), ops.P(dz_got), M, C, ops.P(beta) if mask == "x" else None,
+             ops._stream())
+    torch.cuda.synchronize()
+    bound = float(word.max().view(torch.float32))
+    assert float(want.abs().max()) <= bound <= 64 * float(want.abs().max())        # a bound, and not a loose one
+    assert torch.equal(dz_got, dz_want)
+    assert torch.equal(_unplanes(ops, got, word), _h2_round(want.cpu(), bound).cuda())
+
+
+def _stack(seed=0):
+    from tris_amd.CLIP.clip.model import Bottleneck
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(Bottleneck(64, 32, 1), Bottleneck(128, 32, 1), Bottleneck(128, 64, 2), Bottleneck(256, 64, 1)).cuda().train()
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if p.dim() == 1:
+                p.copy_(1 + 0.2 * torch.randn_like(p) if n_.endswith("weight") else 0.1 * torch.randn_like(p))
+    return net
+
+
+def test_bottleneck_stack_with_planes_matches_without(ops):
+    """four Bottlenecks (identity, down-sampling with and without stride) forward + backward: operand planes on vs off, same h2
+    arithmetic -- the difference is the 22-bit rounding of what is stored between a BatchNorm and its consumers"""
+    from tris_amd.config import cfg
+    x0 = torch.relu(torch.randn(4, 16, 16, 64, device="cuda"))
+    res = {}
+    for planes in (True, False):
+        cfg.h2_planes = planes
+        net = _stack()
+        ops.h2_begin_step()
+        before = dict(ops.PL_STATS)
+        x = x0.clone().requires_grad_()
+        y = net(x)
+        y = ops.unplanes(y)
+        assert (ops.pl_word(y) is None)
+        loss = (y * torch.linspace(-1, 1, y.shape[-1], device="cuda")).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[planes] = (y.detach().clone(), x.grad.clone(), {n_: p.grad.clone() for n_, p in net.named_parameters()})
+        if planes:
+            d = {k: ops.PL_STATS[k] - before[k] for k in before}
+            assert d["products"] >= 3 * 4 * 3 and d["dx_planes"] == d["dy_planes"] > 0 and d["mixed"] == 0, d
+    cfg.h2_planes = True
+    y1, gx1, g1 = res[True]
+    y0, gx0, g0 = res[False]
+    assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+    assert float((gx1 - gx0).norm() / gx0.norm()) < 2e-5
+    for n_ in g0:
+        assert float((g1[n_] - g0[n_]).norm() / g0[n_].norm().clamp_min(1e-12)) < 5e-5, n_
+
+
+def test_training_step_with_planes_against_the_golden_step(ops, golden):
+    """the B = 2 step of tests/test_gpu_parity.py (G5) with operand planes on: the trunk's products run on planes (counted), nothing
+    falls back to rebuilt fp32 tensors on the hot path, every plane gradient finds its one consumer, and the losses are the
+    reference's within the north star's 1e-3"""
+    import warnings
+    from tris_amd.args import get_parser
+    from tris_amd.CLIP import clip
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import freeze_aux, train_step
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    args = get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20", "--negative_samples", "3",
+                                    "--batch_size", "2"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = TRIS(args).cuda()
+        aux, _ = clip.load("ViT-B-32", device="cuda", txt_length=20)
+    seed_fill(model.state_dict(), 1234)
+    seed_fill(aux.state_dict(), 4321)
+    aux = freeze_aux(aux)
+    batch = synthetic_batch(2, 320, 20, 3, seed=7)
+    model.train()
+    bb, new = model.trainable_parameters()
+    opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr, weight_decay=args.weight_decay)
+    before = dict(ops.PL_STATS)
+    losses = train_step(model, aux, opt, batch["img"].cuda(), batch["word_ids"].cuda(), batch["neg_word_ids"].cuda(), args).tolist()
+    d = {k: ops.PL_STATS[k] - before[k] for k in before}
+    # 16 Bottlenecks x (3 convolutions + 4 shortcut convolutions) x (forward, data gradient, weight gradient) + the stem + vis_project
+    assert d["products"] >= 150 and d["dx_planes"] == d["dy_planes"] >= 50 and d["mixed"] <= 1 and d["unplanes"] <= 3, d
+    ref = golden("g5_g6_step.npz")["losses"]
+    assert abs(losses[0] - ref[0]) < 1e-3 and abs(losses[1] - ref[1]) < 1e-3
+    assert abs(losses[2] - ref[2]) < 1e-4 and abs(losses[3] - ref[3]) < 1e-4

@@ -1,0 +1,261 @@
+// Dev probe: the h2 GEMM core fed by OPERAND PLANES through LDS-DMA -- C[M,N] = A[M,K] . B[N,K]^T, A and B given as P8 fp16 piece
+// planes (tris_amd/csrc/planes.h), fp32 out.  The main loop has no VALU work on the operands at all: global_load_lds_dwordx4 streams
+// 8 rows x 128 bytes (= 32 k of both planes) per wave instruction into a lane-linear LDS image whose 16-byte pieces are XOR-swizzled
+// on the SOURCE side (piece ^= (row >> 1) & 7: the 16 lanes of every ds_read_b128 service group hit 16 distinct slots), fragments are
+// single ds_read_b128, three v_mfma_f32_32x32x16_f16 per product into two accumulator sets.
+// Variants (template): tile, wave grid, LDS stages (2: two barriers per k step; 3: one barrier, a tile in flight across it), and
+// ablations of the loop (ABL 1: no MFMA; 2: no fragment reads; 4: no global loads after the prologue).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tris_amd/csrc tools/probes/h2_plane_probe.hip -o tools/probes/h2_plane_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include "x3_split.h"
+#include "planes.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void to_planes(const float* __restrict__ x, float* __restrict__ out, long n8, float s) {
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += (long)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(x + g * 8), b = *reinterpret_cast<const float4*>(x + g * 8 + 4);
+    pl8_store(out, g, pl8_split(a, b, s));
+  }
+}
+__global__ void ref_rows(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int rows, int N, int K) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (n >= N || m >= rows) return;
+  double s = 0.0;
+  for (int k = 0; k < K; ++k) s += (double)A[(long)m * K + k] * (double)B[(long)n * K + k];
+  C[(long)m * N + n] = (float)s;
+}
+
+template <int BM, int BN, int NWM, int NWN, int NST, int OCC, int ABL = 0>
+__global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void plane_kernel(const float* __restrict__ A,
+                                                                                       const float* __restrict__ B,
+                                                                                       float* __restrict__ C, int M, int N, int K,
+                                                                                       float inv_scale) {
+  constexpr int NW = NWM * NWN, NTHR = NW * 64;
+  constexpr int WM = BM / NWM, WN = BN / NWN, FM = WM / 32, FN = WN / 32;
+  constexpr int A_ST = BM * 128, B_ST = BN * 128, ST = A_ST + B_ST;   // bytes per stage (32 k x 2 planes = 128 bytes per row)
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;                   // LDS-DMA instructions per wave per stage (8 rows each)
+  static_assert(GA >= 1 && GB >= 1 && GA * 8 * NW == BM && GB * 8 * NW == BN, "tile / wave count mismatch");
+  __shared__ __attribute__((aligned(1024))) char lds[NST * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  // this lane's source rows / pieces for its LDS-DMA instructions: instruction q of the wave covers tile rows (wave * G + q) * 8 .. + 7
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const char* a_src[GA];
+  const char* b_src[GB];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int r = (wave * GA + q) * 8 + lrow;
+    a_src[q] = reinterpret_cast<const char*>(A + (long)min(m0 + r, M - 1) * K) + ((lslot ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const int r = (wave * GB + q) * 8 + lrow;
+    b_src[q] = reinterpret_cast<const char*>(B + (long)min(n0 + r, N - 1) * K) + ((lslot ^ ((r >> 1) & 7)) << 4);
+  }
+  auto issue = [&](int stage, int kt) {
+    if ((ABL & 4) && kt >= NST - 1) return;
+    char* sa = lds + stage * ST + (wave * GA) * 1024;
+    char* sb = lds + stage * ST + A_ST + (wave * GB) * 1024;
+#pragma unroll
+    for (int q = 0; q < GA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < GB; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + (long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(sb + q * 1024), 16, 0, 0);
+  };
+  f32x16 acc[FM][FN], acx[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
+  const int li = lane & 31, kh = lane >> 5;
+  // fragment addresses inside a stage: row * 128 + ((2 (2 g + kh) + plane) ^ ((row >> 1) & 7)) * 16
+  int a_row[FM], b_row[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_row[i] = wm * WM + i * 32 + li;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) b_row[j] = wn * WN + j * 32 + li;
+  auto compute = [&](int stage) {
+    const char* sa = lds + stage * ST;
+    const char* sb = sa + A_ST;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f16x8 ah[FM], al[FM], bh[FN], bl[FN];
+      if (!(ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int sw = (a_row[i] >> 1) & 7, p0 = 2 * (2 * g + kh);
+          ah[i] = *reinterpret_cast<const f16x8*>(sa + a_row[i] * 128 + ((p0 ^ sw) << 4));
+          al[i] = *reinterpret_cast<const f16x8*>(sa + a_row[i] * 128 + (((p0 + 1) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int sw = (b_row[j] >> 1) & 7, p0 = 2 * (2 * g + kh);
+          bh[j] = *reinterpret_cast<const f16x8*>(sb + b_row[j] * 128 + ((p0 ^ sw) << 4));
+          bl[j] = *reinterpret_cast<const f16x8*>(sb + b_row[j] * 128 + (((p0 + 1) ^ sw) << 4));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) { ah[i] = (f16x8)(_Float16)(1.0f + lane); al[i] = ah[i]; }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { bh[j] = (f16x8)(_Float16)(0.5f); bl[j] = bh[j]; }
+      }
+      if (!(ABL & 1)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j][0] += (float)ah[i][0] * (float)bh[j][0] + (float)al[i][1] * (float)bl[j][1];
+      }
+    }
+  };
+  const int nk = K / 32;
+  constexpr int GPS = GA + GB;   // LDS-DMA instructions per wave per stage
+  if constexpr (NST == 2) {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      // (everyone has finished reading stage (kt + 1) & 1 -- the barrier that closed the previous step)
+      if (kt + 1 < nk) {
+        issue((kt + 1) & 1, kt + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // every wave's pieces of stage kt have landed
+      compute(kt & 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // stage kt landed everywhere AND everyone is done reading stage (kt - 1) % 3 = (kt + 2) % 3
+      if (kt + 2 < nk) issue((kt + 2) % 3, kt + 2);
+      compute(kt % 3);
+    }
+  }
+  // epilogue (probe: direct stores of the accumulator layout)
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < M && col < N) C[(long)row * N + col] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]) * inv_scale;
+      }
+    }
+}
+
+static float host_scale(float amax) {
+  int e;
+  frexpf(amax, &e);          // amax = f * 2^e, f in [0.5, 1)  ->  floor(log2 amax) = e - 1
+  return ldexpf(1.0f, 13 - (e - 1));
+}
+
+template <int BM, int BN, int NWM, int NWN, int NST, int OCC, int ABL>
+static void run(const char* name, const float* Ap, const float* Bp, float* C, const float* Cref, int M, int N, int K, float inv,
+                int ref_rows_n) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  auto launch = [&]() {
+    hipLaunchKernelGGL((plane_kernel<BM, BN, NWM, NWN, NST, OCC, ABL>), dim3(tiles), dim3(NWM * NWN * 64), 0, 0, Ap, Bp, C, M, N, K, inv);
+  };
+  for (int i = 0; i < 3; ++i) launch();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  const int it = 10;
+  for (int i = 0; i < it; ++i) launch();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= it;
+  double err = -1.0;
+  if (ABL == 0 && Cref) {
+    std::vector<float> h((size_t)ref_rows_n * N), r((size_t)ref_rows_n * N);
+    hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), Cref, r.size() * 4, hipMemcpyDeviceToHost);
+    double num = 0, den = 0;
+    for (size_t i = 0; i < h.size(); ++i) { num = fmax(num, fabs((double)h[i] - r[i])); den = fmax(den, fabs((double)r[i])); }
+    err = num / den;
+  }
+  printf("%-44s M%-7d N%-5d K%-5d %9.1f us %7.1f TF/s  err/max %.2e\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) * 1e-12, err);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  struct Shape { int M, N, K; };
+  std::vector<Shape> shapes = {{4096, 4096, 4096}, {76800, 256, 2304}, {19200, 512, 4608}, {19200, 1024, 1024}, {19200, 1024, 256}, {4800, 2048, 1024}};
+  for (const Shape& s : shapes) {
+    const int M = s.M, N = s.N, K = s.K;
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    float amA = 0, amB = 0;
+    for (auto& v : hA) { v = rnd(); amA = fmaxf(amA, fabsf(v)); }
+    for (auto& v : hB) { v = rnd(); amB = fmaxf(amB, fabsf(v)); }
+    float *A, *B, *Ap, *Bp, *C, *Cref;
+    hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&Ap, hA.size() * 4); hipMalloc(&Bp, hB.size() * 4);
+    hipMalloc(&C, (size_t)M * N * 4);
+    const int RR = 128;
+    hipMalloc(&Cref, (size_t)RR * N * 4);
+    hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+    const float sA = host_scale(amA), sB = host_scale(amB);
+    hipLaunchKernelGGL(to_planes, dim3(2048), dim3(256), 0, 0, A, Ap, (long)M * K / 8, sA);
+    hipLaunchKernelGGL(to_planes, dim3(2048), dim3(256), 0, 0, B, Bp, (long)N * K / 8, sB);
+    hipLaunchKernelGGL(ref_rows, dim3((N + 255) / 256, RR), dim3(256), 0, 0, A, B, Cref, RR, N, K);
+    hipDeviceSynchronize();
+    const float inv = 1.0f / (sA * sB);
+#define RUN(BM, BN, NWM, NWN, NST, OCC, ABL, NAME) run<BM, BN, NWM, NWN, NST, OCC, ABL>(NAME, Ap, Bp, C, Cref, M, N, K, inv, RR)
+    RUN(128, 128, 2, 4, 2, 2, 0, "128x128 8w(2x4) 2 stages occ2");
+    RUN(128, 128, 2, 4, 3, 1, 0, "128x128 8w(2x4) 3 stages occ1");
+    RUN(128, 128, 2, 2, 2, 2, 0, "128x128 4w(2x2) 2 stages occ2");
+    RUN(128, 128, 2, 2, 3, 1, 0, "128x128 4w(2x2) 3 stages occ1");
+    RUN(256, 128, 4, 2, 2, 1, 0, "256x128 8w(4x2) 2 stages occ1");
+    RUN(256, 128, 4, 2, 3, 1, 0, "256x128 8w(4x2) 3 stages occ1");
+    RUN(256, 128, 2, 2, 2, 1, 0, "256x128 4w(2x2) 2 stages occ1");
+    RUN(256, 128, 2, 2, 3, 1, 0, "256x128 4w(2x2) 3 stages occ1");
+    RUN(256, 256, 2, 4, 2, 1, 0, "256x256 8w(2x4) 2 stages occ1");
+    RUN(128, 64, 2, 2, 2, 2, 0, "128x64  4w(2x2) 2 stages occ2");
+    RUN(128, 64, 2, 2, 3, 2, 0, "128x64  4w(2x2) 3 stages occ2");
+    // ablations of the two leading candidates
+    RUN(128, 128, 2, 4, 2, 2, 1, "128x128 8w 2st  -mfma");
+    RUN(128, 128, 2, 4, 2, 2, 2, "128x128 8w 2st  -fragreads");
+    RUN(128, 128, 2, 4, 2, 2, 4, "128x128 8w 2st  -loads");
+    RUN(128, 128, 2, 4, 2, 2, 6, "128x128 8w 2st  mfma + barriers only");
+    RUN(256, 128, 4, 2, 3, 1, 1, "256x128 8w 3st  -mfma");
+    RUN(256, 128, 4, 2, 3, 1, 2, "256x128 8w 3st  -fragreads");
+    RUN(256, 128, 4, 2, 3, 1, 4, "256x128 8w 3st  -loads");
+    RUN(256, 128, 4, 2, 3, 1, 6, "256x128 8w 3st  mfma + barriers only");
+    hipFree(A); hipFree(B); hipFree(Ap); hipFree(Bp); hipFree(C); hipFree(Cref);
+  }
+  return 0;
+}

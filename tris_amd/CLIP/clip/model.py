@@ -68,7 +68,7 @@ class BatchNorm2d(nn.Module):
             self.num_batches_tracked += self._nbt_pending
             self._nbt_pending = 0
 
-    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False, bwd_link=False, pool=False):
+    def forward(self, x, resid=None, relu=False, grad_box=None, lazy=False, bwd_link=False, pool=False, planes=False, dx_planes=False):
         """pool=True: returns avgpool2(relu(bn(x))) -- the AvgPool2d(2) that follows is part of the op (train mode: one kernel,
         the full-size activation is never written).
         bwd_link=True: the caller guarantees that the output has exactly ONE autograd consumer; if that is a 1x1 convolution
@@ -77,7 +77,7 @@ class BatchNorm2d(nn.Module):
             self._nbt_pending += 1
         group = self.process_group if self.training else None
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, resid, relu,
-                              self.training, self.momentum, self.eps, group, grad_box, lazy, bwd_link, pool)
+                              self.training, self.momentum, self.eps, group, grad_box, lazy, bwd_link, pool, planes, dx_planes)
 
 
 class AvgPool2d(nn.Module):
@@ -124,20 +124,24 @@ class Bottleneck(nn.Module):
         out = self.conv1(x, stats=tr, grad_box=box)
         # bn1 + ReLU feed conv2 only: where direct kernels serve conv2 (forward and weight gradient) the normalised tensor is
         # never written -- they normalise conv1's raw output while staging it (ops.batch_norm lazy=True)
-        out = self.bn1(out, relu=True, lazy=tr and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout), bwd_link=True)
+        # (h2 with operand planes: every BatchNorm of the block writes its output -- and the gradient of its input, which only the
+        #  backward of the convolution before it reads -- as fp16 piece planes, ops.batch_norm planes / dx_planes; the lazy form is off then)
+        pl = tr and ops.planes_on()
+        out = self.bn1(out, relu=True, lazy=tr and not pl and ops.conv3x3_bnin_ok(out.shape, self.conv2.cout), bwd_link=True,
+                       planes=pl, dx_planes=pl)
         if self.stride > 1:   # bn2 + ReLU + AvgPool2d(stride) as one op
-            out = self.bn2(self.conv2(out, stats=tr), relu=True, pool=True)
+            out = self.bn2(self.conv2(out, stats=tr), relu=True, pool=True, planes=pl, dx_planes=pl)
         else:
-            out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True)   # one consumer: conv3
+            out = self.bn2(self.conv2(out, stats=tr), relu=True, bwd_link=True, planes=pl, dx_planes=pl)   # one consumer: conv3
         out = self.conv3(out, stats=tr)
         if self.downsample is not None:
             if isinstance(self.downsample[0], AvgPool2d):
                 idn = self.downsample[1](self.downsample[0](x, grad_box_out=box), stats=tr)
             else:
                 idn = self.downsample[1](self.downsample[0](x), stats=tr, grad_box_out=box)
-            idn = self.downsample[2](idn)
-            return self.bn3(out, resid=idn, relu=True, bwd_link=link_out)
-        return self.bn3(out, resid=x, relu=True, grad_box=box, bwd_link=link_out)  # relu(bn3(conv3) + identity), fused
+            idn = self.downsample[2](idn, dx_planes=pl)     # (the shortcut's output stays fp32: bn3's pass is its only reader)
+            return self.bn3(out, resid=idn, relu=True, bwd_link=link_out, planes=pl, dx_planes=pl)
+        return self.bn3(out, resid=x, relu=True, grad_box=box, bwd_link=link_out, planes=pl, dx_planes=pl)  # relu(bn3(conv3) + identity), fused
 
 
 class Linear(nn.Module):
@@ -204,12 +208,15 @@ class ModifiedResNet(nn.Module):
         it to issue the text encoder (side stream) in the middle of the trunk, see model_stage1.TRIS.forward."""
         x = ops.nchw_to_nhwc(x.float())
         tr = self.training
+        pl = tr and ops.planes_on()    # (h2 with operand planes: see Bottleneck.forward; conv1 reads the image, its gradient stays fp32)
         x = self.conv1(x, stats=tr)                        # (conv1 has Cin=3: not eligible, separate statistics pass)
-        x = self.bn1(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout), bwd_link=True)   # folded into conv2 where possible
+        x = self.bn1(x, relu=True, lazy=tr and not pl and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout), bwd_link=True,
+                     planes=pl)   # folded into conv2 where possible
         x = self.conv2(ops.cut(x), stats=tr)    # (cuts: the stem is the END of backward -- a segmented capture releases each of its
-        x = self.bn2(x, relu=True, lazy=tr and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout), bwd_link=True)   # ... into conv3
+        x = self.bn2(x, relu=True, lazy=tr and not pl and ops.conv3x3_bnin_ok(x.shape, self.conv3.cout), bwd_link=True,
+                     planes=pl, dx_planes=pl)   # ... into conv3
         x = ops.cut(x)                          # weight gradients behind its own convolution, not behind the whole stem)
-        x = self.bn3(self.conv3(x, stats=tr), relu=True, pool=True)   # bn3 + ReLU + AvgPool2d(2) as one op
+        x = self.bn3(self.conv3(x, stats=tr), relu=True, pool=True, planes=pl, dx_planes=pl)   # bn3 + ReLU + AvgPool2d(2) as one op
         x = ops.cut(x)                                     # (segment boundary of a segmented capture; otherwise x itself)
         if hooks and "stem" in hooks:
             hooks["stem"]()
@@ -231,7 +238,7 @@ class ModifiedResNet(nn.Module):
 
     def forward(self, x):
         # reference returns NCHW tensors; hand out NCHW-shaped views of the channels-last buffers (no copy)
-        outs = [o.permute(0, 3, 1, 2) for o in self.forward_cl(x)]
+        outs = [ops.unplanes(o).permute(0, 3, 1, 2) for o in self.forward_cl(x)]   # (h2 operand planes: callers get fp32 values)
         outs.append(None)  # [x_global, x_local] of attnpool: discarded by every Stage-1 caller
         return tuple(outs)
 

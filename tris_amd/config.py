@@ -28,6 +28,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   ddp_check          TRIS_DDP_CHECK            NaN-poison check of the gradient reducer's release order
   ddp_sparse_embed   TRIS_DDP_SPARSE_EMBED     token-embedding gradient as a sparse (ids, rows) exchange
   random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
+  h2_planes          TRIS_H2_PLANES            h2 arithmetic: the RN50 trunk's activations / gradients / weights travel as fp16 operand planes
 """
 import contextlib
 import os
@@ -62,6 +63,7 @@ class _Config:
         self.ddp_check = e("TRIS_DDP_CHECK") == "1"
         self.ddp_sparse_embed = _flag("TRIS_DDP_SPARSE_EMBED", True)
         self.random_init = e("TRIS_RANDOM_INIT") == "1"
+        self.h2_planes = _flag("TRIS_H2_PLANES", True)
 
     @contextlib.contextmanager
     def override(self, **kw):

@@ -28,14 +28,14 @@ for pair in 00 01 10 11 20 22 13; do
     pids+=($!)
   fi
 done
-for prec in 1 3; do   # the direct 3x3 kernels, one unit per arithmetic (x3, h2)
+for prec in 1 3 4; do   # the direct 3x3 kernels, one unit per arithmetic (x3, h2, h2 on operand planes)
   o="$OBJ/conv_direct_$prec.o"
   if stale "$o" "$HERE/conv_direct.hip"; then
     $HIPCC $FLAGS -DTRIS_DIRECT_PREC=$prec -c "$HERE/conv_direct.hip" -o "$o" &
     pids+=($!)
   fi
 done
-for f in gemm_conv norm attn attn_mfma heads optim eval xattn xattn_fused xattn_px data comm; do
+for f in gemm_conv norm planes attn attn_mfma heads optim eval xattn xattn_fused xattn_px data comm; do
   [ -f "$HERE/$f.hip" ] || continue
   if stale "$OBJ/$f.o" "$HERE/$f.hip"; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &

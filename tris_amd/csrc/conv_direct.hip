@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
                                                                  const float* __restrict__ in_mean, const float* __restrict__ in_invstd,
                                                                  const float* __restrict__ in_gamma, const float* __restrict__ in_beta,
                                                                  const unsigned* __restrict__ amax_dy, const unsigned* __restrict__ amax_x) {
-  constexpr bool H2 = (PREC == 3);
+  constexpr bool H2 = (PREC == 3 || PREC == 4);
+  constexpr bool PLN = (PREC == 4);   // X and dY arrive as fp16 piece planes (gemm_fast.h PREC 4): pieces go to LDS as they are
   constexpr int NPL = H2 ? 2 : 3;   // 16-bit planes per operand
   // XW = window width in pixels: 16 (a 16-pixel k group = one window row) or 8 (= two window rows: W = 40)
   constexpr int NPX = R * XW, NSL = (R + 2) * (XW + 2), PITCH = XW + 2, NG = NPX / 16;
@@ -217,6 +218,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
     for (int q = 0; q < PA; ++q) {
       const int j = tid + q * 256;
       const int px = j / (COT / 4), c4 = j - px * (COT / 4);
+      if constexpr (PLN) {
+        *reinterpret_cast<float4*>(Ash + (c4 & 1) * (NPX * KS_A) + px * KS_A + (c4 >> 1) * 16) = ra[q];
+        continue;
+      }
       const Split4 sp = split_a(ra[q]);
       char* d = Ash + px * KS_A + c4 * 8;
       *reinterpret_cast<uint2*>(d) = sp.hi;
@@ -229,6 +234,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad3x3_direct_kernel(const float* 
       const int sl = j / (CIT / 4), c4 = j - sl * (CIT / 4);
       if (PX * 256 * 4 == NSL * CIT || sl < NSL) {
         float4 v = rx[q];
+        if constexpr (PLN) {
+          *reinterpret_cast<float4*>(Xsh + (c4 & 1) * (NSL * KS_X) + sl * KS_X + (c4 >> 1) * 16) = v;
+          continue;
+        }
         if (in_mean != nullptr && ((rx_ok >> q) & 1u)) {
           v.x = fmaxf((v.x - x_mu.x) * x_sc.x + x_be.x, 0.f);
           v.y = fmaxf((v.y - x_mu.y) * x_sc.y + x_be.y, 0.f);
@@ -387,7 +396,7 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
                      bn.mean, bn.invstd, bn.gamma, bn.beta, amax_dy, amax_x)
   // blocks per CU the kernel is compiled for: two in x3; h2 holds the tap accumulators PLUS a transient set and the fragments of
   // all its k groups -- more than 256 registers -- and runs one block per CU
-  constexpr int OCC = PREC == 3 ? 1 : 2;
+  constexpr int OCC = (PREC == 3 || PREC == 4) ? 1 : 2;
   switch (id) {
     case 1: TRIS_WG_GO(32, 32, 1, 1, 4, 4, OCC, 16); break;
     case 2: TRIS_WG_GO(64, 32, 2, 1, 2, 4, OCC, 16); break;
@@ -407,10 +416,10 @@ static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, 
 }  // namespace
 
 #define TRIS_HIDDEN extern "C" __attribute__((visibility("hidden")))
-// One arithmetic per translation unit (build.sh: -DTRIS_DIRECT_PREC=1 -> x3, =3 -> h2); the stem's first convolution (exact f32
+// One arithmetic per translation unit (build.sh: -DTRIS_DIRECT_PREC=1 -> x3, =3 -> h2, =4 -> h2 on operand planes); the stem's first convolution (exact f32
 // MFMA) lives in the x3 unit.
 #ifndef TRIS_DIRECT_PREC
-#error "compile with -DTRIS_DIRECT_PREC=1 or 3"
+#error "compile with -DTRIS_DIRECT_PREC=1, 3 or 4"
 #endif
 #define TRIS_CAT2(a, b) a##b
 #define TRIS_DIRECT_NAME(base, prec) TRIS_CAT2(base, prec)

@@ -103,6 +103,9 @@ static Options g_opt = init_options();
 static int g_mode_default = 1;
 static thread_local int g_mode_thread = -1;
 #define g_gemm_mode (g_mode_thread >= 0 ? g_mode_thread : g_mode_default)
+// 4 = h2 with both operands arriving as fp16 piece planes (gemm_fast.h PREC 4): never a process default, only ever set for ONE
+// product by its arming (tris_h2_next_planes)
+static inline bool mode_h2() { return g_gemm_mode == 3 || g_gemm_mode == 4; }
 
 }  // namespace
 // one configuration of one operand-kind pair: gemm_inst.hip (hidden symbols of the same shared object)
@@ -131,8 +134,8 @@ int run_cfg(const GemmParams& p0, int batch, float* ws, hipStream_t st, const Cf
 // "h2" for ONE product: tris_h2_next() arms the calling thread; the next dense product launched from it (tris_gemm_f32,
 // tris_gemm_bnstat_f32, tris_gemm_bnbwd_f32) runs with two fp16 pieces per operand (PREC 3) and these operand scales, whatever
 // the process-wide mode -- if the fast kernel serves its shape; otherwise it runs as usual.  One shot.
-struct H2Next { const unsigned* a; const unsigned* b; float sa, sb; bool armed; };
-static thread_local H2Next g_h2_next = {nullptr, nullptr, 0.f, 0.f, false};
+struct H2Next { const unsigned* a; const unsigned* b; float sa, sb; bool armed; bool planes; int flags; };
+static thread_local H2Next g_h2_next = {nullptr, nullptr, 0.f, 0.f, false, false, 0};
 // every entry point that honours the arming TAKES it first thing (h2_take), whether or not it then launches anything: an arming
 // never survives the call it was made for
 static H2Next h2_take() {
@@ -143,17 +146,19 @@ static H2Next h2_take() {
 struct H2Guard {
   int saved;
   bool on;
-  H2Guard(GemmParams& p, const H2Next& n) : saved(g_mode_thread), on(false) {
+  bool bad;   // operand planes handed to a product the fast kernel does not serve: the entry point fails (there is no fp32 operand to fall back on)
+  H2Guard(GemmParams& p, const H2Next& n) : saved(g_mode_thread), on(false), bad(false) {
     if (!n.armed) return;
-    if (!gemm_fast_ok(p)) return;
+    if (!gemm_fast_ok(p)) { bad = n.planes; return; }
     p.h2_amaxA = n.a; p.h2_amaxB = n.b; p.h2_sA = n.sa; p.h2_sB = n.sb;
-    g_mode_thread = 3;
+    g_mode_thread = n.planes ? 4 : 3;
+    p.bnb_y_pl = (n.planes && (n.flags & 1)) ? 1 : 0;
     on = true;
   }
   ~H2Guard() { if (on) g_mode_thread = saved; }
 };
 
-static bool pipe_ok(const GemmParams& p) { return (g_gemm_mode == 1 || g_gemm_mode == 3) && gemm_fast_ok(p); }
+static bool pipe_ok(const GemmParams& p) { return (g_gemm_mode == 1 || mode_h2()) && gemm_fast_ok(p); }
 // static choice of the loop structure (the autotuner times both)
 static int default_pipe(const GemmParams& p, int bm, int bn, int splitk) {
   if (!pipe_ok(p) || bn == 32) return 0;
@@ -162,7 +167,7 @@ static int default_pipe(const GemmParams& p, int bm, int bn, int splitk) {
   // 3-13 % (fwd 40x40x256: 165 -> 175, 20x20x512: 136 -> 154, wgrad 20x20x512: 154 -> 174 TFLOP/s); the short-K 1x1
   // products and the transformer GEMMs are on par or a few % slower -> static default by kind, the autotuner times both
   if (g_opt.pipe_default >= 0) return g_opt.pipe_default;
-  if (g_gemm_mode == 3) return 0;   // (h2: the classic loop unless the tuner finds the pipelined one faster for the shape)
+  if (mode_h2()) return 0;   // (h2: the classic loop unless the tuner finds the pipelined one faster for the shape)
   return p.gC >= 128 ? 1 : 0;
 }
 
@@ -197,7 +202,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
       if (c == 3 && !(p.N <= 32 && fastk)) continue;  // 32-wide outputs (stem convolutions): half of a 64-wide tile would be padding
       const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
       // MFMA cycles of one 32x32 fragment pair per 32-deep step: 16 f32 MFMAs x 64, or 12 bf16 MFMAs x 32 (x3 mode)
-      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 3 ? 192.0 + 200.0 : 1024.0) * pen[c];
+      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 3 ? 192.0 + 200.0 : g_gemm_mode == 4 ? 192.0 + 100.0 : 1024.0) * pen[c];
       const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
       for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
         if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
@@ -334,7 +339,7 @@ static thread_local int g_conv_direct_thread = -1;
       int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co, float* ws, long ws_bytes, int blocks,    \
       void* stream, const float* mean, const float* invstd, const float* gamma, const float* beta, const unsigned* amax_dy,            \
       const unsigned* amax_x);
-TRIS_DIRECT_DECL(1) TRIS_DIRECT_DECL(3)
+TRIS_DIRECT_DECL(1) TRIS_DIRECT_DECL(3) TRIS_DIRECT_DECL(4)
 #undef TRIS_DIRECT_DECL
 extern "C" __attribute__((visibility("hidden"))) int tris_internal_stem_conv1(const float* X, const float* Wt, float* Y, int B, int H, int W,
     int Cin, int Cout, int stride, double* stat_part, void* stream);
@@ -344,7 +349,8 @@ int run_halo(const GemmParams& p0, int id, hipStream_t st) {
   const int dg = BKIND == B_KN_DGRAD ? 1 : 0;
   GemmParams p = p0;
   p.nt = stream_nt(p, 1);
-  const int rc = g_gemm_mode == 3 ? tris_internal_run_halo_p3(&p, id, dg, st) : tris_internal_run_halo_p1(&p, id, dg, st);
+  const int rc = g_gemm_mode == 4 ? tris_internal_run_halo_p4(&p, id, dg, st)
+                 : g_gemm_mode == 3 ? tris_internal_run_halo_p3(&p, id, dg, st) : tris_internal_run_halo_p1(&p, id, dg, st);
   if (rc == 0) ++g_direct_launches[0];
   return rc;
 }
@@ -352,7 +358,9 @@ int run_halo(const GemmParams& p0, int id, hipStream_t st) {
 static int run_wgrad_direct(int id, const float* X, const float* dY, float* dW, int B, int H, int W, int Ci, int Co, float* ws,
                             long ws_bytes, hipStream_t st, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr},
                             const unsigned* amax_dy = nullptr, const unsigned* amax_x = nullptr) {
-  const int rc = g_gemm_mode == 3 ? tris_internal_run_wgrad_direct_p3(id, X, dY, dW, B, H, W, Ci, Co, ws, ws_bytes, g_opt.wg_blocks, st,
+  const int rc = g_gemm_mode == 4 ? tris_internal_run_wgrad_direct_p4(id, X, dY, dW, B, H, W, Ci, Co, ws, ws_bytes, g_opt.wg_blocks, st,
+                                                                      nullptr, nullptr, nullptr, nullptr, amax_dy, amax_x)
+                 : g_gemm_mode == 3 ? tris_internal_run_wgrad_direct_p3(id, X, dY, dW, B, H, W, Ci, Co, ws, ws_bytes, g_opt.wg_blocks, st,
                                                                       bn.mean, bn.invstd, bn.gamma, bn.beta, amax_dy, amax_x)
                                   : tris_internal_run_wgrad_direct_p1(id, X, dY, dW, B, H, W, Ci, Co, ws, ws_bytes, g_opt.wg_blocks, st,
                                                                       bn.mean, bn.invstd, bn.gamma, bn.beta, nullptr, nullptr);
@@ -366,7 +374,7 @@ static int run_stem_conv1(const float* X, const float* Wt, float* Y, int B, int 
 }
 
 static bool halo_shape_ok(const GemmParams& p) {
-  return (g_gemm_mode == 1 || g_gemm_mode == 3) && p.gStride == 1 && p.gC % 16 == 0 && p.fastB && al16(p.A) && al16(p.B) && p.N % 4 == 0 &&
+  return (g_gemm_mode == 1 || mode_h2()) && p.gStride == 1 && p.gC % 16 == 0 && p.fastB && al16(p.A) && al16(p.B) && p.N % 4 == 0 &&
          p.gHo == p.gH && p.gWo == p.gW && (long)p.gB * p.gH * p.gW * p.gC < (1L << 31);
 }
 // static choice (no autotuning, or under stream capture), from the measured table in DESIGN.md: the 2-D patch kernels win
@@ -499,6 +507,7 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
     ws_bytes = 0;
   }
   H2Guard h2(p, h2n);
+  if (h2.bad) return (int)hipErrorInvalidValue;
   if (!transA && transB) return launch_cfg<A_ROWK, B_NK>(p, batch, workspace, ws_bytes, st);
   if (!transA && !transB) return launch_cfg<A_ROWK, B_KN>(p, batch, workspace, ws_bytes, st);
   if (transA && !transB) return launch_cfg<A_COLK, B_KN>(p, batch, workspace, ws_bytes, st);
@@ -522,6 +531,7 @@ extern "C" int tris_conv3x3_fwd_f32(const float* X, const float* Wt, float* Y, i
   if (const int rows = run_stem_conv1(X, Wt, Y, B, H, W, Cin, Cout, stride, nullptr, (hipStream_t)stream))
     return rows > 0 ? 0 : (int)hipErrorLaunchFailure;
   H2Guard h2(p, h2n);   // (armed: the implicit GEMM in h2 -- the direct kernels exist in x3 only)
+  if (h2.bad) return (int)hipErrorInvalidValue;
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, nullptr);
 }
 
@@ -541,6 +551,7 @@ extern "C" int tris_conv3x3_dgrad_f32(const float* dY, const float* Wt, float* d
   p.fastB = p.vecB;
   if (Cout % 16 != 0) return (int)hipErrorInvalidValue;  // k tile must not straddle taps for the B loader
   H2Guard h2(p, h2n);
+  if (h2.bad) return (int)hipErrorInvalidValue;
   return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, nullptr);
 }
 
@@ -551,9 +562,11 @@ extern "C" int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, fl
                                             const float* bn_x, const float* mean, const float* invstd, const float* gamma,
                                             const float* beta, double* part, int* part_rows, void* stream) {
   const H2Next h2n = h2_take();
+  unsigned* amax_out = tris_internal_take_amax_next();   // (one-shot by-product: the amax word of the masked gradient dZ)
   *part_rows = 0;
   if (bn_x == nullptr || part == nullptr || gamma == nullptr || beta == nullptr) return (int)hipErrorInvalidValue;
   GemmParams p = {};
+  p.amax_out = amax_out;
   p.A = dY; p.B = Wt; p.C = dZ;
   p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
   p.ldc = Cin; p.alpha = 1.f;
@@ -569,6 +582,7 @@ extern "C" int tris_conv3x3_dgrad_bnbwd_f32(const float* dY, const float* Wt, fl
   p.stat_part = part;
   p.bnb_x = bn_x; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
   H2Guard h2(p, h2n);
+  if (h2.bad) return (int)hipErrorInvalidValue;
   return conv3_dispatch<B_KN_DGRAD>(p, (hipStream_t)stream, part_rows);
 }
 
@@ -664,7 +678,7 @@ int wgrad_pick(int B, int H, int W, int Cin, int Cout, long ws_bytes, bool bnin,
   int first = 0;   // static choice: the measured winners; the autotuner times every usable configuration
   for (int id : {1, 2, 5})
     if (!first && usable(id)) first = id;
-  if (g_gemm_mode == 3 && usable(4)) first = 4;   // (h2: the 64 x 64 single-wave-per-quadrant tile folds its cross products least often)
+  if (mode_h2() && usable(4)) first = 4;   // (h2: the 64 x 64 single-wave-per-quadrant tile folds its cross products least often)
   if (forced == 0 && !bnin) return gemm();
   if (forced > 0) return (forced < kWgN && usable(forced)) ? direct(forced) : (bnin ? (first ? direct(first) : (int)hipErrorInvalidValue) : gemm());
   if (!first) return bnin ? (int)hipErrorInvalidValue : gemm();
@@ -756,8 +770,9 @@ extern "C" int tris_conv3x3_wgrad_f32(const float* X, const float* dY, float* dW
   p.fastB = p.vecB;
   hipStream_t st = (hipStream_t)stream;
   H2Guard h2(p, h2n);   // (armed: A = dY, B = X)
+  if (h2.bad) return (int)hipErrorInvalidValue;
   auto gemm = [&]() { return launch_cfg<A_COLK, B_KN_IM2COL>(p, 1, workspace, ws_bytes, st); };
-  const bool shape_ok = (g_gemm_mode == 1 || g_gemm_mode == 3) && stride == 1 && workspace != nullptr && al16(X) && al16(dY) && al16(dW) && al16(workspace) &&
+  const bool shape_ok = (g_gemm_mode == 1 || mode_h2()) && stride == 1 && workspace != nullptr && al16(X) && al16(dY) && al16(dW) && al16(workspace) &&
                         (long)B * H * W * std::max(Cin, Cout) < (1L << 31);
   auto direct = [&](int id) {
     return run_wgrad_direct(id, X, dY, dW, B, H, W, Cin, Cout, workspace, ws_bytes, st, BnIn{nullptr, nullptr, nullptr, nullptr},
@@ -784,6 +799,7 @@ extern "C" int tris_gemm_bnstat_f32(const float* A, const float* B, float* C, in
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   *stat_rows = p.stat_part ? cdiv(M, 128) : 0;
   H2Guard h2(p, h2n);
+  if (h2.bad) return (int)hipErrorInvalidValue;
   return launch_cfg<A_ROWK, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -796,10 +812,12 @@ extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, 
                                    long ldr, const float* bn_x, const float* bn_y, const float* mean, const float* invstd,
                                    const float* gamma, const float* beta, double* part, int* part_rows, void* stream) {
   const H2Next h2n = h2_take();
+  unsigned* amax_out = tris_internal_take_amax_next();   // (one-shot by-product: the amax word of the masked gradient dZ)
   *part_rows = 0;
   if (M <= 0 || N <= 0 || K <= 0 || bn_x == nullptr || part == nullptr) return (int)hipErrorInvalidValue;
   if (bn_y == nullptr && (gamma == nullptr || beta == nullptr)) return (int)hipErrorInvalidValue;
   GemmParams p = {};
+  p.amax_out = amax_out;
   p.A = dY; p.B = Wt; p.C = dZ; p.M = M; p.N = N; p.K = K;
   p.lda = K; p.ldb = N; p.ldc = N; p.alpha = 1.f;
   p.resid = resid; p.ldr = ldr;
@@ -814,6 +832,7 @@ extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, 
   p.bnb_x = bn_x; p.bnb_y = bn_y; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_gamma = gamma; p.bnb_beta = beta;
   *part_rows = cdiv(M, 128);
   H2Guard h2(p, h2n);
+  if (h2.bad) return (int)hipErrorInvalidValue;
   return launch_cfg<A_ROWK, B_KN>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -836,6 +855,7 @@ extern "C" int tris_conv3x3_fwd_bnstat_f32(const float* X, const float* Wt, floa
   }
   p.stat_part = stats_eligible(p) ? stat_part : nullptr;
   H2Guard h2(p, h2n);
+  if (h2.bad) return (int)hipErrorInvalidValue;
   return conv3_dispatch<B_NK>(p, (hipStream_t)stream, stat_rows);
 }
 
@@ -879,6 +899,7 @@ extern "C" int tris_conv3x3_fwd_bnin_f32(const float* X, const float* mean, cons
   const H2Next h2n = h2_take();
   GemmParams p = conv3_fwd_params(X, Wt, Y, B, H, W, Cin, Cout);
   H2Guard h2(p, h2n);
+  if (h2.bad || g_gemm_mode == 4) return (int)hipErrorInvalidValue;   // (raw fp32 input, normalised while it is staged: no planes)
   if (!bnin_enabled() || !halo_shape_ok(p) || halo_static_choice(p, false) == 0 || !al16(mean) || !al16(invstd) || !al16(gamma) ||
       !al16(beta))
     return (int)hipErrorInvalidValue;   // ask tris_conv3x3_bnin_ok first
@@ -897,6 +918,7 @@ extern "C" int tris_conv3x3_wgrad_bnin_f32(const float* X, const float* mean, co
   pq.fastA = al16(dY) && (Cout % 4 == 0);
   pq.fastB = al16(X) && (Cin % 4 == 0);
   H2Guard h2(pq, h2n);
+  if (h2.bad || g_gemm_mode == 4) return (int)hipErrorInvalidValue;   // (the folded form normalises fp32 input while staging it: no planes)
   if (!bnin_enabled() || workspace == nullptr || !al16(X) || !al16(dY) || !al16(dW) || !al16(workspace) || !al16(mean) ||
       !al16(invstd) || !al16(gamma) || !al16(beta))
     return (int)hipErrorInvalidValue;
@@ -925,7 +947,14 @@ extern "C" int tris_set_autotune(int on) {
 extern "C" int tris_get_gemm_mode(void) { return g_gemm_mode; }
 
 extern "C" int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, float scaleB) {
-  g_h2_next = H2Next{amaxA, amaxB, scaleA, scaleB, true};
+  g_h2_next = H2Next{amaxA, amaxB, scaleA, scaleB, true, false, 0};
+  return 0;
+}
+// the next dense product of the calling thread takes BOTH operands as fp16 piece planes (tris_h2_planes_f32 layout) scaled by the
+// powers of two that *amaxA / *amaxB imply; flags bit 0: the bn_y operand of tris_gemm_bnbwd_f32 is such a plane tensor too
+extern "C" int tris_h2_next_planes(const unsigned* amaxA, const unsigned* amaxB, int flags) {
+  if (amaxA == nullptr || amaxB == nullptr) return (int)hipErrorInvalidValue;
+  g_h2_next = H2Next{amaxA, amaxB, 0.f, 0.f, true, true, flags};
   return 0;
 }
 

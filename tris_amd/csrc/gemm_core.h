@@ -449,14 +449,16 @@ __global__ __launch_bounds__(64 * G) void splitk_reduce_wide_kernel(const float*
 
 #include "gemm_fast.h"
 
-// launch one configuration (+ split-K reduce).  mode: 0 = f32-input MFMA, 1 = split-bf16 x3, 3 = two-piece fp16 h2
+// launch one configuration (+ split-K reduce).  mode: 0 = f32-input MFMA, 1 = split-bf16 x3, 3 = two-piece fp16 h2,
+// 4 = h2 with both operands arriving as fp16 piece planes (gemm_fast.h PREC 4)
 template <int AK, int BKIND>
 int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mode) {
   int bm = cfg.bm, bn = cfg.bn, splitk = ws != nullptr ? cfg.splitk : 1;   // (a tuned split-K choice without a workspace: one slice)
   const bool fast = gemm_fast_ok(p);
   if (bn == 32 && !fast) bm = bn = 64;  // the 128x32 tile exists in the fast kernel only
   const bool xtra = p.pre_out != nullptr || p.dact_x != nullptr;   // (tris_gemm_epilogue_next: classic loop, one slice, fast kernel)
-  const bool pipe = cfg.pipe && (mode == 1 || mode == 3) && fast && bn != 32 && !xtra;   // (the pipelined loop: x3 and h2)
+  if (mode == 4 && !fast) return (int)hipErrorInvalidValue;   // (operand planes exist for the fast kernel only: the caller checks)
+  const bool pipe = cfg.pipe && (mode == 1 || mode == 3 || mode == 4) && fast && bn != 32 && !xtra;   // (the pipelined loop: x3 and h2)
   if (bm == 256 && !pipe) bm = 128;     // the 256-row tile exists in the pipelined form only
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
@@ -482,6 +484,7 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   do {                                                                      \
     if (mode == 1) TRIS_FAST(BM_, BN_, EPI_, 1);                            \
     else if (mode == 3) TRIS_FAST(BM_, BN_, EPI_, 3);                       \
+    else if (mode == 4) TRIS_FAST(BM_, BN_, EPI_, 4);                       \
     else TRIS_FAST(BM_, BN_, EPI_, 0);                                      \
   } while (0)
 #define TRIS_GO(BM_, BN_, GENERIC_OK_)                                                             \
@@ -509,6 +512,8 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   do {                                                                                                                             \
     if (mode == 3)                                                                                                                 \
       hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, 3, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p);      \
+    else if (mode == 4)                                                                                                            \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, 4, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p);      \
     else                                                                                                                           \
       hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_, 1, NW_, 16, 2, NWM_>), grid, dim3(NW_ * 64), 0, st, p);      \
   } while (0)

@@ -48,23 +48,23 @@ __device__ __forceinline__ bf16x8 tr_frag8(const char* plane, int ks, int k0, in
 
 // LDS bytes of one operand stage (host + device): see the layout notes in the kernel
 constexpr int gf_stage_floats(int BMN, int FBK, int PREC, bool row_major) {
-  const int NPLN = PREC == 3 ? 2 : 3;
+  const int NPLN = (PREC == 3 || PREC == 4) ? 2 : 3;
   return PREC >= 1 ? (row_major ? BMN * (2 * FBK + 16) * NPLN / 4 : NPLN * FBK * (2 * BMN + 64) / 4)
                    : (row_major ? BMN * (FBK + 4) : FBK * (BMN + 4));
 }
-constexpr int gf_halo_floats(int HS, int PREC) { return HS * (PREC == 3 ? 16 : 24); }   // HS pixel slots x 3 (h2: 2) planes x 16 channels, 16-bit (no padding)
+constexpr int gf_halo_floats(int HS, int PREC) { return HS * ((PREC == 3 || PREC == 4) ? 16 : 24); }   // HS pixel slots x 3 (h2: 2) planes x 16 channels, 16-bit (no padding)
 constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm, int HS = 0) {
   // (the classic kernels: two co-resident 8-wave blocks per CU, as tuned in round 1; h2's 4-wave 128 x 64 / 64 x 64 kernels fit
   // 128 registers with both accumulator sets and keep four waves per SIMD)
-  if (NSTG == 1) return (NW == 8 || (PREC == 3 && NW == 4 && BM * BN <= 128 * 64)) ? 4 : 2;
+  if (NSTG == 1) return (NW == 8 || ((PREC == 3 || PREC == 4) && NW == 4 && BM * BN <= 128 * 64)) ? 4 : 2;
   const int lds = HS > 0 ? 4 * (gf_halo_floats(HS, PREC) + NSTG * gf_stage_floats(BN, FBK, PREC, b_rm))
                          : 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
   // (h2, 256-row tiles: 128 accumulator registers per wave -- one block per CU whatever the LDS would allow)
-  const int blocks = (lds * 2 <= 160 * 1024 && !(PREC == 3 && BM == 256)) ? 2 : 1;
+  const int blocks = (lds * 2 <= 160 * 1024 && !((PREC == 3 || PREC == 4) && BM == 256)) ? 2 : 1;
   const int w = blocks * NW / 4;
   if (HS > 0) {   // (direct 3x3: the window registers need more than 128 VGPRs; h2 with four 32 x 32 blocks per wave -- eight
     // accumulator blocks -- more than 256: one wave per SIMD)
-    if (PREC == 3 && NW == 4 && BM * BN >= 128 * 128) return 1;
+    if ((PREC == 3 || PREC == 4) && NW == 4 && BM * BN >= 128 * 128) return 1;
     return w > 2 ? 2 : (w < 1 ? 1 : w);
   }
   return w < 1 ? 1 : w;
@@ -89,13 +89,13 @@ void gemm_fast_kernel(GemmParams p) {
   //   1: BM consecutive pixels of the flattened [B, H, W] grid, held in PADDED coordinates (pitch W + 2, one zero row between
   //      images): any H, W; the window is BM + ~2 W slots, so this is for the narrow late stages (W <= 40).
   constexpr bool HALO = (AK == A_HALO);
-  static_assert(!HALO || ((PREC == 1 || PREC == 3) && FBK == 16 && NSTG == 2 && HS % 8 == 4), "A_HALO: x3 / h2, 16-channel chunks, pipelined B");
+  static_assert(!HALO || ((PREC == 1 || PREC == 3 || PREC == 4) && FBK == 16 && NSTG == 2 && HS % 8 == 4), "A_HALO: x3 / h2, 16-channel chunks, pipelined B");
   constexpr int KL = FBK / 4;          // 16-byte pieces per row of a row-major tile
   constexpr int RPASS = NTHR / KL;     // rows of a row-major tile covered per pass
   constexpr int LDK = FBK + 4;
   constexpr bool A_RM = (AK != A_COLK);
   constexpr bool B_RM = (BKIND == B_NK);
-  static_assert(PREC == 0 || PREC == 1 || PREC == 3, "arithmetic: 0 = f32 MFMA, 1 = x3, 3 = h2");
+  static_assert(PREC == 0 || PREC == 1 || PREC == 3 || PREC == 4, "arithmetic: 0 = f32 MFMA, 1 = x3, 3 = h2, 4 = h2 on pre-split planes");
   static_assert(PREC >= 1 || (FBK == 32 && NSTG == 1), "the f32-MFMA path exists as the classic 32-deep loop only");
   static_assert(NW % NWM == 0 && BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0, "wave grid does not tile the block");
   constexpr int WM = BM / NWM, WN = BN / NWN;
@@ -110,7 +110,13 @@ void gemm_fast_kernel(GemmParams p) {
   // [plane][row][FBK + 8 pad] (row stride PLB = 2 FBK + 16 bytes: 80 -> 5, 48 -> 3 sixteen-byte slots, both odd, so the 16
   // lanes of a ds_read_b128 service group fall on 16 distinct slots).
   constexpr bool A_PL = (PREC >= 1), B_PL = (PREC >= 1);
-  constexpr int NPLN = PREC == 3 ? 2 : 3;  // 16-bit planes per operand (PREC 3: fp16 pieces)
+  constexpr bool H2 = (PREC == 3 || PREC == 4);
+  // PREC 4: both operands ARRIVE as fp16 piece planes ("P8": per 8 consecutive elements of the contiguous dimension 16 bytes of hi
+  // pieces, then 16 bytes of pre-scaled lo pieces -- the byte geometry of the fp32 tensor, include/tris_hip.h tris_h2_planes_f32),
+  // written once by the pass that produced the tensor.  The loaders fetch the same 16-byte pieces at the same addresses as in
+  // PREC 3; a piece is eight fp16 values of ONE plane and goes to LDS as it is (one ds_write_b128, no VALU).
+  constexpr bool PLN = (PREC == 4);
+  constexpr int NPLN = H2 ? 2 : 3;  // 16-bit planes per operand (h2: fp16 pieces)
   // m-/n-contiguous operands: 16-byte loads along the contiguous dimension, split, 8-byte LDS stores into k-major planes
   // [plane][k][m], and the MFMA fragments (8 consecutive k per lane) are gathered by the LDS transpose read
   // ds_read_b64_tr_b16: per 16-lane group, lane i points at the 8-byte piece [k0 + i/4][m0 + 4(i%4) ..+3] and receives
@@ -209,13 +215,13 @@ void gemm_fast_kernel(GemmParams p) {
   // PREC 3 ("h2"): power-of-two operand scales (gemm_params.h): from the bit pattern of the tensor's largest magnitude -- or of an
   // UPPER BOUND of it -- in device memory, or from the host; the epilogue takes them out again (exact: powers of two)
   float h2a = 1.f, h2b = 1.f;
-  if constexpr (PREC == 3) {
+  if constexpr (H2) {
     h2a = p.h2_amaxA ? h2_scale_from_bits(h2_amax_of(p.h2_amaxA, lane)) : (p.h2_sA != 0.f ? p.h2_sA : 1.f);
     h2b = p.h2_amaxB ? h2_scale_from_bits(h2_amax_of(p.h2_amaxB, lane)) : (p.h2_sB != 0.f ? p.h2_sB : 1.f);
   }
   const float h2inv = 1.0f / (h2a * h2b);
-  auto splitA = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2a); else return split4(v); };
-  auto splitB = [&](const float4& v) { if constexpr (PREC == 3) return split4h(v, h2b); else return split4(v); };
+  auto splitA = [&](const float4& v) { if constexpr (H2) return split4h(v, h2a); else return split4(v); };
+  auto splitB = [&](const float4& v) { if constexpr (H2) return split4h(v, h2b); else return split4(v); };
   // ---- direct 3x3: window geometry (see the head of the kernel) -------------------------------------------------------------
   constexpr int HP = HALO ? (HS * 4 + NTHR - 1) / NTHR : 1;   // 16-byte pieces (4 channels of one slot) per thread per chunk
   int h_pitch = 0, h_b = 0, h_y0 = 0, h_x0 = 0;
@@ -296,6 +302,12 @@ void gemm_fast_kernel(GemmParams p) {
       const int j = tid + q * NTHR;
       if (HP * NTHR == HS * 4 || j < HS * 4) {
         float4 v = hr[q];
+        if constexpr (PLN) {
+          // a slot's 16 channels are 64 bytes [hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15]: piece j & 3 -> plane (j & 1), channel half (j >> 1) & 1
+          char* d = reinterpret_cast<char*>(Ad) + (j >> 2) * 16 + ((j >> 1) & 1) * (HS * 16) + (j & 1) * (HS * 32);
+          *reinterpret_cast<float4*>(d) = v;
+          continue;
+        }
         if (p.in_mean != nullptr && h_pix[q] >= 0) {   // (padding slots stay zero: the convolution pads y, not x)
           v.x = fmaxf((v.x - h_mu.x) * h_sc.x + h_be.x, 0.f);
           v.y = fmaxf((v.y - h_mu.y) * h_sc.y + h_be.y, 0.f);
@@ -395,6 +407,15 @@ void gemm_fast_kernel(GemmParams p) {
 
   // ---- LDS stores: one 16-byte piece (chunk) of a tile at a time, so that the pipelined loop can spread them -----------
   auto store_A = [&](float* Ad, const float4& v, int q) {
+    if constexpr (PLN) {   // piece j of a row: plane (j & 1), elements 8 (j >> 1) .. + 7 of the contiguous dimension
+      if (A_TR) {
+        const int j = tid % AF4;
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(Ad) + (j & 1) * (FBK * A_KS) + (tid / AF4 + q * ARPP) * A_KS + (j >> 1) * 16) = v;
+      } else {
+        const int j = tid % KL;
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(Ad) + (j & 1) * (BM * PLB) + (trow + q * RPASS) * PLB + (j >> 1) * 16) = v;
+      }
+    } else
     if (A_TR) {
       const Split4 sp = splitA(v);
       char* d = reinterpret_cast<char*>(Ad) + (tid / AF4 + q * ARPP) * A_KS + (tid % AF4) * 8;
@@ -414,6 +435,15 @@ void gemm_fast_kernel(GemmParams p) {
     }
   };
   auto store_B = [&](float* Bd, const float4& v, int q) {
+    if constexpr (PLN) {
+      if (B_TR) {
+        const int j = tid % BF4;
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(Bd) + (j & 1) * (FBK * B_KS) + (tid / BF4 + q * BRPP) * B_KS + (j >> 1) * 16) = v;
+      } else {
+        const int j = tid % KL;
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(Bd) + (j & 1) * (BN * PLB) + (trow + q * RPASS) * PLB + (j >> 1) * 16) = v;
+      }
+    } else
     if (B_TR) {
       const Split4 sp = splitB(v);
       char* d = reinterpret_cast<char*>(Bd) + (tid / BF4 + q * BRPP) * B_KS + (tid % BF4) * 8;
@@ -434,7 +464,6 @@ void gemm_fast_kernel(GemmParams p) {
   };
   f32x16 acc[FM][FN];
   // h2: a second accumulator set for the two cross products (hi x lo', lo' x hi), whose lo' pieces carry a factor 2^11 (x3_split.h)
-  constexpr bool H2 = (PREC == 3);
   f32x16 acx[H2 ? FM : 1][H2 ? FN : 1];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -731,7 +760,7 @@ void gemm_fast_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]);
   }
-  const float alpha_e = (PREC == 3) ? p.alpha * h2inv : p.alpha;   // (h2: the operand scales leave with alpha; slabs likewise)
+  const float alpha_e = H2 ? p.alpha * h2inv : p.alpha;   // (h2: the operand scales leave with alpha; slabs likewise)
   float st_s[FN], st_q[FN];  // fused BatchNorm statistics: per-column sum / sum of squares of this block's rows
 #pragma unroll
   for (int j = 0; j < FN; ++j) st_s[j] = st_q[j] = 0.f;
@@ -788,7 +817,7 @@ void gemm_fast_kernel(GemmParams p) {
           float4 v = *reinterpret_cast<const float4*>(stg + (er + 8 * t) * ELD + ec);
           if (row < p.M && col < p.N) {  // N % 4 == 0: a vector never straddles the edge
             if (EPI == EPI_SLAB) {
-              if (PREC == 3) { v.x *= h2inv; v.y *= h2inv; v.z *= h2inv; v.w *= h2inv; }
+              if (H2) { v.x *= h2inv; v.y *= h2inv; v.z *= h2inv; v.w *= h2inv; }
               *reinterpret_cast<float4*>(p.C + ((long)bid_z * p.M + row) * p.N + col) = v;
             } else {
               v.x *= alpha_e; v.y *= alpha_e; v.z *= alpha_e; v.w *= alpha_e;
@@ -808,7 +837,16 @@ void gemm_fast_kernel(GemmParams p) {
               if (p.bnb_x != nullptr) {
                 const long o = (long)row * p.ldc + col;
                 const float4 xx = ld4s(p.bnb_x + o, nt_e);
-                if (p.bnb_y != nullptr) {
+                if (p.bnb_y != nullptr && p.bnb_y_pl) {
+                  // y = relu(..) as fp16 piece planes (8 columns = 16 bytes of hi pieces, then 16 of lo pieces): y > 0 <=> a piece is non-zero
+                  const char* yb = reinterpret_cast<const char*>(p.bnb_y + (long)row * p.ldc + (col & ~7)) + (col & 4) * 2;
+                  const uint2 yh = *reinterpret_cast<const uint2*>(yb), yl = *reinterpret_cast<const uint2*>(yb + 16);
+                  const unsigned m0 = (yh.x | yl.x) & 0x7fff7fffu, m1 = (yh.y | yl.y) & 0x7fff7fffu;
+                  if (!(m0 & 0xffffu)) v.x = 0.f;
+                  if (!(m0 >> 16)) v.y = 0.f;
+                  if (!(m1 & 0xffffu)) v.z = 0.f;
+                  if (!(m1 >> 16)) v.w = 0.f;
+                } else if (p.bnb_y != nullptr) {
                   const float4 yy = ld4s(p.bnb_y + o, nt_e);
                   if (!(yy.x > 0.f)) v.x = 0.f;
                   if (!(yy.y > 0.f)) v.y = 0.f;
@@ -821,6 +859,7 @@ void gemm_fast_kernel(GemmParams p) {
                   if (!((xx.w - nmu.w) * nsc.w + nbe.w > 0.f)) v.w = 0.f;
                 }
                 st4s(p.C + o, v, nt_e);
+                e_am = max(e_am, abits4(v));   // (the masked gradient's amax: the bound of the BatchNorm's dx, tris_bn_bwd_bound_f32)
                 vs_s[j].x += v.x; vs_s[j].y += v.y; vs_s[j].z += v.z; vs_s[j].w += v.w;
                 vs_q[j].x += v.x * ((xx.x - nmu.x) * nis.x); vs_q[j].y += v.y * ((xx.y - nmu.y) * nis.y);
                 vs_q[j].z += v.z * ((xx.z - nmu.z) * nis.z); vs_q[j].w += v.w * ((xx.w - nmu.w) * nis.w);
@@ -852,7 +891,7 @@ void gemm_fast_kernel(GemmParams p) {
         if (row < p.M && col < p.N) {
           float v = acc[i][j][r];
           if (EPI == EPI_SLAB) {
-            p.C[((long)bid_z * p.M + row) * p.N + col] = (PREC == 3) ? v * h2inv : v;
+            p.C[((long)bid_z * p.M + row) * p.N + col] = H2 ? v * h2inv : v;
           } else {
             v *= alpha_e;
             if (p.bias_mode == 1) v += p.bias[col];
@@ -865,10 +904,15 @@ void gemm_fast_kernel(GemmParams p) {
             if (p.bnb_x != nullptr) {   // (fused BatchNorm-backward reduction, scalar form: see the vector epilogue)
               const long o = (long)row * p.ldc + col;
               const float xx = p.bnb_x[o], mu1 = p.bnb_mean[col], is1 = p.bnb_invstd[col];
-              const bool on = p.bnb_y != nullptr ? (p.bnb_y[o] > 0.f)
-                                                 : ((xx - mu1) * (is1 * p.bnb_gamma[col]) + p.bnb_beta[col] > 0.f);
+              bool on;
+              if (p.bnb_y != nullptr && p.bnb_y_pl) {
+                const unsigned short* yb = reinterpret_cast<const unsigned short*>(p.bnb_y + (long)row * p.ldc + (col & ~7)) + (col & 7);
+                on = ((yb[0] | yb[8]) & 0x7fffu) != 0;
+              } else
+                on = p.bnb_y != nullptr ? (p.bnb_y[o] > 0.f) : ((xx - mu1) * (is1 * p.bnb_gamma[col]) + p.bnb_beta[col] > 0.f);
               if (!on) v = 0.f;
               p.C[o] = v;
+              e_am = max(e_am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu);
               st_s[j] += v;
               st_q[j] += v * ((xx - mu1) * is1);
             } else {

@@ -68,7 +68,18 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
                                                           long rows_per_block, double* __restrict__ part,
                                                           const float* __restrict__ gamma = nullptr,
                                                           const float* __restrict__ beta = nullptr,
-                                                          float* __restrict__ dZ = nullptr, int pool_h = 0, int pool_w = 0) {
+                                                          float* __restrict__ dZ = nullptr, int pool_h = 0, int pool_w = 0,
+                                                          int y_pl = 0, unsigned* __restrict__ amax = nullptr) {
+  // y_pl (MODE 1): Y is an fp16-plane tensor (csrc/planes.h): y = relu(..) > 0 <=> one of its two pieces is non-zero
+  // amax (MODE 1): by-product, the largest magnitude of the masked gradient dz (the bound of the BatchNorm's dx needs it)
+  unsigned am = 0u;
+  auto ldy = [&](long o) -> float4 {
+    if (!y_pl) return ld4(Y + o);
+    const char* yb = reinterpret_cast<const char*>(Y + (o & ~7L)) + (o & 4) * 2;
+    const uint2 h = *reinterpret_cast<const uint2*>(yb), l = *reinterpret_cast<const uint2*>(yb + 16);
+    const unsigned m0 = (h.x | l.x) & 0x7fff7fffu, m1 = (h.y | l.y) & 0x7fff7fffu;
+    return make_float4((m0 & 0xffffu) ? 1.f : 0.f, (m0 >> 16) ? 1.f : 0.f, (m1 & 0xffffu) ? 1.f : 0.f, (m1 >> 16) ? 1.f : 0.f);
+  };
   __shared__ d4 l0[256];
   __shared__ d4 l1[256];
   const int CV = C >> 2;
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
             if (!(y.w > 0.f)) g.w = 0.f;
           }
           if (dZ) st4(dZ + o, g);
+          am = max(am, abits4(g));
           s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
           s1.x += (double)(g.x * ((x.x - mu.x) * is.x)); s1.y += (double)(g.y * ((x.y - mu.y) * is.y));
           s1.z += (double)(g.z * ((x.z - mu.z) * is.z)); s1.w += (double)(g.w * ((x.w - mu.w) * is.w));
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           } else {
             g[u] = (MODE == 1) ? ld4(dY + o) : z4;
           }
-          y[u] = (MODE == 1 && Y) ? ld4(Y + o) : z4;
+          y[u] = (MODE == 1 && Y) ? ldy(o) : z4;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) accum(x[u], g[u], y[u], (r + (long)u * RS) * ld + c);
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         } else if (MODE == 1) {
           g1 = ld4(dY + o);
         }
-        accum(ld4(X + o), g1, (MODE == 1 && Y) ? ld4(Y + o) : z4, o);
+        accum(ld4(X + o), g1, (MODE == 1 && Y) ? ldy(o) : z4, o);
       }
     }
     __syncthreads();
@@ -166,6 +178,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       if (MODE != 2) st4d(o + C + c, s1);
     }
   }
+  if (MODE == 1 && amax != nullptr) amax_commit(am, amax);   // (per wave; every thread arrives here)
 }
 
 // Partial-sum finalizers.  Block = 4 channels x (blockDim/4) slices of the nb partial rows, reduced through LDS in a
@@ -867,7 +880,23 @@ extern "C" int tris_bn_bwd_reduce_f32(const float* dY, const float* Y, const flo
   ColPlan p = col_plan(M, C);
   if ((gamma_mask == nullptr) != (beta_mask == nullptr)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, gamma_mask ? nullptr : Y, mean, invstd, M, C,
-                     (long)C, p.rpb, (double*)workspace, gamma_mask, beta_mask, dz_out);
+                     (long)C, p.rpb, (double*)workspace, gamma_mask, beta_mask, dz_out, 0, 0, 0, take_amax_next());
+  TRIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace, p.nb, C,
+                     sum_dz, sum_dzx);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same with the BatchNorm's OUTPUT given as fp16 planes (csrc/planes.h): its ReLU mask is "a piece is non-zero"
+extern "C" int tris_bn_bwd_reduce_pl_f32(const float* dY, const float* Ypl, const float* X, const float* mean, const float* invstd,
+                                         long M, int C, float* sum_dz, float* sum_dzx, float* workspace, float* dz_out,
+                                         void* stream) {
+  if (C % 8 || Ypl == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  ColPlan p = col_plan(M, C);
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(p.nb), dim3(256), 0, st, X, dY, Ypl, mean, invstd, M, C, (long)C, p.rpb,
+                     (double*)workspace, (const float*)nullptr, (const float*)nullptr, dz_out, 0, 0, 1, take_amax_next());
   TRIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace, p.nb, C,
                      sum_dz, sum_dzx);
@@ -894,7 +923,7 @@ extern "C" int tris_bn_bwd_reduce_pool_f32(const float* dYp, const float* X, con
   const long M = (long)B * H * W;
   ColPlan p = col_plan(M, C);
   hipLaunchKernelGGL((col_partial_kernel<1, true>), dim3(p.nb), dim3(256), 0, st, X, dYp, (const float*)nullptr, mean, invstd, M, C,
-                     (long)C, p.rpb, (double*)workspace, gamma, beta, (float*)nullptr, H, W);
+                     (long)C, p.rpb, (double*)workspace, gamma, beta, (float*)nullptr, H, W, 0, take_amax_next());
   TRIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, p.nb)), dim3(fin_block(p.nb)), 0, st, (const double*)workspace,
                      p.nb, C, sum_dz, sum_dzx);

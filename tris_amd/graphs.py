@@ -446,7 +446,7 @@ class SegmentedTrainStep:
         if not self.cutting:           # (only the trainable trunk is cut: its weight gradients are what the cuts release)
             return x
         leaf = x.detach().requires_grad_()
-        for attr in ("_bn_link", "_bn_lazy"):  # (hand-offs that ride on the tensor: the cut is an identity)
+        for attr in ("_bn_link", "_bn_lazy", "_pl", "_h2"):  # (hand-offs / plane tags that ride on the tensor: the cut is an identity)
             v = getattr(x, attr, None)
             if v is not None:
                 setattr(leaf, attr, v)

@@ -452,10 +452,13 @@ class batch_invariant:
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
-         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True, pre_out=None, dact=None):
+         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True, pre_out=None, dact=None, w_a=False, w_b=False):
     """pre_out / dact (tris_gemm_epilogue_next): also store the pre-activation value / multiply the result by quickgelu'(dact);
-    the call then returns False -- nothing launched -- when the fast kernel does not serve the operands (caller falls back)."""
+    the call then returns False -- nothing launched -- when the fast kernel does not serve the operands (caller falls back).
+    w_a / w_b: that operand is a convolution weight, which exists as operand planes when the other operand is a plane tensor."""
     _chk(A, B, C, bias, resid)
+    if pre_out is not None or dact is not None or batch != 1 or _BATCH_INVARIANT:
+        A, B = unplanes(A), unplanes(B)
     if pre_out is not None or dact is not None:
         if _BATCH_INVARIANT or batch != 1:
             return False
@@ -481,11 +484,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
         C.reshape(M, N).copy_(C4[:M])
         return C
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
-    if batch == 1:
-        h2_arm(A, B)
+    pA, pB = h2_pp(A, B, w_a=w_a, w_b=w_b) if batch == 1 else (P(A), P(B))
     h2_mark_next(C)      # (h2: the product also leaves the amax of what it writes -- another product may consume C directly)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
-        "tris_gemm_f32", P(A), P(B), P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
+        "tris_gemm_f32", pA, pB, P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
         tag=(f"{'T' if tA else 'N'}{'T' if tB else 'N'} M{M} N{N} K{K} b{batch}" if _PROF_SHAPES else None),
         nbytes=4.0 * ((M * K if (sA == 0 and batch > 1) else batch * M * K) + batch * K * N
@@ -629,8 +631,27 @@ def h2_weights_amax(arenas=None):
                          torch.tensor([p.numel() for p in a.params], device=a.p.device, dtype=torch.int64))
         call("tris_amax_segments_f32", P(a.p), a._h2_dev[0].data_ptr(), a._h2_dev[1].data_ptr(), len(a.params),
              _H2["pool"].data_ptr() + 4 * H2_SUB * base, _stream())
+        if cfg.h2_planes:
+            # operand planes of the convolution weights (csrc/planes.h), refreshed with the amaxes: one more launch per arena
+            if not hasattr(a, "_pl_dev"):
+                idx = [i for i, p in enumerate(a.params) if _pl_weight_ok(p)]
+                a._pl_idx = idx
+                a._pl_dev = None if not idx else (
+                    torch.tensor([a.offsets[i] for i in idx], device=a.p.device, dtype=torch.int64),
+                    torch.tensor([a.params[i].numel() for i in idx], device=a.p.device, dtype=torch.int64),
+                    torch.tensor(idx, device=a.p.device, dtype=torch.int64))
+                a.pl = torch.zeros_like(a.p) if idx else None
+            if a._pl_dev is not None:
+                call("tris_h2_planes_segments_f32", P(a.p), a._pl_dev[0].data_ptr(), a._pl_dev[1].data_ptr(), a._pl_dev[2].data_ptr(),
+                     len(a._pl_idx), _H2["pool"].data_ptr() + 4 * H2_SUB * base, P(a.pl), _stream())
         base += len(a.params)
     return base
+
+
+def _pl_weight_ok(p):
+    """a parameter that dense products of the trunk read as fp16 operand planes: a convolution weight [Cout, Cin, kh, kw] whose
+    contiguous dimension (Cin: channels_last memory) is a multiple of 8"""
+    return p.dim() == 4 and p.shape[1] % 8 == 0 and (p.is_contiguous(memory_format=torch.channels_last) or p.shape[2] * p.shape[3] == 1)
 
 
 def _h2_new_step_id():
@@ -651,6 +672,7 @@ def h2_begin_step():
     else:
         _H2["pool"].zero_()
     _H2["step"] = _h2_new_step_id()
+    _PL_GRAD.clear()
     base = 0
     arenas = _h2_live_arenas() if not _H2.get("private") else []
     for a in arenas:
@@ -660,6 +682,11 @@ def h2_begin_step():
     _H2["next"] = base
     _H2["arenas"] = arenas
     h2_weights_amax(arenas)
+    if cfg.h2_planes:
+        for a in arenas:
+            for i in (a._pl_idx if getattr(a, "pl", None) is not None else ()):
+                p = a.params[i]
+                p._plw = (_H2["step"], a.pl.data_ptr() + 4 * a.offsets[i], p._h2[1])
     return _H2["pool"]
 
 
@@ -807,6 +834,130 @@ def h2_arm(A, B, a_slot=None, b_slot=None):
     return True
 
 
+# ---- operand planes (csrc/planes.h, DESIGN.md "operand planes") --------------------------------------------------------------
+# In h2 the activations of the RN50 trunk between a BatchNorm and the convolutions that read it, the gradients between a BatchNorm
+# backward and the convolution backward that reads it, and the convolution weights exist as fp16 PIECE PLANES: float32 tensors in
+# torch's eyes whose bytes are the two fp16 pieces of every element, scaled by the power of two their amax word implies.  The tensor
+# carries `_pl = (step, word)`; only the ops below that say so accept one, everything else must see `unplanes(t)`.
+PL_STATS = {"unplanes": 0, "dx_planes": 0, "dy_planes": 0, "products": 0, "mixed": 0}
+
+
+def planes_on():
+    return cfg.h2_planes and h2_on() and not _BATCH_INVARIANT
+
+
+def pl_word(t):
+    """amax word of a plane tensor (None: `t` is an ordinary fp32 tensor)"""
+    tag = getattr(t, "_pl", None) if t is not None else None
+    if tag is None:
+        return None
+    if tag[0] != _H2["step"] or tag[2] != t.data_ptr():
+        raise RuntimeError("a plane tensor outlived the step whose amax pool scales it")
+    return tag[1]
+
+
+def pl_tag(t, word):
+    t._pl = (_H2["step"], word, t.data_ptr())
+    t._h2 = (_H2["step"], word, t._version)
+    return t
+
+
+def unplanes(t):
+    """the fp32 tensor a plane tensor stands for (its h2 operand rounding: 22 significand bits); fp32 tensors pass through"""
+    w = pl_word(t)
+    if w is None:
+        return t
+    c = getattr(t, "_pl_f32", None)
+    if c is None:
+        c = torch.empty_like(t)
+        call("tris_h2_unplanes_f32", P(t), P(c), t.numel(), w, _stream())
+        c._h2 = (_H2["step"], w, c._version)   # (the word bounds the rebuilt values as well)
+        t._pl_f32 = c
+        PL_STATS["unplanes"] += 1
+    return c
+
+
+_PL_CONST = {}   # id(parameter) -> (version, data_ptr, word, planes tensor, weakref): parameters outside the optimiser arenas
+
+
+def _pl_weight(w):
+    """(pointer to the planes of a convolution weight, its amax word) or None"""
+    tag = getattr(w, "_plw", None)
+    if tag is not None and tag[0] == _H2["step"]:
+        return tag[1], tag[2]
+    if not _pl_weight_ok(w):
+        return None
+    word = _h2_amax(w)
+    if word is None:
+        return None
+    c = _PL_CONST.get(id(w))
+    if c is not None and c[0] == w._version and c[1] == w.data_ptr() and c[2] == word and c[4]() is w:
+        return c[3].data_ptr(), word
+    import weakref
+    wc = cl_weight(w)
+    pl = torch.empty(wc.numel(), device=w.device, dtype=torch.float32)
+    call("tris_h2_planes_f32", wc.data_ptr(), P(pl), wc.numel(), word, _stream())
+    if len(_PL_CONST) > 4096:
+        _PL_CONST.clear()
+    _PL_CONST[id(w)] = (w._version, w.data_ptr(), word, pl, weakref.ref(w))
+    return pl.data_ptr(), word
+
+
+def _retag(t, tag):
+    """a tensor that comes back from ctx.saved_tensors keeps its plane tag (set again in case autograd re-wrapped the object)"""
+    if tag is not None and t is not None and getattr(t, "_pl", None) is None:
+        t._pl = tag
+        t._h2 = (tag[0], tag[1], t._version)
+    return t
+
+
+_PL_GRAD = {}   # data_ptr -> (step, word, shape): gradients a BatchNorm backward wrote as planes, until their one consumer takes them
+
+
+def pl_grad_out(t, word):
+    pl_tag(t, word)
+    _PL_GRAD[t.data_ptr()] = (_H2["step"], word, tuple(t.shape))
+    PL_STATS["dx_planes"] += 1
+    return t
+
+
+def pl_grad_in(dy):
+    """the gradient a backward is handed: tag it as a plane tensor if a BatchNorm backward wrote it as one (one consumer: the entry
+    is taken).  Returns dy."""
+    ent = _PL_GRAD.pop(dy.data_ptr(), None)
+    if ent is not None and ent[0] == _H2["step"] and ent[2] == tuple(dy.shape):
+        if getattr(dy, "_pl", None) is None:
+            dy._pl = (ent[0], ent[1], dy.data_ptr())
+            dy._h2 = (ent[0], ent[1], dy._version)
+        PL_STATS["dy_planes"] += 1
+    elif getattr(dy, "_pl", None) is not None:
+        raise RuntimeError("a plane gradient reached a second consumer")
+    return dy
+
+
+def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False):
+    """Arm the next dense product for h2 (as h2_arm) and return the pointers of its operands A, B to hand to the entry point.  With
+    operand planes on: if one operand IS a plane tensor and the other one is too, or is a convolution weight (w_a / w_b: that
+    operand is a parameter), the product runs on planes; a plane tensor next to an fp32 operand is rebuilt (counted in PL_STATS)."""
+    if A is None or B is None or a_slot is not None or b_slot is not None or not planes_on():
+        if pl_word(A) is not None or pl_word(B) is not None:
+            A, B = unplanes(A), unplanes(B)
+        h2_arm(A, B, a_slot, b_slot)
+        return P(A), P(B)
+    wa, wb = pl_word(A), pl_word(B)
+    if wa is not None or wb is not None:
+        pa = (P(A), wa) if wa is not None else (_pl_weight(A) if w_a else None)
+        pb = (P(B), wb) if wb is not None else (_pl_weight(B) if w_b else None)
+        if pa is not None and pb is not None:
+            call("tris_h2_next_planes", pa[1], pb[1], 1 if y_planes else 0)
+            PL_STATS["products"] += 1
+            return pa[0], pb[0]
+        PL_STATS["mixed"] += 1
+        A, B = unplanes(A), unplanes(B)
+    h2_arm(A, B)
+    return P(A), P(B)
+
+
 class _BnBwdLink:
     """Hand-off between a train-mode BatchNorm(+ReLU) and the 1x1 convolution / Linear that consumes its output.
 
@@ -820,17 +971,18 @@ class _BnBwdLink:
     on whatever arrived, which is why the masked gradient is only ever produced when the BatchNorm is known to be behind it.
     The model marks the BatchNorms whose output has exactly one autograd consumer (Bottleneck: bn2 -> conv3; bn3 -> the next
     block's conv1, the residual branch rides a GradBox) with bwd_link=True."""
-    __slots__ = ("x", "mean", "invstd", "gamma", "beta", "from_y", "dz", "part", "rows")
+    __slots__ = ("x", "mean", "invstd", "gamma", "beta", "from_y", "dz", "part", "rows", "dzw")
 
     def __init__(self, x, mean, invstd, gamma, beta, from_y):
         # (no reference to the BatchNorm's OUTPUT, which carries this object: the consumer has that tensor as its own input)
         self.x, self.mean, self.invstd, self.gamma, self.beta, self.from_y = x, mean, invstd, gamma, beta, from_y
-        self.dz = self.part = None
+        self.dz = self.part = self.dzw = None
         self.rows = 0
 
-    def fill(self, dz, part, rows):
+    def fill(self, dz, part, rows, dzw=None):
         # (identity of the gradient tensor, not a reference to it: autograd hands a sole-owner gradient on without a copy)
-        self.dz, self.part, self.rows = (dz.data_ptr(), dz._version, tuple(dz.shape)), part, rows
+        # dzw: amax word of the masked gradient (operand planes: the bound of the BatchNorm's dx is formed from it)
+        self.dz, self.part, self.rows, self.dzw = (dz.data_ptr(), dz._version, tuple(dz.shape)), part, rows, dzw
 
     def take(self, dy):
         """(part, rows) if dy IS the masked gradient this link's product left (same storage, version and shape); None if no product
@@ -838,11 +990,11 @@ class _BnBwdLink:
         down-sampling block whose shortcut backward ran late, a model that uses the BatchNorm output twice).  The caller then runs
         the usual two passes on whatever arrived, which is correct for any sum of gradients (the ReLU mask is idempotent: masking
         an already-masked term again changes nothing).  One use."""
-        dz, part, rows = self.dz, self.part, self.rows
-        self.dz = self.part = None
+        dz, part, rows, dzw = self.dz, self.part, self.rows, self.dzw
+        self.dz = self.part = self.dzw = None
         if dz is None or (dy.data_ptr(), dy._version, tuple(dy.shape)) != dz:
             return None
-        return part, rows
+        return part, rows, dzw
 
 
 def _bn_bwd_fuse_enabled():
@@ -869,15 +1021,16 @@ class LinearFn(torch.autograd.Function):
         want_stats = stats and b is None and resid is None and act == 0
         if want_stats:
             _launch_with_stats(y, M, N, lambda part, rows: _timed(
-                "gemm", 2.0 * M * N * K, lambda: (h2_arm(x, w), call("tris_gemm_bnstat_f32", P(x), P(w), P(y), M, N, K,
-                                                                     part.data_ptr(), rows, _stream()))[1],
+                "gemm", 2.0 * M * N * K, lambda: (lambda pp: call("tris_gemm_bnstat_f32", pp[0], pp[1], P(y), M, N, K,
+                                                                  part.data_ptr(), rows, _stream()))(h2_pp(x, w, w_b=True)),
                 nbytes=4.0 * (M * K + K * N + M * N)))
         else:
             gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid,
-                 ldr=N, act=act)
+                 ldr=N, act=act, w_b=True)
         ctx.act, ctx.dims = act, (M, N, K)
         ctx.has_b, ctx.has_r = b is not None, resid is not None
         ctx.params = (w, b)
+        ctx.x_pl = getattr(x, "_pl", None)
         ctx.save_for_backward(x, w, b, y if act == 1 else None)
         return y
 
@@ -890,7 +1043,12 @@ class LinearFn(torch.autograd.Function):
         x, w, b, y = ctx.saved_tensors
         pw, pb = ctx.params
         M, N, K = ctx.dims
-        dy = dy.contiguous()
+        dy = pl_grad_in(dy.contiguous())
+        _retag(x, ctx.x_pl)
+        if pl_word(dy) is not None and (ctx.has_r or ctx.has_b or ctx.act == 1):
+            dy = unplanes(dy)      # (bias / residual / ReLU backward read the gradient element-wise: never on the trunk's path)
+        if pl_word(dy) is None:
+            x = unplanes(x)        # (a plane input next to an fp32 gradient -- vis_project: the weight gradient reads the rebuilt tensor)
         d_res = dy if ctx.has_r and ctx.needs_input_grad[3] else None
         if d_res is not None and ctx.grad_box_res is not None and ctx.grad_box_res.deposit(d_res):
             d_res = None   # picked up by the block's LayerNorm backward (read-only there: no copy needed)
@@ -918,14 +1076,22 @@ class LinearFn(torch.autograd.Function):
                 import ctypes
                 part = torch.empty(((M + 127) // 128) * 2 * K, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("gemm_bnbwd", 2.0 * M * N * K, lambda: (h2_arm(dy, w), call(
-                    "tris_gemm_bnbwd_f32", P(dy), P(w), P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
-                    P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()),
-                    rows.value > 0)[2],     # (False: the entry point declined the shape, nothing was launched)
-                    nbytes=4.0 * (M * N + N * K + M * K * (2 + int(link.from_y) + int(extra is not None))))
-                if rows.value > 0:
-                    fused = True
-                    link.fill(dx, part, rows.value)
+                ypl = link.from_y and pl_word(x) is not None   # (the BatchNorm's output as planes: only a plane product masks from it)
+                if not ypl or pl_word(dy) is not None:
+                    dzw = _h2_slot() if planes_on() else None   # (the masked gradient's amax: the bound of that BatchNorm's dx)
+
+                    def launch():
+                        pp = h2_pp(dy, w, w_b=True, y_planes=ypl)
+                        if dzw is not None:
+                            call("tris_amax_next", dzw)
+                        call("tris_gemm_bnbwd_f32", pp[0], pp[1], P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
+                             P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream())
+                        return rows.value > 0     # (False: the entry point declined the shape, nothing was launched)
+                    _timed("gemm_bnbwd", 2.0 * M * N * K, launch,
+                           nbytes=4.0 * (M * N + N * K + M * K * (2 + int(link.from_y) + int(extra is not None))))
+                    if rows.value > 0:
+                        fused = True
+                        link.fill(dx, part, rows.value, dzw)
             alink = ctx.act_link
             if not fused and alink is not None and extra is None:
                 # x = QuickGELU(pre) with this product as its only consumer (linear_qgelu): the data gradient comes out of the
@@ -933,7 +1099,7 @@ class LinearFn(torch.autograd.Function):
                 if gemm(dy, w, dx, M, K, N, N, K, K, False, False, dact=alink.pre) is not False:
                     fused = alink.applied = True
             if not fused:
-                gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K)
+                gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K, w_b=True)
         elif extra is not None:
             raise RuntimeError("a residual gradient was handed to a layer whose input needs no gradient")
         if dx is not None and ctx.grad_box_out is not None and ctx.grad_box_out.deposit(dx):
@@ -1150,19 +1316,22 @@ class Conv3x3Fn(torch.autograd.Function):
                 return y
             h2_mark_next(x)
             call("tris_bn_apply_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta), None, P(x), B * H * W, Cin, 1, _stream())
+        if pl_word(x) is not None and (Cin % 32 != 0 or stride != 1):
+            x = unplanes(x)        # (the fast kernels' gather needs 32-channel pieces; the stem's strided first convolution reads the image)
+        ctx.x_pl = getattr(x, "_pl", None)
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
         fl = 2.0 * B * Ho * Wo * Cout * 9 * Cin
         nb = 4.0 * (B * H * W * Cin + B * Ho * Wo * Cout + 9 * Cin * Cout)
         if stats:
             _launch_with_stats(y, B * Ho * Wo, Cout, lambda part, rows: _timed(
-                "conv3x3_fwd", fl, lambda: (h2_arm(x, ctx.params[0]),
-                                            call("tris_conv3x3_fwd_bnstat_f32", P(x), P(w), P(y), B, H, W, Cin, Cout,
-                                                 stride, part.data_ptr(), rows, _stream()))[1], nbytes=nb))
+                "conv3x3_fwd", fl, lambda: (lambda pp: call("tris_conv3x3_fwd_bnstat_f32", pp[0], pp[1], P(y), B, H, W, Cin, Cout,
+                                                            stride, part.data_ptr(), rows, _stream()))(_conv_pp(x, ctx.params[0], w)),
+                nbytes=nb))
         else:
             _timed("conv3x3_fwd", fl,
-                   lambda: (h2_arm(x, ctx.params[0]),
-                            call("tris_conv3x3_fwd_f32", P(x), P(w), P(y), B, H, W, Cin, Cout, stride, _stream()))[1], nbytes=nb)
+                   lambda: (lambda pp: call("tris_conv3x3_fwd_f32", pp[0], pp[1], P(y), B, H, W, Cin, Cout, stride, _stream()))(
+                       _conv_pp(x, ctx.params[0], w)), nbytes=nb)
         ctx.save_for_backward(x, w)
         return y
 
@@ -1174,7 +1343,13 @@ class Conv3x3Fn(torch.autograd.Function):
             x, w = ctx.saved_tensors
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
-        dy = dy.contiguous()
+        dy = pl_grad_in(dy.contiguous())
+        if not ctx.lazy:
+            _retag(x, ctx.x_pl)
+        if pl_word(dy) is not None and (ctx.lazy or pl_word(x) is None or Cout % 32 != 0):
+            dy = unplanes(dy)      # (the BatchNorm-folded forms and the stem's first convolution read fp32)
+        if pl_word(dy) is None:
+            x = unplanes(x)
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.stride != 1:
@@ -1186,17 +1361,23 @@ class Conv3x3Fn(torch.autograd.Function):
                 import ctypes
                 part = torch.empty(((B * H * W + 127) // 128) * 2 * Cin, device=x.device, dtype=torch.float64)
                 rows = ctypes.c_int(0)
-                _timed("conv3x3_dgrad_bnbwd", fl, lambda: (h2_arm(dy, ctx.params[0]), call(
-                    "tris_conv3x3_dgrad_bnbwd_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
-                    P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream()), rows.value > 0)[2],
-                    nbytes=4.0 * (B * H * W * (Cout + 2 * Cin) + 9 * Cin * Cout))
+                dzw = _h2_slot() if planes_on() else None   # (the masked gradient's amax: the bound of that BatchNorm's dx)
+
+                def launch():
+                    pp = _conv_pp(dy, ctx.params[0], w)
+                    if dzw is not None:
+                        call("tris_amax_next", dzw)
+                    call("tris_conv3x3_dgrad_bnbwd_f32", pp[0], pp[1], P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
+                         P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream())
+                    return rows.value > 0
+                _timed("conv3x3_dgrad_bnbwd", fl, launch, nbytes=4.0 * (B * H * W * (Cout + 2 * Cin) + 9 * Cin * Cout))
                 if rows.value > 0:
                     fused = True
-                    link.fill(dx, part, rows.value)
+                    link.fill(dx, part, rows.value, dzw)
             if not fused:
                 _timed("conv3x3_dgrad", fl,
-                       lambda: (h2_arm(dy, ctx.params[0]),
-                                call("tris_conv3x3_dgrad_f32", P(dy), P(w), P(dx), B, H, W, Cin, Cout, _stream()))[1],
+                       lambda: (lambda pp: call("tris_conv3x3_dgrad_f32", pp[0], pp[1], P(dx), B, H, W, Cin, Cout, _stream()))(
+                           _conv_pp(dy, ctx.params[0], w)),
                        nbytes=4.0 * (B * H * W * (Cout + Cin) + 9 * Cin * Cout))
 
         def wgrad(o):
@@ -1212,9 +1393,9 @@ class Conv3x3Fn(torch.autograd.Function):
                 xin = torch.empty_like(x)   # materialise relu(bn(x)) after all
                 h2_mark_next(xin)
                 call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
-            return _timed("conv3x3_wgrad", fl, lambda: (h2_arm(dy, xin), call(
-                "tris_conv3x3_wgrad_f32", P(xin), P(dy), P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))[1],
-                nbytes=nb)
+            return _timed("conv3x3_wgrad", fl, lambda: (lambda pp: call(
+                "tris_conv3x3_wgrad_f32", pp[1], pp[0], P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))(
+                    h2_pp(dy, xin)), nbytes=nb)
         dw = None
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
@@ -1225,6 +1406,12 @@ class Conv3x3Fn(torch.autograd.Function):
             else:
                 dw = _emit(ctx.params[0], wgrad, True)
         return dx, dw, None, None, None, None
+
+
+def _conv_pp(a, w_param, w_cl):
+    """operand pointers of a 3x3 product (activation or gradient `a`, weight parameter `w_param` whose kernel layout is `w_cl`)"""
+    pa, pw = h2_pp(a, w_param, w_b=True)
+    return pa, (pw if pw != P(w_param) else P(w_cl))
 
 
 def conv3x3_bnin_ok(xshape, Cout):
@@ -1249,11 +1436,17 @@ class BatchNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part=None, grad_box=None,
-                lazy=False, bwd_link=False, pool=False):
+                lazy=False, bwd_link=False, pool=False, planes=False, dx_planes=False):
+        """planes: the output is WRITTEN as fp16 operand planes (every consumer is a product, a plane-aware BatchNorm / pool, or goes
+        through ops.unplanes); dx_planes: so is the input gradient (its one consumer is the backward of the convolution before)."""
         _chk(x, gamma, beta, rmean, rvar, resid)
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
+        use_pl = bool(planes and training and C % 8 == 0 and planes_on())
+        ctx.dx_pl = bool(dx_planes and training and C % 8 == 0 and planes_on())
+        if use_pl:
+            lazy = False
         # pool: the output is avgpool2(relu(bn(x))) -- BatchNorm + ReLU + AvgPool2d(2) as one op, the full-size tensor never written
         pool = bool(pool)   # (ops.batch_norm has checked: train mode, ReLU, no residual, even map)
         y = (torch.empty(x.shape[0], x.shape[1] // 2, x.shape[2] // 2, C, device=x.device, dtype=torch.float32) if pool
@@ -1295,7 +1488,29 @@ class BatchNormFn(torch.autograd.Function):
             invstd = torch.rsqrt(rvar + eps)
         # lazy: y stays UNWRITTEN -- its only consumer (a 3x3 convolution with direct kernels) normalises x while staging it
         lazy = bool(lazy and training and relu and resid is None)
-        if pool:
+        if not use_pl and resid is not None:
+            resid = unplanes(resid)
+        if use_pl:
+            # the scale must exist before the pass writes: Samuelson's bound of the normalised values from the affine parameters,
+            # plus the bound (or amax) of the residual it is added to
+            word = _h2_slot()
+            rk, rw = 0, None
+            if resid is not None:
+                rw = pl_word(resid)
+                rk = 2 if rw is not None else 1
+                if rw is None:
+                    rw = _h2_amax(resid)
+            if word is None or (resid is not None and rw is None):
+                raise RuntimeError("operand planes: no amax word for a BatchNorm output / its residual")
+            call("tris_bn_out_bound2_f32", P(gamma), P(beta), C, math.sqrt(max(count - 1, 1)), rw, word, _stream())
+            if pool:
+                call("tris_bn_apply_pool_pl_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), word, x.shape[0], x.shape[1],
+                     x.shape[2], C, _stream())
+            else:
+                call("tris_bn_apply_pl_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), rk, rw if rk == 2 else None, P(y),
+                     word, M, C, int(relu), _stream())
+            pl_tag(y, word)
+        elif pool:
             h2_mark_next(y)
             call("tris_bn_apply_pool_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), x.shape[0], x.shape[1], x.shape[2], C,
                  _stream())
@@ -1313,6 +1528,7 @@ class BatchNormFn(torch.autograd.Function):
         ctx.training = bool(training)
         ctx.link = None
         ctx.pool = pool
+        ctx.y_pl = getattr(y, "_pl", None)
         if training:
             keep_y = relu and not pool and resid is not None
             ctx.save_for_backward(x, gamma, beta, mean, invstd, y if keep_y else None)
@@ -1327,7 +1543,11 @@ class BatchNormFn(torch.autograd.Function):
             raise NotImplementedError("BatchNorm in eval mode is forward-only on this path")
         x, gamma, beta, mean, invstd, y = ctx.saved_tensors
         M, C, relu, has_res, count, group = ctx.cfg
-        dy = dy.contiguous()
+        dy = unplanes(pl_grad_in(dy.contiguous()))   # (the gradient of a BatchNorm OUTPUT is fp32 on every path of the trunk)
+        _retag(y, ctx.y_pl)
+        y_is_pl = pl_word(y) is not None
+        dx_pl = ctx.dx_pl and planes_on()
+        dzw = _h2_slot() if dx_pl else None    # amax word of the masked gradient dz: left by whichever pass reduces it
         d_res = None
         want_dz = has_res and ctx.needs_input_grad[5]
         if has_res and not relu:
@@ -1354,8 +1574,12 @@ class BatchNormFn(torch.autograd.Function):
         # residual blocks (out = relu(bn(x) + identity)): the reduce pass writes the masked gradient dz -- which IS the identity
         # branch's gradient -- and the apply pass reads it back instead of masking dy from y a second time
         got = ctx.link.take(dy) if ctx.link is not None else None
+        if got is not None and dx_pl:
+            dzw = got[2] if got[2] is not None else _h2_amax(dy)
         if ctx.pool:   # dy is the POOLED gradient: both passes read it in place of a full-size tensor (mask from x)
             Bn, H, W = x.shape[0], x.shape[1], x.shape[2]
+            if dzw is not None:
+                call("tris_amax_next", dzw)
             call("tris_bn_bwd_reduce_pool_f32", P(dy), P(x), P(mean), P(invstd), Bn, H, W, C, p_dz, p_dzx, P(ws), P(gamma), P(beta),
                  _stream())
         dz_first = got is None and not ctx.pool and want_dz and relu and y is not None
@@ -1365,8 +1589,14 @@ class BatchNormFn(torch.autograd.Function):
             # dy came out of the consuming 1x1 convolution's data gradient already MASKED, with the two sums as partial rows
             call("tris_part_finalize_f32", got[0].data_ptr(), got[1], C, p_dz, p_dzx, _stream())
         elif not ctx.pool:
-            call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
-                 P(gamma) if mask_x else None, P(beta) if mask_x else None, P(d_res) if dz_first else None, _stream())
+            if dzw is not None:
+                call("tris_amax_next", dzw)
+            if y_is_pl and not mask_x:
+                call("tris_bn_bwd_reduce_pl_f32", P(dy), P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
+                     P(d_res) if dz_first else None, _stream())
+            else:
+                call("tris_bn_bwd_reduce_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), M, C, p_dz, p_dzx, P(ws),
+                     P(gamma) if mask_x else None, P(beta) if mask_x else None, P(d_res) if dz_first else None, _stream())
         if mb is not None:
             # SyncBatchNorm: the arena keeps this rank's dbeta / dgamma (the data-parallel reducer averages them like every
             # other gradient); the sums over ALL ranks that dX needs come from one peer-mailbox launch reading the arena
@@ -1380,51 +1610,70 @@ class BatchNormFn(torch.autograd.Function):
                 from . import comm
                 comm.syncbn_all_reduce_sum(sums, group=group)
         dx = None
+        inv_cnt = 1.0 / float(count)
+
+        def apply(g, ymask, dz_out, beta_m):
+            """dx from the (masked or to-be-masked) gradient g; as operand planes where the convolution before takes them"""
+            if dx_pl:
+                word = _h2_slot()
+                call("tris_bn_bwd_bound_f32", P(gamma), P(invstd), p_dz, p_dzx, C, inv_cnt, math.sqrt(max(count - 1, 1)), dzw, word,
+                     _stream())
+                if ctx.pool:
+                    call("tris_bn_bwd_apply_pool_pl_f32", P(g), P(x), P(mean), P(invstd), P(gamma), P(beta), p_dz, p_dzx, inv_cnt, P(dx),
+                         word, x.shape[0], x.shape[1], x.shape[2], C, _stream())
+                else:
+                    if ymask is not None and not y_is_pl:
+                        raise RuntimeError("operand planes: the ReLU mask of a plane-output BatchNorm must come from plane y")
+                    call("tris_bn_bwd_apply_pl_f32", P(g), P(ymask), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx, inv_cnt, P(dx),
+                         word, P(dz_out), M, C, P(beta_m), _stream())
+                pl_grad_out(dx, word)
+                return
+            h2_mark_next(dx)
+            if ctx.pool:
+                call("tris_bn_bwd_apply_pool_f32", P(g), P(x), P(mean), P(invstd), P(gamma), P(beta), p_dz, p_dzx, inv_cnt, P(dx),
+                     x.shape[0], x.shape[1], x.shape[2], C, _stream())
+            else:
+                call("tris_bn_bwd_apply_f32", P(g), P(unplanes(ymask)) if ymask is not None else None, P(x), P(mean), P(invstd),
+                     P(gamma), p_dz, p_dzx, inv_cnt, P(dx), P(dz_out), M, C, P(beta_m), _stream())
         if ctx.pool:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                h2_mark_next(dx)
-                call("tris_bn_bwd_apply_pool_f32", P(dy), P(x), P(mean), P(invstd), P(gamma), P(beta), p_dz, p_dzx,
-                     1.0 / float(count), P(dx), x.shape[0], x.shape[1], x.shape[2], C, _stream())
+                apply(dy, None, None, None)
         elif got is not None:
             if want_dz:
                 d_res = dy          # the masked gradient IS the identity branch's gradient
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                h2_mark_next(dx)
-                call("tris_bn_bwd_apply_f32", P(dy), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
-                     1.0 / float(count), P(dx), None, M, C, None, _stream())
+                apply(dy, None, None, None)
         elif dz_first:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                h2_mark_next(dx)
-                call("tris_bn_bwd_apply_f32", P(d_res), None, P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
-                     1.0 / float(count), P(dx), None, M, C, None, _stream())
+                apply(d_res, None, None, None)
         elif ctx.needs_input_grad[0] or want_dz:
             dx = torch.empty_like(x)
             if want_dz:
                 d_res = torch.empty_like(x)
-            h2_mark_next(dx)
-            call("tris_bn_bwd_apply_f32", P(dy), None if mask_x else P(y), P(x), P(mean), P(invstd), P(gamma), p_dz, p_dzx,
-                 1.0 / float(count), P(dx), P(d_res) if want_dz else None, M, C, P(beta) if mask_x else None, _stream())
+            apply(dy, None if mask_x else y, d_res if want_dz else None, beta if mask_x else None)
         if ctx.grad_box is not None and d_res is not None and ctx.grad_box.deposit(d_res):
             d_res = None   # handed to the block's first conv
-        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, d_res, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, rmean, rvar, resid=None, relu=False, training=True, momentum=0.1, eps=1e-5, group=None,
-               grad_box=None, lazy=False, bwd_link=False, pool=False):
+               grad_box=None, lazy=False, bwd_link=False, pool=False, planes=False, dx_planes=False):
     """lazy=True (train-mode BatchNorm + ReLU whose ONLY consumer is ops.conv3x3, and conv3x3_bnin_ok said yes): the returned
-    tensor is an unwritten buffer carrying `_bn_lazy`; pass it to ops.conv3x3 and nowhere else."""
+    tensor is an unwritten buffer carrying `_bn_lazy`; pass it to ops.conv3x3 and nowhere else.
+    planes / dx_planes (h2 with operand planes, train mode): the output / the input gradient is written as fp16 operand planes --
+    the caller vouches that every consumer takes them (BatchNormFn.forward)."""
     part = getattr(x, "_bn_part", None) if training else None
     bwd_link = bool(bwd_link and training and torch.is_grad_enabled() and x.requires_grad and _bn_bwd_fuse_enabled())
     if pool and not (training and relu and resid is None and not lazy and x.dim() == 4 and x.shape[1] % 2 == 0
                      and x.shape[2] % 2 == 0 and cfg.bn_pool):
         # eval mode / shapes the fused op does not take: the two ops one after the other
         return avgpool2(BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box,
-                                          lazy, bwd_link, False))
+                                          lazy, bwd_link, False, planes, dx_planes))
     return BatchNormFn.apply(x, gamma, beta, rmean, rvar, resid, relu, training, momentum, eps, group, part, grad_box, lazy,
-                             bwd_link, pool)
+                             bwd_link, pool, planes, dx_planes)
 
 
 class AvgPool2Fn(torch.autograd.Function):
@@ -1435,14 +1684,19 @@ class AvgPool2Fn(torch.autograd.Function):
         x = x.contiguous()
         B, H, W, C = x.shape
         y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
-        call("tris_avgpool2_fwd_f32", P(x), P(y), B, H, W, C, _stream())
+        w = pl_word(x)
+        if w is not None and C % 8 == 0:   # planes in, planes out at the same scale (a mean never exceeds the bound of its terms)
+            call("tris_avgpool2_fwd_pl_f32", P(x), P(y), w, B, H, W, C, _stream())
+            pl_tag(y, w)
+        else:
+            call("tris_avgpool2_fwd_f32", P(unplanes(x)), P(y), B, H, W, C, _stream())
         ctx.shape = (B, H, W, C)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         B, H, W, C = ctx.shape
-        dy = dy.contiguous()
+        dy = unplanes(pl_grad_in(dy.contiguous()))
         dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
         call("tris_avgpool2_bwd_f32", P(dy), P(dx), B, H, W, C, _stream())
         if ctx.grad_box_out is not None and ctx.grad_box_out.deposit(dx):

@@ -234,9 +234,10 @@ class GradReducer:
         if not self.active or not torch.is_grad_enabled() or not x.requires_grad:
             return x
         y = _Boundary.apply(x, self, key)
-        link = getattr(x, "_bn_link", None)   # (ops._BnBwdLink rides on the tensor: the boundary is an identity)
-        if link is not None:
-            y._bn_link = link
+        for attr in ("_bn_link", "_pl", "_h2"):   # (ops._BnBwdLink / the plane tag ride on the tensor: the boundary is an identity)
+            v = getattr(x, attr, None)
+            if v is not None:
+                setattr(y, attr, v)
         return y
 
     def finish(self):
