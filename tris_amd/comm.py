@@ -82,8 +82,13 @@ class Mailbox:
     # polls before an exchange gives up, raises the error flag and poisons its outputs with NaN.  A poll is an uncached
     # system-scope load + s_sleep 8 (~1-2.5 us): the default 4e7 polls is about a minute -- a dead peer fails the step instead of
     # pinning a spinning workgroup on every surviving GPU for long (the slow-rank-0 case, checkpoint saves, is covered by the
-    # barrier train_stage1.main puts behind them); cfg.mbox_spin / TRIS_MBOX_SPIN
-    SPIN_LIMIT = cfg.mbox_spin
+    # barrier train_stage1.main puts behind them); cfg.mbox_spin / TRIS_MBOX_SPIN, read when an exchange is ISSUED (so that
+    # cfg.override(mbox_spin=...) and later assignments count); an instance attribute `spin_limit` overrides it (self_test)
+    spin_limit = None
+
+    @property
+    def SPIN_LIMIT(self):
+        return int(self.spin_limit if self.spin_limit is not None else cfg.mbox_spin)
 
     def __init__(self, group):
         from . import _lib
@@ -156,12 +161,12 @@ class Mailbox:
         silently aliases local memory, ... -> exception -> the caller falls back to torch.distributed on EVERY rank)."""
         src = torch.arange(1, 5, device="cuda", dtype=torch.float32) * float(self.rank + 1)
         out = torch.zeros(self.world * 4, device="cuda", dtype=torch.float32)
-        limit, self.SPIN_LIMIT = self.SPIN_LIMIT, min(self.SPIN_LIMIT, 4000000)
+        self.spin_limit = min(self.SPIN_LIMIT, 4000000)
         try:
             self.exchange(src, out, 0)
             torch.cuda.synchronize()
         finally:
-            self.SPIN_LIMIT = limit
+            self.spin_limit = None
         want = (torch.arange(1, self.world + 1, device="cuda", dtype=torch.float32)[:, None] *
                 torch.arange(1, 5, device="cuda", dtype=torch.float32)[None, :]).reshape(-1)
         if int(self.err.item()) != 0 or not torch.equal(out, want):

@@ -77,7 +77,8 @@ class _Config:
                 setattr(self, k, v)
 
     def key(self):
-        """what a captured step depends on (tris_amd.train_stage1: a captured step is re-recorded when it changes)"""
+        """what a captured step depends on: tris_amd.train_stage1.train_step records the step again when this (or the arithmetic, the
+        optimiser, the reducer, the aux model) changes; a batch of another shape runs eagerly next to the kept recording"""
         return tuple(sorted(self.__dict__.items()))
 
 

@@ -69,13 +69,14 @@ def workspace(nbytes):
 
 
 # ---- arithmetic of the dense products --------------------------------------------------------------------------------------
-# 'x3' (default): split-bf16 -- three bf16 pieces per fp32 operand, six bf16 MFMAs per product, fp32 accumulate: fp32-class
-#   accuracy at ~2.6x the f32-MFMA rate.
-# 'h2': two fp16 pieces per operand (the residual pre-scaled by 2^11), three f16 MFMAs per product, one power-of-two scale per
-#   TENSOR formed on the device from its largest magnitude: fp32-class accuracy over a 2^27 dynamic range inside a tensor, half the
-#   matrix work of x3 (csrc/x3_split.h, "h2 products" below).  A product whose operands have no amax runs in x3.
+# 'h2' (default since round 5 -- the arithmetic bench.py reports and the trainer runs are one and the same): two fp16 pieces per
+#   operand (the residual pre-scaled by 2^11), three f16 MFMAs per product, one power-of-two scale per TENSOR formed on the device from
+#   its largest magnitude: fp32-class accuracy over a 2^27 dynamic range inside a tensor, half the matrix work of x3
+#   (csrc/x3_split.h, "h2 products" below).  A product whose operands have no amax runs in x3.
+# 'x3': split-bf16 -- three bf16 pieces per fp32 operand, six bf16 MFMAs per product, fp32 accumulate: fp32-class accuracy at ~2.6x
+#   the f32-MFMA rate; also what the kernel library itself runs when a product is not armed for h2.
 # 'f32': the f32-input MFMA (bit-equal to an fmaf chain).
-_ARITH = "x3"
+_ARITH = "h2"     # (TRIS_GEMM_MODE at import overrides; the library's own default for unarmed products is x3 either way)
 
 
 def set_gemm_mode(mode):
@@ -781,7 +782,15 @@ def _h2_const_slot(t):
     """amax word of a parameter outside the optimiser arenas (a frozen model's): computed once, valid until it is written to"""
     key = id(t)
     tag = _H2["const_tags"].get(key)
-    if tag is not None and tag[0] == t._version and tag[1] == t.data_ptr() and tag[3]() is t:
+    if tag is not None and tag[1] == t.data_ptr() and tag[3]() is t and _H2["const"] is not None and _H2["const"].device == t.device:
+        if tag[0] == t._version:
+            return tag[2]
+        # written to since (load_state_dict, seed_fill): refresh the SAME word on the stream -- a hipGraph that recorded its address
+        # (the frozen aux text tower, the evaluation graphs) goes on reading a valid amax, and no new slot is used up
+        i = (tag[2] - _H2["const"].data_ptr()) // (4 * H2_SUB)
+        _H2["const"][i * H2_SUB:(i + 1) * H2_SUB].zero_()
+        call("tris_amax_bits_f32", P(t), t.numel(), tag[2], _stream())
+        _H2["const_tags"][key] = (t._version, t.data_ptr(), tag[2], tag[3])
         return tag[2]
     if _H2["const"] is None or _H2["const"].device != t.device:
         _H2["const"] = torch.zeros(H2_CONST_SLOTS * H2_SUB, device=t.device, dtype=torch.int32)
@@ -2018,25 +2027,50 @@ def instance_norm(x, g, b, relu=False, eps=1e-5):
 
 
 _XATTN_SYNC = {}
+_XATTN_SPARE = {}      # device -> zeroed buffers allocated OUTSIDE any stream capture, for streams first seen under one
+_XATTN_WORDS = 16 + 8 * 64
 
 
 def _xattn_sync(dev, B):
     """the fused cross-attention kernel's device-side bookkeeping (launch epoch, finish ticket, time-out flag, publish flags):
-    zeroed once, then owned by the kernel.  One buffer per (device, stream): launches on one stream are ordered."""
+    zeroed once, then owned by the kernel.  One buffer per (device, stream): launches on one stream are ordered.
+    Nothing is allocated -- or cleared -- inside a stream capture: a capture runs on a stream of its own, so its first launch meets a
+    stream without a buffer; a buffer created there would live in the graph's private pool and its zero-fill would be a graph node,
+    i.e. every replay would clear the STICKY time-out word (sync[2]) before anyone looked at it.  Eager launches (the priming steps
+    every capture is preceded by) keep spare buffers ready; a capture takes one of those."""
     key = (dev, torch.cuda.current_stream().cuda_stream)
-    n = max(int(query("tris_xattn_fused_sync_words", B)), int(query("tris_xattn_px_sync_words", B)))
+    n = max(int(query("tris_xattn_fused_sync_words", B)), int(query("tris_xattn_px_sync_words", B)), _XATTN_WORDS)
+    capturing = torch.cuda.is_current_stream_capturing()
+    spare = _XATTN_SPARE.setdefault(dev, [])
+    if not capturing:
+        while len(spare) < 3 or any(b.numel() < n for b in spare):
+            spare[:] = [b for b in spare if b.numel() >= n]
+            spare.append(torch.zeros(n, device=dev, dtype=torch.int32))
     t = _XATTN_SYNC.get(key)
     if t is None or t.numel() < n:
-        if torch.cuda.is_current_stream_capturing() and t is not None:
-            raise RuntimeError("fused cross attention: batch grew under stream capture (prime with the largest batch first)")
-        t = torch.zeros(max(n, 16 + 8 * 64), device=dev, dtype=torch.int32)
+        if capturing:
+            fit = [b for b in spare if b.numel() >= n]
+            if not fit:
+                raise RuntimeError("fused cross attention: no sync buffer for a stream first seen under capture "
+                                   "(run one eager step with the largest batch before capturing)")
+            t = fit[0]
+            spare.remove(t)
+        else:
+            t = torch.zeros(n, device=dev, dtype=torch.int32)
         _XATTN_SYNC[key] = t
     return t
 
 
-def xattn_timed_out():
-    """True if a wait inside any fused cross-attention launch gave up (host sync; tests / debugging)"""
-    return any(int(t[2].item()) != 0 for t in _XATTN_SYNC.values())
+def xattn_timed_out(collective=False):
+    """True if a wait inside any fused cross-attention launch gave up (host sync).  The word is sticky: nothing but this process's
+    exit clears it.  collective=True (every rank calls it at the same point): the answer is the group's, so that all ranks stop
+    together instead of one raising while its peers wait for it in a collective."""
+    hit = any(int(t[2].item()) != 0 for t in _XATTN_SYNC.values())
+    if collective and torch.distributed.is_available() and torch.distributed.is_initialized():
+        f = torch.tensor([1.0 if hit else 0.0], device="cuda" if torch.cuda.is_available() else "cpu")
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
+        hit = bool(f.item() > 0)
+    return hit
 
 
 class XAttnFn(torch.autograd.Function):

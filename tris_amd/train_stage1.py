@@ -144,6 +144,12 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
                img.dtype, word_ids.dtype, id(clip_model), id(optimizer), id(lr_scheduler), id(reducer), ops.get_gemm_mode(),
                cfg.key())
         slot = net.__dict__.get("_tris_step_graph")
+        if slot is not None and slot[0][5:] != key[5:]:
+            # something the captured launches depend on changed for good (configuration, arithmetic, another optimiser / reducer /
+            # aux model): what was recorded no longer describes the step -- record again.  (A different batch SHAPE alone, key[:5], is
+            # the ragged last batch of an epoch: it runs eagerly below and the recording for the main shape is kept.)
+            net.__dict__.pop("_tris_step_graph")
+            slot = None
         if slot is None:
             from .graphs import GraphedTrainStep, NotCapturable, SegmentedTrainStep
             cls = SegmentedTrainStep if cfg.step_graph == "seg" else GraphedTrainStep
@@ -157,6 +163,10 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
             slot = net.__dict__["_tris_step_graph"] = (key, g)
         if slot[0] == key and slot[1] is not None:
             return slot[1](img, word_ids, neg_word_ids)
+        if slot[1] is not None and not net.__dict__.get("_tris_step_graph_warned"):
+            import warnings
+            net.__dict__["_tris_step_graph_warned"] = True
+            warnings.warn(f"train_step: batch shape {tuple(img.shape)} differs from the captured one {slot[0][0]}: this step runs eagerly")
     losses = _step_body(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, reducer)
     if lr_scheduler is not None:
         lr_scheduler.step()
@@ -189,7 +199,7 @@ def train_one_epoch(train_loader, model, optimizer, epoch, local_rank, args, ite
             # the loop on all ranks): a rank that gave up on an exchange has NaN statistics, and training must stop on all of them
             from . import comm
             comm.check_errors(collective=True)
-        if idx % args.print_freq == 0 and ops.xattn_timed_out():
+        if idx % args.print_freq == 0 and ops.xattn_timed_out(collective=bool(args.distributed)):
             # a wait inside a persistent cross-attention launch gave up (a peer workgroup never became resident): that launch's
             # outputs are undefined -- stop instead of training on them (host sync: only where the loop prints)
             raise RuntimeError("fused cross attention: an in-kernel wait timed out; rerun with TRIS_XATTN_FUSED=0 (the two-launch pair)")
@@ -341,7 +351,11 @@ def main(args, tokenizer=None):
             # a SyncBatchNorm exchange that timed out poisoned its outputs: stop on every rank BEFORE validating / checkpointing
             from . import comm
             comm.check_errors(collective=True)
+        if ops.xattn_timed_out(collective=bool(args.distributed)):    # (the sticky word: also covers the steps between two prints)
+            raise RuntimeError("fused cross attention: an in-kernel wait timed out during the epoch; rerun with TRIS_XATTN_FUSED=0")
         res = evaluate()
+        if ops.xattn_timed_out(collective=bool(args.distributed)):
+            raise RuntimeError("fused cross attention: an in-kernel wait timed out during validation; rerun with TRIS_XATTN_FUSED=0")
         oIoU, val_acc, hit = res[0]
         if float(val_acc) > best["val_acc"] and local_rank == 0:
             if os.path.exists(best["path"]):
