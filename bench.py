@@ -117,6 +117,13 @@ def main():
         cs = ops.place_streams()
         if cs is not None:
             torch.cuda.set_stream(cs)
+    elif cfg.own_stream:
+        # never compute on the process's DEFAULT stream: whatever is launched there -- eager kernels and hipGraphs alike -- runs
+        # EXCLUSIVELY with respect to hipGraphs launched on other streams (tools/graph_step_overlap_probe2.py: every graph of the step,
+        # and plain eager kernels, next to a graph of sleeping one-thread kernels on another stream: the sum of the two times, not the
+        # maximum), i.e. the text towers replayed from graphs stop the trunk for as long as they run.  ops.compute_stream() hands out
+        # one non-default stream per device.
+        torch.cuda.set_stream(ops.compute_stream())
     torch.cuda.synchronize()
 
     from tris_amd.args import get_parser

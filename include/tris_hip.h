@@ -184,11 +184,16 @@ int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, flo
  * tris_h2_next_planes arms the calling thread like tris_h2_next, for a product whose operands A and B are BOTH such plane tensors
  * (same pointers, shapes and leading dimensions as the fp32 form; contiguous dimensions multiples of 8): the kernels store the
  * pieces as they arrive instead of splitting fp32 values, and the result is bit-identical to the h2 product of the fp32 originals at
- * the same scales.  flags bit 0: the bn_y operand of tris_gemm_bnbwd_f32 is a plane tensor as well.  A product the fast kernels do not
+ * the same scales.  flags bit 0: the bn_y operand of tris_gemm_bnbwd_f32 is a plane tensor as well; bit 1: the weight operand of
+ * tris_gemm_bnbwd_f32 is given TRANSPOSED ([N][K] = W^T, tris_h2_planes_t_segments_f32).  A product the fast kernels do not
  * serve FAILS (hipErrorInvalidValue): there is no fp32 operand to fall back on; the *_bnin forms refuse planes. */
 int tris_h2_planes_f32(const float* x, float* planes_out, long n, const unsigned* word, void* stream);
 int tris_h2_planes_segments_f32(const float* base, const long* offs, const long* sizes, const long* slot_index, int nseg,
                                 const unsigned* slots, float* out_base, void* stream);
+/* the same for nseg row-major matrices [rows[i]][cols[i]] (multiples of 64), written TRANSPOSED: planes of W^T [cols][rows] -- the 1x1
+ * convolution weights as the B^T operand of their data gradient */
+int tris_h2_planes_t_segments_f32(const float* base, const long* offs, const long* rows, const long* cols, const long* slot_index,
+                                  int nseg, const unsigned* slots, float* out_base, void* stream);
 int tris_h2_unplanes_f32(const float* planes, float* out, long n, const unsigned* word, void* stream);
 int tris_h2_next_planes(const unsigned* amaxA, const unsigned* amaxB, int flags);
 /* The RN50 trunk's element-wise passes with plane OUTPUT (csrc/planes.hip; reference: CLIP/clip/model.py:42-55 Bottleneck.forward,
@@ -219,6 +224,13 @@ int tris_bn_bwd_apply_pool_pl_f32(const float* dYp, const float* X, const float*
                                   const unsigned* out_word, int B, int H, int W, int C, void* stream);
 int tris_bn_out_bound2_f32(const float* gamma, const float* beta, int C, float xhat_max, const unsigned* add_word, unsigned* out,
                            void* stream);
+/* tris_bn_finalize_f32 + tris_bn_out_bound2_f32, and tris_part_finalize_f32 + tris_bn_bwd_bound_f32, as ONE launch each (the bound is
+ * atomically maxed into the zeroed word by the threads that finish the channels) */
+int tris_bn_finalize_bound_f32(const double* part, int rows, long M, int C, float eps, float momentum, float* stats,
+                               float* running_mean, float* running_var, const float* gamma, const float* beta, float xhat_max,
+                               const unsigned* add_word, unsigned* bound_out, void* stream);
+int tris_part_finalize_bound_f32(const double* part, int rows, int C, float* out0, float* out1, const float* gamma, const float* invstd,
+                                 float inv_count, float xhat_max, const unsigned* dz_word, unsigned* bound_out, void* stream);
 int tris_bn_bwd_bound_f32(const float* gamma, const float* invstd, const float* sum_dz, const float* sum_dzx, int C, float inv_count,
                           float xhat_max, const unsigned* dz_word, unsigned* out, void* stream);
 /* *out (an amax word, zeroed by the caller) <- bits of max over c of |gamma[c]| * xhat_max + |beta[c]|: an upper bound of

@@ -44,7 +44,13 @@ __global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void plan
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   const int tiles_n = (N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  int bid = blockIdx.x;
+  if (ABL & 8) {   // XCD-aware order: consecutive workgroups go to consecutive XCDs -> give every XCD a CONTIGUOUS range of tiles, so that
+    // the column tiles of one row block (same A rows) run on one XCD and share its L2 (bijective for any grid size)
+    const int T = gridDim.x, q = T >> 3, r = T & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   // this lane's source rows / pieces for its LDS-DMA instructions: instruction q of the wave covers tile rows (wave * G + q) * 8 .. + 7
   const int lrow = lane >> 3, lslot = lane & 7;
   const char* a_src[GA];
@@ -212,7 +218,8 @@ static void run(const char* name, const float* Ap, const float* Bp, float* C, co
 
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; };
-  std::vector<Shape> shapes = {{4096, 4096, 4096}, {76800, 256, 2304}, {19200, 512, 4608}, {19200, 1024, 1024}, {19200, 1024, 256}, {4800, 2048, 1024}};
+  std::vector<Shape> shapes = {{4096, 4096, 4096}, {76800, 256, 2304}, {19200, 512, 4608}, {19200, 1024, 1024}, {19200, 1024, 256}, {4800, 2048, 1024},
+                               {76800, 128, 512}, {76800, 512, 256}, {307200, 256, 64}, {307200, 64, 256}};
   for (const Shape& s : shapes) {
     const int M = s.M, N = s.N, K = s.K;
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
@@ -236,25 +243,18 @@ int main(int argc, char** argv) {
     const float inv = 1.0f / (sA * sB);
 #define RUN(BM, BN, NWM, NWN, NST, OCC, ABL, NAME) run<BM, BN, NWM, NWN, NST, OCC, ABL>(NAME, Ap, Bp, C, Cref, M, N, K, inv, RR)
     RUN(128, 128, 2, 4, 2, 2, 0, "128x128 8w(2x4) 2 stages occ2");
-    RUN(128, 128, 2, 4, 3, 1, 0, "128x128 8w(2x4) 3 stages occ1");
+    RUN(128, 128, 2, 4, 2, 2, 8, "128x128 8w(2x4) 2 stages occ2 xcd");
     RUN(128, 128, 2, 2, 2, 2, 0, "128x128 4w(2x2) 2 stages occ2");
-    RUN(128, 128, 2, 2, 3, 1, 0, "128x128 4w(2x2) 3 stages occ1");
-    RUN(256, 128, 4, 2, 2, 1, 0, "256x128 8w(4x2) 2 stages occ1");
+    RUN(128, 128, 2, 2, 2, 2, 8, "128x128 4w(2x2) 2 stages occ2 xcd");
+    RUN(128, 256, 2, 4, 2, 1, 0, "128x256 8w(2x4) 2 stages occ1");
+    RUN(128, 256, 2, 4, 2, 1, 8, "128x256 8w(2x4) 2 stages occ1 xcd");
+    RUN(128, 256, 2, 4, 3, 1, 0, "128x256 8w(2x4) 3 stages occ1");
+    RUN(128, 256, 2, 4, 3, 1, 8, "128x256 8w(2x4) 3 stages occ1 xcd");
     RUN(256, 128, 4, 2, 3, 1, 0, "256x128 8w(4x2) 3 stages occ1");
-    RUN(256, 128, 2, 2, 2, 1, 0, "256x128 4w(2x2) 2 stages occ1");
-    RUN(256, 128, 2, 2, 3, 1, 0, "256x128 4w(2x2) 3 stages occ1");
-    RUN(256, 256, 2, 4, 2, 1, 0, "256x256 8w(2x4) 2 stages occ1");
+    RUN(256, 128, 4, 2, 3, 1, 8, "256x128 8w(4x2) 3 stages occ1 xcd");
     RUN(128, 64, 2, 2, 2, 2, 0, "128x64  4w(2x2) 2 stages occ2");
-    RUN(128, 64, 2, 2, 3, 2, 0, "128x64  4w(2x2) 3 stages occ2");
-    // ablations of the two leading candidates
-    RUN(128, 128, 2, 4, 2, 2, 1, "128x128 8w 2st  -mfma");
-    RUN(128, 128, 2, 4, 2, 2, 2, "128x128 8w 2st  -fragreads");
-    RUN(128, 128, 2, 4, 2, 2, 4, "128x128 8w 2st  -loads");
-    RUN(128, 128, 2, 4, 2, 2, 6, "128x128 8w 2st  mfma + barriers only");
-    RUN(256, 128, 4, 2, 3, 1, 1, "256x128 8w 3st  -mfma");
-    RUN(256, 128, 4, 2, 3, 1, 2, "256x128 8w 3st  -fragreads");
-    RUN(256, 128, 4, 2, 3, 1, 4, "256x128 8w 3st  -loads");
-    RUN(256, 128, 4, 2, 3, 1, 6, "256x128 8w 3st  mfma + barriers only");
+    RUN(128, 64, 2, 2, 2, 2, 8, "128x64  4w(2x2) 2 stages occ2 xcd");
+    RUN(128, 128, 2, 4, 2, 2, 9, "128x128 8w 2st xcd -mfma");
     hipFree(A); hipFree(B); hipFree(Ap); hipFree(Bp); hipFree(C); hipFree(Cref);
   }
   return 0;

@@ -28,6 +28,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   ddp_check          TRIS_DDP_CHECK            NaN-poison check of the gradient reducer's release order
   ddp_sparse_embed   TRIS_DDP_SPARSE_EMBED     token-embedding gradient as a sparse (ids, rows) exchange
   random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
+  own_stream         TRIS_OWN_STREAM           the trainer / bench compute on a non-default stream (the default stream serialises with hipGraphs elsewhere)
   h2_planes          TRIS_H2_PLANES            h2 arithmetic: the RN50 trunk's activations / gradients / weights travel as fp16 operand planes
 """
 import contextlib
@@ -64,6 +65,7 @@ class _Config:
         self.ddp_sparse_embed = _flag("TRIS_DDP_SPARSE_EMBED", True)
         self.random_init = e("TRIS_RANDOM_INIT") == "1"
         self.h2_planes = _flag("TRIS_H2_PLANES", True)
+        self.own_stream = _flag("TRIS_OWN_STREAM", True)
 
     @contextlib.contextmanager
     def override(self, **kw):

@@ -27,6 +27,8 @@ extern __attribute__((visibility("hidden"))) int tris_internal_fin_block;
 // REDUCE_WIDE=0: split-K slabs of small outputs are summed by the one-thread-per-four-columns kernel as well; 4 | 8 | 16: slab
 // groups (waves) per block of the wide kernel (gemm_core.h)
 __attribute__((visibility("hidden"))) int tris_internal_reduce_wide = 4;
+// XCD_ORDER: -1 = the tuner's choice (LDS-DMA products only), 0 = never, 1 = every fast-kernel launch (gemm_core.h run_cfg)
+__attribute__((visibility("hidden"))) int tris_internal_xcd_order = -1;
 // option that lives in xattn_px.hip's translation unit
 extern __attribute__((visibility("hidden"))) int tris_internal_xattn_px_slots;
 }
@@ -67,7 +69,7 @@ static int parse_tile(const char* e) {
 static bool set_option(Options& o, const char* name, const char* v) {
   const bool unset = (v == nullptr || v[0] == 0);
   if (!strcmp(name, "FORCE_TILE")) o.force_tile = parse_tile(v);
-  else if (!strcmp(name, "FORCE_PIPE")) o.force_pipe = unset ? -1 : (v[0] == '1' ? 1 : 0);
+  else if (!strcmp(name, "FORCE_PIPE")) o.force_pipe = unset ? -1 : std::min(5, std::max(0, atoi(v)));   // (2 .. 5: the LDS-DMA loop where it applies)
   else if (!strcmp(name, "PIPE")) o.pipe_default = unset ? -1 : (v[0] == '0' ? 0 : 1);
   else if (!strcmp(name, "CONV_DIRECT")) o.conv_direct = unset ? -1 : atoi(v);
   else if (!strcmp(name, "WGRAD_DIRECT")) o.wgrad_direct = unset ? -1 : atoi(v);
@@ -79,6 +81,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "LN_BWD_BLOCKS")) tris_internal_ln_bwd_blocks = unset ? 512 : std::min(512, std::max(1, atoi(v)));
   else if (!strcmp(name, "FIN_BLOCK")) tris_internal_fin_block = unset ? 256 : (atoi(v) >= 1024 ? 1024 : atoi(v) >= 512 ? 512 : 256);
   else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 4 : std::max(0, atoi(v));
+  else if (!strcmp(name, "XCD_ORDER")) tris_internal_xcd_order = unset ? -1 : (atoi(v) > 0 ? 1 : 0);
   else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
   else return false;
@@ -86,7 +89,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
 }
 static Options init_options() {
   Options o;
-  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "TUNE_LOG"}) {
+  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "XCD_ORDER", "TUNE_LOG"}) {
     char env[64];
     snprintf(env, sizeof(env), "TRIS_%s", n);
     if (const char* v = getenv(env)) set_option(o, n, v);
@@ -162,7 +165,7 @@ static bool pipe_ok(const GemmParams& p) { return (g_gemm_mode == 1 || mode_h2()
 // static choice of the loop structure (the autotuner times both)
 static int default_pipe(const GemmParams& p, int bm, int bn, int splitk) {
   if (!pipe_ok(p) || bn == 32) return 0;
-  if (g_opt.force_pipe >= 0) return g_opt.force_pipe;
+  if (g_opt.force_pipe >= 0) return g_opt.force_pipe;   // (2 | 3 where the LDS-DMA loop does not apply: run_cfg runs the classic loop)
   // measured (tools/gemm_bench.py, autotuned tiles, classic | pipelined): the 3x3 convolutions from 128 channels up gain
   // 3-13 % (fwd 40x40x256: 165 -> 175, 20x20x512: 136 -> 154, wgrad 20x20x512: 154 -> 174 TFLOP/s); the short-K 1x1
   // products and the transformer GEMMs are on par or a few % slower -> static default by kind, the autotuner times both
@@ -202,7 +205,7 @@ static Cfg heuristic_cfg(const GemmParams& p, int batch, const float* ws, long w
       if (c == 3 && !(p.N <= 32 && fastk)) continue;  // 32-wide outputs (stem convolutions): half of a 64-wide tile would be padding
       const long tiles = (long)cdiv(p.M, cbm) * cdiv(p.N, cbn) * batch;
       // MFMA cycles of one 32x32 fragment pair per 32-deep step: 16 f32 MFMAs x 64, or 12 bf16 MFMAs x 32 (x3 mode)
-      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : g_gemm_mode == 3 ? 192.0 + 200.0 : g_gemm_mode == 4 ? 192.0 + 100.0 : 1024.0) * pen[c];
+      const double per_k32 = (cbm / 64) * (cbn / 64.0) * (g_gemm_mode == 1 ? 384.0 + 250.0 : mode_h2() ? 192.0 + 200.0 : 1024.0) * pen[c];
       const int smax = can_split ? (int)min((long)64, (long)(p.K / 256)) : 1;
       for (int sk = 1; sk <= smax; sk = (sk < 4 ? sk + 1 : sk + sk / 2)) {
         if (sk > 1 && (long)sk * p.M * p.N * (long)sizeof(float) > ws_bytes) break;
@@ -299,6 +302,16 @@ int launch_cfg(GemmParams& p, int batch, float* ws, long ws_bytes, hipStream_t s
         const Cfg c = {cbm, cbn, sk, pipe};
         const float ms = time_cfg(c);
         if (ms < best_ms) { best_ms = ms; best = c; }
+      }
+      if (g_gemm_mode == 4 && AK == A_ROWK && BKIND == B_NK && t != 3 && fastk && g_opt.force_pipe < 0) {
+        // operand planes, row-major A x B^T: the LDS-DMA loop (gemm_fast.h NSTG 4), eight- and four-wave forms of the 128 x 128 tile
+        // (+ 2: with the XCD-contiguous tile order)
+        for (int gp : {2, 3, 4, 5}) {
+          if ((gp == 3 || gp == 5) && t != 0) continue;
+          const Cfg c = {cbm, cbn, sk, gp};
+          const float ms = time_cfg(c);
+          if (ms < best_ms) { best_ms = ms; best = c; }
+        }
       }
     }
   }
@@ -833,6 +846,12 @@ extern "C" int tris_gemm_bnbwd_f32(const float* dY, const float* Wt, float* dZ, 
   *part_rows = cdiv(M, 128);
   H2Guard h2(p, h2n);
   if (h2.bad) return (int)hipErrorInvalidValue;
+  if (h2n.armed && h2n.planes && (h2n.flags & 2)) {   // the weight arrives as planes of W^T [N][K]: the forward's operand kinds
+    p.ldb = K;
+    p.vecB = al16(Wt) && (K % 4 == 0);
+    p.fastB = p.vecB;
+    return launch_cfg<A_ROWK, B_NK>(p, 1, nullptr, 0, (hipStream_t)stream);
+  }
   return launch_cfg<A_ROWK, B_KN>(p, 1, nullptr, 0, (hipStream_t)stream);
 }
 

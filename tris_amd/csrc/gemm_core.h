@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_reduce_wide; }   // option REDUCE_WIDE (gemm_conv.hip)
+extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_xcd_order; }     // option XCD_ORDER (gemm_conv.hip)
 // The same sum for outputs too SMALL to fill the chip with one thread per four columns (a 64 x 64 weight gradient cut into 128
 // slabs is 4 blocks of the kernel above, each thread walking 128 slabs four at a time: ~30 us of latency for 2 MB): a block of
 // G waves owns 64 float4 columns, wave w takes the slabs s = w, w + G, ..., the partial sums meet in LDS in a fixed order
@@ -458,8 +459,13 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   if (bn == 32 && !fast) bm = bn = 64;  // the 128x32 tile exists in the fast kernel only
   const bool xtra = p.pre_out != nullptr || p.dact_x != nullptr;   // (tris_gemm_epilogue_next: classic loop, one slice, fast kernel)
   if (mode == 4 && !fast) return (int)hipErrorInvalidValue;   // (operand planes exist for the fast kernel only: the caller checks)
-  const bool pipe = cfg.pipe && (mode == 1 || mode == 3 || mode == 4) && fast && bn != 32 && !xtra;   // (the pipelined loop: x3 and h2)
-  if (bm == 256 && !pipe) bm = 128;     // the 256-row tile exists in the pipelined form only
+  const bool pipe = cfg.pipe == 1 && (mode == 1 || mode == 3 || mode == 4) && fast && bn != 32 && !xtra;   // (the pipelined loop: x3 and h2)
+  // cfg.pipe 2 | 3: the LDS-DMA loop of gemm_fast.h (operand planes, row-major A x B^T): 2 = eight waves per 128 x 128 tile (2 x 4),
+  // 3 = four (2 x 2: 64 x 64 per wave); the other tiles have one form
+  // 4 | 5: the same with the XCD-contiguous tile order (gemm_fast.h xcd_remap 2)
+  const bool glds = cfg.pipe >= 2 && mode == 4 && fast && !xtra && bn != 32 && AK == A_ROWK && BKIND == B_NK;
+  const int gform = glds ? (cfg.pipe >= 4 ? cfg.pipe - 2 : cfg.pipe) : 0;   // 2: eight waves, 3: four
+  if (bm == 256 && !pipe && !glds) bm = 128;     // the 256-row tile exists in the pipelined / LDS-DMA forms only
   int tiles_m = cdiv(p.M, bm), tiles_n = cdiv(p.N, bn);
   p.tiles_n = tiles_n;
   const int kalign = fast ? 32 : BK;
@@ -469,6 +475,11 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(batch * splitk));
   // 3x3 weight gradients: the tap tiles of a k slice share their operands -> one XCD per slice
   p.xcd_remap = (fast && BKIND == B_KN_IM2COL && batch == 1 && splitk >= 8 && splitk % 8 == 0 && tiles_m * tiles_n > 1) ? 1 : 0;
+  if (glds && cfg.pipe >= 4) p.xcd_remap = 2;
+  // developer option XCD_ORDER = 1: the XCD-contiguous tile order for EVERY fast-kernel launch with at least two tiles per XCD that has
+  // no placement of its own (consecutive tiles share their A rows: one L2 instead of eight fetches them); 0: never
+  if (tris_internal_xcd_order >= 0 && fast && p.xcd_remap != 1)
+    p.xcd_remap = (tris_internal_xcd_order && tiles_m * tiles_n >= 16 && tiles_n > 1) ? 2 : 0;
   float* Cfinal = p.C;
   if (splitk > 1)
     p.vecC = (p.N % 4 == 0) && al16(ws);
@@ -526,6 +537,29 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
       TRIS_PIPE_ONE(BM_, BN_, NW_, NWM_, EPI_STD);               \
     }                                                            \
   } while (0)
+#define TRIS_GLDS_GO(BM_, BN_, NW_, NWM_)                                                                                          \
+  do {                                                                                                                           \
+    if (splitk > 1) {                                                                                                            \
+      p.C = ws;                                                                                                                  \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_SLAB, 4, NW_, 32, 4, NWM_>), grid, dim3(NW_ * 64), 0, st, p); \
+    } else {                                                                                                                     \
+      hipLaunchKernelGGL((gemm_fast_kernel<BM_, BN_, AK, BKIND, EPI_STD, 4, NW_, 32, 4, NWM_>), grid, dim3(NW_ * 64), 0, st, p);  \
+    }                                                                                                                            \
+  } while (0)
+  bool launched = false;
+  if constexpr (AK == A_ROWK && BKIND == B_NK) {
+    if (glds) {
+      launched = true;
+      if (bm == 256 && bn == 128) TRIS_GLDS_GO(256, 128, 8, 4);
+      else if (bm == 128 && bn == 128 && gform == 3) TRIS_GLDS_GO(128, 128, 4, 2);
+      else if (bm == 128 && bn == 128) TRIS_GLDS_GO(128, 128, 8, 2);
+      else if (bm == 128 && bn == 64) TRIS_GLDS_GO(128, 64, 4, 2);
+      else TRIS_GLDS_GO(64, 64, 4, 2);
+    }
+  }
+#undef TRIS_GLDS_GO
+  if (launched) {
+  } else
   if (pipe) {
     if (bm == 256 && bn == 128) TRIS_PIPE_GO(256, 128, 8, 4);
     else if (bm == 128 && bn == 128) TRIS_PIPE_GO(128, 128, 8, 2);

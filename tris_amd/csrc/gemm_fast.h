@@ -19,6 +19,8 @@
 //         the split + LDS stores of tile k+1 with the fragment reads + MFMAs of tile k), ONE barrier per K tile, global
 //         loads two tiles ahead in two register sets, branch-free steady state (a load inside a conditional block makes
 //         the compiler's wait-count pass wait for the loads it has just issued).  FBK = 16 keeps two such blocks per CU.
+//       NSTG = 4 ("LDS-DMA", PREC 4, row-major A x B^T only): operand planes are streamed into LDS by global_load_lds_dwordx4 --
+//         no staging registers, no ds_write, no VALU on the operands; see "LDS-DMA loop" in the kernel.
 //   * epilogue: bias / activation / residual / BN statistics, stored as 16-byte rows after an in-LDS turn of each wave's
 //     accumulator block (scalar fallback for unaligned or N % 4 != 0 outputs).
 // Preconditions (checked on the host, otherwise the generic kernel runs): K % 32 == 0 per k-slice, 16-byte aligned
@@ -56,6 +58,12 @@ constexpr int gf_halo_floats(int HS, int PREC) { return HS * ((PREC == 3 || PREC
 constexpr int gf_min_waves_per_simd(int BM, int BN, int PREC, int NW, int FBK, int NSTG, bool a_rm, bool b_rm, int HS = 0) {
   // (the classic kernels: two co-resident 8-wave blocks per CU, as tuned in round 1; h2's 4-wave 128 x 64 / 64 x 64 kernels fit
   // 128 registers with both accumulator sets and keep four waves per SIMD)
+  if (NSTG == 4) {   // LDS-DMA loop: two stages of (BM + BN) rows x 128 bytes; 32 accumulator registers per 32 x 32 block pair
+    const int blocks = (2 * (BM + BN) * 128 * 2 <= 160 * 1024) ? 2 : 1;
+    const int acc = (BM * BN / (NW * 1024)) * 32;
+    const int w = blocks * NW / 4;
+    return acc >= 256 ? 1 : (acc >= 128 && w > 2) ? 2 : (w < 1 ? 1 : w);
+  }
   if (NSTG == 1) return (NW == 8 || ((PREC == 3 || PREC == 4) && NW == 4 && BM * BN <= 128 * 64)) ? 4 : 2;
   const int lds = HS > 0 ? 4 * (gf_halo_floats(HS, PREC) + NSTG * gf_stage_floats(BN, FBK, PREC, b_rm))
                          : 4 * NSTG * (gf_stage_floats(BM, FBK, PREC, a_rm) + gf_stage_floats(BN, FBK, PREC, b_rm));
@@ -127,9 +135,14 @@ void gemm_fast_kernel(GemmParams p) {
   constexpr int PLB = 2 * FBK + 16;                      // bytes per row of one row-major bf16 plane
   constexpr int A_SZ = HALO ? gf_halo_floats(HS, PREC) : gf_stage_floats(BM, FBK, PREC, A_RM);
   constexpr int B_SZ = gf_stage_floats(BN, FBK, PREC, B_RM);
-  constexpr int AS_ALL = A_SZ;
-  __shared__ __attribute__((aligned(16))) float As[AS_ALL];
-  __shared__ __attribute__((aligned(16))) float Bs_[B_SZ];
+  // LDS-DMA loop (NSTG 4): ALL of the kernel's LDS is ONE object (with a second one, however small, the compiler waits for
+  // vmcnt(0) before the first fragment read of every k step): two stages of [A rows | B rows] x 128 bytes
+  constexpr bool GLDS = (NSTG == 4);
+  static_assert(!GLDS || (PLN && AK == A_ROWK && BKIND == B_NK && FBK == 32 && !HALO), "LDS-DMA loop: operand planes, row-major A x B^T");
+  constexpr int G_ST = (BM + BN) * 128;                      // bytes per stage
+  constexpr int AS_ALL = GLDS ? 2 * G_ST / 4 : A_SZ;         // floats the epilogue may use through `As`
+  __shared__ __attribute__((aligned(1024))) float As[AS_ALL];
+  __shared__ __attribute__((aligned(16))) float Bs_[GLDS ? 4 : B_SZ];
   __shared__ __attribute__((aligned(16))) float As1[(NSTG == 2 && !HALO) ? A_SZ : 4];   // second stage (pipelined loop): separate objects
   __shared__ __attribute__((aligned(16))) float Bs1_[NSTG == 2 ? B_SZ : 4];
   float* const Bs = Bs_;
@@ -144,6 +157,13 @@ void gemm_fast_kernel(GemmParams p) {
   // 1.6 GB of fabric traffic per layer1 launch for 157 MB of operands).  With xcd_remap (host: split-K slices % 8 == 0) all
   // tiles of a slice run on ONE XCD, so that L2 serves eight of the nine reads.  Pure placement: any mapping is correct.
   int bid_x = blockIdx.x, bid_z = blockIdx.z;
+  if (p.xcd_remap == 2) {
+    // every XCD takes a CONTIGUOUS range of tiles: the column tiles of one row block -- same A rows -- run on one XCD and share its
+    // L2 instead of eight L2s fetching a copy each (the M-large / N-small products of the trunk: +7 ... +30 %, tools/probes/
+    // h2_plane_probe.hip; square products lose -- the tuner times both).  Bijective for any grid size.
+    const int T = gridDim.x, q = T >> 3, r = T & 7, x = bid_x & 7;
+    bid_x = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid_x >> 3);
+  } else
   if (p.xcd_remap) {
     const int T = gridDim.x;
     const int L = bid_x + T * bid_z;          // dispatch order (gridDim.y == 1)
@@ -608,6 +628,86 @@ void gemm_fast_kernel(GemmParams p) {
     }
     if (c < nch) chunk(Bs, Bs1, rb0, rb1, c);
   } else
+  if constexpr (GLDS) {
+    // ---- LDS-DMA loop (operand planes: the pieces arrive split; probe: tools/probes/h2_plane_probe.hip) ------------------------
+    // A tile row is 32 k of both planes = 128 bytes = 8 pieces [hi 0-7 | lo 0-7 | hi 8-15 | ...]; one wave instruction moves 8 rows
+    // (64 lanes x 16 bytes) into a LANE-LINEAR 1 KB of LDS.  Bank conflicts of the ds_read_b128 fragment reads (16-lane service
+    // groups: 16 rows, same piece) are avoided by a swizzle applied to the SOURCE address: LDS slot s of row r holds piece
+    // s ^ ((r >> 1) & 7), so the group's rows fall on 16 distinct 16-byte slots of the 256-byte bank row.  Two stages, raw
+    // s_barrier and counted vmcnt: the loads of tile k + 1 are in flight while tile k is computed; the MFMA k order is the classic
+    // loop's (lane half kh, step g <-> k = 16 g + 8 kh + j), so the sums are bit-identical to it.
+    char* const gs = reinterpret_cast<char*>(As);
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;     // LDS-DMA instructions per wave and stage
+    static_assert(GA >= 1 && GB >= 1 && GA * 8 * NW == BM && GB * 8 * NW == BN, "LDS-DMA loop: tile rows / waves mismatch");
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const char* a_src[GA];
+    const char* b_src[GB];
+#pragma unroll
+    for (int q = 0; q < GA; ++q) {
+      const int r = (wave * GA + q) * 8 + lrow;
+      a_src[q] = reinterpret_cast<const char*>(A + (long)min(m0 + r, p.M - 1) * p.lda + kbeg) + ((lslot ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+      const int r = (wave * GB + q) * 8 + lrow;
+      b_src[q] = reinterpret_cast<const char*>(Bp + (long)min(n0 + r, p.N - 1) * p.ldb + kbeg) + ((lslot ^ ((r >> 1) & 7)) << 4);
+    }
+    auto issue = [&](int stage, int kt) {
+      char* sa = gs + stage * G_ST + (wave * GA) * 1024;
+      char* sb = gs + stage * G_ST + BM * 128 + (wave * GB) * 1024;
+#pragma unroll
+      for (int q = 0; q < GA; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (long)kt * 128),
+                                         (__attribute__((address_space(3))) void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+      for (int q = 0; q < GB; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + (long)kt * 128),
+                                         (__attribute__((address_space(3))) void*)(sb + q * 1024), 16, 0, 0);
+    };
+    int a_ro[FM], b_ro[FN], a_sw[FM], b_sw[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) { const int r = wm * WM + i * 32 + li; a_ro[i] = r * 128; a_sw[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { const int r = wn * WN + j * 32 + li; b_ro[j] = BM * 128 + r * 128; b_sw[j] = (r >> 1) & 7; }
+    auto compute = [&](int stage) {
+      const char* st = gs + stage * G_ST;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        Split8 sa[FM], sb[FN];
+        const int p0 = 2 * (2 * g + kh);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          sa[i].hi = *reinterpret_cast<const bf16x8*>(st + a_ro[i] + ((p0 ^ a_sw[i]) << 4));
+          sa[i].mid = *reinterpret_cast<const bf16x8*>(st + a_ro[i] + (((p0 + 1) ^ a_sw[i]) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          sb[j].hi = *reinterpret_cast<const bf16x8*>(st + b_ro[j] + ((p0 ^ b_sw[j]) << 4));
+          sb[j].mid = *reinterpret_cast<const bf16x8*>(st + b_ro[j] + (((p0 + 1) ^ b_sw[j]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) mfma_x(sa[i], sb[j], i, j);
+      }
+    };
+    const int nk = (kend - kbeg) / 32;
+    constexpr int GPS = GA + GB;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      // (everyone has finished reading stage (kt + 1) & 1: the barrier that closed the previous step)
+      if (kt + 1 < nk) {
+        issue((kt + 1) & 1, kt + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt have landed
+      compute(kt & 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else
   if constexpr (NSTG == 2) {
     // ---- pipelined loop: one barrier per K tile -----------------------------------------------------------------------------
     constexpr int G = FBK / 16, NCH = PA + PB, NPR = FM * FN * G;
@@ -771,7 +871,7 @@ void gemm_fast_kernel(GemmParams p) {
   // + a wave fence) and handles rows: 8 lanes x 16 bytes per row, 8 rows per instruction -- 4 loads/stores per block.
   constexpr int ELD = 36;
   // waves whose 32 x 36 turn-around block fits an array
-  constexpr int EW_A = AS_ALL / (32 * ELD), EW_B = B_SZ / (32 * ELD);
+  constexpr int EW_A = AS_ALL / (32 * ELD), EW_B = GLDS ? 0 : B_SZ / (32 * ELD);
   constexpr int EW_A1 = (NSTG == 2 && !HALO) ? EW_A : 0, EW_B1 = NSTG == 2 ? EW_B : 0;
   constexpr bool EPI_LDS = EW_A + EW_B + EW_A1 + EW_B1 >= NW;
   float4 vs_s[FN], vs_q[FN];
@@ -782,7 +882,9 @@ void gemm_fast_kernel(GemmParams p) {
   const bool nt_e = EPI != EPI_SLAB && p.nt != 0;   // uniform: epilogue streams larger than the memory-side cache (gemm_conv.hip stream_nt)
   if (vec_epi) {
     float* stg;
-    {
+    if constexpr (GLDS) {
+      stg = As + wave * 32 * ELD;     // (the one LDS object of the LDS-DMA loop)
+    } else {
       int w = wave;
       if (w < EW_A) stg = As + w * 32 * ELD;
       else if ((w -= EW_A) < EW_B) stg = Bs_ + w * 32 * ELD;

@@ -231,14 +231,30 @@ extern "C" { __attribute__((visibility("hidden"))) int tris_internal_fin_block =
 inline int fin_block(int nb) { return nb > 2048 ? tris_internal_fin_block : 256; }
 
 // BN forward finalize: stats[0]=mean, stats[1]=invstd, stats[2]=biased var; optional running-stat update.
+// bound_out != NULL (operand planes, csrc/planes.hip): the launch also leaves the Samuelson bound of the BatchNorm's OUTPUT, max_c
+// |gamma_c| xhat_max + |beta_c| (+ the value of *add_word: the bound of the residual it is added to), in the amax word bound_out --
+// tris_bn_out_bound2_f32 without a launch of its own (the bound depends on the parameters alone; it rides here because this launch
+// exists anyway and precedes the pass that needs the word)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
                                                           float eps, float momentum, float* __restrict__ stats,
-                                                          float* running_mean, float* running_var) {
+                                                          float* running_mean, float* running_var,
+                                                          const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                                          float xhat_max = 0.f, const unsigned* __restrict__ add_word = nullptr,
+                                                          unsigned* __restrict__ bound_out = nullptr) {
+  __shared__ float sh_add;
+  if (bound_out != nullptr && threadIdx.x < 64) {
+    const unsigned v = add_word != nullptr ? max(add_word[threadIdx.x * 16], add_word[(threadIdx.x + 64) * 16]) : 0u;
+    unsigned m = v;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
+    if (threadIdx.x == 0) sh_add = __builtin_bit_cast(float, m);
+  }
   double s, ss;
   int c;
   bool lead;
   reduce_parts(part, nb, C, true, s, ss, c, lead);
   if (!lead) return;
+  if (bound_out != nullptr) amax_raise(__builtin_bit_cast(unsigned, fabsf(gamma[c]) * xhat_max + fabsf(beta[c]) + sh_add), bound_out);
   double mean = s / (double)M;
   double var = ss / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -253,9 +269,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 }
 
 // Sum partials [nb][2][C] -> out0[C] (and out1[C] if given).
+// bound_out != NULL (operand planes; the sums are sum(dz), sum(dz xhat) of a BatchNorm backward): the launch also leaves the bound of
+// that BatchNorm's dx, max_c |gamma invstd| (amax_dz + |sum_dz| / n + xhat_max |sum_dzx| / n), in the amax word bound_out
+// (tris_bn_bwd_bound_f32 without a launch of its own); *dz_word: the amax of the masked gradient, left by the pass that made the partials
 template <typename T>
 __global__ __launch_bounds__(1024) void part_finalize_kernel(const T* __restrict__ part, int nb, int C,
-                                                            float* __restrict__ out0, float* __restrict__ out1) {
+                                                            float* __restrict__ out0, float* __restrict__ out1,
+                                                            const float* __restrict__ gamma = nullptr, const float* __restrict__ invstd = nullptr,
+                                                            float inv_cnt = 0.f, float xhat_max = 0.f,
+                                                            const unsigned* __restrict__ dz_word = nullptr,
+                                                            unsigned* __restrict__ bound_out = nullptr) {
+  __shared__ float sh_adz;
+  if (bound_out != nullptr && threadIdx.x < 64) {
+    unsigned m = max(dz_word[threadIdx.x * 16], dz_word[(threadIdx.x + 64) * 16]);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sft, 64));
+    if (threadIdx.x == 0) sh_adz = __builtin_bit_cast(float, m);
+  }
   double s, ss;
   int c;
   bool lead;
@@ -263,6 +293,9 @@ __global__ __launch_bounds__(1024) void part_finalize_kernel(const T* __restrict
   if (!lead) return;
   out0[c] = (float)s;
   if (out1) out1[c] = (float)ss;
+  if (bound_out != nullptr)
+    amax_raise(__builtin_bit_cast(unsigned, fabsf(gamma[c] * invstd[c]) * (sh_adz + fabsf((float)s) * inv_cnt + xhat_max * fabsf((float)ss) * inv_cnt)),
+               bound_out);
 }
 
 // SyncBN: combine the per-rank statistics blocks [mean | invstd | biased var] (3*C floats each, exactly what
@@ -847,6 +880,16 @@ extern "C" int tris_bn_finalize_f32(const double* part, int rows, long M, int C,
   return 0;
 }
 
+extern "C" int tris_bn_finalize_bound_f32(const double* part, int rows, long M, int C, float eps, float momentum, float* stats,
+                                          float* running_mean, float* running_var, const float* gamma, const float* beta, float xhat_max,
+                                          const unsigned* add_word, unsigned* bound_out, void* stream) {
+  if (gamma == nullptr || beta == nullptr || bound_out == nullptr) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_grid(C, rows)), dim3(fin_block(rows)), 0, (hipStream_t)stream, part, rows, M, C, eps,
+                     momentum, stats, running_mean, running_var, gamma, beta, xhat_max, add_word, bound_out);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tris_bn_sync_combine_f32(const float* gathered, int world, int C, long count_per_rank, float eps,
                                         float momentum, float* stats, float* running_mean, float* running_var,
                                         void* stream) {
@@ -1011,6 +1054,17 @@ extern "C" int tris_part_finalize_f32(const double* part, int rows, int C, float
   if (rows < 1 || C < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, rows)), dim3(fin_block(rows)), 0, (hipStream_t)stream, part, rows,
                      C, out0, out1);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_part_finalize_bound_f32(const double* part, int rows, int C, float* out0, float* out1, const float* gamma,
+                                            const float* invstd, float inv_count, float xhat_max, const unsigned* dz_word,
+                                            unsigned* bound_out, void* stream) {
+  if (rows < 1 || C < 1 || out1 == nullptr || gamma == nullptr || invstd == nullptr || dz_word == nullptr || bound_out == nullptr)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(part_finalize_kernel<double>, dim3(fin_grid(C, rows)), dim3(fin_block(rows)), 0, (hipStream_t)stream, part, rows,
+                     C, out0, out1, gamma, invstd, inv_count, xhat_max, dz_word, bound_out);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -35,6 +35,36 @@ __global__ __launch_bounds__(256) void to_planes_segments_kernel(const float* __
   for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += stride)
     pl8_store(out, g, pl8_split(ldf4(x + g * 8), ldf4(x + g * 8 + 4), s));
 }
+// TRANSPOSED planes of 1x1-convolution weights W [rows = Cout][cols = Cin] -> planes of W^T [Cin][Cout] (P8 along Cout), so that the
+// data gradient dX = dY . W is the same row-major A x B^T product as the forward (B^T = W^T, k = Cout contiguous).  grid (tiles, segments):
+// a block turns 64 x 64 tiles around through LDS (coalesced reads along Cin, 32-byte group stores along Cout).
+__global__ __launch_bounds__(256) void to_planes_t_segments_kernel(const float* __restrict__ base, const long* __restrict__ offs,
+                                                                   const long* __restrict__ rows, const long* __restrict__ cols,
+                                                                   const long* __restrict__ slot_index,
+                                                                   const unsigned* __restrict__ slots, float* __restrict__ out_base) {
+  __shared__ float t[64][65];
+  const int R = (int)rows[blockIdx.y], C = (int)cols[blockIdx.y];
+  const float* x = base + offs[blockIdx.y];
+  float* out = out_base + offs[blockIdx.y];
+  const float s = pl_scale(slots + slot_index[blockIdx.y] * 2048);
+  const int tr = R / 64, tc = C / 64;
+  for (int tile = blockIdx.x; tile < tr * tc; tile += gridDim.x) {
+    const int r0 = (tile / tc) * 64, c0 = (tile % tc) * 64;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const float4 v = ldf4(x + (long)(r0 + r) * C + c0 + c4);
+      t[r][c4] = v.x; t[r][c4 + 1] = v.y; t[r][c4 + 2] = v.z; t[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {   // group (column c of W = row of W^T, 8 consecutive rows of W)
+      const int c = i >> 3, g = i & 7;
+      const float4 a = make_float4(t[g * 8][c], t[g * 8 + 1][c], t[g * 8 + 2][c], t[g * 8 + 3][c]);
+      const float4 b = make_float4(t[g * 8 + 4][c], t[g * 8 + 5][c], t[g * 8 + 6][c], t[g * 8 + 7][c]);
+      pl8_store(out, ((long)(c0 + c) * R + r0 + g * 8) >> 3, pl8_split(a, b, s));
+    }
+  }
+}
 __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restrict__ pl, float* __restrict__ out, long n8,
                                                           const unsigned* __restrict__ word) {
   const float inv = 1.0f / pl_scale(word);
@@ -70,6 +100,14 @@ extern "C" int tris_h2_planes_segments_f32(const float* base, const long* offs, 
   TRIS_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int tris_h2_planes_t_segments_f32(const float* base, const long* offs, const long* rows, const long* cols,
+                                             const long* slot_index, int nseg, const unsigned* slots, float* out_base, void* stream) {
+  if (nseg < 1 || !al16p(base) || !al16p(out_base)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(to_planes_t_segments_kernel, dim3(64, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, base, offs, rows, cols,
+                     slot_index, slots, out_base);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int tris_h2_unplanes_f32(const float* planes, float* out, long n, const unsigned* word, void* stream) {
   if (n < 8 || (n & 7) || !al16p(planes) || !al16p(out) || word == nullptr) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(from_planes_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, planes, out, n >> 3, word);
@@ -98,8 +136,6 @@ template <bool NT> __device__ __forceinline__ void stu(float* p, const uint4 v) 
   else *reinterpret_cast<uint4*>(p) = v;
 }
 // the streaming form of norm.hip ("BIG": one contiguous piece per block, nontemporal, PL_U groups of 8 elements per thread and stream)
-constexpr int PL_U = 2;
-constexpr long PL_PIECE = 256L * PL_U;
 struct Ch8 { float4 a, b; };
 __device__ __forceinline__ Ch8 ld8(const float* p) { Ch8 v; v.a = ldf4(p); v.b = ldf4(p + 4); return v; }
 __device__ __forceinline__ float4 mul4(const float4 x, const float4 y) { return make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w); }
@@ -109,8 +145,41 @@ __device__ __forceinline__ float4 bn4(const float4 x, const float4 mu, const flo
 __device__ __forceinline__ float4 add4(const float4 x, const float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
 __device__ __forceinline__ float4 relu4(const float4 x) { return make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f)); }
 
+// ---- access pattern of the streaming passes below ----------------------------------------------------------------------------
+// A group of 8 elements is 32 bytes; a thread that loaded / stored its own group with two 16-byte instructions would touch memory at
+// a 32-byte lane stride -- every instruction half-covers its cache lines (measured: the first version of these passes ran at half
+// the rate of their fp32 forms).  Instead a wave walks UNITS of 512 elements = two 1 KB chunks; an instruction is lane-linear (lane l
+// <-> bytes 16 l of the chunk, fully coalesced), and the two lanes of a pair (2p, 2p + 1) trade one register quad through DPP so
+// that the even lane ends up with the whole group p of chunk 0 and the odd lane with group p of chunk 1 -- for fp32 data (elements
+// 0-3 | 4-7 of a group sit in adjacent lanes) and for plane data (hi piece | lo piece sit in adjacent lanes) alike, and the same
+// trade turns results back into the chunks' lane-linear order (pair_xchg is its own inverse).
+__device__ __forceinline__ float dpp_nb(const float v) {   // the value of lane ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void pair_xchg(float4& a, float4& b, const bool odd) {
+  const float4 send = odd ? a : b;
+  const float4 recv = make_float4(dpp_nb(send.x), dpp_nb(send.y), dpp_nb(send.z), dpp_nb(send.w));
+  if (odd) a = recv; else b = recv;
+}
+__device__ __forceinline__ void pair_xchg(uint4& a, uint4& b, const bool odd) {
+  float4 fa = __builtin_bit_cast(float4, a), fb = __builtin_bit_cast(float4, b);
+  pair_xchg(fa, fb, odd);
+  a = __builtin_bit_cast(uint4, fa);
+  b = __builtin_bit_cast(uint4, fb);
+}
+constexpr int PL_UPB = 8;   // units per block of the streaming ("BIG") form: two per wave, both in flight (16 KB per block and stream)
+// the units a wave walks: BIG: block b owns units [b PL_UPB, (b + 1) PL_UPB), wave w takes b PL_UPB + w and + 4; otherwise a grid-stride
+// walk.  Either way a thread's units are a multiple of 2048 elements apart, so it sees ONE group of 8 channels (C divides 2048).
+template <bool BIG> struct UnitWalk {
+  long u, step, end;
+  __device__ UnitWalk(long units, int wave) {
+    if (BIG) { u = (long)blockIdx.x * PL_UPB + wave; step = 4; end = min(units, (long)(blockIdx.x + 1) * PL_UPB); }
+    else { u = (long)blockIdx.x * 4 + wave; step = (long)gridDim.x * 4; end = units; }
+  }
+};
+
 // Y (planes, scale from out_word) = [relu]((X - mean) * invstd * gamma + beta [+ resid]); resid: fp32 (rk 1) or planes with the scale
-// of resid_word (rk 2).  The launch keeps gridDim * 256 (BIG: the piece) a multiple of C / 8: a thread sees ONE group of 8 channels.
+// of resid_word (rk 2).
 template <bool BIG>
 __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restrict__ X, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -119,48 +188,55 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
                                                           const unsigned* __restrict__ out_word, long n8, int C, int relu) {
   const float s = pl_scale(out_word);
   const float rinv = rk == 2 ? 1.0f / pl_scale(resid_word) : 1.0f;
-  const long stride = (long)gridDim.x * blockDim.x;
-  long i = BIG ? (long)blockIdx.x * PL_PIECE + threadIdx.x : (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = (int)((i * 8) % C);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool odd = lane & 1;
+  const long n = n8 * 8;
+  UnitWalk<BIG> w((n + 511) / 512, wave);
+  const int c = (int)((w.u * 512 + (odd ? 256 : 0) + 8 * (lane >> 1)) % C);
   const Ch8 mu = ld8(mean + c), is = ld8(invstd + c), g = ld8(gamma + c), b = ld8(beta + c);
   const float4 sca = mul4(is.a, g.a), scb = mul4(is.b, g.b);
-  auto finish = [&](long j, const float4 x0, const float4 x1, const uint4 r0, const uint4 r1) {
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  auto finish = [&](long e0, float4 x0, float4 x1, float4 r0, float4 r1) {
+    const long e1 = e0 + 256;
+    pair_xchg(x0, x1, odd);
     float4 y0 = bn4(x0, mu.a, sca, b.a), y1 = bn4(x1, mu.b, scb, b.b);
-    if (rk == 1) {
-      y0 = add4(y0, __builtin_bit_cast(float4, r0));
-      y1 = add4(y1, __builtin_bit_cast(float4, r1));
-    } else if (rk == 2) {
-      float4 ra, rb;
-      pl8_join(r0, r1, rinv, ra, rb);
-      y0 = add4(y0, ra);
-      y1 = add4(y1, rb);
+    if (rk) {
+      pair_xchg(r0, r1, odd);      // fp32: the group's elements 0-3 | 4-7; planes: its hi | lo piece
+      if (rk == 2) {
+        float4 ra, rb;
+        pl8_join(__builtin_bit_cast(uint4, r0), __builtin_bit_cast(uint4, r1), rinv, ra, rb);
+        r0 = ra;
+        r1 = rb;
+      }
+      y0 = add4(y0, r0);
+      y1 = add4(y1, r1);
     }
     if (relu) { y0 = relu4(y0); y1 = relu4(y1); }
-    const Pl8 o = pl8_split(y0, y1, s);
-    stu<BIG>(Y + j * 8, o.hi);
-    stu<BIG>(Y + j * 8 + 4, o.lo);
+    Pl8 o = pl8_split(y0, y1, s);
+    pair_xchg(o.hi, o.lo, odd);
+    if (e0 < n) stu<BIG>(Y + e0, o.hi);
+    if (e1 < n) stu<BIG>(Y + e1, o.lo);
   };
-  const uint4 zu = make_uint4(0u, 0u, 0u, 0u);
   if (BIG) {
-    float4 x0[PL_U], x1[PL_U];
-    uint4 r0[PL_U], r1[PL_U];
+    float4 x0[2], x1[2], r0[2], r1[2];
 #pragma unroll
-    for (int u = 0; u < PL_U; ++u) {
-      const long j = i + u * 256;
-      const bool ok = j < n8;
-      x0[u] = ok ? ldx<true>(X + j * 8) : make_float4(0, 0, 0, 0);
-      x1[u] = ok ? ldx<true>(X + j * 8 + 4) : make_float4(0, 0, 0, 0);
-      r0[u] = (ok && rk) ? ldu<true>(resid + j * 8) : zu;
-      r1[u] = (ok && rk) ? ldu<true>(resid + j * 8 + 4) : zu;
+    for (int q = 0; q < 2; ++q) {
+      const long e0 = (w.u + 4 * q) * 512 + lane * 4, e1 = e0 + 256;
+      const bool ok0 = (w.u + 4 * q) < w.end && e0 < n, ok1 = (w.u + 4 * q) < w.end && e1 < n;
+      x0[q] = ok0 ? ldx<true>(X + e0) : z4;
+      x1[q] = ok1 ? ldx<true>(X + e1) : z4;
+      r0[q] = (ok0 && rk) ? ldx<true>(resid + e0) : z4;
+      r1[q] = (ok1 && rk) ? ldx<true>(resid + e1) : z4;
     }
 #pragma unroll
-    for (int u = 0; u < PL_U; ++u) {
-      const long j = i + u * 256;
-      if (j < n8) finish(j, x0[u], x1[u], r0[u], r1[u]);
-    }
+    for (int q = 0; q < 2; ++q)
+      if ((w.u + 4 * q) < w.end) finish((w.u + 4 * q) * 512 + lane * 4, x0[q], x1[q], r0[q], r1[q]);   // (wave-uniform)
   } else {
-    for (; i < n8; i += stride)
-      finish(i, ldf4(X + i * 8), ldf4(X + i * 8 + 4), rk ? ldu<false>(resid + i * 8) : zu, rk ? ldu<false>(resid + i * 8 + 4) : zu);
+    for (; w.u < w.end; w.u += w.step) {
+      const long e0 = w.u * 512 + lane * 4, e1 = e0 + 256;
+      finish(e0, e0 < n ? ldf4(X + e0) : z4, e1 < n ? ldf4(X + e1) : z4, (rk && e0 < n) ? ldf4(resid + e0) : z4,
+             (rk && e1 < n) ? ldf4(resid + e1) : z4);
+    }
   }
 }
 
@@ -240,7 +316,8 @@ __device__ __forceinline__ long pooled_row_pl(long row, int H, int W) {   // (no
 }
 // dX (planes, scale from out_word) = gamma * invstd * (dz - sum_dz / cnt - xhat * sum_dzxhat / cnt), dz = dY masked by the ReLU
 // (Y given as planes: y > 0 <=> a piece is non-zero; beta_mask: recomputed from X; neither: no ReLU); optional dZ (fp32) <- dz.
-// norm.hip bn_bwd_apply_kernel's arithmetic on groups of 8 channels.  POOL: dY is the gradient of avgpool2 of the output.
+// norm.hip bn_bwd_apply_kernel's arithmetic on groups of 8 channels, in the unit walk above.  POOL: dY is the gradient of avgpool2 of
+// the output (read per group, a quarter of the traffic).
 template <bool POOL, bool BIG>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __restrict__ dY, const float* __restrict__ Ypl,
                                                               const float* __restrict__ X, const float* __restrict__ mean,
@@ -250,9 +327,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
                                                               float* __restrict__ dZ, long n8, int C, const float* __restrict__ beta_mask,
                                                               int pool_h, int pool_w) {
   const float s = pl_scale(out_word);
-  const long stride = (long)gridDim.x * blockDim.x;
-  long i = BIG ? (long)blockIdx.x * PL_PIECE + threadIdx.x : (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = (int)((i * 8) % C);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool odd = lane & 1;
+  const long n = n8 * 8;
+  UnitWalk<BIG> w((n + 511) / 512, wave);
+  const int c = (int)((w.u * 512 + (odd ? 256 : 0) + 8 * (lane >> 1)) % C);
   const Ch8 mu = ld8(mean + c), is = ld8(invstd + c), ga = ld8(gamma + c), sa = ld8(sum_dz + c), sb = ld8(sum_dzx + c);
   Ch8 be;
   be.a = be.b = make_float4(0, 0, 0, 0);
@@ -263,18 +342,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
   const float4 k3a = make_float4(is.a.x * sb.a.x * inv_cnt, is.a.y * sb.a.y * inv_cnt, is.a.z * sb.a.z * inv_cnt, is.a.w * sb.a.w * inv_cnt);
   const float4 k3b = make_float4(is.b.x * sb.b.x * inv_cnt, is.b.y * sb.b.y * inv_cnt, is.b.z * sb.b.z * inv_cnt, is.b.w * sb.b.w * inv_cnt);
   const bool use_y = !beta_mask && Ypl != nullptr;
-  auto load_g = [&](long j, float4& g0, float4& g1) {
-    if (POOL) {
-      const float* q = dY + pooled_row_pl(j * 8 / C, pool_h, pool_w) * C + c;
-      g0 = ldf4(q);
-      g1 = ldf4(q + 4);
-      g0 = make_float4(g0.x * 0.25f, g0.y * 0.25f, g0.z * 0.25f, g0.w * 0.25f);
-      g1 = make_float4(g1.x * 0.25f, g1.y * 0.25f, g1.z * 0.25f, g1.w * 0.25f);
-    } else {
-      g0 = ldx<BIG>(dY + j * 8);
-      g1 = ldx<BIG>(dY + j * 8 + 4);
-    }
-  };
+  const float4 z4 = make_float4(0, 0, 0, 0);
   auto half = [&](float4 g, const float4 x, const float4 mu4, const float4 k1, const float4 k2, const float4 k3, const float4 be4,
                   unsigned pos, float4& gm) {
     if (beta_mask) {
@@ -292,43 +360,70 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
     return make_float4(k1.x * (g.x - k2.x - (x.x - mu4.x) * k3.x), k1.y * (g.y - k2.y - (x.y - mu4.y) * k3.y),
                        k1.z * (g.z - k2.z - (x.z - mu4.z) * k3.z), k1.w * (g.w - k2.w - (x.w - mu4.w) * k3.w));
   };
-  auto finish = [&](long j, const float4 g0, const float4 g1, const float4 x0, const float4 x1, const uint4 yh, const uint4 yl) {
-    const unsigned pos = use_y ? pl8_positive(yh, yl) : 0u;
+  // (chunk-ordered registers of one unit -> this thread's group -> chunk-ordered results)
+  auto finish = [&](long e0, float4 g0, float4 g1, float4 x0, float4 x1, float4 y0, float4 y1) {
+    const long e1 = e0 + 256;
+    pair_xchg(x0, x1, odd);
+    if (!POOL) pair_xchg(g0, g1, odd);
+    unsigned pos = 0u;
+    if (use_y) {
+      pair_xchg(y0, y1, odd);
+      pos = pl8_positive(__builtin_bit_cast(uint4, y0), __builtin_bit_cast(uint4, y1));
+    }
     float4 m0, m1;
     const float4 o0 = half(g0, x0, mu.a, k1a, k2a, k3a, be.a, pos & 15u, m0);
     const float4 o1 = half(g1, x1, mu.b, k1b, k2b, k3b, be.b, pos >> 4, m1);
-    if (dZ) { stx<BIG>(dZ + j * 8, m0); stx<BIG>(dZ + j * 8 + 4, m1); }
-    const Pl8 o = pl8_split(o0, o1, s);
-    stu<BIG>(dX + j * 8, o.hi);
-    stu<BIG>(dX + j * 8 + 4, o.lo);
+    if (dZ) {
+      pair_xchg(m0, m1, odd);
+      if (e0 < n) stx<BIG>(dZ + e0, m0);
+      if (e1 < n) stx<BIG>(dZ + e1, m1);
+    }
+    Pl8 o = pl8_split(o0, o1, s);
+    pair_xchg(o.hi, o.lo, odd);
+    if (e0 < n) stu<BIG>(dX + e0, o.hi);
+    if (e1 < n) stu<BIG>(dX + e1, o.lo);
   };
-  const uint4 zu = make_uint4(0u, 0u, 0u, 0u);
+  // POOL: the pooled gradient of THIS thread's group (its own 8 channels of the pooled pixel), already a quarter
+  auto pooled_g = [&](long u, float4& g0, float4& g1) {
+    const long eg = u * 512 + (odd ? 256 : 0) + 8 * (lane >> 1);
+    g0 = g1 = z4;
+    if (eg < n) {
+      const float* q = dY + pooled_row_pl(eg / C, pool_h, pool_w) * C + c;
+      g0 = ldf4(q);
+      g1 = ldf4(q + 4);
+      g0 = make_float4(g0.x * 0.25f, g0.y * 0.25f, g0.z * 0.25f, g0.w * 0.25f);
+      g1 = make_float4(g1.x * 0.25f, g1.y * 0.25f, g1.z * 0.25f, g1.w * 0.25f);
+    }
+  };
   if (BIG) {
-    float4 g0[PL_U], g1[PL_U], x0[PL_U], x1[PL_U];
-    uint4 yh[PL_U], yl[PL_U];
+    float4 g0[2], g1[2], x0[2], x1[2], y0[2], y1[2];
 #pragma unroll
-    for (int u = 0; u < PL_U; ++u) {
-      const long j = i + u * 256;
-      const bool ok = j < n8;
-      g0[u] = g1[u] = x0[u] = x1[u] = make_float4(0, 0, 0, 0);
-      yh[u] = yl[u] = zu;
-      if (ok) {
-        load_g(j, g0[u], g1[u]);
-        x0[u] = ldx<true>(X + j * 8);
-        x1[u] = ldx<true>(X + j * 8 + 4);
-        if (use_y) { yh[u] = ldu<true>(Ypl + j * 8); yl[u] = ldu<true>(Ypl + j * 8 + 4); }
+    for (int q = 0; q < 2; ++q) {
+      const long u = w.u + 4 * q;
+      const long e0 = u * 512 + lane * 4, e1 = e0 + 256;
+      const bool ok0 = u < w.end && e0 < n, ok1 = u < w.end && e1 < n;
+      if (POOL) {
+        if (u < w.end) pooled_g(u, g0[q], g1[q]); else g0[q] = g1[q] = z4;
+      } else {
+        g0[q] = ok0 ? ldx<true>(dY + e0) : z4;
+        g1[q] = ok1 ? ldx<true>(dY + e1) : z4;
       }
+      x0[q] = ok0 ? ldx<true>(X + e0) : z4;
+      x1[q] = ok1 ? ldx<true>(X + e1) : z4;
+      y0[q] = (ok0 && use_y) ? ldx<true>(Ypl + e0) : z4;
+      y1[q] = (ok1 && use_y) ? ldx<true>(Ypl + e1) : z4;
     }
 #pragma unroll
-    for (int u = 0; u < PL_U; ++u) {
-      const long j = i + u * 256;
-      if (j < n8) finish(j, g0[u], g1[u], x0[u], x1[u], yh[u], yl[u]);
-    }
+    for (int q = 0; q < 2; ++q)
+      if ((w.u + 4 * q) < w.end) finish((w.u + 4 * q) * 512 + lane * 4, g0[q], g1[q], x0[q], x1[q], y0[q], y1[q]);
   } else {
-    for (; i < n8; i += stride) {
+    for (; w.u < w.end; w.u += w.step) {
+      const long e0 = w.u * 512 + lane * 4, e1 = e0 + 256;
       float4 g0, g1;
-      load_g(i, g0, g1);
-      finish(i, g0, g1, ldf4(X + i * 8), ldf4(X + i * 8 + 4), use_y ? ldu<false>(Ypl + i * 8) : zu, use_y ? ldu<false>(Ypl + i * 8 + 4) : zu);
+      if (POOL) pooled_g(w.u, g0, g1);
+      else { g0 = e0 < n ? ldf4(dY + e0) : z4; g1 = e1 < n ? ldf4(dY + e1) : z4; }
+      finish(e0, g0, g1, e0 < n ? ldf4(X + e0) : z4, e1 < n ? ldf4(X + e1) : z4, (use_y && e0 < n) ? ldf4(Ypl + e0) : z4,
+             (use_y && e1 < n) ? ldf4(Ypl + e1) : z4);
     }
   }
 }
@@ -357,26 +452,20 @@ __global__ __launch_bounds__(256) void bn_bwd_bound_kernel(const float* __restri
   if (threadIdx.x == 0) out[0] = __builtin_bit_cast(unsigned, m);
 }
 
-inline bool pl_big(long n8, int C, int streams) {   // (norm.hip big_form, on groups of 8)
-  return C >= 8 && 2048 % C == 0 && n8 * 32 * streams > (256L << 20) && n8 >= 4 * PL_PIECE;
+inline bool pl_big(long n8, int C, int streams) {   // (norm.hip big_form: the launch's streams exceed the 256 MB memory-side cache)
+  return n8 * 32 * streams > (256L << 20) && n8 >= 64L * 16 * PL_UPB;
 }
-inline int pl_big_grid(long n8) { return (int)((n8 + PL_PIECE - 1) / PL_PIECE); }
-inline int pl_grid(long n8, int C) {   // gridDim * 256 a multiple of C / 8 (norm.hip bn_grid)
-  const long cv = C / 8;
+inline int pl_big_grid(long n8) { return (int)((n8 / 64 + 1 + PL_UPB - 1) / PL_UPB); }   // units = ceil(n8 / 64)
+inline int pl_grid(long n8, int C) {   // one unit (64 groups) per wave and trip, four waves per block
   long g = (n8 + 255) / 256;
-  if (g > 4096) g = 4096;
-  if (g < 1) g = 1;
-  long a = cv, b = 256;
-  while (b) { const long t = a % b; a = b; b = t; }
-  const long unit = cv / a;
-  return (int)((g + unit - 1) / unit * unit);
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 }  // namespace
 
 extern "C" int tris_bn_apply_pl_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                     const float* resid, int resid_kind, const unsigned* resid_word, float* Ypl, const unsigned* out_word,
                                     long M, int C, int relu, void* stream) {
-  if (C % 8 || out_word == nullptr || (resid_kind != 0 && resid == nullptr) || (resid_kind == 2 && resid_word == nullptr) ||
+  if (C % 8 || 2048 % C || out_word == nullptr || (resid_kind != 0 && resid == nullptr) || (resid_kind == 2 && resid_word == nullptr) ||
       resid_kind < 0 || resid_kind > 2 || !al16p(X) || !al16p(Ypl) || !al16p(resid))
     return (int)hipErrorInvalidValue;
   const long n8 = M * C / 8;
@@ -408,7 +497,7 @@ extern "C" int tris_avgpool2_fwd_pl_f32(const float* Xpl, float* Ypl, const unsi
 extern "C" int tris_bn_bwd_apply_pl_f32(const float* dY, const float* Ypl, const float* X, const float* mean, const float* invstd,
                                         const float* gamma, const float* sum_dz, const float* sum_dzx, float inv_count, float* dXpl,
                                         const unsigned* out_word, float* dZ, long M, int C, const float* beta_mask, void* stream) {
-  if (C % 8 || out_word == nullptr || !al16p(dY) || !al16p(X) || !al16p(dXpl) || !al16p(Ypl) || !al16p(dZ)) return (int)hipErrorInvalidValue;
+  if (C % 8 || 2048 % C || out_word == nullptr || !al16p(dY) || !al16p(X) || !al16p(dXpl) || !al16p(Ypl) || !al16p(dZ)) return (int)hipErrorInvalidValue;
   const long n8 = M * C / 8;
   const int streams = 3 + ((Ypl && !beta_mask) ? 1 : 0) + (dZ ? 1 : 0);
   if (pl_big(n8, C, streams))
@@ -423,7 +512,7 @@ extern "C" int tris_bn_bwd_apply_pl_f32(const float* dY, const float* Ypl, const
 extern "C" int tris_bn_bwd_apply_pool_pl_f32(const float* dYp, const float* X, const float* mean, const float* invstd, const float* gamma,
                                              const float* beta, const float* sum_dz, const float* sum_dzx, float inv_count, float* dXpl,
                                              const unsigned* out_word, int B, int H, int W, int C, void* stream) {
-  if (C % 8 || (H & 1) || (W & 1) || out_word == nullptr || beta == nullptr || !al16p(dYp) || !al16p(X) || !al16p(dXpl))
+  if (C % 8 || 2048 % C || (H & 1) || (W & 1) || out_word == nullptr || beta == nullptr || !al16p(dYp) || !al16p(X) || !al16p(dXpl))
     return (int)hipErrorInvalidValue;
   const long n8 = (long)B * H * W * C / 8;
   hipLaunchKernelGGL((bn_bwd_apply_pl_kernel<true, false>), dim3(pl_grid(n8, C)), dim3(256), 0, (hipStream_t)stream, dYp,

@@ -232,6 +232,20 @@ def _calibrated_streams(dev):
     return picked
 
 
+_COMPUTE_STREAM = {}
+
+
+def compute_stream(dev=None):
+    """one non-default stream per device to compute on (torch.cuda.set_stream(ops.compute_stream())): on this runtime the process's
+    default stream runs exclusively with respect to hipGraphs launched on other streams, so a step that replays its text towers
+    from graphs must not compute on it (bench.py, train_stage1.main; data-parallel runs get theirs from place_streams)"""
+    dev = torch.cuda.current_device() if dev is None else dev
+    s = _COMPUTE_STREAM.get(dev)
+    if s is None:
+        s = _COMPUTE_STREAM[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def place_streams(group=None):
     """Data-parallel start-up (call once on every rank right after init_process_group, before anything else touches the
     device): sort out which stream runs on which of the four hardware queues WITH the collective backend in the picture.
@@ -453,7 +467,7 @@ class batch_invariant:
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bias=None, bias_mode=0, resid=None,
-         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True, pre_out=None, dact=None, w_a=False, w_b=False):
+         ldr=0, sR=0, act=0, alpha=1.0, use_ws=True, pre_out=None, dact=None, w_a=False, w_b=False, w_bt=False):
     """pre_out / dact (tris_gemm_epilogue_next): also store the pre-activation value / multiply the result by quickgelu'(dact);
     the call then returns False -- nothing launched -- when the fast kernel does not serve the operands (caller falls back).
     w_a / w_b: that operand is a convolution weight, which exists as operand planes when the other operand is a plane tensor."""
@@ -485,7 +499,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
         C.reshape(M, N).copy_(C4[:M])
         return C
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
-    pA, pB = h2_pp(A, B, w_a=w_a, w_b=w_b) if batch == 1 else (P(A), P(B))
+    pA, pB = h2_pp(A, B, w_a=w_a, w_b=w_b, k_red=K, w_bt=w_bt and not tB) if batch == 1 else (P(A), P(B))
+    if batch == 1 and PL_STATS["last_t"]:    # B = W [K][N] arrived as the planes of its transpose [N][K]
+        tB, ldb = True, K
     h2_mark_next(C)      # (h2: the product also leaves the amax of what it writes -- another product may consume C directly)
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", pA, pB, P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
@@ -645,8 +661,24 @@ def h2_weights_amax(arenas=None):
             if a._pl_dev is not None:
                 call("tris_h2_planes_segments_f32", P(a.p), a._pl_dev[0].data_ptr(), a._pl_dev[1].data_ptr(), a._pl_dev[2].data_ptr(),
                      len(a._pl_idx), _H2["pool"].data_ptr() + 4 * H2_SUB * base, P(a.pl), _stream())
+            # ... and of the 1x1 weights TRANSPOSED: their data gradient dX = dY . W is then the forward's row-major A x B^T product
+            if not hasattr(a, "_plt_dev"):
+                idt = [i for i in getattr(a, "_pl_idx", []) if _pl_weight_t_ok(a.params[i])]
+                a._plt_idx = idt
+                mk = lambda v: torch.tensor(v, device=a.p.device, dtype=torch.int64)
+                a._plt_dev = None if not idt else (mk([a.offsets[i] for i in idt]), mk([a.params[i].shape[0] for i in idt]),
+                                                   mk([a.params[i].shape[1] for i in idt]), mk(idt))
+                a.plt = torch.zeros_like(a.p) if idt else None
+            if a._plt_dev is not None:
+                call("tris_h2_planes_t_segments_f32", P(a.p), a._plt_dev[0].data_ptr(), a._plt_dev[1].data_ptr(), a._plt_dev[2].data_ptr(),
+                     a._plt_dev[3].data_ptr(), len(a._plt_idx), _H2["pool"].data_ptr() + 4 * H2_SUB * base, P(a.plt), _stream())
         base += len(a.params)
     return base
+
+
+def _pl_weight_t_ok(p):
+    """a 1x1-convolution weight [Cout, Cin, 1, 1] whose transposed planes exist (64 x 64 tiles of the transposing pass)"""
+    return p.dim() == 4 and p.shape[2] * p.shape[3] == 1 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
 
 
 def _pl_weight_ok(p):
@@ -688,6 +720,9 @@ def h2_begin_step():
             for i in (a._pl_idx if getattr(a, "pl", None) is not None else ()):
                 p = a.params[i]
                 p._plw = (_H2["step"], a.pl.data_ptr() + 4 * a.offsets[i], p._h2[1])
+            for i in (a._plt_idx if getattr(a, "plt", None) is not None else ()):
+                p = a.params[i]
+                p._plwt = (_H2["step"], a.plt.data_ptr() + 4 * a.offsets[i], p._h2[1])
     return _H2["pool"]
 
 
@@ -848,7 +883,7 @@ def h2_arm(A, B, a_slot=None, b_slot=None):
 # backward and the convolution backward that reads it, and the convolution weights exist as fp16 PIECE PLANES: float32 tensors in
 # torch's eyes whose bytes are the two fp16 pieces of every element, scaled by the power of two their amax word implies.  The tensor
 # carries `_pl = (step, word)`; only the ops below that say so accept one, everything else must see `unplanes(t)`.
-PL_STATS = {"unplanes": 0, "dx_planes": 0, "dy_planes": 0, "products": 0, "mixed": 0}
+PL_STATS = {"unplanes": 0, "dx_planes": 0, "dy_planes": 0, "products": 0, "mixed": 0, "last": False, "last_t": False}
 
 
 def planes_on():
@@ -871,19 +906,38 @@ def pl_tag(t, word):
     return t
 
 
-def unplanes(t):
-    """the fp32 tensor a plane tensor stands for (its h2 operand rounding: 22 significand bits); fp32 tensors pass through"""
+def _unplanes_raw(t, cache=True):
     w = pl_word(t)
-    if w is None:
-        return t
-    c = getattr(t, "_pl_f32", None)
+    c = getattr(t, "_pl_f32", None) if cache else None
     if c is None:
         c = torch.empty_like(t)
         call("tris_h2_unplanes_f32", P(t), P(c), t.numel(), w, _stream())
         c._h2 = (_H2["step"], w, c._version)   # (the word bounds the rebuilt values as well)
-        t._pl_f32 = c
+        if cache:
+            t._pl_f32 = c
         PL_STATS["unplanes"] += 1
     return c
+
+
+class _UnplanesFn(torch.autograd.Function):
+    """differentiable form of unplanes: the gradient of the rebuilt tensor IS the gradient of the plane tensor (fp32 either way)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return _unplanes_raw(t, cache=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def unplanes(t):
+    """the fp32 tensor a plane tensor stands for (its h2 operand rounding: 22 significand bits); fp32 tensors pass through"""
+    if pl_word(t) is None:
+        return t
+    if t.requires_grad and torch.is_grad_enabled():
+        return _UnplanesFn.apply(t)
+    return _unplanes_raw(t)
 
 
 _PL_CONST = {}   # id(parameter) -> (version, data_ptr, word, planes tensor, weakref): parameters outside the optimiser arenas
@@ -944,11 +998,16 @@ def pl_grad_in(dy):
     return dy
 
 
-def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False):
+def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False, k_red=32, w_bt=False):
     """Arm the next dense product for h2 (as h2_arm) and return the pointers of its operands A, B to hand to the entry point.  With
     operand planes on: if one operand IS a plane tensor and the other one is too, or is a convolution weight (w_a / w_b: that
-    operand is a parameter), the product runs on planes; a plane tensor next to an fp32 operand is rebuilt (counted in PL_STATS)."""
-    if A is None or B is None or a_slot is not None or b_slot is not None or not planes_on():
+    operand is a parameter), the product runs on planes; a plane tensor next to an fp32 operand is rebuilt (counted in PL_STATS).
+    k_red: the reduction length of the product -- the plane kernels (the fast kernels) need a multiple of 32; anything else (the weight
+    gradients of a 10 x 10 map at batch 2: 200 pixels) runs on the rebuilt tensors through the generic kernel."""
+    # w_bt: B is a 1x1 weight used as [k][n] (a data gradient): if its TRANSPOSED planes exist the caller gets those -- and must then
+    # run the product with B as [n][k] (PL_STATS["last_t"] says so)
+    PL_STATS["last"] = PL_STATS["last_t"] = False   # (did the product just armed take planes?  read by callers)
+    if A is None or B is None or a_slot is not None or b_slot is not None or not planes_on() or k_red % 32 != 0:
         if pl_word(A) is not None or pl_word(B) is not None:
             A, B = unplanes(A), unplanes(B)
         h2_arm(A, B, a_slot, b_slot)
@@ -957,9 +1016,15 @@ def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False):
     if wa is not None or wb is not None:
         pa = (P(A), wa) if wa is not None else (_pl_weight(A) if w_a else None)
         pb = (P(B), wb) if wb is not None else (_pl_weight(B) if w_b else None)
+        if w_bt and wb is None and pa is not None:
+            tt = getattr(B, "_plwt", None)
+            if tt is not None and tt[0] == _H2["step"]:
+                pb = (tt[1], tt[2])
+                PL_STATS["last_t"] = True
         if pa is not None and pb is not None:
-            call("tris_h2_next_planes", pa[1], pb[1], 1 if y_planes else 0)
+            call("tris_h2_next_planes", pa[1], pb[1], (1 if y_planes else 0) | (2 if PL_STATS["last_t"] else 0))
             PL_STATS["products"] += 1
+            PL_STATS["last"] = True
             return pa[0], pb[0]
         PL_STATS["mixed"] += 1
         A, B = unplanes(A), unplanes(B)
@@ -1031,7 +1096,7 @@ class LinearFn(torch.autograd.Function):
         if want_stats:
             _launch_with_stats(y, M, N, lambda part, rows: _timed(
                 "gemm", 2.0 * M * N * K, lambda: (lambda pp: call("tris_gemm_bnstat_f32", pp[0], pp[1], P(y), M, N, K,
-                                                                  part.data_ptr(), rows, _stream()))(h2_pp(x, w, w_b=True)),
+                                                                  part.data_ptr(), rows, _stream()))(h2_pp(x, w, w_b=True, k_red=K)),
                 nbytes=4.0 * (M * K + K * N + M * N)))
         else:
             gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid,
@@ -1090,10 +1155,11 @@ class LinearFn(torch.autograd.Function):
                     dzw = _h2_slot() if planes_on() else None   # (the masked gradient's amax: the bound of that BatchNorm's dx)
 
                     def launch():
-                        pp = h2_pp(dy, w, w_b=True, y_planes=ypl)
+                        pp = h2_pp(dy, w, w_b=True, y_planes=ypl, k_red=N, w_bt=True)
                         if dzw is not None:
                             call("tris_amax_next", dzw)
-                        call("tris_gemm_bnbwd_f32", pp[0], pp[1], P(dx), M, K, N, P(extra), K, P(link.x), P(x) if link.from_y else None,
+                        by = (P(x) if (PL_STATS["last"] or not ypl) else P(unplanes(x))) if link.from_y else None
+                        call("tris_gemm_bnbwd_f32", pp[0], pp[1], P(dx), M, K, N, P(extra), K, P(link.x), by,
                              P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream())
                         return rows.value > 0     # (False: the entry point declined the shape, nothing was launched)
                     _timed("gemm_bnbwd", 2.0 * M * N * K, launch,
@@ -1108,7 +1174,7 @@ class LinearFn(torch.autograd.Function):
                 if gemm(dy, w, dx, M, K, N, N, K, K, False, False, dact=alink.pre) is not False:
                     fused = alink.applied = True
             if not fused:
-                gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K, w_b=True)
+                gemm(dy, w, dx, M, K, N, N, K, K, False, False, resid=extra, ldr=K, w_b=True, w_bt=True)
         elif extra is not None:
             raise RuntimeError("a residual gradient was handed to a layer whose input needs no gradient")
         if dx is not None and ctx.grad_box_out is not None and ctx.grad_box_out.deposit(dx):
@@ -1404,7 +1470,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
             return _timed("conv3x3_wgrad", fl, lambda: (lambda pp: call(
                 "tris_conv3x3_wgrad_f32", pp[1], pp[0], P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))(
-                    h2_pp(dy, xin)), nbytes=nb)
+                    h2_pp(dy, xin, k_red=dy.shape[0] * dy.shape[1] * dy.shape[2])), nbytes=nb)
         dw = None
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
@@ -1452,8 +1518,8 @@ class BatchNormFn(torch.autograd.Function):
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
-        use_pl = bool(planes and training and C % 8 == 0 and planes_on())
-        ctx.dx_pl = bool(dx_planes and training and C % 8 == 0 and planes_on())
+        use_pl = bool(planes and training and C % 8 == 0 and 2048 % C == 0 and planes_on())
+        ctx.dx_pl = bool(dx_planes and training and C % 8 == 0 and 2048 % C == 0 and planes_on())
         if use_pl:
             lazy = False
         # pool: the output is avgpool2(relu(bn(x))) -- BatchNorm + ReLU + AvgPool2d(2) as one op, the full-size tensor never written
@@ -1466,8 +1532,22 @@ class BatchNormFn(torch.autograd.Function):
         if training:
             stats = torch.empty(3 * C, device=x.device, dtype=torch.float32)
 
+            pl_bound = {"word": None, "resid": None}   # (operand planes: the output's bound word, formed by the finalizer where it can)
+
             def local_stats(rm, rv, dst=None):
                 dst = stats if dst is None else dst
+                if part is not None and use_pl and group is None:
+                    # partial sums from the producing conv's epilogue; the same launch leaves the bound of the plane output
+                    w_, rw_ = _h2_slot(), None
+                    if resid is not None:
+                        rw_ = pl_word(resid)
+                        if rw_ is None:
+                            rw_ = _h2_amax(resid)
+                    if w_ is not None and (resid is None or rw_ is not None):
+                        call("tris_bn_finalize_bound_f32", part[0].data_ptr(), part[1], M, C, eps, momentum, P(dst), P(rm), P(rv),
+                             P(gamma), P(beta), math.sqrt(max(M - 1, 1)), rw_, w_, _stream())
+                        pl_bound["word"], pl_bound["resid"] = w_, rw_
+                        return
                 if part is not None:  # partial sums came out of the producing conv's epilogue
                     call("tris_bn_finalize_f32", part[0].data_ptr(), part[1], M, C, eps, momentum, P(dst), P(rm),
                          P(rv), _stream())
@@ -1502,16 +1582,18 @@ class BatchNormFn(torch.autograd.Function):
         if use_pl:
             # the scale must exist before the pass writes: Samuelson's bound of the normalised values from the affine parameters,
             # plus the bound (or amax) of the residual it is added to
-            word = _h2_slot()
-            rk, rw = 0, None
-            if resid is not None:
-                rw = pl_word(resid)
-                rk = 2 if rw is not None else 1
-                if rw is None:
-                    rw = _h2_amax(resid)
-            if word is None or (resid is not None and rw is None):
-                raise RuntimeError("operand planes: no amax word for a BatchNorm output / its residual")
-            call("tris_bn_out_bound2_f32", P(gamma), P(beta), C, math.sqrt(max(count - 1, 1)), rw, word, _stream())
+            rk = 0 if resid is None else (2 if pl_word(resid) is not None else 1)
+            word = pl_bound["word"] if training else None
+            rw = pl_bound["resid"] if word is not None else None
+            if word is None:
+                word = _h2_slot()
+                if resid is not None:
+                    rw = pl_word(resid)
+                    if rw is None:
+                        rw = _h2_amax(resid)
+                if word is None or (resid is not None and rw is None):
+                    raise RuntimeError("operand planes: no amax word for a BatchNorm output / its residual")
+                call("tris_bn_out_bound2_f32", P(gamma), P(beta), C, math.sqrt(max(count - 1, 1)), rw, word, _stream())
             if pool:
                 call("tris_bn_apply_pool_pl_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), word, x.shape[0], x.shape[1],
                      x.shape[2], C, _stream())
@@ -1594,7 +1676,13 @@ class BatchNormFn(torch.autograd.Function):
         dz_first = got is None and not ctx.pool and want_dz and relu and y is not None
         if dz_first:
             d_res = torch.empty_like(x)
-        if got is not None:
+        bound_word = None     # (operand planes: dx's bound word when the finalizer below formed it)
+        if got is not None and dx_pl and mb is None and (direct or group is None) and ctx.needs_input_grad[0]:
+            bound_word = _h2_slot()
+        if got is not None and bound_word is not None:
+            call("tris_part_finalize_bound_f32", got[0].data_ptr(), got[1], C, p_dz, p_dzx, P(gamma), P(invstd), 1.0 / float(count),
+                 math.sqrt(max(count - 1, 1)), dzw, bound_word, _stream())
+        elif got is not None:
             # dy came out of the consuming 1x1 convolution's data gradient already MASKED, with the two sums as partial rows
             call("tris_part_finalize_f32", got[0].data_ptr(), got[1], C, p_dz, p_dzx, _stream())
         elif not ctx.pool:
@@ -1624,9 +1712,11 @@ class BatchNormFn(torch.autograd.Function):
         def apply(g, ymask, dz_out, beta_m):
             """dx from the (masked or to-be-masked) gradient g; as operand planes where the convolution before takes them"""
             if dx_pl:
-                word = _h2_slot()
-                call("tris_bn_bwd_bound_f32", P(gamma), P(invstd), p_dz, p_dzx, C, inv_cnt, math.sqrt(max(count - 1, 1)), dzw, word,
-                     _stream())
+                word = bound_word
+                if word is None:
+                    word = _h2_slot()
+                    call("tris_bn_bwd_bound_f32", P(gamma), P(invstd), p_dz, p_dzx, C, inv_cnt, math.sqrt(max(count - 1, 1)), dzw, word,
+                         _stream())
                 if ctx.pool:
                     call("tris_bn_bwd_apply_pool_pl_f32", P(g), P(x), P(mean), P(invstd), P(gamma), P(beta), p_dz, p_dzx, inv_cnt, P(dx),
                          word, x.shape[0], x.shape[1], x.shape[2], C, _stream())
