@@ -110,6 +110,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    rccl = None
+    if world > 1:
+        # the collective backend really spans N ranks on N distinct devices: one all-reduce of ones and an all-gather of device ids
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        devs = [torch.zeros(1, device="cuda", dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([local], device="cuda", dtype=torch.int64))
+        rccl = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()), "devices": [int(d.item()) for d in devs]}
+        assert rccl["backend"] == "nccl" and rccl["ranks_seen"] == a.gpus and len(set(rccl["devices"])) == a.gpus, \
+            f"RCCL saw {rccl} but --gpus {a.gpus}"
     from tris_amd import ops
     from tris_amd.config import cfg
     if world > 1:
@@ -135,7 +145,9 @@ def main():
     from tris_amd.utils.synth import seed_fill, synthetic_batch
 
     if not os.environ.get("TRIS_GEMM_MODE"):
-        ops.set_gemm_mode("h2")                  # the headline arithmetic (module docstring); value_x3 is measured beside it
+        ops.set_gemm_mode("h2")                  # the package default (ops._ARITH); value_x3 is measured beside it
+    if "TRIS_STEP_GRAPH" not in os.environ:
+        cfg.step_graph = "seg"                   # `value` = the step as the trainer issues it (train_stage1.main): segmented hipGraph replay
     mode = ops.get_gemm_mode()
     QL = 20
 
@@ -193,6 +205,9 @@ def main():
     step()   # one untimed priming step, always: first-encounter GEMM autotuning, allocator growth, RCCL channel set-up
     dt, host_issue, losses = timed(step, a.steps, a.warmup)
     loss_vals = losses.tolist()
+    # h2 operand planes: the range tell-tale of the last step (plane tensors with > 1 % of their elements below the 2^-27 floor of their
+    # scale: ops.h2_range_report) and how the products / gradients of a step travelled (ops.PL_STATS)
+    h2_range = ops.h2_range_report() if (mode == "h2" and cfg.h2_planes) else None
     comm_exposed = reducer.exposed_ms() if reducer is not None else None   # compute-stream wait for collectives, last timed step
     transport = None
     if world > 1:
@@ -225,7 +240,7 @@ def main():
     # ---- live roofline measurement of the dominant kernel family (one extra, untimed, instrumented step) ----
     # (kernels are timed one at a time: the stream overlap of the production step is switched off for this pass so that a
     # launch's HIP-event bracket measures that kernel alone, not whatever else shares the GPU with it)
-    with cfg.override(text_stream=False, wgrad_stream=False):
+    with cfg.override(step_graph="0", text_stream=False, wgrad_stream=False):
         step()
         ops.profile_begin()
         step()
@@ -353,8 +368,12 @@ def main():
                "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
                "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 3),
                "sparse_embed_exchange": bool(reducer is not None and reducer.sparse_embed),
-               "streams": {"text_encoders_on_side_stream": cfg.text_stream, "weight_gradients_on_side_stream": cfg.wgrad_stream},
+               "streams": {"text_encoders_on_side_stream": cfg.text_stream, "weight_gradients_on_side_stream": cfg.wgrad_stream,
+                           "compute_on_own_stream": bool(cfg.own_stream and world == 1)},
+               "h2_operand_planes": bool(cfg.h2_planes and mode == "h2"),
+               "h2_out_of_range_operands": None if h2_range is None else h2_range["out_of_range_operands"], "h2_range": h2_range,
                "step_issue": {"0": "eager launches", "1": "one hipGraph", "seg": "chain of single-stream hipGraphs"}[cfg.step_graph],
+               "rccl": rccl,    # (N > 1: what the collective backend saw -- N ranks on N distinct devices, asserted at start-up)
                "roofline": roof, "roofline_xattn": roof_x}
         if value_x3 is not None:
             out["value_x3"] = value_x3["value"]

@@ -111,14 +111,30 @@ def test_g3_bilateral_prompt(model, golden):
         vis = vis / vis.norm(dim=1, keepdim=True)
         lan = torch.randn(B, 1024, B, generator=gen)
         lan = lan / lan.norm(dim=1, keepdim=True)
-        if B > 1:  # golden inputs use per-image sentence sets; the Stage-1 path shares one set -> check via oracle below
-            continue
+        # (B = 2, 4: the golden inputs are PER-IMAGE sentence sets -- bilateral_prompt.forward_sets, the general form of the module)
         with torch.no_grad():
             nv, nl = model.attn_fusion(vis.cuda(), lan.cuda())
-        assert err(nl, g[f"B{B}_new_lan"]) < 1e-4
-        assert err(nv[:, :64], g[f"B{B}_new_vis_crop"]) < 1e-4
-    # shared sentence set, B=3 images x N=5 sentences, against the oracle
+        assert err(nl, g[f"B{B}_new_lan"]) < 1e-4, B
+        assert err(nv[:, :64], g[f"B{B}_new_vis_crop"]) < 1e-4, B
+    # per-image sets, gradients included: B = 3 images x N = 5 own sentences each, against the oracle
     from oracle import tris_oracle as O
+    vis = torch.randn(3, 1024, 10, 10, generator=gen)
+    vis = vis / vis.norm(dim=1, keepdim=True)
+    lan = torch.randn(3, 1024, 5, generator=gen)
+    lan = lan / lan.norm(dim=1, keepdim=True)
+    wv, wl = torch.randn(3, 1024, 10, 10, generator=gen), torch.randn(3, 5, 1024, generator=gen)
+    vo, lo = vis.clone().requires_grad_(), lan.clone().requires_grad_()
+    onv, onl = O.bilateral_prompt(cpu_sd(model), "attn_fusion", vo, lo)
+    ((onv * wv).sum() + (onl * wl).sum()).backward()
+    vg, lg = vis.cuda().requires_grad_(), lan.cuda().requires_grad_()
+    nv, nl = model.attn_fusion(vg, lg)
+    ((nv * wv.cuda()).sum() + (nl * wl.cuda()).sum()).backward()
+    assert err(nv, onv) < 1e-4 and err(nl, onl) < 1e-4
+    # (gradients pass four InstanceNorm backwards: two correct fp32-class implementations agree to ~1e-4 ... 1e-3 of the largest element)
+    assert err(vg.grad, vo.grad) < 1e-3 * float(vo.grad.abs().max()) + 1e-6
+    assert err(lg.grad, lo.grad) < 1e-3 * float(lo.grad.abs().max()) + 1e-6
+    model.zero_grad(set_to_none=True)
+    # shared sentence set, B=3 images x N=5 sentences, against the oracle
     vis = torch.randn(3, 1024, 10, 10, generator=gen)
     vis = vis / vis.norm(dim=1, keepdim=True)
     lan = torch.randn(1, 1024, 5, generator=gen).repeat(3, 1, 1)
@@ -206,11 +222,17 @@ def test_g5_g6_train_step(model, aux, batch, golden):
         assert getattr(named[k], "_tris_no_grad_path", False), k
 
 
-def test_full_train_step_at_the_headline_batch_48(model, aux):
+_B48_ORACLE = {}    # the CPU oracle's B = 48 step (losses, cls, sig, gradients): computed once, shared by the parametrisations below
+
+
+@pytest.mark.parametrize("tuned", [False, True], ids=["static-tiles", "autotuned"])
+def test_full_train_step_at_the_headline_batch_48(model, aux, tuned):
     """BASELINE configs[2] at its REAL size: one full Stage-1 train step on 48 x 320px images (+ 3 negatives each) against
     the CPU oracle's step on the same inputs -- losses, cls_out and the sigmoid map within the north star's 1e-3, the
     gradient arenas in direction and size.  At batch 48 train-mode BatchNorm noise is far below the batch-2 golden case,
-    so this is the sharper pin of the whole step (VERDICT r1, weak #9 / next #5)."""
+    so this is the sharper pin of the whole step (VERDICT r1, weak #9 / next #5).
+    tuned: with the first-encounter autotuner ON -- the (tile, split-K, loop, direct-vs-implicit, LDS-DMA form) choices bench.py
+    actually runs at these shapes, which the static-tile suite cannot see (VERDICT r4 next #5); both arithmetics (module fixture)."""
     import os
     from oracle import tris_oracle as O
     from tris_amd.optim import FusedAdamW
@@ -228,29 +250,48 @@ def test_full_train_step_at_the_headline_batch_48(model, aux):
     bb, new = model.trainable_parameters()
     opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr,
                      weight_decay=args.weight_decay)
-    losses, cls, sig = stage1_forward_losses(model, aux, b["img"].cuda(), b["word_ids"].cuda(),
-                                             b["neg_word_ids"].cuda(), args)
-    opt.zero_grad()
-    losses[0].backward()
-    ops.wgrad_join()
+    ops.set_autotune(tuned)
+    try:
+        before = dict(ops.PL_STATS)
+        ops.h2_begin_step()
+        losses, cls, sig = stage1_forward_losses(model, aux, b["img"].cuda(), b["word_ids"].cuda(),
+                                                 b["neg_word_ids"].cuda(), args)
+        opt.zero_grad()
+        losses[0].backward()
+        ops.wgrad_join()
+        ops.h2_end_step()
+    finally:
+        ops.set_autotune(False)
+    if ops.planes_on():
+        # operand planes at the headline batch: every product of the trunk took planes, none fell back to rebuilt fp32 tensors
+        # except vis_project's weight gradient (a plane activation next to the heads' fp32 gradient)
+        d = {k: ops.PL_STATS[k] - before[k] for k in before if not k.startswith("last")}
+        assert d["products"] >= 150 and d["dx_planes"] == d["dy_planes"] >= 50 and d["mixed"] == 0 and d["unplanes"] <= 1, d
+        # range tell-tale: no plane tensor of the step has more than 1 % of its elements below the 2^-27 floor of its scale
+        rep = ops.h2_range_report()
+        assert rep["plane_tensors"] >= 100 and rep["out_of_range_operands"] == 0, rep
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     oleaves = [k for k in O.trainable_split(sd)[0] + O.trainable_split(sd)[1]]
-    for k in oleaves:
-        sd[k].requires_grad_(True)
-    ref = O.stage1_losses(sd, auxsd, b, faithful=False)
-    ref["loss"].backward()
+    if not _B48_ORACLE:
+        for k in oleaves:
+            sd[k].requires_grad_(True)
+        ref = O.stage1_losses(sd, auxsd, b, faithful=False)
+        ref["loss"].backward()
+        _B48_ORACLE.update(want=[float(ref[k].detach()) for k in ("loss", "l1", "l4", "l5")], cls=ref["cls"].detach().clone(),
+                           sig=ref["sig"].detach().clone(), grads={k: sd[k].grad.clone() for k in oleaves if sd[k].grad is not None})
+    ref_g = _B48_ORACLE["grads"]
     got = losses.tolist()
-    want = [float(ref[k].detach()) for k in ("loss", "l1", "l4", "l5")]
+    want = _B48_ORACLE["want"]
     assert all(abs(a - c) < TOL for a, c in zip(got, want)), (got, want)
-    assert err(cls, ref["cls"]) < TOL
-    assert err(sig, ref["sig"]) < TOL
+    assert err(cls, _B48_ORACLE["cls"]) < TOL
+    assert err(sig, _B48_ORACLE["sig"]) < TOL
     named = dict(model.named_parameters())
     dot = na = nb = 0.0
     low = []
     for k in oleaves:
-        if sd[k].grad is None:
+        if k not in ref_g:
             continue
-        a, c = named[k].grad.detach().double().cpu().reshape(-1), sd[k].grad.double().reshape(-1)
+        a, c = named[k].grad.detach().double().cpu().reshape(-1), ref_g[k].double().reshape(-1)
         dot += float(a @ c)
         na += float(a @ a)
         nb += float(c @ c)

@@ -206,8 +206,10 @@ class ModifiedResNet(nn.Module):
         consumer but the next stage, which lets the last block of every stage link its bn3 backward like the others.
         hooks: optional {"stem" | "layer1" | "layer2" | "layer3" | "layer4": callable} run right after that stage has been ISSUED -- TRIS uses
         it to issue the text encoder (side stream) in the middle of the trunk, see model_stage1.TRIS.forward."""
-        x = ops.nchw_to_nhwc(x.float())
         tr = self.training
+        if tr:
+            ops.h2_auto_step()     # (operand planes: a trunk forward outside any step bracket starts an amax pool of its own)
+        x = ops.nchw_to_nhwc(x.float())
         pl = tr and ops.planes_on()    # (h2 with operand planes: see Bottleneck.forward; conv1 reads the image, its gradient stays fp32)
         x = self.conv1(x, stats=tr)                        # (conv1 has Cin=3: not eligible, separate statistics pass)
         x = self.bn1(x, relu=True, lazy=tr and not pl and ops.conv3x3_bnin_ok(x.shape, self.conv2.cout), bwd_link=True,

@@ -49,3 +49,27 @@ __device__ __forceinline__ unsigned pl8_positive(const uint4 hi, const uint4 lo)
 __device__ __forceinline__ float pl_scale(const unsigned* __restrict__ word) {
   return h2_scale_from_bits(h2_amax_of(word, threadIdx.x & 63));
 }
+
+// ---- range tell-tale ----------------------------------------------------------------------------------
+// An element keeps its 22 bits only while its hi piece is a NORMAL fp16 number, i.e. |x s| >= 2^-14 = 2^-27 of the scaled bound; below
+// that the representation error is absolute.  The passes that write plane tensors count the non-zero elements that fall below that
+// floor and add the count into the SECOND unsigned of a line of the tensor's amax word (the consumers of the word read the first
+// unsigned of each line only): per-XCD lines and workgroup-scope atomics, as for the amax itself (amax.h).  ops.h2_range_report()
+// turns the counts of a step into "how many operands have more than 1 % of their elements in the absolute-accuracy regime".
+__device__ __forceinline__ unsigned pl_below_floor(const float4 a, const float4 b, const float s) {
+  const float f = 6.103515625e-05f;   // 2^-14
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned n = 0u;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) n += (v[e] != 0.f && fabsf(v[e]) * s < f) ? 1u : 0u;
+  return n;
+}
+__device__ __forceinline__ void pl_floor_commit(unsigned n, const unsigned* __restrict__ word) {   // every lane of the wave calls it
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) n += (unsigned)__shfl_xor((int)n, sft, 64);
+  if ((threadIdx.x & 63) == 0 && n != 0u) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+    unsigned* w = const_cast<unsigned*>(word) + (xcc * 16 + ((blockIdx.x >> 3) & 15)) * 16 + 1;
+    __hip_atomic_fetch_add(w, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}

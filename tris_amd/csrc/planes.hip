@@ -30,10 +30,16 @@ __global__ __launch_bounds__(256) void to_planes_segments_kernel(const float* __
   const long n8 = sizes[blockIdx.y] >> 3;
   const float* x = base + offs[blockIdx.y];
   float* out = out_base + offs[blockIdx.y];
-  const float s = pl_scale(slots + slot_index[blockIdx.y] * 2048);
+  const unsigned* word = slots + slot_index[blockIdx.y] * 2048;
+  const float s = pl_scale(word);
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += stride)
-    pl8_store(out, g, pl8_split(ldf4(x + g * 8), ldf4(x + g * 8 + 4), s));
+  unsigned below = 0u;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += stride) {
+    const float4 a = ldf4(x + g * 8), b = ldf4(x + g * 8 + 4);
+    below += pl_below_floor(a, b, s);
+    pl8_store(out, g, pl8_split(a, b, s));
+  }
+  pl_floor_commit(below, word);
 }
 // TRANSPOSED planes of 1x1-convolution weights W [rows = Cout][cols = Cin] -> planes of W^T [Cin][Cout] (P8 along Cout), so that the
 // data gradient dX = dY . W is the same row-major A x B^T product as the forward (B^T = W^T, k = Cout contiguous).  grid (tiles, segments):
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
   const Ch8 mu = ld8(mean + c), is = ld8(invstd + c), g = ld8(gamma + c), b = ld8(beta + c);
   const float4 sca = mul4(is.a, g.a), scb = mul4(is.b, g.b);
   const float4 z4 = make_float4(0, 0, 0, 0);
+  unsigned below = 0u;     // non-zero outputs under the 2^-27 floor of the scale (planes.h range tell-tale)
   auto finish = [&](long e0, float4 x0, float4 x1, float4 r0, float4 r1) {
     const long e1 = e0 + 256;
     pair_xchg(x0, x1, odd);
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
       y1 = add4(y1, r1);
     }
     if (relu) { y0 = relu4(y0); y1 = relu4(y1); }
+    below += pl_below_floor(y0, y1, s);
     Pl8 o = pl8_split(y0, y1, s);
     pair_xchg(o.hi, o.lo, odd);
     if (e0 < n) stu<BIG>(Y + e0, o.hi);
@@ -238,6 +246,7 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
              (rk && e1 < n) ? ldf4(resid + e1) : z4);
     }
   }
+  pl_floor_commit(below, out_word);
 }
 
 // Yp (planes) = avgpool2(relu(bn(X)))  (norm.hip bn_apply_pool_kernel's expression on the four normalised pixels)
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
   const float4 k3b = make_float4(is.b.x * sb.b.x * inv_cnt, is.b.y * sb.b.y * inv_cnt, is.b.z * sb.b.z * inv_cnt, is.b.w * sb.b.w * inv_cnt);
   const bool use_y = !beta_mask && Ypl != nullptr;
   const float4 z4 = make_float4(0, 0, 0, 0);
+  unsigned below = 0u;
   auto half = [&](float4 g, const float4 x, const float4 mu4, const float4 k1, const float4 k2, const float4 k3, const float4 be4,
                   unsigned pos, float4& gm) {
     if (beta_mask) {
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
       if (e0 < n) stx<BIG>(dZ + e0, m0);
       if (e1 < n) stx<BIG>(dZ + e1, m1);
     }
+    below += pl_below_floor(o0, o1, s);
     Pl8 o = pl8_split(o0, o1, s);
     pair_xchg(o.hi, o.lo, odd);
     if (e0 < n) stu<BIG>(dX + e0, o.hi);
@@ -426,6 +437,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
              (use_y && e1 < n) ? ldf4(Ypl + e1) : z4);
     }
   }
+  pl_floor_commit(below, out_word);
 }
 
 // amax words that are bounds (one block; only line 0 of the word is written, the others stay zero -- the caller zeroes the word)

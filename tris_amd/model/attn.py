@@ -103,12 +103,33 @@ class bilateral_prompt(nn.Module):
         new_lan = self.t_output[0](torch.cat(nl, 0))
         return new_vis, new_lan
 
+    def forward_sets(self, vis, lan):
+        """vis [B,P,C], lan [B,N,C]: EVERY image attends over its OWN sentence set -- what the reference module computes for any
+        `lan [B,C,N]` (model/attn.py:111-136); Stage-1 itself only ever passes one set repeated (forward_cl).  Composed from the
+        batched products of the GEMM core and the row soft-max: image b's logits are Qv[b] . Kt[b]^T / sqrt(C) (soft-max over its
+        N sentences) and Qt[b] . Kv[b]^T / sqrt(C) (soft-max over its P pixels)."""
+        B, Pp, C = vis.shape
+        N = lan.shape[1]
+        scale = 1.0 / math.sqrt(lan.shape[-1])
+        Qv, Kv, Vv = (_vbranch(getattr(self, f"v_proj{i}"), vis, True) for i in (1, 2, 3))
+        flat = lan.reshape(B * N, lan.shape[-1])
+        Qt, Kt, Vt = (getattr(self, f"t_proj{i}")[0](flat, act=1).reshape(B, N, -1) for i in (1, 2, 3))
+        Av = ops.softmax(ops.bmm(Qv, Kt, tB=True), scale)           # [B,P,N]  soft-max over the image's sentences
+        At = ops.softmax(ops.bmm(Qt, Kv, tB=True), scale)           # [B,N,P]  soft-max over the image's pixels
+        new_vis = ops.bmm(Av, Vt, tB=False)                         # [B,P,C]
+        new_lan = ops.bmm(At, Vv, tB=False)                         # [B,N,C]
+        new_vis = _vbranch(self.v_output, new_vis, False)
+        new_lan = self.t_output[0](new_lan)
+        return new_vis, new_lan
+
     def forward(self, vis, lan):
         B, C, H, W = vis.shape
         lan_t = lan.transpose(1, 2)  # [B,N,C]
+        vis_cl = vis.permute(0, 2, 3, 1).reshape(B, H * W, C)
         if B > 1 and not bool((lan_t[0:1] == lan_t).all()):
-            raise NotImplementedError("per-image sentence sets are not on the Stage-1 path (model_stage1.py:66 repeats one set)")
-        nv, nl = self.forward_cl(vis.permute(0, 2, 3, 1).reshape(B, H * W, C), lan_t[0].contiguous())
+            nv, nl = self.forward_sets(vis_cl.contiguous(), lan_t.contiguous())   # per-image sentence sets: the general form
+        else:
+            nv, nl = self.forward_cl(vis_cl, lan_t[0].contiguous())               # one set shared by all images (Stage-1)
         return nv.reshape(B, H, W, C).permute(0, 3, 1, 2), nl
 
 

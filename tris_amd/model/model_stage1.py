@@ -141,6 +141,12 @@ class TRIS(nn.Module):
         return ops.score_heads(full, h_, w_, out_size, False)
 
     def forward(self, x, word_id):
+        if self.training:
+            ops.h2_auto_step()     # (h2 operand planes: a forward outside train_step's bracket runs under an amax pool of its own)
+        with ops.h2_auto_lock():
+            return self._forward(x, word_id)
+
+    def _forward(self, x, word_id):
         if not _overlap_enabled():
             return self.forward_cached(self.encode_visual(x), word_id, x.shape[2])
         # The text encoder (short GEMMs that cannot fill 256 CUs) runs on a second HIP stream, concurrently with the

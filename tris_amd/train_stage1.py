@@ -293,6 +293,12 @@ def main(args, tokenizer=None):
                 torch.cuda.set_stream(cs)
     else:
         local_rank = 0
+        if cfg.own_stream and torch.cuda.is_available():
+            torch.cuda.set_stream(ops.compute_stream())   # (never compute on the default stream: ops.compute_stream)
+    if "TRIS_STEP_GRAPH" not in os.environ:
+        # the trainer replays its steps from the segmented hipGraphs (what bench.py reports as `value`): the host issues a step in
+        # ~2 ms instead of ~30 ms of eager launches; batches of another shape (the last one of an epoch) run eagerly (train_step)
+        cfg.step_graph = "seg"
     log = _logger(args, local_rank)
     net = TRIS(args).cuda(local_rank)
     param_groups = net.trainable_parameters()
