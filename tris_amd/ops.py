@@ -919,8 +919,14 @@ def h2_arm(A, B, a_slot=None, b_slot=None):
 PL_STATS = {"unplanes": 0, "dx_planes": 0, "dy_planes": 0, "products": 0, "mixed": 0, "last": False, "last_t": False}
 
 
+_HAS_GPU = None
+
+
 def planes_on():
-    return cfg.h2_planes and h2_on() and not _BATCH_INVARIANT
+    global _HAS_GPU
+    if _HAS_GPU is None:
+        _HAS_GPU = torch.cuda.is_available()     # (host-logic tests run the model's control flow on CPU stand-ins)
+    return _HAS_GPU and cfg.h2_planes and h2_on() and not _BATCH_INVARIANT
 
 
 def pl_word(t):
