@@ -288,27 +288,35 @@ def main():
 
     # PMC-derived HBM traffic / matrix-pipe utilisation of the same kernel family: separate rocprofv3 --pmc passes of THIS command
     # (tools/closing_profiles.sh), committed under profiles/ -- read, not measured here; the files are named in the notes
-    for tag in ((f"r4_{mode}",) if mode in ("h2", "x3") else ()):
+    def _prof(name):   # this round's committed profile if present, else the last round's (the note names the file that was read)
+        for rd in ("r5", "r4"):
+            p = os.path.join(ROOT, "profiles", f"{rd}_{name}")
+            if os.path.exists(p):
+                return p, f"{rd}_{name}"
+        return os.path.join(ROOT, "profiles", f"r5_{name}"), f"r5_{name}"
+    for tag in ((mode,) if mode in ("h2", "x3") else ()):
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")))["gemm_family"]
+            pfile, pname = _prof(f"{tag}_pmc_hbm_traffic.json")
+            pmc = json.load(open(pfile))["gemm_family"]
             roof["traffic"] = int((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / pmc["launches_per_step"])
             roof["hbm_frac_pmc"] = round((pmc["fetch_bytes_per_step"] + pmc["write_bytes_per_step"]) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             roof["traffic_note"] = ("bytes per launch, averaged over the family: (FETCH_SIZE x2 + WRITE_SIZE) per step / launches per "
-                                    f"step from profiles/{tag}_pmc_hbm_traffic.json (rocprofv3 --pmc pass of this command, "
+                                    f"step from profiles/{pname} (rocprofv3 --pmc pass of this command, "
                                     "tools/closing_profiles.sh; not re-measured in this run)")
         except Exception:
             pass
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_util.json")))
+            sfile, sname = _prof(f"{tag}_pmc_mfma_util.json")
+            sq = json.load(open(sfile))
             roof["mfma_utilisation_pmc"] = sq["families"]["gemm_family"]["mfma_utilisation"]
             roof["mfma_utilisation_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family, "
-                                             f"profiles/{tag}_pmc_mfma_util.json (rocprofv3 --pmc, kernels serialised, static tile choice)")
+                                             f"profiles/{sname} (rocprofv3 --pmc, kernels serialised, static tile choice)")
         except Exception:
             pass
-    try:   # per-kind rate of the tuner's winners on an IDLE device (profiles/r4_autotune_log_<mode>.txt): the in-step loss to
+    try:   # per-kind rate of the tuner's winners on an IDLE device (profiles/r5_autotune_log_<mode>.txt): the in-step loss to
         # co-scheduling with the other streams is the gap between these and by_kind above
         from tools.tune_report import idle_rates
-        roof["idle_device_tflops"] = idle_rates(os.path.join(ROOT, "profiles", f"r4_autotune_log_{mode}.txt"))
+        roof["idle_device_tflops"] = idle_rates(_prof(f"autotune_log_{mode}.txt")[0])
     except Exception:
         pass
     roof_x = None
@@ -340,13 +348,14 @@ def main():
         try:   # HBM bytes of the cross-attention launches from the same --pmc passes
             import csv as _csv
             tr = 0
-            for r in _csv.DictReader(open(os.path.join(ROOT, "profiles", f"r4_{mode}_pmc_hbm_traffic.csv"))):
+            xfile, xpname = _prof(f"{mode}_pmc_hbm_traffic.csv")
+            for r in _csv.DictReader(open(xfile)):
                 if "xattn_" in r["Kernel"]:
                     tr += int(r["FetchBytesPerStep(x2 corrected)"]) + int(r["WriteBytesPerStep"])
             if tr:
                 roof_x["traffic"] = tr
-                roof_x["traffic_note"] = (f"FETCH_SIZE x2 + WRITE_SIZE of the cross-attention launches of one forward (profiles/r4_{mode}_"
-                                          f"pmc_hbm_traffic.csv, rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes")
+                roof_x["traffic_note"] = (f"FETCH_SIZE x2 + WRITE_SIZE of the cross-attention launches of one forward (profiles/{xpname}, "
+                                          f"rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes")
         except Exception:
             pass
     out = None

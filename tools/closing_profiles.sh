@@ -1,7 +1,7 @@
 # measurement set of a round for ONE arithmetic (run on the GPU box through gpurun):
-#   TAG=r4 MODE=h2 bash tools/closing_profiles.sh      -> gpurun_out/${TAG}_${MODE}_*   (MODE = h2 | x3; copy what is to be kept into profiles/)
+#   TAG=r5 MODE=h2 bash tools/closing_profiles.sh      -> gpurun_out/${TAG}_${MODE}_*   (MODE = h2 | x3; copy what is to be kept into profiles/)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-TAG=${TAG:-r4}; MODE=${MODE:-h2}; P=${TAG}_${MODE}
+TAG=${TAG:-r5}; MODE=${MODE:-h2}; P=${TAG}_${MODE}
 export TRIS_GEMM_MODE=$MODE
 B="python bench.py --steps 2 --warmup 1 --headline-only"
 # 1. kernel trace of the production configuration (autotuned, three streams), the timed steps of `value` only
@@ -9,8 +9,8 @@ timeout 500 rocprofv3 --kernel-trace -d gpurun_out/${P}_trace -- python bench.py
 DB=$(ls gpurun_out/${P}_trace/*/*.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py $DB gpurun_out/${P}_kernel_stats.csv 30 6 > gpurun_out/${P}_kernel_stats_summary.txt < /dev/null; python tools/stream_gaps.py $DB 6 > gpurun_out/${P}_stream_gaps.txt < /dev/null; fi
 rm -rf gpurun_out/${P}_trace
-# 2. PMC passes (separate runs, static tile choice, kernels serialised by the profiler)
-export TRIS_AUTOTUNE=0
+# 2. PMC passes (separate runs, static tile choice, eager launches: the profiler serialises kernels and reads counters per dispatch)
+export TRIS_AUTOTUNE=0 TRIS_STEP_GRAPH=0
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${P}_fetch -o f -- $B > gpurun_out/${P}_fetch.log 2>&1 < /dev/null; echo fetch $?
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${P}_write -o w -- $B > gpurun_out/${P}_write.log 2>&1 < /dev/null; echo write $?
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${P}_sq -o s -- $B > gpurun_out/${P}_sq.log 2>&1 < /dev/null; echo sq $?
