@@ -177,6 +177,162 @@ __global__ __launch_bounds__(NWM* NWN * 64, (OCC * NWM * NWN + 3) / 4) void plan
     }
 }
 
+
+// ---- 8-wave PING-PONG: 256 x 128 tile, wave tile 64 x 64, three LDS stages; waves 0-3 (one per SIMD) and waves 4-7 run the same
+// two-phase loop half a step apart: while one group issues its 24 MFMAs of a k tile from registers, the other reads its 16 fragments
+// of the next tile from LDS (and group A issues the LDS-DMA of the tile two ahead).  Every phase ends with one s_barrier of all
+// eight waves; group B enters one barrier late.  ABL as above.
+template <int ABL = 0, int PRIO = 1>
+__global__ __launch_bounds__(512, 2) void pingpong_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int K, float inv_scale) {
+  constexpr int BM = 256, BN = 128, NW = 8, NST = 3;
+  constexpr int A_ST = BM * 128, B_ST = BN * 128, ST = A_ST + B_ST;
+  constexpr int GA = BM / 8 / 4, GB = BN / 8 / 4;        // LDS-DMA instructions per ISSUING wave (group A: 4 waves) and stage
+  __shared__ __attribute__((aligned(1024))) char lds[NST * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 wave grid, 64 x 64 each
+  const int tiles_n = (N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  if (ABL & 8) {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const char* a_src[GA];
+  const char* b_src[GB];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int r = (wq * GA + q) * 8 + lrow;
+    a_src[q] = reinterpret_cast<const char*>(A + (long)min(m0 + r, M - 1) * K) + ((lslot ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const int r = (wq * GB + q) * 8 + lrow;
+    b_src[q] = reinterpret_cast<const char*>(B + (long)min(n0 + r, N - 1) * K) + ((lslot ^ ((r >> 1) & 7)) << 4);
+  }
+  auto issue = [&](int stage, int kt) {
+    if ((ABL & 4) && kt >= 2) return;
+    char* sa = lds + stage * ST + (wq * GA) * 1024;
+    char* sb = lds + stage * ST + A_ST + (wq * GB) * 1024;
+#pragma unroll
+    for (int q = 0; q < GA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < GB; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + (long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(sb + q * 1024), 16, 0, 0);
+  };
+  f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
+  const int li = lane & 31, kh = lane >> 5;
+  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int r = wm * 64 + i * 32 + li; a_off[i] = r * 128; a_sw[i] = (r >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + li; b_off[j] = A_ST + r * 128; b_sw[j] = (r >> 1) & 7; }
+  f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];   // [g][i]
+  auto read_frags = [&](int stage) {
+    const char* st = lds + stage * ST;
+    if (ABL & 2) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ah[g][i] = (f16x8)(_Float16)(1.0f + lane); al[g][i] = ah[g][i]; bh[g][i] = (f16x8)(_Float16)(0.5f); bl[g][i] = bh[g][i]; }
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int p0 = 2 * (2 * g + kh);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[g][i] = *reinterpret_cast<const f16x8*>(st + a_off[i] + ((p0 ^ a_sw[i]) << 4));
+        al[g][i] = *reinterpret_cast<const f16x8*>(st + a_off[i] + (((p0 + 1) ^ a_sw[i]) << 4));
+        bh[g][i] = *reinterpret_cast<const f16x8*>(st + b_off[i] + ((p0 ^ b_sw[i]) << 4));
+        bl[g][i] = *reinterpret_cast<const f16x8*>(st + b_off[i] + (((p0 + 1) ^ b_sw[i]) << 4));
+      }
+    }
+  };
+  auto mfmas = [&]() {
+    if (ABL & 1) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j][0] += (float)ah[g][i][0] * (float)bh[g][j][0] + (float)al[g][i][1] * (float)bl[g][j][1];
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g][i], bh[g][j], acx[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g][i], bl[g][j], acx[i][j], 0, 0, 0);
+        }
+  };
+  const int nk = K / 32;
+  constexpr int GPS = GA + GB;
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (grp == 0) {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();                                       // tile 0 is in LDS
+    for (int kt = 0; kt < nk; ++kt) {
+      read_frags(kt % 3);
+      if (kt + 2 < nk) issue((kt + 2) % 3, kt + 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar();
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      mfmas();
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");   // tile kt + 1 has landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+    }
+    bar();
+  } else {
+    bar();
+    bar();
+    for (int kt = 0; kt < nk; ++kt) {
+      read_frags(kt % 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar();
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      mfmas();
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      bar();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < M && col < N) C[(long)row * N + col] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]) * inv_scale;
+      }
+    }
+}
+
 static float host_scale(float amax) {
   int e;
   frexpf(amax, &e);          // amax = f * 2^e, f in [0.5, 1)  ->  floor(log2 amax) = e - 1
@@ -216,6 +372,37 @@ static void run(const char* name, const float* Ap, const float* Bp, float* C, co
   fflush(stdout);
 }
 
+template <int ABL, int PRIO>
+static void run_pp(const char* name, const float* Ap, const float* Bp, float* C, const float* Cref, int M, int N, int K, float inv,
+                   int ref_rows_n) {
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  auto launch = [&]() { hipLaunchKernelGGL((pingpong_kernel<ABL, PRIO>), dim3(tiles), dim3(512), 0, 0, Ap, Bp, C, M, N, K, inv); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  const int it = 10;
+  for (int i = 0; i < it; ++i) launch();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= it;
+  double err = -1.0;
+  if ((ABL & 7) == 0 && Cref) {
+    std::vector<float> h((size_t)ref_rows_n * N), r((size_t)ref_rows_n * N);
+    hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), Cref, r.size() * 4, hipMemcpyDeviceToHost);
+    double num = 0, den = 0;
+    for (size_t i = 0; i < h.size(); ++i) { num = fmax(num, fabs((double)h[i] - r[i])); den = fmax(den, fabs((double)r[i])); }
+    err = num / den;
+  }
+  printf("%-44s M%-7d N%-5d K%-5d %9.1f us %7.1f TF/s  err/max %.2e\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) * 1e-12, err);
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; };
   std::vector<Shape> shapes = {{4096, 4096, 4096}, {76800, 256, 2304}, {19200, 512, 4608}, {19200, 1024, 1024}, {19200, 1024, 256}, {4800, 2048, 1024},
@@ -242,6 +429,13 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     const float inv = 1.0f / (sA * sB);
 #define RUN(BM, BN, NWM, NWN, NST, OCC, ABL, NAME) run<BM, BN, NWM, NWN, NST, OCC, ABL>(NAME, Ap, Bp, C, Cref, M, N, K, inv, RR)
+    run_pp<0, 1>("256x128 8w ping-pong 3st prio", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_pp<0, 0>("256x128 8w ping-pong 3st", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_pp<8, 1>("256x128 8w ping-pong 3st prio xcd", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_pp<1, 1>("256x128 8w ping-pong -mfma", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_pp<2, 1>("256x128 8w ping-pong -fragreads", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_pp<4, 1>("256x128 8w ping-pong -loads", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_pp<6, 1>("256x128 8w ping-pong mfma+barriers", Ap, Bp, C, Cref, M, N, K, inv, RR);
     RUN(128, 128, 2, 4, 2, 2, 0, "128x128 8w(2x4) 2 stages occ2");
     RUN(128, 128, 2, 4, 2, 2, 8, "128x128 8w(2x4) 2 stages occ2 xcd");
     RUN(128, 128, 2, 2, 2, 2, 0, "128x128 4w(2x2) 2 stages occ2");
