@@ -368,6 +368,13 @@ int tris_xattn_fused_fwd_f32(const float* Qv, const float* Kv, const float* Vv, 
  * TRIS_DECLINED behaviour as tris_xattn_fused_fwd_f32; the sync words may be the same buffer. */
 long tris_xattn_px_ws_bytes(int B, int N, int C);
 long tris_xattn_px_sync_words(int B);
+/* h2 arithmetic for ONE call of the pixel-row launch: arms the calling thread with the amax words (2048 unsigned each, as
+ * tris_h2_next) of Qv, Kv, Vv, Qt, Kt, Vt; the next tris_xattn_px_fwd_f32 of the thread computes its four products on two fp16
+ * pieces per operand (three MFMAs per product, two sentence planes instead of three) with one power-of-two scale per tensor, the
+ * probabilities with the fixed scale 2^13, and disarms.  Unarmed calls run the split-bf16 form. */
+long tris_xattn_px_last_form(void);   /* arithmetic of the last pixel-row launch: 0 none yet, 1 split-bf16, 2 h2 */
+int tris_xattn_amax_next(const unsigned* qv, const unsigned* kv, const unsigned* vv, const unsigned* qt, const unsigned* kt,
+                         const unsigned* vt);
 /* host-side plan of the pixel-row launch: workgroups per image S on a device of `cus` compute units (0 = the call would decline:
  * B * S workgroups must be resident one per CU, a workgroup owns <= 32 pixels and <= 8 of the C / 32 channel units).  Workgroup s
  * owns pixels [s P / S, (s + 1) P / S) and units [s U / S, (s + 1) U / S), U = C / 32 (integer division). */

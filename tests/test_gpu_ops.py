@@ -881,6 +881,8 @@ def test_xattn_single_launch_kernels_match_the_two_launch_pair(ops, monkeypatch,
         kinds = {r[0] for r in ops.profile_end() if r[0].startswith("xattn")}
         if form == "px" and ops.get_gemm_mode() != "f32" and B * max((P + 31) // 32, C // 256) <= 256:   # inside the pixel-row form's domain: it must have run
             assert kinds == {"xattn_fwd_px"}, kinds
+            # ... in the arithmetic of the step: two fp16 pieces inside h2, three bf16 pieces otherwise
+            assert int(ops.query("tris_xattn_px_last_form")) == (2 if ops.get_gemm_mode() == "h2" else 1)
         (nv.sum() + nl.sum()).backward()
         outs[form] = (nv.detach(), nl.detach(), [t.grad for t in q])
         close(nv.detach().cpu(), rv.float(), 2e-5, name=f"new_vis {form}")

@@ -15,8 +15,8 @@ by = B * (4 * P * C + N * C) * 4 + 3 * N * C * 4
 import os
 if os.environ.get("PX_SLOTS"):
     ops.set_option("XATTN_PX_SLOTS", os.environ["PX_SLOTS"])
-for form in ("pair", "slices", "px"):
-    cfg.xattn_fused, cfg.xattn_px = form != "pair", form == "px"
+for form in ("pair", "slices", "px-x3", "px"):
+    cfg.xattn_fused, cfg.xattn_px, cfg.xattn_h2 = form != "pair", form.startswith("px"), form == "px"
     with torch.no_grad():
         ops.profile_begin()
         for _ in range(3):
@@ -29,5 +29,7 @@ for form in ("pair", "slices", "px"):
         b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 50 * 1e3
     ev = float((nv.double() - rv).abs().max() / rv.abs().max()); el = float((nl.double() - rl).abs().max() / rl.abs().max())
+    if form.startswith("px"):
+        kinds.append({0: "-", 1: "x3 pieces", 2: "h2 pieces"}[int(ops.query("tris_xattn_px_last_form"))])
     print(f"{form:7s} {kinds}  {us:6.1f} us  {by / us / 1e3:7.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}   rel err new_vis {ev:.2e} new_lan {el:.2e}"
           f"  timed out: {ops.xattn_timed_out()}")

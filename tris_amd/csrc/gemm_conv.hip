@@ -513,6 +513,12 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.vecB = al16(B) && (ldb % 4 == 0) && (sB % 4 == 0);
   p.fastA = p.vecA && (!transA || M % 4 == 0);
   p.fastB = p.vecB && (transB || N % 4 == 0);
+  if (transA && !transB && K % 32 != 0 && K > 32 && p.fastA && p.fastB && M >= 4 && N >= 4 && !epi.armed) {
+    // both operands k-major (a weight gradient) over a k extent that is not a multiple of 32: the fast kernel runs over K rounded
+    // up and its loaders zero the rows past the end (the generic kernel took 1.4 ms for the 768 x 768 x 19248 products of ViT-B/16)
+    p.Kv = K;
+    p.K = (K + 31) & ~31;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (epi.armed) {   // the extras live in the fast kernel's one-pass epilogue only: no split-K, no generic kernel
     if (batch != 1 || transA || !gemm_fast_ok(p)) return TRIS_DECLINED;

@@ -375,7 +375,15 @@ void gemm_fast_kernel(GemmParams p) {
       }
     } else {  // A_COLK: A[k*lda + m]
 #pragma unroll
-      for (int q = 0; q < PA; ++q) ra[q] = ld4(A + (long)(k0 + tid / AF4 + q * ARPP) * p.lda + a_mc);
+      for (int q = 0; q < PA; ++q) {
+        const int kk = k0 + tid / AF4 + q * ARPP;
+        if (p.Kv > 0) {   // (uniform) K rounded up: rows past the last valid one read as zeros
+          const float4 v = ld4(A + (long)min(kk, p.Kv - 1) * p.lda + a_mc);
+          ra[q] = kk < p.Kv ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          ra[q] = ld4(A + (long)kk * p.lda + a_mc);
+        }
+      }
     }
   };
 
@@ -385,7 +393,15 @@ void gemm_fast_kernel(GemmParams p) {
       for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + b_off[q] + k0);
     } else if (BKIND == B_KN) {
 #pragma unroll
-      for (int q = 0; q < PB; ++q) rb[q] = ld4(Bp + (long)(k0 + tid / BF4 + q * BRPP) * p.ldb + b_nc);
+      for (int q = 0; q < PB; ++q) {
+        const int kk = k0 + tid / BF4 + q * BRPP;
+        if (p.Kv > 0) {
+          const float4 v = ld4(Bp + (long)min(kk, p.Kv - 1) * p.ldb + b_nc);
+          rb[q] = kk < p.Kv ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          rb[q] = ld4(Bp + (long)kk * p.ldb + b_nc);
+        }
+      }
     } else if (BKIND == B_KN_DGRAD) {  // k = tap'*Cout + co ; B[k][ci] = W[co][8 - tap'][ci]
 #pragma unroll
       for (int q = 0; q < PB; ++q) {

@@ -11,6 +11,9 @@ struct GemmParams {
   const float* B;
   float* C;
   int M, N, K;
+  int Kv;           // 0, or the number of VALID k rows when both operands are k-major (A_COLK x B_KN) and K was rounded up to a
+                    // multiple of 32 for the fast kernel: its loaders read rows >= Kv as zeros (tris_gemm_f32: weight gradients
+                    // over a token count that is not a multiple of 32, e.g. 48 x 401 ViT-B/16 tokens)
   long lda, ldb, ldc;
   long sA, sB, sC;  // batch strides (elements)
   const float* bias;

@@ -546,7 +546,7 @@ int launch_fused(const float* Qv, const float* Kv, const float* Vv, const float*
   uint4* VtF = reinterpret_cast<uint4*>(ws + pl.vtf);
   float* Sx = reinterpret_cast<float*>(ws + pl.sx);
   const int slots = 2 * NT * (C / 32) * 64 + (C / 16) * pl.KS2 * 64;
-  hipLaunchKernelGGL(xattn_text_planes_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, st, Qt, Kt, Vt, QtF, KtF, VtF, N, C, NT,
+  hipLaunchKernelGGL(xattn_text_planes_kernel<false>, dim3(cdiv(slots, 256)), dim3(256), 0, st, Qt, Kt, Vt, QtF, KtF, VtF, N, C, NT,
                      pl.KS2);
   const long lds = xf_lds_bytes(P, NT);
   static bool attr_done = false;   // (one instantiation = one function-local flag)

@@ -1,5 +1,6 @@
-// Sentence operands of the fused cross attention (xattn_fused.hip, xattn_px.hip) pre-split into bf16 piece planes in MFMA fragment
-// order: one small launch in front of the persistent kernel, shared by both of its forms.
+// Sentence operands of the fused cross attention (xattn_fused.hip, xattn_px.hip) pre-split into piece planes in MFMA fragment
+// order: one small launch in front of the persistent kernel, shared by both of its forms.  H2 = false: three bf16 pieces (x3);
+// H2 = true: two fp16 pieces hi | lo' of x * s (x3_split.h "h2"), s from the tensor's amax word (am[0..2] = Qt, Kt, Vt).
 #pragma once
 #include "common.h"
 #include "x3_split.h"
@@ -8,15 +9,43 @@ namespace {
 
 __device__ __forceinline__ float4 xp_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// eight values -> h2 pieces carried in a Split8 (hi = fp16 hi pieces, mid = lo = fp16 pre-scaled residuals)
+__device__ __forceinline__ Split8 split8h(const float4 u, const float4 w, const float s) {
+  const Split4 p = split4h(u, s), q = split4h(w, s);
+  typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+  Split8 o;
+  o.hi = __builtin_bit_cast(bf16x8, (xu32x4){p.hi.x, p.hi.y, q.hi.x, q.hi.y});
+  o.mid = __builtin_bit_cast(bf16x8, (xu32x4){p.mid.x, p.mid.y, q.mid.x, q.mid.y});
+  o.lo = o.mid;
+  return o;
+}
+struct XpAmax { const unsigned* w[6]; };   // amax words of Qv, Kv, Vv, Qt, Kt, Vt (h2 form)
+
 // ---- sentence operands -> bf16 piece planes in MFMA fragment order ------------------------------------------------------------
 // QtF / KtF (A operand of phase A: rows = sentences, k = channels):  [NT][C/32][3 planes][64 lanes] x 16 B;
 //     lane l of fragment (j, s): sentence n = 16 j + (l & 15), channels c = 32 s + 8 (l >> 4) .. + 7      (n >= N -> zeros)
 // VtF (B operand of phase B1: k = sentences, columns = channels):    [C/16][KS2][3 planes][64 lanes] x 16 B;
 //     lane l of fragment (ct, ks): channel c = 16 ct + (l & 15), sentences n = 32 ks + 8 (l >> 4) .. + 7   (n >= N -> zeros)
+template <bool H2 = false>
 __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __restrict__ Qt, const float* __restrict__ Kt,
                                                                 const float* __restrict__ Vt, uint4* __restrict__ QtF,
                                                                 uint4* __restrict__ KtF, uint4* __restrict__ VtF, int N, int C,
-                                                                int NT, int KS2) {
+                                                                int NT, int KS2, XpAmax am = XpAmax(),
+                                                                float* __restrict__ scl_out = nullptr) {
+  constexpr int NP = H2 ? 2 : 3;
+  float sc[3] = {1.f, 1.f, 1.f};
+  if constexpr (H2) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) sc[t] = h2_scale_from_bits(h2_amax_of(am.w[3 + t], threadIdx.x & 63));
+    if (blockIdx.x == 0 && threadIdx.x < 64) {   // the six scales for the persistent launch (scalar loads there)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const float v = h2_scale_from_bits(h2_amax_of(am.w[t], threadIdx.x));
+        if (threadIdx.x == 0) scl_out[t] = v;
+      }
+    }
+  }
+  int which = 0;
   const int KST = C / 32;
   const int nA = NT * KST * 64;           // lane slots of one A-operand tensor
   const int nB = (C / 16) * KS2 * 64;     // lane slots of VtF
@@ -33,7 +62,8 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
     const bool ok = n < N;
     x[0] = ok ? u.x : 0.f; x[1] = ok ? u.y : 0.f; x[2] = ok ? u.z : 0.f; x[3] = ok ? u.w : 0.f;
     x[4] = ok ? w.x : 0.f; x[5] = ok ? w.y : 0.f; x[6] = ok ? w.z : 0.f; x[7] = ok ? w.w : 0.f;
-    dst = (t == 0 ? QtF : KtF) + ((long)fs * 3) * 64 + l;
+    dst = (t == 0 ? QtF : KtF) + ((long)fs * NP) * 64 + l;
+    which = t;
   } else if (g < 2 * nA + nB) {
     const int e = g - 2 * nA;
     const int l = e & 63, fs = e >> 6;    // fs = ct * KS2 + ks
@@ -41,14 +71,22 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
     const int c = ct * 16 + (l & 15), n0 = ks * 32 + (l >> 4) * 8;
 #pragma unroll
     for (int q = 0; q < 8; ++q) x[q] = (n0 + q < N) ? Vt[(long)(n0 + q) * C + c] : 0.f;
-    dst = VtF + ((long)fs * 3) * 64 + l;
+    dst = VtF + ((long)fs * NP) * 64 + l;
+    which = 2;
   } else {
     return;
   }
-  const Split8 sp = split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
-  dst[0] = __builtin_bit_cast(uint4, sp.hi);
-  dst[64] = __builtin_bit_cast(uint4, sp.mid);
-  dst[128] = __builtin_bit_cast(uint4, sp.lo);
+  if constexpr (H2) {
+    const Split8 sp = split8h(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]),
+                              which == 0 ? sc[0] : which == 1 ? sc[1] : sc[2]);
+    dst[0] = __builtin_bit_cast(uint4, sp.hi);
+    dst[64] = __builtin_bit_cast(uint4, sp.mid);
+  } else {
+    const Split8 sp = split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
+    dst[0] = __builtin_bit_cast(uint4, sp.hi);
+    dst[64] = __builtin_bit_cast(uint4, sp.mid);
+    dst[128] = __builtin_bit_cast(uint4, sp.lo);
+  }
 }
 
 }  // namespace

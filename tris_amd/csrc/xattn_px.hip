@@ -1,5 +1,7 @@
 // Bilateral image<->text cross attention (reference model/attn.py:117-128) as ONE persistent launch, cut by PIXELS
-// (gfx950, split-bf16 x3).
+// (gfx950; arithmetic x3 = three bf16 pieces / six MFMAs per product, or -- template H2, armed per call by tris_xattn_amax_next --
+// h2 = two fp16 pieces of x * s / three MFMAs, two accumulator sets, the scales from the six operands' amax words; the
+// probabilities, which are <= 1, take the fixed scale 2^13).
 //
 //   Av  = softmax_n(Qv Kt^T / sqrt(C))   [B,P,N]      new_vis = Av  Vt      [B,P,C]
 //   AtT = softmax_p(Kv Qt^T / sqrt(C))   [B,P,N]      new_lan = AtT^T Vv    [B,N,C]
@@ -103,32 +105,64 @@ __device__ __forceinline__ void mfma6_n(const Split8 (&a)[NCH], const Split8 (&b
 #undef XP_PIECE
 }
 
+// h2: the same chains on fp16 pieces (carried in Split8: hi | mid = lo'): lo' x hi and hi x lo' into cx, hi x hi into c
+template <int NCH>
+__device__ __forceinline__ void mfma3_n(const Split8 (&a)[NCH], const Split8 (&b)[NCH], f32x4v (&c)[NCH], f32x4v (&cx)[NCH]) {
+#define XP_H(x) __builtin_bit_cast(f16x8, x)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) cx[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(XP_H(a[i].mid), XP_H(b[i].hi), cx[i], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) cx[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(XP_H(a[i].hi), XP_H(b[i].mid), cx[i], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(XP_H(a[i].hi), XP_H(b[i].hi), c[i], 0, 0, 0);
+#undef XP_H
+}
+template <bool H2, int NCH>
+__device__ __forceinline__ void xp_mfma_n(const Split8 (&a)[NCH], const Split8 (&b)[NCH], f32x4v (&c)[NCH], f32x4v (&cx)[NCH]) {
+  if constexpr (H2) mfma3_n<NCH>(a, b, c, cx);
+  else mfma6_n<NCH>(a, b, c);
+}
+template <bool H2> __device__ __forceinline__ Split8 xp_split8(const float4 u, const float4 w, const float s) {
+  if constexpr (H2) return split8h(u, w, s);
+  else return split8(u, w);
+}
+template <bool H2> __device__ __forceinline__ f32x4v xp_join(const f32x4v c, const f32x4v cx) {
+  if constexpr (H2) return c + cx * (1.0f / 2048.0f);
+  else return c;
+}
+constexpr float XP_PS = 8192.f;   // h2 scale of the probabilities (<= 1 -> hi <= 2^13)
+
 constexpr int xp_max(int a, int b) { return a > b ? a : b; }
-template <int NT, int NPT> struct XpLds {
+template <int NT, int NPT, int NP = 3> struct XpLds {
   static constexpr int turn = 8 * NPT * 16 * XP_TLD * 4;              // wave-private turn-around tiles (logits phase)
   static constexpr int red = 8 * NPT * NT * 1024;                    // partial logit blocks of the eight waves
   static constexpr int av = 32 * XP_AVS * 4;                         // Av rows, behind turn | red
-  static constexpr int planes = 8 * 3 * XP_PLANE;                    // wave-private Vv planes (new_lan phase), aliases turn | red
-  static constexpr int atf = NT * 4 * 3 * 1024;                      // At as bf16 piece planes in MFMA fragment order, behind the Vv planes
+  static constexpr int planes = 8 * NP * XP_PLANE;                   // wave-private Vv planes (new_lan phase), aliases turn | red
+  static constexpr int atf = NT * 4 * NP * 1024;                     // At as piece planes in MFMA fragment order, behind the Vv planes
   static constexpr int arena = xp_max(turn + red + av, planes + atf);
   static constexpr int at = NT * 16 * XP_ATS * 4;                    // gathered logits / At rows (fp32)
   static constexpr int total = arena + at + 16;
 };
 
 // grid B * S, block 512.  KQ = 32-channel steps per wave of the logits phase (C = 128 KQ).
-template <int NT, int NPT, int KQ>
+template <int NT, int NPT, int KQ, bool H2>
 __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restrict__ Qv, const float* __restrict__ Kv,
                                                           const float* __restrict__ Vv, const uint4* __restrict__ QtF,
                                                           const uint4* __restrict__ KtF, const uint4* __restrict__ VtF,
                                                           float* __restrict__ new_vis, float* __restrict__ new_lan,
                                                           float* __restrict__ probs, float* __restrict__ Sx, int sx_bytes,
-                                                          unsigned* __restrict__ sync, int B, int P, int N, int S, float scale) {
+                                                          unsigned* __restrict__ sync, int B, int P, int N, int S, float scale,
+                                                          const float* __restrict__ scl) {
   constexpr int C = 128 * KQ;
+  constexpr int NP = H2 ? 2 : 3;         // piece planes per operand
+  // h2: scl[0..5] = the power-of-two scales of Qv, Kv, Vv, Qt, Kt, Vt (written by the plane preparation launch from the amax words)
+  const float s_qv = H2 ? scl[0] : 1.f, s_kv = H2 ? scl[1] : 1.f, s_vv = H2 ? scl[2] : 1.f;
+  const float s_qt = H2 ? scl[3] : 1.f, s_kt = H2 ? scl[4] : 1.f, s_vt = H2 ? scl[5] : 1.f;
   constexpr int KST = C / 32;
   constexpr int KS2 = (NT + 1) / 2;      // 32-sentence steps of the new_vis product
   constexpr int CT = C / 16;             // channel tiles
   constexpr int U = C / 32;              // 32-channel units
-  using L = XpLds<NT, NPT>;
+  using L = XpLds<NT, NPT, NP>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* AvL = reinterpret_cast<float*>(lds + L::turn + L::red);
   float* AtL = reinterpret_cast<float*>(lds + L::arena);
@@ -156,7 +190,9 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
   {
     const int g = wave >> 2, q = wave & 3;
     const float* X = g ? Qv : Kv;
-    const uint4* F = (g ? KtF : QtF) + ((long)(q * KQ) * 3) * 64 + lane;
+    const uint4* F = (g ? KtF : QtF) + ((long)(q * KQ) * NP) * 64 + lane;
+    const float s_x = g ? s_qv : s_kv;                      // h2 scale of the pixel rows of this half
+    const float inv_l = H2 ? 1.0f / (s_x * (g ? s_kt : s_qt)) : 1.0f;
     float* tile = reinterpret_cast<float*>(lds) + wave * (NPT * 16 * XP_TLD);
     const int lr = lane >> 3, lc = (lane & 7) * 4;   // loader coordinates: row within an 8-row half, float offset in the 128-B piece
     const float* gp[NPT][2];
@@ -164,9 +200,9 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     for (int t = 0; t < NPT; ++t)
 #pragma unroll
       for (int h = 0; h < 2; ++h) gp[t][h] = X + ((long)b * P + min(p0 + t * 16 + lr + 8 * h, p1 - 1)) * C + q * (C / 4) + lc;
-    f32x4v acc[NPT * NT];
+    f32x4v acc[NPT * NT], acx[NPT * NT];
 #pragma unroll
-    for (int i = 0; i < NPT * NT; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NPT * NT; ++i) acc[i] = acx[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     constexpr int AHEAD = KQ < 3 ? KQ : 3;           // k-steps of pixel rows in flight (4: no faster, spills)
     float4 v[KQ][NPT][2];
     Split8 fr[KQ][NT];
@@ -179,8 +215,9 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     auto load_fr = [&](int i) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const uint4* f = F + ((long)(j * KST + i) * 3) * 64;
-        fr[i][j].hi = ldf(f); fr[i][j].mid = ldf(f + 64); fr[i][j].lo = ldf(f + 128);
+        const uint4* f = F + ((long)(j * KST + i) * NP) * 64;
+        fr[i][j].hi = ldf(f); fr[i][j].mid = ldf(f + 64);
+        if constexpr (!H2) fr[i][j].lo = ldf(f + 128);
       }
     };
     constexpr int FAHEAD = (KQ < 2 || NT * NPT >= 8) ? 1 : 2;          // k-steps of sentence fragments in flight (throughput = bytes in flight / latency)
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
 #pragma unroll
       for (int t = 0; t < NPT; ++t) {
         const float* f = tile + t * (16 * XP_TLD) + r16 * XP_TLD + kg * 8;
-        sp[t] = split8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
+        sp[t] = xp_split8<H2>(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4), s_x);
       }
       wave_lds_fence();
       Split8 ca[NPT * NT], cb[NPT * NT];
@@ -209,15 +246,17 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       for (int t = 0; t < NPT; ++t)
 #pragma unroll
         for (int j = 0; j < NT; ++j) { ca[t * NT + j] = sp[t]; cb[t * NT + j] = fr[i][j]; }
-      mfma6_n<NPT * NT>(ca, cb, acc);
+      xp_mfma_n<H2, NPT * NT>(ca, cb, acc, acx);
     }
     XP_STAMP(1);
     XP_STAMP_W(16);
     // partial blocks -> LDS  (red[wave][t * NT + j][lane] x 16 B; behind the turn-around tiles of all waves)
     float* red = reinterpret_cast<float*>(lds + L::turn) + wave * (NPT * NT * 256);
 #pragma unroll
-    for (int i = 0; i < NPT * NT; ++i)
-      *reinterpret_cast<float4*>(red + i * 256 + lane * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    for (int i = 0; i < NPT * NT; ++i) {
+      const f32x4v a = xp_join<H2>(acc[i], acx[i]) * inv_l;
+      *reinterpret_cast<float4*>(red + i * 256 + lane * 4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
   }
   lds_barrier();
   const unsigned epoch = *s_epoch_p;
@@ -300,14 +339,16 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     for (int e = tg; e < NPT * KS2 * 64; e += 256) {
       const int fk = e >> 6, l = e & 63, t = fk / KS2, ks = fk - t * KS2;
       const float* a = AvL + (t * 16 + (l & 15)) * XP_AVS + ks * 32 + (l >> 4) * 8;
-      const Split8 sp = split8(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4));
-      uint4* d = AvF + (fk * 3) * 64 + l;
-      d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid); d[128] = __builtin_bit_cast(uint4, sp.lo);
+      const Split8 sp = xp_split8<H2>(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4), XP_PS);
+      uint4* d = AvF + (fk * NP) * 64 + l;
+      d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid);
+      if constexpr (!H2) d[128] = __builtin_bit_cast(uint4, sp.lo);
     }
     group_sync();   // (third arrival: this half is done with the partial blocks and the Av rows -- the other half may reuse their LDS)
     // Vt^T fragments through a buffer resource: lanes whose eight sentences are all >= N ask for an out-of-range offset and get
     // zeros without a byte moved (N = 48: a quarter of the second 32-sentence step) -- and without a branch around the load
-    const __amdgpu_buffer_rsrc_t vtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(VtF), 0, CT * KS2 * 3 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(VtF), 0, CT * KS2 * NP * 1024, 0x00020000);
+    const float inv_v = H2 ? 1.0f / (XP_PS * s_vt) : 1.0f;
     constexpr int NIT = CT / 4;
 #ifndef XP_VA
 #define XP_VA (NPT == 2 ? 4 : 5)
@@ -318,10 +359,10 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
     auto load_vt = [&](int ct, Split8 (&d)[KS2]) {
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
-        const int off = (ks * 32 + kg * 8 < N) ? (((ct * KS2 + ks) * 3) * 64 + lane) * 16 : 0x7fffffff;
+        const int off = (ks * 32 + kg * 8 < N) ? (((ct * KS2 + ks) * NP) * 64 + lane) * 16 : 0x7fffffff;
         d[ks].hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 0, 0));
         d[ks].mid = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 1024, 0));
-        d[ks].lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 2048, 0));
+        if constexpr (!H2) d[ks].lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 2048, 0));
       }
     };
 #pragma unroll
@@ -332,22 +373,24 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       if (it + VA < NIT) load_vt(ct + 4 * VA, vt[(it + VA) % (VA + 1)]);
       constexpr int NCH = NPT * KS2;
       Split8 ca[NCH], cb[NCH];
-      f32x4v co[NCH];
+      f32x4v co[NCH], cox[NCH];
 #pragma unroll
       for (int t = 0; t < NPT; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
-          const uint4* f = AvF + ((t * KS2 + ks) * 3) * 64 + lane;
+          const uint4* f = AvF + ((t * KS2 + ks) * NP) * 64 + lane;
           ca[t * KS2 + ks] = vt[it % (VA + 1)][ks];
-          cb[t * KS2 + ks].hi = ldf(f); cb[t * KS2 + ks].mid = ldf(f + 64); cb[t * KS2 + ks].lo = ldf(f + 128);
-          co[t * KS2 + ks] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+          cb[t * KS2 + ks].hi = ldf(f); cb[t * KS2 + ks].mid = ldf(f + 64);
+          if constexpr (!H2) cb[t * KS2 + ks].lo = ldf(f + 128);
+          co[t * KS2 + ks] = cox[t * KS2 + ks] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         }
-      mfma6_n<NCH>(ca, cb, co);        // D[c = 4 kg + r][p = r16]
+      xp_mfma_n<H2, NCH>(ca, cb, co, cox);        // D[c = 4 kg + r][p = r16]
 #pragma unroll
       for (int t = 0; t < NPT; ++t) {
-        f32x4v o = co[t * KS2];
+        f32x4v o = xp_join<H2>(co[t * KS2], cox[t * KS2]);
 #pragma unroll
-        for (int ks = 1; ks < KS2; ++ks) o += co[t * KS2 + ks];
+        for (int ks = 1; ks < KS2; ++ks) o += xp_join<H2>(co[t * KS2 + ks], cox[t * KS2 + ks]);
+        o *= inv_v;
         if (t * 16 + r16 < PW)   // 4 consecutive channels of one pixel per lane: one 16-byte store
           st4_nt(new_vis + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
       }
@@ -456,9 +499,10 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       const int fk = e >> 6, l = e & 63, j = fk >> 2, ks = fk & 3;
       if (ks < nks) {
         const float* a = AtL + (j * 16 + (l & 15)) * XP_ATS + ks * 32 + (l >> 4) * 8;
-        const Split8 sp = split8(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4));
-        uint4* d = AtF + (fk * 3) * 64 + l;
-        d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid); d[128] = __builtin_bit_cast(uint4, sp.lo);
+        const Split8 sp = xp_split8<H2>(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4), XP_PS);
+        uint4* d = AtF + (fk * NP) * 64 + l;
+        d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid);
+        if constexpr (!H2) d[128] = __builtin_bit_cast(uint4, sp.lo);
       }
     }
     XP_STAMP(10);
@@ -468,7 +512,11 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
   {
     const int prow = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < VR; ++i) vsp[i] = split4(i * 8 + prow < P ? vreg[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int i = 0; i < VR; ++i) {
+      const float4 v = i * 8 + prow < P ? vreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (H2) vsp[i] = split4h(v, s_vv);
+      else vsp[i] = split4(v);
+    }
   }
   XP_STAMP_W(24);
   lds_barrier();   // both directions meet
@@ -480,7 +528,8 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
   // new_lan[b, :, unit] = At . Vv[b, :, unit]: wave w = unit w of the workgroup; per 32-pixel step the pieces of the Vv rows are
   // stored k-major in the wave's own plane buffer and gathered as MFMA fragments by the transpose read
   if (wave < NU) {
-    char* pl = lds + wave * (3 * XP_PLANE);
+    char* pl = lds + wave * (NP * XP_PLANE);
+    const float inv_n = H2 ? 1.0f / (XP_PS * s_vv) : 1.0f;
     const int prow = lane >> 3, c8 = (lane & 7) * 8;
     const int k0 = kg * 8 + (r16 >> 2);
     const int tro0 = k0 * XP_KS + 8 * (r16 & 3), tro1 = (k0 + 4) * XP_KS + 8 * (r16 & 3);
@@ -491,9 +540,9 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
       const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       return __builtin_bit_cast(bf16x8, v);
     };
-    f32x4v co[2 * NT];
+    f32x4v co[2 * NT], cox[2 * NT];
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) co[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2 * NT; ++i) co[i] = cox[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < nks) {
@@ -504,25 +553,29 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
           const uint2 z = make_uint2(0u, 0u);
           *reinterpret_cast<uint2*>(d) = vi < VR ? vsp[vi < VR ? vi : 0].hi : z;
           *reinterpret_cast<uint2*>(d + XP_PLANE) = vi < VR ? vsp[vi < VR ? vi : 0].mid : z;
-          *reinterpret_cast<uint2*>(d + 2 * XP_PLANE) = vi < VR ? vsp[vi < VR ? vi : 0].lo : z;
+          if constexpr (!H2) *reinterpret_cast<uint2*>(d + 2 * XP_PLANE) = vi < VR ? vsp[vi < VR ? vi : 0].lo : z;
         }
         wave_lds_fence();
         Split8 ca[2 * NT], cb[2 * NT];
         Split8 va[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          va[ct].hi = trf(pl, ct); va[ct].mid = trf(pl + XP_PLANE, ct); va[ct].lo = trf(pl + 2 * XP_PLANE, ct);
+          va[ct].hi = trf(pl, ct); va[ct].mid = trf(pl + XP_PLANE, ct);
+          if constexpr (!H2) va[ct].lo = trf(pl + 2 * XP_PLANE, ct);
+          else va[ct].lo = va[ct].mid;
         }
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const uint4* f = AtF + ((j * 4 + ks) * 3) * 64 + lane;
+          const uint4* f = AtF + ((j * 4 + ks) * NP) * 64 + lane;
           Split8 at;
-          at.hi = ldf(f); at.mid = ldf(f + 64); at.lo = ldf(f + 128);
+          at.hi = ldf(f); at.mid = ldf(f + 64);
+          if constexpr (!H2) at.lo = ldf(f + 128);
+          else at.lo = at.mid;
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) { ca[ct * NT + j] = va[ct]; cb[ct * NT + j] = at; }
         }
-        mfma6_n<2 * NT>(ca, cb, co);      // D[c = 4 kg + r][n = r16]
+        xp_mfma_n<H2, 2 * NT>(ca, cb, co, cox);      // D[c = 4 kg + r][n = r16]
       }
     }
     const int c0 = (u0 + wave) * 32;
@@ -531,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         if (j * 16 + r16 < N) {
-          const f32x4v o = co[ct * NT + j];
+          const f32x4v o = xp_join<H2>(co[ct * NT + j], cox[ct * NT + j]) * inv_n;
           st4_nt(new_lan + ((long)b * N + j * 16 + r16) * C + c0 + ct * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
         }
   }
@@ -546,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
   }
 }
 
-struct XpPlan { long qtf, ktf, vtf, sx, total; int NT, KS2; };
+struct XpPlan { long qtf, ktf, vtf, sx, scl, total; int NT, KS2; };
 inline XpPlan xp_plan(int B, int N, int C) {
   XpPlan p;
   p.NT = (N + 15) / 16;
@@ -557,6 +610,8 @@ inline XpPlan xp_plan(int B, int N, int C) {
 #ifdef TRIS_XP_TRACE
   p.total += (long)B * XP_MAXS * 32 * 8;
 #endif
+  p.scl = p.total;     // six h2 scales (the planes above are sized for three pieces; the h2 form uses two)
+  p.total += 64;
   return p;
 }
 
@@ -572,28 +627,29 @@ inline int xp_slots(int B, int P, int C, int cus) {
   return smax >= smin ? smax : 0;
 }
 
-template <int NT, int NPT, int KQ>
+template <int NT, int NPT, int KQ, bool H2>
 int launch_px(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt, const float* Vt,
               float* new_vis, float* new_lan, float* probs, int B, int P, int N, int C, int S, char* ws, unsigned* sync,
-              hipStream_t st) {
+              hipStream_t st, const XpAmax& am) {
   const XpPlan pl = xp_plan(B, N, C);
   uint4* QtF = reinterpret_cast<uint4*>(ws + pl.qtf);
   uint4* KtF = reinterpret_cast<uint4*>(ws + pl.ktf);
   uint4* VtF = reinterpret_cast<uint4*>(ws + pl.vtf);
   float* Sx = reinterpret_cast<float*>(ws + pl.sx);
+  float* scl = reinterpret_cast<float*>(ws + pl.scl);
   const int slots = 2 * NT * (C / 32) * 64 + (C / 16) * pl.KS2 * 64;
-  hipLaunchKernelGGL(xattn_text_planes_kernel, dim3(cdiv(slots, 256)), dim3(256), 0, st, Qt, Kt, Vt, QtF, KtF, VtF, N, C, NT,
-                     pl.KS2);
-  constexpr int lds = XpLds<NT, NPT>::total;
+  hipLaunchKernelGGL(xattn_text_planes_kernel<H2>, dim3(cdiv(slots, 256)), dim3(256), 0, st, Qt, Kt, Vt, QtF, KtF, VtF, N, C, NT,
+                     pl.KS2, am, scl);
+  constexpr int lds = XpLds<NT, NPT, H2 ? 2 : 3>::total;
   static bool attr_done = false;   // (one instantiation = one function-local flag)
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_px_kernel<NT, NPT, KQ>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_px_kernel<NT, NPT, KQ, H2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds > 65536 ? lds : 65536);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((xattn_px_kernel<NT, NPT, KQ>), dim3(B * S), dim3(512), (size_t)lds, st, Qv, Kv, Vv, QtF, KtF, VtF,
-                     new_vis, new_lan, probs, Sx, (int)(pl.total - pl.sx), sync, B, P, N, S, 1.0f / sqrtf((float)C));
+  hipLaunchKernelGGL((xattn_px_kernel<NT, NPT, KQ, H2>), dim3(B * S), dim3(512), (size_t)lds, st, Qv, Kv, Vv, QtF, KtF, VtF,
+                     new_vis, new_lan, probs, Sx, (int)(pl.scl - pl.sx), sync, B, P, N, S, 1.0f / sqrtf((float)C), scl);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -611,6 +667,22 @@ int xp_cus() {
 
 }  // namespace
 
+// h2 for ONE call: arms the calling thread with the amax words of Qv, Kv, Vv, Qt, Kt, Vt (ops.XAttnFn passes the words of the
+// producing products); the next tris_xattn_px_fwd_f32 of the thread runs the two-piece fp16 form and disarms.
+static thread_local XpAmax g_xp_amax = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+static thread_local bool g_xp_amax_armed = false;
+extern "C" int tris_xattn_amax_next(const unsigned* qv, const unsigned* kv, const unsigned* vv, const unsigned* qt,
+                                    const unsigned* kt, const unsigned* vt) {
+  if (!qv || !kv || !vv || !qt || !kt || !vt) { g_xp_amax_armed = false; return (int)hipErrorInvalidValue; }
+  g_xp_amax = XpAmax{{qv, kv, vv, qt, kt, vt}};
+  g_xp_amax_armed = true;
+  return 0;
+}
+
+static int g_xp_last_form = 0;
+// arithmetic of the last pixel-row launch of the process: 0 none yet, 1 split-bf16 (x3), 2 h2 (tests, tools/xattn_check.py)
+extern "C" long tris_xattn_px_last_form(void) { return g_xp_last_form; }
+
 extern "C" long tris_xattn_px_ws_bytes(int B, int N, int C) {
   if (B < 1 || N < 1 || N > 64 || !(C == 512 || C == 1024)) return 0;
   return xp_plan(B, N, C).total;
@@ -626,18 +698,23 @@ extern "C" long tris_xattn_px_slots(int B, int P, int C, int cus) {
 extern "C" int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const float* Vv, const float* Qt, const float* Kt,
                                      const float* Vt, float* new_vis, float* new_lan, float* probs, int B, int P, int N,
                                      int C, float* ws, long ws_bytes, unsigned* sync, void* stream) {
-  // supported: split-bf16 arithmetic, C = 512 | 1024, P <= 104, N <= 64, B * S workgroups co-resident one per CU
+  // supported: split-bf16 arithmetic (or h2 when armed), C = 512 | 1024, P <= 104, N <= 64, B * S workgroups co-resident one per CU
+  const bool h2 = g_xp_amax_armed;
+  const XpAmax am = g_xp_amax;
+  g_xp_amax_armed = false;
   if (tris_get_gemm_mode() < 1 || !(C == 512 || C == 1024) || P < 1 || P > 104 || N < 1 || N > 64 || B < 1 || ws == nullptr ||
       sync == nullptr || ws_bytes < xp_plan(B, N, C).total)
     return TRIS_DECLINED;
   const int S = xp_slots(B, P, C, xp_cus());
   if (S == 0) return TRIS_DECLINED;
+  g_xp_last_form = h2 ? 2 : 1;
   const int npt = ((P + S - 1) / S + 15) / 16;   // pixel tiles of the largest own range
   hipStream_t st = (hipStream_t)stream;
   char* w = reinterpret_cast<char*>(ws);
-#define TRIS_XP3(NT_, NPT_)                                                                                                     \
-  (C == 1024 ? launch_px<NT_, NPT_, 8>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, S, w, sync, st)             \
-             : launch_px<NT_, NPT_, 4>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, S, w, sync, st))
+#define TRIS_XP4(NT_, NPT_, KQ_)                                                                                                \
+  (h2 ? launch_px<NT_, NPT_, KQ_, true>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, S, w, sync, st, am)        \
+      : launch_px<NT_, NPT_, KQ_, false>(Qv, Kv, Vv, Qt, Kt, Vt, new_vis, new_lan, probs, B, P, N, C, S, w, sync, st, am))
+#define TRIS_XP3(NT_, NPT_) (C == 1024 ? TRIS_XP4(NT_, NPT_, 8) : TRIS_XP4(NT_, NPT_, 4))
 #define TRIS_XP(NT_) (npt == 1 ? TRIS_XP3(NT_, 1) : TRIS_XP3(NT_, 2))
   switch ((N + 15) / 16) {
     case 1: return TRIS_XP(1);
@@ -647,4 +724,5 @@ extern "C" int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const flo
   }
 #undef TRIS_XP
 #undef TRIS_XP3
+#undef TRIS_XP4
 }

@@ -2246,6 +2246,12 @@ class XAttnFn(torch.autograd.Function):
             if ws_bytes > 0:
                 ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
                 sync = _xattn_sync(dev, B)
+                if kind == "px" and h2_on() and cfg.xattn_h2:
+                    # h2: the products of the launch run on two fp16 pieces per operand, scaled by the amax words the producing
+                    # projections left behind (a pre-pass where there is none)
+                    words = [_h2_amax(t) for t in (Qv, Kv, Vv, Qt, Kt, Vt)]
+                    if all(w is not None for w in words):
+                        call("tris_xattn_amax_next", *words)
                 done = _timed(f"xattn_fwd_{kind}", 8.0 * B * Pp * N * C, lambda: _declinable(
                     f"tris_xattn_{kind}_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B,
                     Pp, N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
