@@ -372,6 +372,18 @@ long tris_xattn_px_sync_words(int B);
  * tris_h2_next) of Qv, Kv, Vv, Qt, Kt, Vt; the next tris_xattn_px_fwd_f32 of the thread computes its four products on two fp16
  * pieces per operand (three MFMAs per product, two sentence planes instead of three) with one power-of-two scale per tensor, the
  * probabilities with the fixed scale 2^13, and disarms.  Unarmed calls run the split-bf16 form. */
+/* Backward of the pair on the saved probabilities, cut by pixel rows like the forward (csrc/xattn_px.hip): ONE persistent launch
+ * (+ one preparation launch that splits the sentence-side operands into piece planes) produces dQv, dKv, dVv [B, P, C] and leaves
+ * dS [3][B, P, N] = (dS1 = soft-max backward of the pixel -> sentence direction, dS2 = of the sentence -> pixel direction, a copy of
+ * Av) for the three [N, C] gradients that sum over images and pixels (dVt = Av^T d_vis, dKt = dS1^T Qv, dQt = dS2^T Kv: split-K
+ * products of the GEMM core).  probs is the forward's [B][4][P][N] buffer (planes 0 and 2).  Only the column sums of the
+ * sentence -> pixel soft-max cross workgroups (N floats each, the forward's sync words and protocol).  Domain, TRIS_DECLINED and
+ * the h2 arming (tris_xattn_amax_next with the words of d_vis, Vv, d_lan, Qt, Kt, Vt -- in that order) as for the forward.
+ * Replaces the chain of six batched products and two soft-max backward launches of rounds 1-4 (reference model/attn.py:117-128). */
+long tris_xattn_px_bwd_ws_bytes(int B, int N, int C);
+int tris_xattn_px_bwd_f32(const float* d_vis, const float* d_lan, const float* Vv, const float* Qt, const float* Kt,
+                          const float* Vt, const float* probs, float* dQv, float* dKv, float* dVv, float* dS, int B, int P,
+                          int N, int C, float* ws, long ws_bytes, unsigned* sync, void* stream);
 long tris_xattn_px_last_form(void);   /* arithmetic of the last pixel-row launch: 0 none yet, 1 split-bf16, 2 h2 */
 int tris_xattn_amax_next(const unsigned* qv, const unsigned* kv, const unsigned* vv, const unsigned* qt, const unsigned* kt,
                          const unsigned* vt);

@@ -922,7 +922,8 @@ def test_xattn_pixel_row_launch_replays_from_a_graph(ops):
     assert not ops.xattn_timed_out()
 
 
-@pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64)])
+@pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64),
+                                     (7, 104, 33, 1024), (33, 57, 17, 1024), (40, 97, 64, 512), (60, 103, 64, 1024), (5, 8, 3, 512)])
 def test_xattn_fused(ops, B, P, N, C):
     Qv, Kv, Vv = leaf(B, P, C, seed=1), leaf(B, P, C, seed=2), leaf(B, P, C, seed=3)
     Qt, Kt, Vt = leaf(N, C, seed=4), leaf(N, C, seed=5), leaf(N, C, seed=6)
@@ -934,8 +935,13 @@ def test_xattn_fused(ops, B, P, N, C):
     wl = torch.randn(nl.shape, generator=torch.Generator().manual_seed(8))
     ((nv * wv).sum() + (nl * wl).sum()).backward()
     g = [gpu_leaf(t) for t in (Qv, Kv, Vv, Qt, Kt, Vt)]
+    ops.profile_begin()
     gnv, gnl = ops.xattn(*g)
     ((gnv * wv.cuda()).sum() + (gnl * wl.cuda()).sum()).backward()
+    kinds = {r[0] for r in ops.profile_end()}
+    if "xattn_fwd_px" in kinds:   # the pixel-row forward ran: so must the pixel-row backward (one persistent launch, csrc/xattn_px.hip)
+        assert "xattn_bwd_px" in kinds, kinds
+        assert not ops.xattn_timed_out()
     close(gnv, nv, name="new_vis")
     close(gnl, nl, name="new_lan")
     for a, b, name in zip(g, (Qv, Kv, Vv, Qt, Kt, Vt), ("dQv", "dKv", "dVv", "dQt", "dKt", "dVt")):
@@ -969,7 +975,10 @@ def test_fused_bn_statistics_in_conv_epilogue(ops, kind, shape):
 @pytest.mark.parametrize("M,N,K,tA,tB", [(2400, 768, 3072, False, True), (960, 512, 512, False, True),
                                          (1024, 256, 19200, True, False), (19200, 1024, 256, False, True),
                                          (300, 100, 4096, False, False), (5000, 32, 576, False, True),
-                                         (4096, 32, 1024, False, False), (3000, 28, 512, True, False)])
+                                         (4096, 32, 1024, False, False), (3000, 28, 512, True, False),
+                                         # k-major operands over a k extent that is NOT a multiple of 32 (the weight gradients of a
+                                         # ViT-B/16 trunk: 48 x 401 tokens): the fast kernel over K rounded up, tail rows read as zeros
+                                         (768, 768, 19248, True, False), (512, 256, 200, True, False), (256, 64, 1203, True, False)])
 def test_gemm_autotune_every_candidate_and_the_cached_choice(ops, M, N, K, tA, tB):
     """The first-encounter autotuner launches every admissible (tile, split-K) pair on the caller's buffers: after the
     tuning call AND on the cached path the result must be the product; each tile shape is also forced individually."""

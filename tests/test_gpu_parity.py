@@ -116,29 +116,37 @@ def test_g3_bilateral_prompt(model, golden):
             nv, nl = model.attn_fusion(vis.cuda(), lan.cuda())
         assert err(nl, g[f"B{B}_new_lan"]) < 1e-4, B
         assert err(nv[:, :64], g[f"B{B}_new_vis_crop"]) < 1e-4, B
-    # per-image sets, gradients included: B = 3 images x N = 5 own sentences each, against the oracle
+    # per-image sets, gradients included: B = 3 images x N = 5 own sentences each, against the oracle.  The gradient is
+    # DISCONTINUOUS where an input of the projections' ReLUs is zero: an element within round-off of the kink can be masked
+    # differently by two correct implementations, which moves a whole pixel's input gradient by a few percent (seen: x3, one
+    # element of 0.9 M).  The inputs are therefore re-drawn until the oracle's pre-activations keep a margin (4e-6 of their median magnitude,
+    # several times the implementations' round-off) from zero.
     from oracle import tris_oracle as O
-    vis = torch.randn(3, 1024, 10, 10, generator=gen)
-    vis = vis / vis.norm(dim=1, keepdim=True)
-    lan = torch.randn(3, 1024, 5, generator=gen)
-    lan = lan / lan.norm(dim=1, keepdim=True)
-    wv, wl = torch.randn(3, 1024, 10, 10, generator=gen), torch.randn(3, 5, 1024, generator=gen)
+    sd = cpu_sd(model)
+    for attempt in range(200):
+        vis = torch.randn(3, 1024, 4, 4, generator=gen)
+        vis = vis / vis.norm(dim=1, keepdim=True)
+        lan = torch.randn(3, 1024, 5, generator=gen)
+        lan = lan / lan.norm(dim=1, keepdim=True)
+        with torch.no_grad():
+            pre = [O._conv_in_relu(sd, f"attn_fusion.v_proj{i}", vis, relu=False).abs() for i in (1, 2, 3)]
+            pre += [(lan.transpose(1, 2) @ sd[f"attn_fusion.t_proj{i}.0.weight"].t() + sd[f"attn_fusion.t_proj{i}.0.bias"]).abs()
+                    for i in (1, 2, 3)]
+        if all(float(t.min()) > 4e-6 * float(t.median()) for t in pre):
+            break
+    else:
+        pytest.fail("no draw keeps the ReLU inputs away from zero")
+    wv, wl = torch.randn(3, 1024, 4, 4, generator=gen), torch.randn(3, 5, 1024, generator=gen)
     vo, lo = vis.clone().requires_grad_(), lan.clone().requires_grad_()
-    onv, onl = O.bilateral_prompt(cpu_sd(model), "attn_fusion", vo, lo)
+    onv, onl = O.bilateral_prompt(sd, "attn_fusion", vo, lo)
     ((onv * wv).sum() + (onl * wl).sum()).backward()
     vg, lg = vis.cuda().requires_grad_(), lan.cuda().requires_grad_()
     nv, nl = model.attn_fusion(vg, lg)
     ((nv * wv.cuda()).sum() + (nl * wl.cuda()).sum()).backward()
     assert err(nv, onv) < 1e-4 and err(nl, onl) < 1e-4
-    # (gradients pass four InstanceNorm backwards: two correct fp32-class implementations agree to ~1e-4 ... 1e-3 of the largest
-    # element -- except where one of the 0.9 M ReLU inputs of the projections sits within round-off of zero and the two
-    # implementations mask it differently: that moves a handful of gradient elements by a few percent of the largest one (seen in
-    # x3, seed 11: one element, 3 %).  So: all but 1e-4 of the elements to 1e-3, every element to 0.1.)
-    for got, want in ((vg.grad, vo.grad), (lg.grad, lo.grad)):
-        d = (got.detach().cpu() - want).abs().flatten()
-        top = float(want.abs().max())
-        assert float(torch.quantile(d, 0.9999)) < 1e-3 * top + 1e-6
-        assert float(d.max()) < 0.1 * top
+    # (gradients pass four InstanceNorm backwards: two correct fp32-class implementations agree to ~1e-4 ... 1e-3 of the largest element)
+    assert err(vg.grad, vo.grad) < 1e-3 * float(vo.grad.abs().max()) + 1e-6
+    assert err(lg.grad, lo.grad) < 1e-3 * float(lo.grad.abs().max()) + 1e-6
     model.zero_grad(set_to_none=True)
     # shared sentence set, B=3 images x N=5 sentences, against the oracle
     vis = torch.randn(3, 1024, 10, 10, generator=gen)

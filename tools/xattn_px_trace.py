@@ -20,7 +20,18 @@ lib.tris_xattn_px_ws_bytes.restype = ctypes.c_long
 wsb = lib.tris_xattn_px_ws_bytes(B, N, C)
 ws = torch.zeros(wsb // 4 + 4, device="cuda"); sync = torch.zeros(16 + 16 * B, dtype=torch.int32, device="cuda")
 V = ctypes.c_void_p
+H2 = os.environ.get("XP_H2", "1") != "0"     # the h2 form (two fp16 pieces) unless XP_H2=0
+words = []
+if H2:
+    main = _lib.load()
+    for t in (Qv, Kv, Vv, Qt, Kt, Vt):
+        w = torch.zeros(2048, dtype=torch.int32, device="cuda")
+        main.tris_amax_bits_f32(V(t.data_ptr()), ctypes.c_long(t.numel()), V(w.data_ptr()), V(torch.cuda.current_stream().cuda_stream))
+        words.append(w)
+print("arithmetic:", "h2 (two fp16 pieces, three MFMAs per product)" if H2 else "x3 (three bf16 pieces, six MFMAs per product)")
 def run():
+    if H2:
+        assert lib.tris_xattn_amax_next(*[V(w.data_ptr()) for w in words]) == 0
     rc = lib.tris_xattn_px_fwd_f32(V(Qv.data_ptr()), V(Kv.data_ptr()), V(Vv.data_ptr()), V(Qt.data_ptr()), V(Kt.data_ptr()),
                                    V(Vt.data_ptr()), V(nv.data_ptr()), V(nl.data_ptr()), V(probs.data_ptr()), B, P, N, C,
                                    V(ws.data_ptr()), ctypes.c_long(ws.numel() * 4), V(sync.data_ptr()),
@@ -37,7 +48,7 @@ b.record(); torch.cuda.synchronize()
 print(f"prep + px launch (trace build): {a.elapsed_time(b) / 20 * 1e3:.1f} us per call; time-out word {int(sync[2])}")
 S = min(8, 256 // B, P)
 NT = (N + 15) // 16
-off = (wsb - B * 8 * 32 * 8) // 8
+off = (wsb - 64 - B * 8 * 32 * 8) // 8   # (the six h2 scales sit behind the trace region)
 raw = ws[:wsb // 4].view(torch.int64)[off:off + B * S * 32].view(B * S, 32).cpu().double()
 # stamp ids (thread 0 = first wave of the sentence->pixel half T, thread 256 = first wave of the pixel->sentence half V):
 # 0 start | 1 logits done (T) | 2 flag raised | 5 flags seen | 6 gathered | 7 At soft-max done | 10 At planes written |

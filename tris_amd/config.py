@@ -21,6 +21,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   mha                TRIS_MHA                  attention kernel: "auto" | "valu" | "mfma"
   xattn_fused        TRIS_XATTN_FUSED          cross attention as one persistent launch where it applies
   xattn_px           TRIS_XATTN_PX             ... cut by pixel rows (csrc/xattn_px.hip); 0: the channel-slice form (csrc/xattn_fused.hip)
+  xattn_bwd_px       TRIS_XATTN_BWD_PX         backward of the pair as one persistent launch cut by pixel rows; 0: the chain of batched products
   xattn_h2           TRIS_XATTN_H2             pixel-row launch in the h2 arithmetic inside an h2 step (two fp16 pieces); 0: always split-bf16
   hbm_loader         TRIS_HBM_LOADER           HBM-resident input pipeline (0: the reference's DataLoader)
   eval_group         TRIS_EVAL_GROUP           refs per batched evaluation group
@@ -59,6 +60,7 @@ class _Config:
         self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
         self.xattn_px = _flag("TRIS_XATTN_PX", True)
         self.xattn_h2 = _flag("TRIS_XATTN_H2", True)
+        self.xattn_bwd_px = _flag("TRIS_XATTN_BWD_PX", True)
         self.hbm_loader = _flag("TRIS_HBM_LOADER", True)
         self.eval_group = max(1, int(e("TRIS_EVAL_GROUP", "16")))
         self.mbox_spin = int(e("TRIS_MBOX_SPIN", "40000000"))

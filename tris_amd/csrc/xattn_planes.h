@@ -33,16 +33,17 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
                                                                 int NT, int KS2, XpAmax am = XpAmax(),
                                                                 float* __restrict__ scl_out = nullptr) {
   constexpr int NP = H2 ? 2 : 3;
-  float sc[3] = {1.f, 1.f, 1.f};
+  const int KST0 = C / 32, nA0 = NT * KST0 * 64;     // (the tensor a thread works on is wave-uniform: the slot counts are multiples of 64)
+  const int g0 = blockIdx.x * 256 + threadIdx.x;
+  float sc = 1.f;
   if constexpr (H2) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t) sc[t] = h2_scale_from_bits(h2_amax_of(am.w[3 + t], threadIdx.x & 63));
-    if (blockIdx.x == 0 && threadIdx.x < 64) {   // the six scales for the persistent launch (scalar loads there)
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const float v = h2_scale_from_bits(h2_amax_of(am.w[t], threadIdx.x));
-        if (threadIdx.x == 0) scl_out[t] = v;
-      }
+    // one amax word per wave (the tensor it splits); the six scales of the persistent launch come from six waves of blocks 0 and 1
+    const int which0 = g0 < nA0 ? 0 : (g0 < 2 * nA0 ? 1 : 2);
+    sc = h2_scale_from_bits(h2_amax_of(am.w[3 + which0], threadIdx.x & 63));
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t < 6) {
+      const float v = h2_scale_from_bits(h2_amax_of(am.w[t], threadIdx.x & 63));
+      if ((threadIdx.x & 63) == 0) scl_out[t] = v;
     }
   }
   int which = 0;
@@ -77,8 +78,7 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
     return;
   }
   if constexpr (H2) {
-    const Split8 sp = split8h(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]),
-                              which == 0 ? sc[0] : which == 1 ? sc[1] : sc[2]);
+    const Split8 sp = split8h(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sc);
     dst[0] = __builtin_bit_cast(uint4, sp.hi);
     dst[64] = __builtin_bit_cast(uint4, sp.mid);
   } else {

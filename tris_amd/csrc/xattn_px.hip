@@ -599,6 +599,446 @@ __global__ __launch_bounds__(512, 2) void xattn_px_kernel(const float* __restric
   }
 }
 
+// ======================================================================================================================== backward
+// The backward of the pair on the saved probabilities (ops.XAttnFn.backward), cut by pixel rows like the forward: workgroup s of image b
+// owns pixels [s P / S, (s + 1) P / S) and computes, for its rows,
+//   dAv  = d_vis . Vt^T            (all channels)          dS1 = Av  o (dAv  - rowsum_n(Av o dAv)) / sqrt(C)      dQv = dS1 . Kt
+//   dAtT = Vv . d_lan[b]^T         (all channels)          dS2 = AtT o (dAtT - colsum_p(AtT o dAtT)) / sqrt(C)    dKv = dS2 . Qt
+//   dVv  = AtT . d_lan[b]
+// i.e. two products of the forward's "logits" form (pixel rows from HBM x sentence fragments from L2; waves 0-3 / 4-7, a quarter of the
+// channels each) and three of its "new_vis" form (k = sentences).  Only the column sums of the sentence -> pixel soft-max cross the
+// workgroup: N floats per workgroup through the forward's fence-free write-through protocol (same sync words, same epoch).  The
+// three [N, C] gradients that sum over images and pixels (dVt = Av^T d_vis, dKt = dS1^T Qv, dQt = dS2^T Kv) stay split-K products of
+// the GEMM core on dS1 / dS2 / Av, which this launch leaves in dS [3][B, P, N].  The sentence-side operands arrive as piece planes in
+// fragment order from xattn_bwd_planes_kernel: Vt and d_lan[b] in the A layout (rows = sentences, k = channels), Kt, Qt and d_lan[b]
+// in the B layout (k = sentences, columns = channels).  h2: dS1 / dS2 take a power-of-two scale from the largest magnitude of the
+// workgroup's own rows (a product only needs ONE scale per operand, and the rows of a workgroup are a product of their own).
+template <int NT, int NPT> struct XbLds {
+  static constexpr int turn = 8 * NPT * 16 * XP_TLD * 4;     // phase 1: wave-private turn-around tiles; afterwards three sets of row planes
+  static constexpr int red = 8 * NPT * NT * 1024;            // partial blocks of the eight waves
+  static constexpr int rows = NPT * 16 * XP_AVS * 4;         // one [own pixels][64] fp32 block
+  static constexpr int misc = turn + red + 3 * rows;         // column sums [64], epoch, counters, amax words
+  static constexpr int total = misc + 64 * 4 + 32;
+};
+
+// out[b, own pixels, :] = R . T over k = sentences: R = the workgroup's rows as piece planes in LDS (AF, [NPT * KS2][NP][64] x 16 B),
+// T = a sentence operand as B-layout planes in global memory (BF); the four waves of a half own the channel tiles wv + 4 i (the
+// forward's new_vis loop)
+template <int NT, int NPT, int KQ, bool H2>
+__device__ __forceinline__ void xp_rows_product(const uint4* AF, const uint4* BF, float* __restrict__ out, const float inv, const int wv,
+                                                const int lane, const int b, const int P, const int p0, const int PW, const int N) {
+  constexpr int C = 128 * KQ, NP = H2 ? 2 : 3, KS2 = (NT + 1) / 2, CT = C / 16, NIT = CT / 4;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t vtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(BF), 0, CT * KS2 * NP * 1024, 0x00020000);
+  constexpr int VA = XP_VA;
+  Split8 vt[VA + 1][KS2];
+  auto load_vt = [&](int ct, Split8 (&d)[KS2]) {
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+      const int off = (ks * 32 + kg * 8 < N) ? (((ct * KS2 + ks) * NP) * 64 + lane) * 16 : 0x7fffffff;
+      d[ks].hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 0, 0));
+      d[ks].mid = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 1024, 0));
+      if constexpr (!H2) d[ks].lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(vtr, off, 2048, 0));
+      else d[ks].lo = d[ks].mid;
+    }
+  };
+#pragma unroll
+  for (int it = 0; it < VA; ++it) load_vt(wv + 4 * it, vt[it]);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ct = wv + 4 * it;
+    if (it + VA < NIT) load_vt(ct + 4 * VA, vt[(it + VA) % (VA + 1)]);
+    constexpr int NCH = NPT * KS2;
+    Split8 ca[NCH], cb[NCH];
+    f32x4v co[NCH], cox[NCH];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const uint4* f = AF + ((t * KS2 + ks) * NP) * 64 + lane;
+        ca[t * KS2 + ks] = vt[it % (VA + 1)][ks];
+        cb[t * KS2 + ks].hi = ldf(f); cb[t * KS2 + ks].mid = ldf(f + 64);
+        if constexpr (!H2) cb[t * KS2 + ks].lo = ldf(f + 128);
+        else cb[t * KS2 + ks].lo = cb[t * KS2 + ks].mid;
+        co[t * KS2 + ks] = cox[t * KS2 + ks] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      }
+    xp_mfma_n<H2, NCH>(ca, cb, co, cox);        // D[c = 4 kg + r][p = r16]
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+      f32x4v o = xp_join<H2>(co[t * KS2], cox[t * KS2]);
+#pragma unroll
+      for (int ks = 1; ks < KS2; ++ks) o += xp_join<H2>(co[t * KS2 + ks], cox[t * KS2 + ks]);
+      o *= inv;
+      if (t * 16 + r16 < PW)
+        st4_nt(out + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
+}
+
+// rows [NPT * 16][XP_AVS] fp32 in LDS (columns >= N and rows >= PW hold zeros) -> piece planes in fragment order; 256 threads of a half
+template <int NT, int NPT, bool H2>
+__device__ __forceinline__ void xp_rows_to_planes(const float* rows, uint4* AF, const float s, const int tg) {
+  constexpr int NP = H2 ? 2 : 3, KS2 = (NT + 1) / 2;
+  for (int e = tg; e < NPT * KS2 * 64; e += 256) {
+    const int fk = e >> 6, l = e & 63, t = fk / KS2, ks = fk - t * KS2;
+    const float* a = rows + (t * 16 + (l & 15)) * XP_AVS + ks * 32 + (l >> 4) * 8;
+    const Split8 sp = xp_split8<H2>(*reinterpret_cast<const float4*>(a), *reinterpret_cast<const float4*>(a + 4), s);
+    uint4* d = AF + (fk * NP) * 64 + l;
+    d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid);
+    if constexpr (!H2) d[128] = __builtin_bit_cast(uint4, sp.lo);
+  }
+}
+
+// grid B * S, block 512.  scl (h2): scales of d_vis, Vv, d_lan, Qt, Kt, Vt.
+template <int NT, int NPT, int KQ, bool H2>
+__global__ __launch_bounds__(512, 2) void xattn_px_bwd_kernel(const float* __restrict__ dvis, const float* __restrict__ Vv,
+                                                              const uint4* __restrict__ VtA, const uint4* __restrict__ dlA,
+                                                              const uint4* __restrict__ KtB, const uint4* __restrict__ QtB,
+                                                              const uint4* __restrict__ dlB, long a_stride, long b_stride,
+                                                              const float* __restrict__ probs, float* __restrict__ dQv,
+                                                              float* __restrict__ dKv, float* __restrict__ dVv,
+                                                              float* __restrict__ dS, float* __restrict__ Sx, int sx_bytes,
+                                                              unsigned* __restrict__ sync, int B, int P, int N, int S, float scale,
+                                                              const float* __restrict__ scl) {
+  constexpr int C = 128 * KQ;
+  constexpr int NP = H2 ? 2 : 3;
+  constexpr int KST = C / 32;
+  constexpr int KS2 = (NT + 1) / 2;
+  constexpr int TILES = NPT * NT;
+  constexpr int SET = NPT * KS2 * NP * 1024;      // bytes of one set of row planes
+  static_assert(3 * SET <= XbLds<NT, NPT>::turn, "the three plane sets live in the turn-around tiles' space");
+  using L = XbLds<NT, NPT>;
+  const float s_dv = H2 ? scl[0] : 1.f, s_vv = H2 ? scl[1] : 1.f, s_dl = H2 ? scl[2] : 1.f;
+  const float s_qt = H2 ? scl[3] : 1.f, s_kt = H2 ? scl[4] : 1.f, s_vt = H2 ? scl[5] : 1.f;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* rowsV = reinterpret_cast<float*>(lds + L::turn + L::red);
+  float* rowsT = rowsV + L::rows / 4;
+  float* rowsP = rowsT + L::rows / 4;
+  float* csum = reinterpret_cast<float*>(lds + L::misc);
+  unsigned* s_epoch_p = reinterpret_cast<unsigned*>(lds + L::misc + 64 * 4);   // [0] epoch, [1] [2] arrivals, [3] [4] amax of dS1 / dS2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int b = blockIdx.x / S, slot = blockIdx.x - b * S;
+  const int p0 = (slot * P) / S, p1 = ((slot + 1) * P) / S, PW = p1 - p0;
+  if (tid == 0) {
+    *s_epoch_p = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    s_epoch_p[1] = 0u; s_epoch_p[2] = 0u; s_epoch_p[3] = 0u; s_epoch_p[4] = 0u;
+  }
+  const __amdgpu_buffer_rsrc_t sxr = __builtin_amdgcn_make_buffer_rsrc(Sx, 0, sx_bytes, 0x00020000);
+  // ---- the two all-channel products: waves 0-3 E_t = Vv rows . d_lan[b]^T, waves 4-7 E_v = d_vis rows . Vt^T -----------------------------
+  {
+    const int g = wave >> 2, q = wave & 3;
+    const float* X = g ? dvis : Vv;
+    const uint4* F = (g ? VtA : dlA + (long)b * a_stride) + ((long)(q * KQ) * NP) * 64 + lane;
+    const float s_x = g ? s_dv : s_vv;
+    const float inv_l = H2 ? 1.0f / (s_x * (g ? s_vt : s_dl)) : 1.0f;
+    float* tile = reinterpret_cast<float*>(lds) + wave * (NPT * 16 * XP_TLD);
+    const int lr = lane >> 3, lc = (lane & 7) * 4;
+    const float* gp[NPT][2];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) gp[t][h] = X + ((long)b * P + min(p0 + t * 16 + lr + 8 * h, p1 - 1)) * C + q * (C / 4) + lc;
+    f32x4v acc[TILES], acx[TILES];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) acc[i] = acx[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    constexpr int AHEAD = KQ < 3 ? KQ : 3;
+    float4 v[KQ][NPT][2];
+    Split8 fr[KQ][NT];
+    auto load_px = [&](int i) {
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) v[i][t][h] = ld4_nt(gp[t][h] + i * 32);
+    };
+    auto load_fr = [&](int i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint4* f = F + ((long)(j * KST + i) * NP) * 64;
+        fr[i][j].hi = ldf(f); fr[i][j].mid = ldf(f + 64);
+        if constexpr (!H2) fr[i][j].lo = ldf(f + 128);
+        else fr[i][j].lo = fr[i][j].mid;
+      }
+    };
+    constexpr int FAHEAD = (KQ < 2 || NT * NPT >= 8) ? 1 : 2;
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) load_px(i);
+#pragma unroll
+    for (int i = 0; i < FAHEAD; ++i) load_fr(i);
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (i + FAHEAD < KQ) load_fr(i + FAHEAD);
+      if (i + AHEAD < KQ) load_px(i + AHEAD);
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(tile + t * (16 * XP_TLD) + (lr + 8 * h) * XP_TLD + lc) = v[i][t][h];
+      wave_lds_fence();
+      Split8 sp[NPT];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t) {
+        const float* f = tile + t * (16 * XP_TLD) + r16 * XP_TLD + kg * 8;
+        sp[t] = xp_split8<H2>(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4), s_x);
+      }
+      wave_lds_fence();
+      Split8 ca[TILES], cb[TILES];
+#pragma unroll
+      for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { ca[t * NT + j] = sp[t]; cb[t * NT + j] = fr[i][j]; }
+      xp_mfma_n<H2, TILES>(ca, cb, acc, acx);
+    }
+    float* red = reinterpret_cast<float*>(lds + L::turn) + wave * (TILES * 256);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      const f32x4v a = xp_join<H2>(acc[i], acx[i]) * inv_l;
+      *reinterpret_cast<float4*>(red + i * 256 + lane * 4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+  }
+  lds_barrier();
+  const unsigned epoch = *s_epoch_p;
+  const int grp = wave >> 2, tg = tid & 255;
+  unsigned* gctr = s_epoch_p + 1 + grp;
+  unsigned gtarget = 0;
+  auto group_sync = [&]() {
+    gtarget += 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(gctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gtarget) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+  };
+  // the quarters of this half's product -> rows [own pixel][sentence] (pixels are the MFMA rows: a lane holds four pixels of one sentence)
+  auto sum_quarters = [&](float* rows) {
+    const float* red = reinterpret_cast<const float*>(lds + L::turn) + (grp ? 4 * TILES * 256 : 0);
+    for (int e = tg; e < TILES * 64; e += 256) {
+      const int tj = e >> 6, l = e & 63, t = tj / NT, j = tj - t * NT;
+      float4 a = *reinterpret_cast<const float4*>(red + tj * 256 + l * 4);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(red + (q * TILES + tj) * 256 + l * 4);
+        a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
+      }
+      const int pl = t * 16 + 4 * (l >> 4), n = j * 16 + (l & 15);
+      rows[(pl + 0) * XP_AVS + n] = a.x; rows[(pl + 1) * XP_AVS + n] = a.y;
+      rows[(pl + 2) * XP_AVS + n] = a.z; rows[(pl + 3) * XP_AVS + n] = a.w;
+    }
+  };
+  // largest magnitude of this half's dS rows -> its h2 scale (integer max: order-independent)
+  auto half_scale = [&](float m) -> float {
+    if constexpr (!H2) return 1.f;
+    unsigned u = __builtin_bit_cast(unsigned, m);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, sft, 64));
+    if (lane == 0 && u != 0u) __hip_atomic_fetch_max(s_epoch_p + 3 + grp, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    group_sync();
+    return h2_scale_from_bits(__hip_atomic_load(s_epoch_p + 3 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  };
+  const int px = tg >> 2, q4 = tg & 3;                       // the row functions: four threads per pixel row, <= 16 sentences each
+  const bool rowok = px < NPT * 16;
+  const long prow = ((long)b * 4) * P + p0 + min(px, PW > 0 ? PW - 1 : 0);   // row of plane 0 in probs [B][4][P][N]
+  const long BPN = (long)B * P * N;
+  uint4* setV = reinterpret_cast<uint4*>(lds);               // dS1 planes
+  uint4* setA = reinterpret_cast<uint4*>(lds + SET);         // AtT planes
+  uint4* setT = reinterpret_cast<uint4*>(lds + 2 * SET);     // dS2 planes
+  if (grp == 1) {
+    // ---- pixel -> sentence direction: dS1, dQv; and dVv, which needs nothing but the saved AtT --------------------------------------------
+    sum_quarters(rowsV);
+    group_sync();
+    float y[16], mx = 0.f;
+    if (rowok) {
+      float* row = rowsV + px * XP_AVS;
+      float a[16], dot = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int n = q4 + 4 * u;
+        a[u] = (px < PW && n < N) ? probs[prow * N + n] : 0.f;
+        y[u] = n < NT * 16 ? row[n] : 0.f;     // (columns >= 16 NT of the row block were never written)
+        dot += a[u] * y[u];
+      }
+      dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int n = q4 + 4 * u;
+        y[u] = scale * a[u] * (y[u] - dot);
+        mx = fmaxf(mx, fabsf(y[u]));
+        row[n] = y[u];
+        if (px < PW && n < N) {
+          const long o = ((long)b * P + p0 + px) * N + n;
+          dS[o] = y[u];
+          dS[2 * BPN + o] = a[u];
+        }
+      }
+    }
+    const float s1 = half_scale(mx);     // (a group barrier in h2)
+    if constexpr (!H2) group_sync();
+    xp_rows_to_planes<NT, NPT, H2>(rowsV, setV, s1, tg);
+    // AtT rows of the own pixels straight from the saved plane -> planes (probabilities: fixed scale)
+    for (int e = tg; e < NPT * KS2 * 64; e += 256) {
+      const int fk = e >> 6, l = e & 63, t = fk / KS2, ks = fk - t * KS2;
+      const int pl = t * 16 + (l & 15), n0 = ks * 32 + (l >> 4) * 8;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = (pl < PW && n0 + i < N) ? probs[(((long)b * 4 + 2) * P + p0 + pl) * N + n0 + i] : 0.f;
+      const Split8 sp = xp_split8<H2>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), XP_PS);
+      uint4* d = setA + (fk * NP) * 64 + l;
+      d[0] = __builtin_bit_cast(uint4, sp.hi); d[64] = __builtin_bit_cast(uint4, sp.mid);
+      if constexpr (!H2) d[128] = __builtin_bit_cast(uint4, sp.lo);
+    }
+    group_sync();
+    xp_rows_product<NT, NPT, KQ, H2>(setV, KtB, dQv, H2 ? 1.0f / (s1 * s_kt) : 1.0f, wave - 4, lane, b, P, p0, PW, N);
+    xp_rows_product<NT, NPT, KQ, H2>(setA, dlB + (long)b * b_stride, dVv, H2 ? 1.0f / (XP_PS * s_dl) : 1.0f, wave - 4, lane, b, P, p0, PW, N);
+  } else {
+    // ---- sentence -> pixel direction: column sums over ALL pixels of the image (one hand-off of N floats), dS2, dKv ------------------------
+    sum_quarters(rowsT);
+    group_sync();
+    float a[16], x[16];
+    if (rowok) {
+      const float* row = rowsT + px * XP_AVS;
+      float* prd = rowsP + px * XP_AVS;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int n = q4 + 4 * u;
+        a[u] = (px < PW && n < N) ? probs[(prow + 2 * P) * N + n] : 0.f;
+        x[u] = n < NT * 16 ? row[n] : 0.f;
+        prd[n] = a[u] * x[u];
+      }
+    }
+    group_sync();
+    if (tg < NT * 4) {   // own partial column sums, four columns per thread, rows in order (deterministic) -> published write-through
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < NPT * 16; ++r) {
+        const float4 w = *reinterpret_cast<const float4*>(rowsP + r * XP_AVS + 4 * tg);
+        cs.x += w.x; cs.y += w.y; cs.z += w.z; cs.w += w.w;
+      }
+      st4_wt(sxr, ((long)b * S + slot) * (NT * 16) + 4 * tg, cs);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    group_sync();
+    if (tg == 0) __hip_atomic_store(&sync[XP_SYNC_FLAGS + b * XP_MAXS + slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      bool ok = true;
+      if (lane < S) {
+        const unsigned* f = &sync[XP_SYNC_FLAGS + b * XP_MAXS + lane];
+        long spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > XP_SPIN) { ok = false; break; }
+        }
+      }
+      if (!ok) atomicExch(&sync[2], epoch);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (tg < NT * 4) {   // everyone's partial sums, workgroups in order
+      float4 w[XP_MAXS];
+#pragma unroll
+      for (int s2 = 0; s2 < XP_MAXS; ++s2)
+        w[s2] = s2 < S ? ld4_wt(sxr, ((long)b * S + s2) * (NT * 16) + 4 * tg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 cs = w[0];
+#pragma unroll
+      for (int s2 = 1; s2 < XP_MAXS; ++s2) { cs.x += w[s2].x; cs.y += w[s2].y; cs.z += w[s2].z; cs.w += w[s2].w; }
+      *reinterpret_cast<float4*>(csum + 4 * tg) = cs;
+    }
+    group_sync();
+    float mx = 0.f;
+    if (rowok) {
+      float* row = rowsT + px * XP_AVS;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int n = q4 + 4 * u;
+        const float y = (n < NT * 16) ? scale * a[u] * (x[u] - csum[n]) : 0.f;   // (csum holds 16 NT columns)
+        mx = fmaxf(mx, fabsf(y));
+        row[n] = y;
+        if (px < PW && n < N) dS[BPN + ((long)b * P + p0 + px) * N + n] = y;
+      }
+    }
+    const float s2s = half_scale(mx);
+    if constexpr (!H2) group_sync();
+    xp_rows_to_planes<NT, NPT, H2>(rowsT, setT, s2s, tg);
+    group_sync();
+    xp_rows_product<NT, NPT, KQ, H2>(setT, QtB, dKv, H2 ? 1.0f / (s2s * s_qt) : 1.0f, wave, lane, b, P, p0, PW, N);
+  }
+  // ---- the last workgroup to finish advances the epoch ----------------------------------------------------------------------------------
+  if (tid == 0) {
+    const unsigned t = atomicAdd(&sync[1], 1u);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// sentence-side operands of the backward -> piece planes in fragment order.  grid (slots / 256, 3 + 2 B): job 0 Vt -> A layout; 1 Kt,
+// 2 Qt -> B layout; 3 + b: d_lan[b] -> A layout; 3 + B + b: d_lan[b] -> B layout.  am.w = amax words of d_vis, Vv, d_lan, Qt, Kt, Vt.
+template <bool H2>
+__global__ __launch_bounds__(256) void xattn_bwd_planes_kernel(const float* __restrict__ Qt, const float* __restrict__ Kt,
+                                                               const float* __restrict__ Vt, const float* __restrict__ dlan,
+                                                               uint4* __restrict__ VtA, uint4* __restrict__ KtB,
+                                                               uint4* __restrict__ QtB, uint4* __restrict__ dlA, uint4* __restrict__ dlB,
+                                                               long a_stride, long b_stride, int B, int N, int C, int NT, int KS2,
+                                                               XpAmax am, float* __restrict__ scl_out) {
+  constexpr int NP = H2 ? 2 : 3;
+  const int job = blockIdx.y;
+  const int KST = C / 32;
+  const int nA = NT * KST * 64, nB = (C / 16) * KS2 * 64;
+  const bool alay = job == 0 || (job >= 3 && job < 3 + B);
+  const float* src;
+  uint4* dst;
+  int widx;
+  if (job == 0) { src = Vt; dst = VtA; widx = 5; }
+  else if (job == 1) { src = Kt; dst = KtB; widx = 4; }
+  else if (job == 2) { src = Qt; dst = QtB; widx = 3; }
+  else if (job < 3 + B) { src = dlan + (long)(job - 3) * N * C; dst = dlA + (long)(job - 3) * a_stride; widx = 2; }
+  else { src = dlan + (long)(job - 3 - B) * N * C; dst = dlB + (long)(job - 3 - B) * b_stride; widx = 2; }
+  float sc = 1.f;
+  if constexpr (H2) {
+    sc = h2_scale_from_bits(h2_amax_of(am.w[widx], threadIdx.x & 63));
+    if (job == 0) {
+      const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+      if (t < 6) {
+        const float v = h2_scale_from_bits(h2_amax_of(am.w[t], threadIdx.x & 63));
+        if ((threadIdx.x & 63) == 0) scl_out[t] = v;
+      }
+    }
+  }
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= (alay ? nA : nB)) return;
+  const int l = g & 63, fs = g >> 6;
+  float x[8];
+  if (alay) {
+    const int j = fs / KST, s = fs - j * KST;
+    const int n = j * 16 + (l & 15), c = s * 32 + (l >> 4) * 8;
+    const float* p = src + (long)min(n, N - 1) * C + c;
+    const float4 u = xp_ld4(p), w = xp_ld4(p + 4);
+    const bool ok = n < N;
+    x[0] = ok ? u.x : 0.f; x[1] = ok ? u.y : 0.f; x[2] = ok ? u.z : 0.f; x[3] = ok ? u.w : 0.f;
+    x[4] = ok ? w.x : 0.f; x[5] = ok ? w.y : 0.f; x[6] = ok ? w.z : 0.f; x[7] = ok ? w.w : 0.f;
+  } else {
+    const int ct = fs / KS2, ks = fs - ct * KS2;
+    const int c = ct * 16 + (l & 15), n0 = ks * 32 + (l >> 4) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = (n0 + q < N) ? src[(long)(n0 + q) * C + c] : 0.f;
+  }
+  uint4* d = dst + ((long)fs * NP) * 64 + l;
+  const Split8 sp = xp_split8<H2>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sc);
+  d[0] = __builtin_bit_cast(uint4, sp.hi);
+  d[64] = __builtin_bit_cast(uint4, sp.mid);
+  if constexpr (!H2) d[128] = __builtin_bit_cast(uint4, sp.lo);
+}
+
+struct XbPlan { long vta, ktb, qtb, dla, dlb, sx, scl, total, a_stride, b_stride; int NT, KS2; };
+inline XbPlan xb_plan(int B, int N, int C) {
+  XbPlan p;
+  p.NT = (N + 15) / 16;
+  p.KS2 = (p.NT + 1) / 2;
+  const long a = (long)p.NT * (C / 32) * 3 * 64 * 16, v = (long)(C / 16) * p.KS2 * 3 * 64 * 16;   // (sized for three pieces)
+  p.a_stride = a / 16; p.b_stride = v / 16;
+  p.vta = 0; p.ktb = a; p.qtb = a + v; p.dla = a + 2 * v; p.dlb = p.dla + (long)B * a;
+  p.sx = p.dlb + (long)B * v;
+  p.scl = p.sx + (long)B * XP_MAXS * p.NT * 16 * 4;
+  p.total = p.scl + 64;
+  return p;
+}
+
 struct XpPlan { long qtf, ktf, vtf, sx, scl, total; int NT, KS2; };
 inline XpPlan xp_plan(int B, int N, int C) {
   XpPlan p;
@@ -679,6 +1119,36 @@ extern "C" int tris_xattn_amax_next(const unsigned* qv, const unsigned* kv, cons
   return 0;
 }
 
+template <int NT, int NPT, int KQ, bool H2>
+int launch_px_bwd(const float* dvis, const float* dlan, const float* Vv, const float* Qt, const float* Kt, const float* Vt,
+                  const float* probs, float* dQv, float* dKv, float* dVv, float* dS, int B, int P, int N, int C, int S, char* ws,
+                  unsigned* sync, hipStream_t st, const XpAmax& am) {
+  const XbPlan pl = xb_plan(B, N, C);
+  uint4* VtA = reinterpret_cast<uint4*>(ws + pl.vta);
+  uint4* KtB = reinterpret_cast<uint4*>(ws + pl.ktb);
+  uint4* QtB = reinterpret_cast<uint4*>(ws + pl.qtb);
+  uint4* dlA = reinterpret_cast<uint4*>(ws + pl.dla);
+  uint4* dlB = reinterpret_cast<uint4*>(ws + pl.dlb);
+  float* Sx = reinterpret_cast<float*>(ws + pl.sx);
+  float* scl = reinterpret_cast<float*>(ws + pl.scl);
+  const int nA = NT * (C / 32) * 64, nB = (C / 16) * pl.KS2 * 64;
+  hipLaunchKernelGGL(xattn_bwd_planes_kernel<H2>, dim3(cdiv(nA > nB ? nA : nB, 256), 3 + 2 * B), dim3(256), 0, st, Qt, Kt, Vt, dlan, VtA,
+                     KtB, QtB, dlA, dlB, pl.a_stride, pl.b_stride, B, N, C, NT, pl.KS2, am, scl);
+  constexpr int lds = XbLds<NT, NPT>::total;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_px_bwd_kernel<NT, NPT, KQ, H2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds > 65536 ? lds : 65536);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((xattn_px_bwd_kernel<NT, NPT, KQ, H2>), dim3(B * S), dim3(512), (size_t)lds, st, dvis, Vv, VtA, dlA, KtB, QtB, dlB,
+                     pl.a_stride, pl.b_stride, probs, dQv, dKv, dVv, dS, Sx, (int)(pl.scl - pl.sx), sync, B, P, N, S,
+                     1.0f / sqrtf((float)C), scl);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
 static int g_xp_last_form = 0;
 // arithmetic of the last pixel-row launch of the process: 0 none yet, 1 split-bf16 (x3), 2 h2 (tests, tools/xattn_check.py)
 extern "C" long tris_xattn_px_last_form(void) { return g_xp_last_form; }
@@ -725,4 +1195,42 @@ extern "C" int tris_xattn_px_fwd_f32(const float* Qv, const float* Kv, const flo
 #undef TRIS_XP
 #undef TRIS_XP3
 #undef TRIS_XP4
+}
+
+extern "C" long tris_xattn_px_bwd_ws_bytes(int B, int N, int C) {
+  if (B < 1 || N < 1 || N > 64 || !(C == 512 || C == 1024)) return 0;
+  return xb_plan(B, N, C).total;
+}
+
+// dQv, dKv, dVv [B, P, C] and dS [3][B, P, N] (dS1, dS2, a copy of Av) from d_vis [B, P, C], d_lan [B, N, C], the forward's operands and
+// its saved probabilities probs [B][4][P][N] (planes 0 = Av, 2 = AtT): one preparation launch + ONE persistent launch; same domain,
+// sync words and TRIS_DECLINED behaviour as tris_xattn_px_fwd_f32.  tris_xattn_amax_next(d_vis, Vv, d_lan, Qt, Kt, Vt) arms the h2 form.
+extern "C" int tris_xattn_px_bwd_f32(const float* d_vis, const float* d_lan, const float* Vv, const float* Qt, const float* Kt,
+                                     const float* Vt, const float* probs, float* dQv, float* dKv, float* dVv, float* dS, int B, int P,
+                                     int N, int C, float* ws, long ws_bytes, unsigned* sync, void* stream) {
+  const bool h2 = g_xp_amax_armed;
+  const XpAmax am = g_xp_amax;
+  g_xp_amax_armed = false;
+  if (tris_get_gemm_mode() < 1 || !(C == 512 || C == 1024) || P < 1 || P > 104 || N < 1 || N > 64 || B < 1 || ws == nullptr ||
+      sync == nullptr || ws_bytes < xb_plan(B, N, C).total)
+    return TRIS_DECLINED;
+  const int S = xp_slots(B, P, C, xp_cus());
+  if (S == 0) return TRIS_DECLINED;
+  const int npt = ((P + S - 1) / S + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  char* w = reinterpret_cast<char*>(ws);
+#define TRIS_XB4(NT_, NPT_, KQ_)                                                                                                       \
+  (h2 ? launch_px_bwd<NT_, NPT_, KQ_, true>(d_vis, d_lan, Vv, Qt, Kt, Vt, probs, dQv, dKv, dVv, dS, B, P, N, C, S, w, sync, st, am)     \
+      : launch_px_bwd<NT_, NPT_, KQ_, false>(d_vis, d_lan, Vv, Qt, Kt, Vt, probs, dQv, dKv, dVv, dS, B, P, N, C, S, w, sync, st, am))
+#define TRIS_XB3(NT_, NPT_) (C == 1024 ? TRIS_XB4(NT_, NPT_, 8) : TRIS_XB4(NT_, NPT_, 4))
+#define TRIS_XB(NT_) (npt == 1 ? TRIS_XB3(NT_, 1) : TRIS_XB3(NT_, 2))
+  switch ((N + 15) / 16) {
+    case 1: return TRIS_XB(1);
+    case 2: return TRIS_XB(2);
+    case 3: return TRIS_XB(3);
+    default: return TRIS_XB(4);
+  }
+#undef TRIS_XB
+#undef TRIS_XB3
+#undef TRIS_XB4
 }

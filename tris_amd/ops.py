@@ -2237,7 +2237,7 @@ class XAttnFn(torch.autograd.Function):
         new_vis = torch.empty(B, Pp, C, device=dev, dtype=torch.float32)
         new_lan = torch.empty(B, N, C, device=dev, dtype=torch.float32)
         probs = torch.empty(B, 4, Pp, N, device=dev, dtype=torch.float32)
-        done = False
+        done = px_ran = False
         # ONE persistent launch where a kernel's domain covers the shape and all its workgroups are co-resident: cut by pixel rows
         # (csrc/xattn_px.hip, S <= 8 workgroups per image, one hand-off) or, failing that, by channel slices (csrc/xattn_fused.hip,
         # eight per image, three hand-offs); TRIS_XATTN_FUSED=0 forces the two-launch pair
@@ -2255,13 +2255,44 @@ class XAttnFn(torch.autograd.Function):
                 done = _timed(f"xattn_fwd_{kind}", 8.0 * B * Pp * N * C, lambda: _declinable(
                     f"tris_xattn_{kind}_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan), P(probs), B,
                     Pp, N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream()))
+                px_ran = done and kind == "px"
         if not done:
             _timed("xattn_fwd_pair", 8.0 * B * Pp * N * C,
                    lambda: call("tris_xattn_fwd_f32", P(Qv), P(Kv), P(Vv), P(Qt), P(Kt), P(Vt), P(new_vis), P(new_lan),
                                 P(probs), B, Pp, N, C, _stream()))
         ctx.dims = (B, Pp, N, C)
+        ctx.px_form = px_ran
         ctx.save_for_backward(Qv, Kv, Vv, Qt, Kt, Vt, probs)
         return new_vis, new_lan
+
+    @staticmethod
+    def _backward_px(ctx, d_vis, d_lan):
+        """the pixel-row form of the backward (csrc/xattn_px.hip): one persistent launch for dQv, dKv, dVv and the two soft-max
+        backwards, then the three [N, C] sums over images and pixels as split-K products.  None: outside its domain."""
+        Qv, Kv, Vv, Qt, Kt, Vt, probs = ctx.saved_tensors
+        B, Pp, N, C = ctx.dims
+        dev = Qv.device
+        ws_bytes = query("tris_xattn_px_bwd_ws_bytes", B, N, C)
+        if ws_bytes <= 0:
+            return None
+        ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
+        sync = _xattn_sync(dev, B)
+        dQv, dKv, dVv = (torch.empty(B, Pp, C, device=dev, dtype=torch.float32) for _ in range(3))
+        dS = torch.empty(3, B * Pp, N, device=dev, dtype=torch.float32)
+        if h2_on() and cfg.xattn_h2:
+            words = [_h2_amax(t) for t in (d_vis, Vv, d_lan, Qt, Kt, Vt)]
+            if all(w is not None for w in words):
+                call("tris_xattn_amax_next", *words)
+        if not _timed("xattn_bwd_px", 10.0 * B * Pp * N * C, lambda: _declinable(
+                "tris_xattn_px_bwd_f32", P(d_vis), P(d_lan), P(Vv), P(Qt), P(Kt), P(Vt), P(probs), P(dQv), P(dKv), P(dVv), P(dS), B, Pp,
+                N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream())):
+            return None
+        BP = B * Pp
+        new = lambda: torch.empty(N, C, device=dev, dtype=torch.float32)
+        dVt = gemm(dS[2], d_vis, new(), N, C, BP, N, C, C, True, False)       # Av^T . d_vis
+        dKt = gemm(dS[0], Qv, new(), N, C, BP, N, C, C, True, False)          # dS1^T . Qv
+        dQt = gemm(dS[1], Kv, new(), N, C, BP, N, C, C, True, False)          # dS2^T . Kv
+        return dQv, dKv, dVv, dQt, dKt, dVt
 
     @staticmethod
     def backward(ctx, d_vis, d_lan):
@@ -2270,6 +2301,10 @@ class XAttnFn(torch.autograd.Function):
         dev = Qv.device
         scale = 1.0 / math.sqrt(C)
         d_vis, d_lan = d_vis.contiguous(), d_lan.contiguous()
+        if ctx.px_form and cfg.xattn_bwd_px:
+            got = XAttnFn._backward_px(ctx, d_vis, d_lan)
+            if got is not None:
+                return got
         BP = B * Pp
         Av = probs[:, 0].contiguous().view(BP, N)
         AtT = probs[:, 2].contiguous().view(B, Pp, N)
