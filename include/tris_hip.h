@@ -383,7 +383,8 @@ long tris_xattn_px_sync_words(int B);
 long tris_xattn_px_bwd_ws_bytes(int B, int N, int C);
 int tris_xattn_px_bwd_f32(const float* d_vis, const float* d_lan, const float* Vv, const float* Qt, const float* Kt,
                           const float* Vt, const float* probs, float* dQv, float* dKv, float* dVv, float* dS, int B, int P,
-                          int N, int C, float* ws, long ws_bytes, unsigned* sync, void* stream);
+                          int N, int C, float* ws, long ws_bytes, unsigned* sync, unsigned* amax_dQv, unsigned* amax_dKv,
+                          unsigned* amax_dVv, void* stream);   /* amax_*: NULL or zeroed amax words the launch raises for its outputs */
 long tris_xattn_px_last_form(void);   /* arithmetic of the last pixel-row launch: 0 none yet, 1 split-bf16, 2 h2 */
 int tris_xattn_amax_next(const unsigned* qv, const unsigned* kv, const unsigned* vv, const unsigned* qt, const unsigned* kt,
                          const unsigned* vt);

@@ -53,6 +53,8 @@ extern "C" { __attribute__((visibility("hidden"))) int tris_internal_xattn_px_sl
 
 namespace {
 
+#include "amax.h"
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -626,7 +628,9 @@ template <int NT, int NPT> struct XbLds {
 // forward's new_vis loop)
 template <int NT, int NPT, int KQ, bool H2>
 __device__ __forceinline__ void xp_rows_product(const uint4* AF, const uint4* BF, float* __restrict__ out, const float inv, const int wv,
-                                                const int lane, const int b, const int P, const int p0, const int PW, const int N) {
+                                                const int lane, const int b, const int P, const int p0, const int PW, const int N,
+                                                unsigned* __restrict__ am_out) {
+  unsigned am = 0u;
   constexpr int C = 128 * KQ, NP = H2 ? 2 : 3, KS2 = (NT + 1) / 2, CT = C / 16, NIT = CT / 4;
   const int r16 = lane & 15, kg = lane >> 4;
   const __amdgpu_buffer_rsrc_t vtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(BF), 0, CT * KS2 * NP * 1024, 0x00020000);
@@ -669,10 +673,14 @@ __device__ __forceinline__ void xp_rows_product(const uint4* AF, const uint4* BF
 #pragma unroll
       for (int ks = 1; ks < KS2; ++ks) o += xp_join<H2>(co[t * KS2 + ks], cox[t * KS2 + ks]);
       o *= inv;
-      if (t * 16 + r16 < PW)
-        st4_nt(out + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
+      if (t * 16 + r16 < PW) {
+        const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+        st4_nt(out + ((long)b * P + p0 + t * 16 + r16) * C + ct * 16 + 4 * kg, o4);
+        am = max(am, abits4(o4));
+      }
     }
   }
+  if (am_out != nullptr) amax_commit(am, am_out);   // (the amax word of `out`: its consumers are h2 products)
 }
 
 // rows [NPT * 16][XP_AVS] fp32 in LDS (columns >= N and rows >= PW hold zeros) -> piece planes in fragment order; 256 threads of a half
@@ -699,7 +707,8 @@ __global__ __launch_bounds__(512, 2) void xattn_px_bwd_kernel(const float* __res
                                                               float* __restrict__ dKv, float* __restrict__ dVv,
                                                               float* __restrict__ dS, float* __restrict__ Sx, int sx_bytes,
                                                               unsigned* __restrict__ sync, int B, int P, int N, int S, float scale,
-                                                              const float* __restrict__ scl) {
+                                                              const float* __restrict__ scl, unsigned* __restrict__ am_dqv,
+                                                              unsigned* __restrict__ am_dkv, unsigned* __restrict__ am_dvv) {
   constexpr int C = 128 * KQ;
   constexpr int NP = H2 ? 2 : 3;
   constexpr int KST = C / 32;
@@ -885,8 +894,8 @@ __global__ __launch_bounds__(512, 2) void xattn_px_bwd_kernel(const float* __res
       if constexpr (!H2) d[128] = __builtin_bit_cast(uint4, sp.lo);
     }
     group_sync();
-    xp_rows_product<NT, NPT, KQ, H2>(setV, KtB, dQv, H2 ? 1.0f / (s1 * s_kt) : 1.0f, wave - 4, lane, b, P, p0, PW, N);
-    xp_rows_product<NT, NPT, KQ, H2>(setA, dlB + (long)b * b_stride, dVv, H2 ? 1.0f / (XP_PS * s_dl) : 1.0f, wave - 4, lane, b, P, p0, PW, N);
+    xp_rows_product<NT, NPT, KQ, H2>(setV, KtB, dQv, H2 ? 1.0f / (s1 * s_kt) : 1.0f, wave - 4, lane, b, P, p0, PW, N, am_dqv);
+    xp_rows_product<NT, NPT, KQ, H2>(setA, dlB + (long)b * b_stride, dVv, H2 ? 1.0f / (XP_PS * s_dl) : 1.0f, wave - 4, lane, b, P, p0, PW, N, am_dvv);
   } else {
     // ---- sentence -> pixel direction: column sums over ALL pixels of the image (one hand-off of N floats), dS2, dKv ------------------------
     sum_quarters(rowsT);
@@ -955,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void xattn_px_bwd_kernel(const float* __res
     if constexpr (!H2) group_sync();
     xp_rows_to_planes<NT, NPT, H2>(rowsT, setT, s2s, tg);
     group_sync();
-    xp_rows_product<NT, NPT, KQ, H2>(setT, QtB, dKv, H2 ? 1.0f / (s2s * s_qt) : 1.0f, wave, lane, b, P, p0, PW, N);
+    xp_rows_product<NT, NPT, KQ, H2>(setT, QtB, dKv, H2 ? 1.0f / (s2s * s_qt) : 1.0f, wave, lane, b, P, p0, PW, N, am_dkv);
   }
   // ---- the last workgroup to finish advances the epoch ----------------------------------------------------------------------------------
   if (tid == 0) {
@@ -1122,7 +1131,7 @@ extern "C" int tris_xattn_amax_next(const unsigned* qv, const unsigned* kv, cons
 template <int NT, int NPT, int KQ, bool H2>
 int launch_px_bwd(const float* dvis, const float* dlan, const float* Vv, const float* Qt, const float* Kt, const float* Vt,
                   const float* probs, float* dQv, float* dKv, float* dVv, float* dS, int B, int P, int N, int C, int S, char* ws,
-                  unsigned* sync, hipStream_t st, const XpAmax& am) {
+                  unsigned* sync, hipStream_t st, const XpAmax& am, unsigned* const* am_out) {
   const XbPlan pl = xb_plan(B, N, C);
   uint4* VtA = reinterpret_cast<uint4*>(ws + pl.vta);
   uint4* KtB = reinterpret_cast<uint4*>(ws + pl.ktb);
@@ -1144,7 +1153,7 @@ int launch_px_bwd(const float* dvis, const float* dlan, const float* Vv, const f
   }
   hipLaunchKernelGGL((xattn_px_bwd_kernel<NT, NPT, KQ, H2>), dim3(B * S), dim3(512), (size_t)lds, st, dvis, Vv, VtA, dlA, KtB, QtB, dlB,
                      pl.a_stride, pl.b_stride, probs, dQv, dKv, dVv, dS, Sx, (int)(pl.scl - pl.sx), sync, B, P, N, S,
-                     1.0f / sqrtf((float)C), scl);
+                     1.0f / sqrtf((float)C), scl, am_out[0], am_out[1], am_out[2]);
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -1207,7 +1216,9 @@ extern "C" long tris_xattn_px_bwd_ws_bytes(int B, int N, int C) {
 // sync words and TRIS_DECLINED behaviour as tris_xattn_px_fwd_f32.  tris_xattn_amax_next(d_vis, Vv, d_lan, Qt, Kt, Vt) arms the h2 form.
 extern "C" int tris_xattn_px_bwd_f32(const float* d_vis, const float* d_lan, const float* Vv, const float* Qt, const float* Kt,
                                      const float* Vt, const float* probs, float* dQv, float* dKv, float* dVv, float* dS, int B, int P,
-                                     int N, int C, float* ws, long ws_bytes, unsigned* sync, void* stream) {
+                                     int N, int C, float* ws, long ws_bytes, unsigned* sync, unsigned* amax_dQv, unsigned* amax_dKv,
+                                     unsigned* amax_dVv, void* stream) {
+  unsigned* const am_out[3] = {amax_dQv, amax_dKv, amax_dVv};
   const bool h2 = g_xp_amax_armed;
   const XpAmax am = g_xp_amax;
   g_xp_amax_armed = false;
@@ -1220,8 +1231,8 @@ extern "C" int tris_xattn_px_bwd_f32(const float* d_vis, const float* d_lan, con
   hipStream_t st = (hipStream_t)stream;
   char* w = reinterpret_cast<char*>(ws);
 #define TRIS_XB4(NT_, NPT_, KQ_)                                                                                                       \
-  (h2 ? launch_px_bwd<NT_, NPT_, KQ_, true>(d_vis, d_lan, Vv, Qt, Kt, Vt, probs, dQv, dKv, dVv, dS, B, P, N, C, S, w, sync, st, am)     \
-      : launch_px_bwd<NT_, NPT_, KQ_, false>(d_vis, d_lan, Vv, Qt, Kt, Vt, probs, dQv, dKv, dVv, dS, B, P, N, C, S, w, sync, st, am))
+  (h2 ? launch_px_bwd<NT_, NPT_, KQ_, true>(d_vis, d_lan, Vv, Qt, Kt, Vt, probs, dQv, dKv, dVv, dS, B, P, N, C, S, w, sync, st, am, am_out) \
+      : launch_px_bwd<NT_, NPT_, KQ_, false>(d_vis, d_lan, Vv, Qt, Kt, Vt, probs, dQv, dKv, dVv, dS, B, P, N, C, S, w, sync, st, am, am_out))
 #define TRIS_XB3(NT_, NPT_) (C == 1024 ? TRIS_XB4(NT_, NPT_, 8) : TRIS_XB4(NT_, NPT_, 4))
 #define TRIS_XB(NT_) (npt == 1 ? TRIS_XB3(NT_, 1) : TRIS_XB3(NT_, 2))
   switch ((N + 15) / 16) {

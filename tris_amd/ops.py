@@ -2283,10 +2283,14 @@ class XAttnFn(torch.autograd.Function):
             words = [_h2_amax(t) for t in (d_vis, Vv, d_lan, Qt, Kt, Vt)]
             if all(w is not None for w in words):
                 call("tris_xattn_amax_next", *words)
+        slots = [_h2_slot() if h2_on() else None for _ in range(3)]   # the launch leaves the amax words of its three outputs
         if not _timed("xattn_bwd_px", 10.0 * B * Pp * N * C, lambda: _declinable(
                 "tris_xattn_px_bwd_f32", P(d_vis), P(d_lan), P(Vv), P(Qt), P(Kt), P(Vt), P(probs), P(dQv), P(dKv), P(dVv), P(dS), B, Pp,
-                N, C, P(ws), ws.numel() * 4, sync.data_ptr(), _stream())):
+                N, C, P(ws), ws.numel() * 4, sync.data_ptr(), slots[0], slots[1], slots[2], _stream())):
             return None
+        for t, slot in zip((dQv, dKv, dVv), slots):
+            if slot is not None:
+                t._h2 = (_H2["step"], slot, t._version)
         BP = B * Pp
         new = lambda: torch.empty(N, C, device=dev, dtype=torch.float32)
         dVt = gemm(dS[2], d_vis, new(), N, C, BP, N, C, C, True, False)       # Av^T . d_vis
