@@ -309,6 +309,15 @@ int tris_mha_mfma_fwd_f32(const float* qkv, float* out, float* lse, int N, int L
                           void* stream);
 int tris_mha_mfma_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
                           float* dqkv, int N, int L, int W, int heads, int causal, void* stream);
+/* The same flash-style attention in the h2 arithmetic on the 16-bit MFMA (csrc/attn_h2.hip): every product on two fp16 pieces per
+ * operand (three v_mfma_f32_16x16x32_f16), one power-of-two scale per tensor from the amax words of the packed qkv and of dout
+ * (2048 unsigned each, as tris_h2_next), 2^13 for the probabilities, the wave's block maximum for dS.  Same arguments, saved
+ * log-sum-exp, delta and amax by-products (tris_amax_next) as the f32-MFMA entry points above. */
+int tris_mha_h2_fwd_f32(const float* qkv, float* out, float* lse, const unsigned* amax_qkv, int N, int L, int W, int heads,
+                        int causal, void* stream);
+int tris_mha_h2_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                        const unsigned* amax_qkv, const unsigned* amax_dout, int N, int L, int W, int heads, int causal,
+                        void* stream);
 /* token_embedding(ids) + positional_embedding[:L]  (model.py:553-554).  bwd: dtok must be zero-filled by the caller */
 int tris_embed_fwd_f32(const long* ids, const float* tok, const float* pos, float* out, int N, int L, int W,
                        void* stream);

@@ -589,6 +589,9 @@ def test_mha(ops, N, L, heads, causal, impl, monkeypatch):
     (go * go).sum().backward()
     close(go, o)
     close(g.grad, qkv.grad)
+    if impl == "mfma":   # inside h2 the flash-style kernels run on the 16-bit MFMA from L = 32 on (csrc/attn_h2.hip)
+        from tris_amd import ops as _o
+        assert _o.MHA_STATS["last"] == ("h2" if (ops.get_gemm_mode() == "h2" and L >= 32) else "f32")
 
 
 def test_embed_eot(ops):

@@ -19,6 +19,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   mlp_fuse           TRIS_MLP_FUSE             QuickGELU forward / backward in the epilogues of the transformer MLP's two products
   grad_box           TRIS_GRAD_BOX             residual-branch gradients handed to the consuming product's epilogue
   mha                TRIS_MHA                  attention kernel: "auto" | "valu" | "mfma"
+  mha_h2             TRIS_MHA_H2               flash-style attention on the 16-bit MFMA (two fp16 pieces) inside an h2 step; 0: the f32 MFMA kernel
   xattn_fused        TRIS_XATTN_FUSED          cross attention as one persistent launch where it applies
   xattn_px           TRIS_XATTN_PX             ... cut by pixel rows (csrc/xattn_px.hip); 0: the channel-slice form (csrc/xattn_fused.hip)
   xattn_bwd_px       TRIS_XATTN_BWD_PX         backward of the pair as one persistent launch cut by pixel rows; 0: the chain of batched products
@@ -57,6 +58,7 @@ class _Config:
         self.grad_box = _flag("TRIS_GRAD_BOX", True)
         self.mlp_fuse = _flag("TRIS_MLP_FUSE", True)
         self.mha = e("TRIS_MHA", "auto")
+        self.mha_h2 = _flag("TRIS_MHA_H2", True)
         self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
         self.xattn_px = _flag("TRIS_XATTN_PX", True)
         self.xattn_h2 = _flag("TRIS_XATTN_H2", True)

@@ -35,7 +35,7 @@ for prec in 1 3 4; do   # the direct 3x3 kernels, one unit per arithmetic (x3, h
     pids+=($!)
   fi
 done
-for f in gemm_conv norm planes attn attn_mfma heads optim eval xattn xattn_fused xattn_px data comm; do
+for f in gemm_conv norm planes attn attn_mfma attn_h2 heads optim eval xattn xattn_fused xattn_px data comm; do
   [ -f "$HERE/$f.hip" ] || continue
   if stale "$OBJ/$f.o" "$HERE/$f.hip"; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &

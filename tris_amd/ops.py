@@ -1946,6 +1946,9 @@ class MhaFn(torch.autograd.Function):
         return dqkv, None, None
 
 
+MHA_STATS = {"last": None}     # arithmetic of the last flash-style forward: "h2" | "f32" (tests)
+
+
 class MhaMfmaFn(torch.autograd.Function):
     """Flash-style attention on the f32 MFMA, any L (csrc/attn_mfma.hip); saves the per-query log-sum-exp."""
 
@@ -1957,9 +1960,18 @@ class MhaMfmaFn(torch.autograd.Function):
         W = W3 // 3
         out = torch.empty(N, L, W, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(N, heads, L, device=qkv.device, dtype=torch.float32)
+        # inside an h2 step the products run on two fp16 pieces per operand (csrc/attn_h2.hip, 16-bit MFMA), scaled by qkv's amax word
+        # (from L = 32 on: at the text encoder's L = 20 the split while staging costs more than the 16-bit MFMA saves, tools/mha_bench.py)
+        w_qkv = _h2_amax(qkv) if (h2_on() and cfg.mha_h2 and L >= 32) else None
         h2_mark_next(out)
-        _timed("mha_fwd", 4.0 * N * heads * L * L * 64 * (0.5 if causal else 1.0),
-               lambda: call("tris_mha_mfma_fwd_f32", P(qkv), P(out), P(lse), N, L, W, heads, int(causal), _stream()))
+        if w_qkv is not None:
+            _timed("mha_fwd", 4.0 * N * heads * L * L * 64 * (0.5 if causal else 1.0),
+                   lambda: call("tris_mha_h2_fwd_f32", P(qkv), P(out), P(lse), w_qkv, N, L, W, heads, int(causal), _stream()))
+        else:
+            _timed("mha_fwd", 4.0 * N * heads * L * L * 64 * (0.5 if causal else 1.0),
+                   lambda: call("tris_mha_mfma_fwd_f32", P(qkv), P(out), P(lse), N, L, W, heads, int(causal), _stream()))
+        MHA_STATS["last"] = "h2" if w_qkv is not None else "f32"
+        ctx.h2 = w_qkv is not None
         ctx.cfg = (N, L, W, heads, int(causal))
         ctx.save_for_backward(qkv, out, lse)
         return out
@@ -1971,8 +1983,14 @@ class MhaMfmaFn(torch.autograd.Function):
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
+        w_qkv = w_do = None
+        if ctx.h2 and h2_on():
+            w_qkv, w_do = _h2_amax(qkv), _h2_amax(do)
         h2_mark_next(dqkv)
-        call("tris_mha_mfma_bwd_f32", P(qkv), P(out), P(do), P(lse), P(delta), P(dqkv), N, L, W, heads, causal, _stream())
+        if w_qkv is not None and w_do is not None:
+            call("tris_mha_h2_bwd_f32", P(qkv), P(out), P(do), P(lse), P(delta), P(dqkv), w_qkv, w_do, N, L, W, heads, causal, _stream())
+        else:
+            call("tris_mha_mfma_bwd_f32", P(qkv), P(out), P(do), P(lse), P(delta), P(dqkv), N, L, W, heads, causal, _stream())
         return dqkv, None, None
 
 
