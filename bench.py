@@ -245,7 +245,8 @@ def main():
         ops.profile_begin()
         step()
         rec_all = ops.profile_end()
-    xa = [r for r in rec_all if r[0].startswith("xattn")]
+    xa = [r for r in rec_all if r[0].startswith("xattn_fwd")]
+    xb = [r for r in rec_all if r[0] == "xattn_bwd_px"]
     rec = [r for r in rec_all if not r[0].startswith("xattn")]
     fl = sum(r[1] for r in rec)
     ms = sum(r[2] for r in rec)
@@ -340,9 +341,10 @@ def main():
                   "single_launch": bool(fused and len(fused) == len(xa)),
                   "algorithmic_bytes_per_launch_pair": xbytes, "us": round(xms * 1e3, 1),
                   "bound_note": ("pixel-row form: one hand-off, 240 workgroups on 256 CUs, traffic ~1.2 x algorithmic; every workgroup reads "
-                                 "the full sentence operands from L2 (0.86 MB of bf16 piece planes against 0.32 MB of its own HBM stream), "
-                                 "the phases are paced per CU by the in-order memory counter, not by bytes or MFMAs: "
-                                 "profiles/r4_xattn_phase_table.txt; 36.5 us on an idle device (0.30)")
+                                 "the full sentence operands from L2 (h2: 0.57 MB of fp16 piece planes, x3: 0.86 MB, against 0.32 MB of its "
+                                 "own HBM stream); the workgroup lifetime is 22.6 us in h2 (28.5 in x3), the rest of the call is the "
+                                 "preparation launch (3-6 us) and the ramp / drain of 240 x 512-thread workgroups with 120 KB of LDS each "
+                                 "(7 us): profiles/r5_xattn_phase_table.txt; 33-35 us on an idle device (0.31-0.33)")
                   if fused and len(fused) == len(xa) and fused[0][0] == "xattn_fwd_px" else None,
                   "mfma_tflops": round(sum(r[1] for r in xa) / (xms * 1e-3) / 1e12, 2)}
         try:   # HBM bytes of the cross-attention launches from the same --pmc passes
@@ -358,6 +360,17 @@ def main():
                                           f"rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes")
         except Exception:
             pass
+    roof_xb = None
+    if xb:   # the backward of the pair as one persistent launch (csrc/xattn_px.hip xattn_px_bwd_kernel + its preparation launch)
+        P_, N_, C_ = 100, a.batch, 1024
+        bb = a.batch * (5 * P_ * C_ + N_ * C_ + 5 * P_ * N_) * 4 + 3 * N_ * C_ * 4
+        bms = sum(r[2] for r in xb) / len(xb)
+        roof_xb = {"bound": "hbm", "achieved": round(bb / (bms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "us": round(bms * 1e3, 1),
+                   "algorithmic_bytes_per_call": bb,
+                   "kernel": "xattn_bwd_planes_kernel + xattn_px_bwd_kernel (dQv, dKv, dVv and both soft-max backwards of the bilateral "
+                             "cross attention in ONE persistent launch cut by pixel rows; the three [N, C] sums over images and pixels "
+                             "follow as split-K products and are in the GEMM family)"}
     out = None
     if rank == 0:
         dtype = {"h2": "f32 storage/accumulate; products h2 = 2 x f16 pieces", "x3": "f32 storage/accumulate; products x3 = 3 x bf16 pieces",
@@ -383,7 +396,7 @@ def main():
                "h2_out_of_range_operands": None if h2_range is None else h2_range["out_of_range_operands"], "h2_range": h2_range,
                "step_issue": {"0": "eager launches", "1": "one hipGraph", "seg": "chain of single-stream hipGraphs"}[cfg.step_graph],
                "rccl": rccl,    # (N > 1: what the collective backend saw -- N ranks on N distinct devices, asserted at start-up)
-               "roofline": roof, "roofline_xattn": roof_x}
+               "roofline": roof, "roofline_xattn": roof_x, "roofline_xattn_bwd": roof_xb}
         if value_x3 is not None:
             out["value_x3"] = value_x3["value"]
             out["x3"] = dict(value_x3, note="the same K steps in the split-bf16 x3 arithmetic (the arithmetic of `value` in rounds 1-3), "
