@@ -274,7 +274,20 @@ def build_loader(args, dataset, batch_size, shuffle, distributed):
 
 def main(args, tokenizer=None):
     """Training driver with the reference's flow: build model / data / AdamW(2 groups) / poly LR, optional resume or
-    --eval, then per epoch train_one_epoch -> validate on every test split -> keep the best-mIoU and best-hit checkpoints."""
+    --eval, then per epoch train_one_epoch -> validate on every test split -> keep the best-mIoU and best-hit checkpoints.
+    The process-wide settings it chooses (step replay, the compute stream) are put back when it returns: a caller that goes on
+    using the package in the same process -- the test suite -- finds them as it left them."""
+    prev_graph = cfg.step_graph
+    prev_stream = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    try:
+        return _main(args, tokenizer)
+    finally:
+        cfg.step_graph = prev_graph
+        if prev_stream is not None:
+            torch.cuda.set_stream(prev_stream)
+
+
+def _main(args, tokenizer=None):
     import torch.distributed as dist
     from .CLIP import clip
     from .model.model_stage1 import TRIS
