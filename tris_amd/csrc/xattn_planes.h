@@ -46,7 +46,6 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
       if ((threadIdx.x & 63) == 0) scl_out[t] = v;
     }
   }
-  int which = 0;
   const int KST = C / 32;
   const int nA = NT * KST * 64;           // lane slots of one A-operand tensor
   const int nB = (C / 16) * KS2 * 64;     // lane slots of VtF
@@ -64,7 +63,6 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
     x[0] = ok ? u.x : 0.f; x[1] = ok ? u.y : 0.f; x[2] = ok ? u.z : 0.f; x[3] = ok ? u.w : 0.f;
     x[4] = ok ? w.x : 0.f; x[5] = ok ? w.y : 0.f; x[6] = ok ? w.z : 0.f; x[7] = ok ? w.w : 0.f;
     dst = (t == 0 ? QtF : KtF) + ((long)fs * NP) * 64 + l;
-    which = t;
   } else if (g < 2 * nA + nB) {
     const int e = g - 2 * nA;
     const int l = e & 63, fs = e >> 6;    // fs = ct * KS2 + ks
@@ -73,7 +71,6 @@ __global__ __launch_bounds__(256) void xattn_text_planes_kernel(const float* __r
 #pragma unroll
     for (int q = 0; q < 8; ++q) x[q] = (n0 + q < N) ? Vt[(long)(n0 + q) * C + c] : 0.f;
     dst = VtF + ((long)fs * NP) * 64 + l;
-    which = 2;
   } else {
     return;
   }
