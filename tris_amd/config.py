@@ -29,6 +29,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   mbox_spin          TRIS_MBOX_SPIN            bound of the SyncBatchNorm mailbox spin (polls)
   syncbn_comm        TRIS_SYNCBN_COMM          "mailbox" | "c10d"
   ddp_check          TRIS_DDP_CHECK            NaN-poison check of the gradient reducer's release order
+  ddp_seg_opt        TRIS_DDP_SEG_OPT          replayed data-parallel step: AdamW per reducer segment right behind its all-reduce (0: one AdamW behind the join)
   ddp_sparse_embed   TRIS_DDP_SPARSE_EMBED     token-embedding gradient as a sparse (ids, rows) exchange
   random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
   own_stream         TRIS_OWN_STREAM           the trainer / bench compute on a non-default stream (the default stream serialises with hipGraphs elsewhere)
@@ -59,6 +60,7 @@ class _Config:
         self.mlp_fuse = _flag("TRIS_MLP_FUSE", True)
         self.mha = e("TRIS_MHA", "auto")
         self.mha_h2 = _flag("TRIS_MHA_H2", True)
+        self.ddp_seg_opt = _flag("TRIS_DDP_SEG_OPT", True)
         self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
         self.xattn_px = _flag("TRIS_XATTN_PX", True)
         self.xattn_h2 = _flag("TRIS_XATTN_H2", True)

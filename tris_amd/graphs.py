@@ -397,6 +397,38 @@ class SegmentedTrainStep:
                 rest = [(gi, lo, hi) for gi, (lo, hi) in spans.items()]
             else:
                 rest = None
+            # Data parallel: AdamW per reducer segment.  The update is element-wise and a segment's gradients are final the moment
+            # its all-reduce has completed, so each segment released DURING the backward is updated right behind its collective,
+            # on the reducer's stream, while the backward goes on; only what is reduced in finish() (and the sparsely exchanged
+            # embedding table) is left for the AdamW graph behind the join.  (A parameter a later-issued launch still reads -- the
+            # gamma / beta a folded BatchNorm's weight-gradient launch re-normalises with -- belongs to a LATER segment, whose
+            # collective waits for that launch.)
+            self.g_opt_seg = {}
+            red = self.reducer
+            from .config import cfg
+            if red is not None and cfg.ddp_seg_opt and red.segments:
+                released = [k for (_, _, _, keys) in self.back for k in keys] + list(self.text_released)
+                pool_o = torch.cuda.graph_pool_handle()
+                covered = {}
+                for k in released:
+                    segs = [(ai, s_, e_) for ai, s_, e_ in red.segments.get(k, []) if e_ > s_]
+                    if not segs or k in self.g_opt_seg or sorted(red._dense_ranges(k)) != sorted(segs):
+                        continue
+                    g = G()
+                    _capture(g, self.cap, pool_o, lambda: optimizer.step(device_hyper=True, ranges=segs))
+                    self.g_opt_seg[k] = g
+                    for ai, s_, e_ in segs:
+                        covered.setdefault(ai, []).append((s_, e_))
+                if self.g_opt_seg:
+                    rest = []
+                    for gi, a in enumerate(optimizer.arenas):
+                        cur = 0
+                        for s_, e_ in sorted(covered.get(gi, [])):
+                            if s_ > cur:
+                                rest.append((gi, cur, s_))
+                            cur = max(cur, e_)
+                        if cur < a.numel:
+                            rest.append((gi, cur, a.numel))
             self.g_opt = G()
             _capture(self.g_opt, self.cap, pool_c, lambda: optimizer.step(device_hyper=True, ranges=rest))
         finally:
@@ -411,6 +443,21 @@ class SegmentedTrainStep:
         self.ev = [torch.cuda.Event() for _ in range(len(self.back) + 8)]
         self.trace = False       # developer switch: per-piece HIP-event time stamps of the next replay -> marks()
         self._marks = None
+
+    def _reduce_and_update(self, red, key):
+        """issue segment `key`'s all-reduce (reducer's stream) and, behind it on the same stream, that segment's AdamW graph"""
+        from . import ops
+        if key in red.done or not red.active:
+            return
+        n0 = len(red.pending)
+        red._launch_now(key)
+        g = self.g_opt_seg.get(key)
+        if g is not None:
+            with torch.cuda.stream(ops.side_stream("reduce")):
+                for h in red.pending[n0:]:
+                    h.wait()              # (RCCL: the reducer's stream waits for the backend's, no host synchronisation)
+                red.scale_now(key)        # (a backend without an averaging all-reduce: the mean of this segment, now)
+                g.replay()
 
     @staticmethod
     def _late_spans(optimizer, touched):
@@ -529,7 +576,7 @@ class SegmentedTrainStep:
                         if self.embed_rows is not None:
                             red.exchange_rows(*self.embed_rows)
                         for k in self.text_released:
-                            red._launch_now(k)
+                            self._reduce_and_update(red, k)
             if gw is not None:
                 wg.wait_event(e)
                 with torch.cuda.stream(wg):
@@ -542,7 +589,7 @@ class SegmentedTrainStep:
                     mark(f"w{i}t_done", text)
             if red is not None:              # segments that became final with this piece of backward (their last weight
                 for k in keys:               # gradients were just queued on the side streams: the reducer's stream waits for them)
-                    red._launch_now(k)
+                    self._reduce_and_update(red, k)
             if i == self.first_late - 1:
                 ev[4].record(wg)        # every weight gradient outside the late span is behind this
         if self.g_opt_early is not None:

@@ -67,6 +67,7 @@ class GradReducer:
         self.active = self.world > 1 or force
         self.check = cfg.ddp_check if check is None else check
         # NCCL/RCCL averages in the collective; gloo has no AVG: sum, then scale in finish()
+        self.prescaled = []
         self.avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         # Sparse exchange of the token-embedding gradient (TRIS_DDP_SPARSE_EMBED=0 switches back to the dense all-reduce): the
@@ -265,10 +266,26 @@ class GradReducer:
                 e1.record()
                 self.exposed = (e0, e1)
             if not self.avg and self.world > 1:
-                for f in self.flats:
-                    f.mul_(1.0 / self.world)
+                for ai, f in enumerate(self.flats):    # (what scale_now() already divided is left alone)
+                    cur = 0
+                    for s, e in sorted((s, e) for a_, s, e in self.prescaled if a_ == ai):
+                        if s > cur:
+                            f[cur:s].mul_(1.0 / self.world)
+                        cur = max(cur, e)
+                    if cur < f.numel():
+                        f[cur:].mul_(1.0 / self.world)
         self.pending = []
+        self.prescaled = []
         self.done = set()
+
+    def scale_now(self, key):
+        """SUM backends: divide segment `key` by the world size on the current stream (its all-reduce has completed there) instead of
+        in finish() -- the replayed step updates the segment's parameters right behind this (graphs.SegmentedTrainStep)"""
+        if self.avg or self.world <= 1:
+            return
+        for ai, s, e in self._dense_ranges(key):
+            self.flats[ai][s:e].mul_(1.0 / self.world)
+            self.prescaled.append((ai, s, e))
 
     def exposed_ms(self):
         """milliseconds the compute stream waited for collectives in the last finish() (host sync; None before the first step)"""
