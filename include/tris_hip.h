@@ -513,6 +513,18 @@ int tris_mbox_exchange_f32(const float* src0, int n0, const float* src1, int n1,
 int tris_mbox_bn_combine_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum, float* stats,
                              float* running_mean, float* running_var, void* const* boxes, int world, int rank, unsigned* seq,
                              int cap_floats, long spin_limit, int* err, void* stream);
+/* The same two exchanges with the amax WORD of the plane tensor the following pass writes as a by-product (h2 with operand
+ * planes, csrc/planes.h) -- what tris_bn_out_bound2_f32 / tris_bn_bwd_bound_f32 compute in launches of their own:
+ * forward bound = max_c |gamma_c| xhat_max + |beta_c| (+ the residual's bound, resid_word or NULL); backward: out[2C] = the sums
+ * [sum dz | sum dz xhat] over all ranks and bound = max_c |gamma_c invstd_c| (amax dz + |sum dz| inv_count + xhat_max |sum dz xhat|
+ * inv_count), amax dz from dz_word.  Two launches less per SyncBatchNorm layer and pass. */
+int tris_mbox_bn_combine_bound_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum, float* stats,
+                                   float* running_mean, float* running_var, void* const* boxes, int world, int rank, unsigned* seq,
+                                   int cap_floats, long spin_limit, int* err, const float* gamma, const float* beta, float xhat_max,
+                                   const unsigned* resid_word, unsigned* bound_word, void* stream);
+int tris_mbox_bn_bwd_exchange_f32(const float* sum_dz, const float* sum_dzx, int C, float* out, void* const* boxes, int world, int rank,
+                                  unsigned* seq, int cap_floats, long spin_limit, int* err, const float* gamma, const float* invstd,
+                                  float inv_count, float xhat_max, const unsigned* dz_word, unsigned* bound_word, void* stream);
 
 #ifdef __cplusplus
 }

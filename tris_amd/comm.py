@@ -155,6 +155,24 @@ class Mailbox:
                                                     self.SPIN_LIMIT, self.err.data_ptr(),
                                                     torch.cuda.current_stream().cuda_stream), "tris_mbox_bn_combine_f32")
 
+    def bn_combine_bound(self, local_stats, C, count_per_rank, eps, momentum, stats, running_mean, running_var, gamma, beta, xhat_max,
+                         resid_word, bound_word):
+        """bn_combine + the bound word of the plane output in the same launch (tris_mbox_bn_combine_bound_f32)"""
+        self._chk(self.lib.tris_mbox_bn_combine_bound_f32(
+            local_stats.data_ptr(), C, count_per_rank, eps, momentum, stats.data_ptr(),
+            None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
+            self.boxes.data_ptr(), self.world, self.rank, self.seq.data_ptr(), self.CAP, self.SPIN_LIMIT, self.err.data_ptr(),
+            gamma.data_ptr(), beta.data_ptr(), float(xhat_max), resid_word, bound_word, torch.cuda.current_stream().cuda_stream),
+            "tris_mbox_bn_combine_bound_f32")
+
+    def bn_bwd_exchange(self, sum_dz, sum_dzx, out, gamma, invstd, inv_count, xhat_max, dz_word, bound_word):
+        """SyncBN backward: out[2C] = the two sums over all ranks + the bound word of dx (tris_mbox_bn_bwd_exchange_f32)"""
+        self._chk(self.lib.tris_mbox_bn_bwd_exchange_f32(
+            sum_dz.data_ptr(), sum_dzx.data_ptr(), sum_dz.numel(), out.data_ptr(), self.boxes.data_ptr(), self.world, self.rank,
+            self.seq.data_ptr(), self.CAP, self.SPIN_LIMIT, self.err.data_ptr(), gamma.data_ptr(), invstd.data_ptr(),
+            float(inv_count), float(xhat_max), dz_word, bound_word, torch.cuda.current_stream().cuda_stream),
+            "tris_mbox_bn_bwd_exchange_f32")
+
     def self_test(self):
         """One real exchange before the transport is trusted: every rank posts (rank + 1) * [1, 2, 3, 4] and must read back
         every peer's block within a short time-out (peer stores over xGMI that never become visible, a peer mapping that

@@ -29,6 +29,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   mbox_spin          TRIS_MBOX_SPIN            bound of the SyncBatchNorm mailbox spin (polls)
   syncbn_comm        TRIS_SYNCBN_COMM          "mailbox" | "c10d"
   ddp_check          TRIS_DDP_CHECK            NaN-poison check of the gradient reducer's release order
+  syncbn_bound       TRIS_SYNCBN_BOUND         SyncBatchNorm mailbox exchanges also leave the bound word of the plane tensor written next (0: separate launches)
   ddp_seg_opt        TRIS_DDP_SEG_OPT          replayed data-parallel step: AdamW per reducer segment right behind its all-reduce (0: one AdamW behind the join)
   ddp_sparse_embed   TRIS_DDP_SPARSE_EMBED     token-embedding gradient as a sparse (ids, rows) exchange
   random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
@@ -61,6 +62,7 @@ class _Config:
         self.mha = e("TRIS_MHA", "auto")
         self.mha_h2 = _flag("TRIS_MHA_H2", True)
         self.ddp_seg_opt = _flag("TRIS_DDP_SEG_OPT", True)
+        self.syncbn_bound = _flag("TRIS_SYNCBN_BOUND", True)
         self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
         self.xattn_px = _flag("TRIS_XATTN_PX", True)
         self.xattn_h2 = _flag("TRIS_XATTN_H2", True)

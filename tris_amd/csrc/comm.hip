@@ -27,6 +27,7 @@
 
 #include "common.h"
 #include "tris_hip.h"
+#include "x3_split.h"
 
 namespace {
 
@@ -90,10 +91,34 @@ __device__ __forceinline__ bool mbox_send_wait(const float* src0, int n0, const 
 // on every rank); the block of a rank is [src0[n0] | src1[n1]]
 // (src0 / out are NOT restrict: the in-place sum of tris_amd.comm.syncbn_all_reduce_sum passes the same buffer for both;
 // every source element is stored to the mailboxes before the first element of `out` is written)
+// Optional by-product of an exchange launch inside an h2 step with operand planes (csrc/planes.h): the amax WORD that bounds the
+// plane tensor the following pass writes -- what tris_bn_out_bound2_f32 (forward: |gamma| xhat_max + |beta| [+ the residual's bound])
+// and tris_bn_bwd_bound_f32 (backward: |gamma invstd| (amax dz + |sum dz| / n + xhat_max |sum dz xhat| / n)) compute in launches of
+// their own.  The statistics are on the chip at the end of the exchange anyway: two launches less per SyncBatchNorm layer and pass.
+struct MboxBound {
+  const float* gamma;       // NULL: no bound wanted
+  const float* other;       // forward: beta; backward: invstd
+  const unsigned* word_in;  // forward: the residual's amax word or NULL; backward: the amax word of dz
+  unsigned* word_out;
+  float xhat_max, inv_cnt;
+};
+__device__ __forceinline__ void mbox_bound_commit(float m, const MboxBound& b, bool fwd) {   // every thread of the 256
+  __shared__ float red[4];
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (fwd && b.word_in != nullptr) v += __builtin_bit_cast(float, h2_amax_of(b.word_in, threadIdx.x));
+    if (threadIdx.x == 0) b.word_out[0] = __builtin_bit_cast(unsigned, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* src0, int n0, const float* src1,
                                                             int n1, float* out, void* const* __restrict__ boxes,
                                                             int world, int rank, unsigned* seq_dev, int cap, int mode, long spin_limit,
-                                                            int* __restrict__ err) {
+                                                            int* __restrict__ err, MboxBound bnd) {
   unsigned seq;
   const bool ok = mbox_send_wait(src0, n0, src1, n1, boxes, world, rank, seq_dev, cap, spin_limit, err, &seq);
   const int tid = threadIdx.x, par = seq & 1u, n = n0 + n1;
@@ -113,6 +138,14 @@ __global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* src0, i
       for (int w = 0; w < world; ++w) acc += __builtin_nontemporal_load(slot_of(boxes[rank], par, w, cap) + i);
       out[i] = acc;
     }
+    if (bnd.gamma != nullptr) {   // SyncBatchNorm backward, out = [sum dz | sum dz xhat] over all ranks: the bound of dx (n0 = n1 = C)
+      __syncthreads();
+      const float adz = __builtin_bit_cast(float, h2_amax_of(bnd.word_in, tid & 63));
+      float m = 0.f;
+      for (int c = tid; c < n0; c += 256)
+        m = fmaxf(m, fabsf(bnd.gamma[c] * bnd.other[c]) * (adz + fabsf(out[c]) * bnd.inv_cnt + bnd.xhat_max * fabsf(out[n0 + c]) * bnd.inv_cnt));
+      mbox_bound_commit(m, bnd, false);
+    }
   }
 }
 
@@ -122,10 +155,16 @@ __global__ __launch_bounds__(256) void mbox_exchange_kernel(const float* src0, i
 __global__ __launch_bounds__(256) void mbox_bn_combine_kernel(const float* __restrict__ local, int C, float count, float eps,
                                                               float momentum, float* __restrict__ stats, float* running_mean,
                                                               float* running_var, void* const* __restrict__ boxes, int world,
-                                                              int rank, unsigned* seq_dev, int cap, long spin_limit, int* __restrict__ err) {
+                                                              int rank, unsigned* seq_dev, int cap, long spin_limit, int* __restrict__ err,
+                                                              MboxBound bnd) {
   unsigned seq;
   const bool ok = mbox_send_wait(local, 3 * C, nullptr, 0, boxes, world, rank, seq_dev, cap, spin_limit, err, &seq);
   const int par = seq & 1u;
+  if (bnd.gamma != nullptr) {   // the bound of the plane output: from the affine parameters alone (Samuelson), whatever arrived
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(bnd.gamma[c]) * bnd.xhat_max + fabsf(bnd.other[c]));
+    mbox_bound_commit(m, bnd, true);
+  }
   if (!ok) {   // a peer never posted: NaN statistics (the step's losses turn NaN), running statistics untouched
     for (int c = threadIdx.x; c < 3 * C; c += 256) stats[c] = __builtin_nanf("");
     return;
@@ -189,7 +228,19 @@ extern "C" int tris_mbox_exchange_f32(const float* src0, int n0, const float* sr
       seq == nullptr)
     return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mbox_exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src0, n0, src1, n1, out, boxes, world, rank,
-                     seq, cap_floats, mode, spin_limit, err);
+                     seq, cap_floats, mode, spin_limit, err, MboxBound{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f});
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int tris_mbox_bn_bwd_exchange_f32(const float* sum_dz, const float* sum_dzx, int C, float* out, void* const* boxes, int world,
+                                             int rank, unsigned* seq, int cap_floats, long spin_limit, int* err, const float* gamma,
+                                             const float* invstd, float inv_count, float xhat_max, const unsigned* dz_word,
+                                             unsigned* bound_word, void* stream) {
+  if (C <= 0 || 2 * C > cap_floats || world < 1 || world > TRIS_MBOX_MAX_WORLD || rank < 0 || rank >= world || seq == nullptr ||
+      gamma == nullptr || invstd == nullptr || dz_word == nullptr || bound_word == nullptr)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mbox_exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sum_dz, C, sum_dzx, C, out, boxes, world, rank,
+                     seq, cap_floats, 1, spin_limit, err, MboxBound{gamma, invstd, dz_word, bound_word, xhat_max, inv_count});
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -200,7 +251,22 @@ extern "C" int tris_mbox_bn_combine_f32(const float* local_stats, int C, long co
   if (C <= 0 || 3 * C > cap_floats || world < 1 || world > TRIS_MBOX_MAX_WORLD || rank < 0 || rank >= world || seq == nullptr)
     return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mbox_bn_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, local_stats, C, (float)count_per_rank, eps,
-                     momentum, stats, running_mean, running_var, boxes, world, rank, seq, cap_floats, spin_limit, err);
+                     momentum, stats, running_mean, running_var, boxes, world, rank, seq, cap_floats, spin_limit, err,
+                     MboxBound{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f});
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int tris_mbox_bn_combine_bound_f32(const float* local_stats, int C, long count_per_rank, float eps, float momentum,
+                                              float* stats, float* running_mean, float* running_var, void* const* boxes, int world,
+                                              int rank, unsigned* seq, int cap_floats, long spin_limit, int* err, const float* gamma,
+                                              const float* beta, float xhat_max, const unsigned* resid_word, unsigned* bound_word,
+                                              void* stream) {
+  if (C <= 0 || 3 * C > cap_floats || world < 1 || world > TRIS_MBOX_MAX_WORLD || rank < 0 || rank >= world || seq == nullptr ||
+      gamma == nullptr || beta == nullptr || bound_word == nullptr)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mbox_bn_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, local_stats, C, (float)count_per_rank, eps,
+                     momentum, stats, running_mean, running_var, boxes, world, rank, seq, cap_floats, spin_limit, err,
+                     MboxBound{gamma, beta, resid_word, bound_word, xhat_max, 0.f});
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -1623,7 +1623,19 @@ class BatchNormFn(torch.autograd.Function):
                 if mb is not None:   # one launch: peer-mailbox exchange + combine (+ running statistics)
                     loc = torch.empty(3 * C, device=x.device, dtype=torch.float32)
                     local_stats(None, None, dst=loc)
-                    mb.bn_combine(loc, C, M, eps, momentum, stats, rmean, rvar)
+                    w_ = rw_ = None
+                    if use_pl and cfg.syncbn_bound:   # ... + the bound word of the plane output (what tris_bn_out_bound2_f32 would launch for)
+                        w_ = _h2_slot()
+                        if resid is not None:
+                            rw_ = pl_word(resid)
+                            if rw_ is None:
+                                rw_ = _h2_amax(resid)
+                    if w_ is not None and (resid is None or rw_ is not None):
+                        mb.bn_combine_bound(loc, C, M, eps, momentum, stats, rmean, rvar, gamma, beta,
+                                            math.sqrt(max(M * world - 1, 1)), rw_, w_)
+                        pl_bound["word"], pl_bound["resid"] = w_, rw_
+                    else:
+                        mb.bn_combine(loc, C, M, eps, momentum, stats, rmean, rvar)
                 else:
                     local_stats(None, None)
                     allv = torch.empty(world * 3 * C, device=x.device, dtype=torch.float32)
@@ -1758,7 +1770,12 @@ class BatchNormFn(torch.autograd.Function):
             # SyncBatchNorm: the arena keeps this rank's dbeta / dgamma (the data-parallel reducer averages them like every
             # other gradient); the sums over ALL ranks that dX needs come from one peer-mailbox launch reading the arena
             sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-            mb.exchange(sb, sums, 1, src1=sg)
+            if dx_pl and dzw is not None and ctx.needs_input_grad[0] and bound_word is None and cfg.syncbn_bound:
+                bound_word = _h2_slot()
+            if bound_word is not None and dx_pl and dzw is not None:   # the same launch leaves the bound word of dx
+                mb.bn_bwd_exchange(sb, sg, sums, gamma, invstd, 1.0 / float(count), math.sqrt(max(count - 1, 1)), dzw, bound_word)
+            else:
+                mb.exchange(sb, sums, 1, src1=sg)
             p_dz, p_dzx = P(sums), P(sums, C)
         elif not direct:
             dg = _emit(ctx.params[0], lambda o: o.copy_(sums[C:]), ctx.needs_input_grad[1])
