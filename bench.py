@@ -326,8 +326,10 @@ def main():
         xbytes = a.batch * (4 * P_ * C_ + N_ * C_) * 4 + 3 * N_ * C_ * 4
         fused = [r for r in xa if r[0] in ("xattn_fwd_fused", "xattn_fwd_px")]
         if fused and len(fused) == len(xa) and fused[0][0] == "xattn_fwd_px":
-            xname = ("xattn_px_kernel (ONE persistent launch cut by pixel rows, csrc/xattn_px.hip) + xattn_text_planes_kernel "
-                     "(sentence bf16 planes)")
+            xname = ("xattn_px_kernel (ONE persistent launch cut by pixel rows, csrc/xattn_px.hip; " +
+                     ("h2: two fp16 pieces per operand, three MFMAs per product" if (mode == "h2" and cfg.xattn_h2) else
+                      "x3: three bf16 pieces per operand, six MFMAs per product") +
+                     ") + xattn_text_planes_kernel (the sentence operands as piece planes)")
         elif fused and len(fused) == len(xa):
             xname = "xattn_fused_kernel (ONE persistent launch, csrc/xattn_fused.hip) + xattn_text_planes_kernel (sentence bf16 planes)"
         elif mode in ("x3", "h2"):
