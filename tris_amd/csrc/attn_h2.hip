@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void mha_h2_fwd_kernel(const float* __restrict
             for (int ks = 0; ks < 2; ++ks) mm3(afrag(Kp, row, ks, kg), qf[ks], sc[j], sx[j]);   // S^T[key 8kg + 4j + t][query r]
           }
           float sv[8], mx = -INFINITY;
+          const bool full = key0 + 32 <= L && !(causal && key0 + 31 > q0);   // (wave-uniform) every key of the step seen by every query
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int key = key0 + 8 * kg + i;
             const float v = (sc[i >> 2][i & 3] + sx[i >> 2][i & 3] * (1.0f / 2048.0f)) * inv_s;
-            sv[i] = (key < L && !(causal && key > q0 + r)) ? v : -INFINITY;
+            sv[i] = (full || (key < L && !(causal && key > q0 + r))) ? v : -INFINITY;
             mx = fmaxf(mx, sv[i]);
           }
           mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(256) void mha_h2_fwd_kernel(const float* __restrict
           const float alpha = mn == -INFINITY ? 1.f : __expf(m - mn);
           l = l * alpha + rs;
           m = mn;
+          if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {   // (no running maximum moved: nothing to rescale)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {  // the accumulator rows are queries 4kg+t: fetch their rescale factors
-            const float ar = __shfl(alpha, 4 * kg + t, 64);
+            for (int t = 0; t < 4; ++t) {  // the accumulator rows are queries 4kg+t: fetch their rescale factors
+              const float ar = __shfl(alpha, 4 * kg + t, 64);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { oc[j][t] *= ar; ox[j][t] *= ar; }
+              for (int j = 0; j < 4; ++j) { oc[j][t] *= ar; ox[j][t] *= ar; }
+            }
           }
           const H8 pf = split8(make_float4(p[0], p[1], p[2], p[3]), make_float4(p[4], p[5], p[6], p[7]), PS);
 #pragma unroll
@@ -248,10 +251,11 @@ __global__ __launch_bounds__(256) void mha_h2_dq_kernel(const float* __restrict_
             }
           }
           float ds[8], mx = 0.f;
+          const bool full = key0 + 32 <= L && !(causal && key0 + 31 > q0);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int key = key0 + 8 * kg + i;
-            const bool ok = key < L && !(causal && key > q0 + r);
+            const bool ok = full || (key < L && !(causal && key > q0 + r));
             const float sv = (sc[i >> 2][i & 3] + sx[i >> 2][i & 3] * (1.0f / 2048.0f)) * inv_s;
             const float dp = (pc[i >> 2][i & 3] + px[i >> 2][i & 3] * (1.0f / 2048.0f)) * inv_p;
             ds[i] = ok ? __expf(sv - ls) * (dp - dl) * scale : 0.f;
@@ -338,10 +342,11 @@ __global__ __launch_bounds__(256) void mha_h2_dkv_kernel(const float* __restrict
             }
           }
           float p[8], ds[8], mx = 0.f;
+          const bool full = qs0 + 32 <= L && !(causal && k0 + 15 > qs0);   // every query of the step sees every key of the wave
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int ql = 32 * pr + 8 * kg + i, q = qb + ql;
-            const bool ok = q < L && !(causal && k0 + r > q);
+            const bool ok = full || (q < L && !(causal && k0 + r > q));
             const float sv = (sc[i >> 2][i & 3] + sx[i >> 2][i & 3] * (1.0f / 2048.0f)) * inv_s;
             const float dp = (pc[i >> 2][i & 3] + px[i >> 2][i & 3] * (1.0f / 2048.0f)) * inv_p;
             p[i] = ok ? __expf(sv - Ls[ql]) : 0.f;
