@@ -320,6 +320,17 @@ def main():
         roof["idle_device_tflops"] = idle_rates(_prof(f"autotune_log_{mode}.txt")[0])
     except Exception:
         pass
+    roof_xb = None
+    if xb:   # the backward of the pair as one persistent launch (csrc/xattn_px.hip xattn_px_bwd_kernel + its preparation launch)
+        P_, N_, C_ = 100, a.batch, 1024
+        bb = a.batch * (5 * P_ * C_ + N_ * C_ + 5 * P_ * N_) * 4 + 3 * N_ * C_ * 4
+        bms = sum(r[2] for r in xb) / len(xb)
+        roof_xb = {"bound": "hbm", "achieved": round(bb / (bms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "us": round(bms * 1e3, 1),
+                   "algorithmic_bytes_per_call": bb,
+                   "kernel": "xattn_bwd_planes_kernel + xattn_px_bwd_kernel (dQv, dKv, dVv and both soft-max backwards of the bilateral "
+                             "cross attention in ONE persistent launch cut by pixel rows; the three [N, C] sums over images and pixels "
+                             "follow as split-K products and are in the GEMM family)"}
     roof_x = None
     if xa:
         P_, N_, C_ = 100, a.batch, 1024
@@ -353,26 +364,24 @@ def main():
             import csv as _csv
             tr = 0
             xfile, xpname = _prof(f"{mode}_pmc_hbm_traffic.csv")
+            trb = 0
             for r in _csv.DictReader(open(xfile)):
                 if "xattn_" in r["Kernel"]:
-                    tr += int(r["FetchBytesPerStep(x2 corrected)"]) + int(r["WriteBytesPerStep"])
+                    by = int(r["FetchBytesPerStep(x2 corrected)"]) + int(r["WriteBytesPerStep"])
+                    if "bwd" in r["Kernel"]:      # (xattn_px_bwd_kernel, xattn_bwd_planes_kernel: the backward's launches)
+                        trb += by
+                    else:
+                        tr += by
+            if trb and roof_xb is not None:
+                roof_xb["traffic"] = trb
+                roof_xb["traffic_note"] = (f"FETCH_SIZE x2 + WRITE_SIZE of the two launches (profiles/{xpname}): "
+                                           f"{trb / roof_xb['algorithmic_bytes_per_call']:.2f}x the algorithmic bytes")
             if tr:
                 roof_x["traffic"] = tr
                 roof_x["traffic_note"] = (f"FETCH_SIZE x2 + WRITE_SIZE of the cross-attention launches of one forward (profiles/{xpname}, "
                                           f"rocprofv3 --pmc, B=48): {tr / xbytes:.2f}x the algorithmic bytes")
         except Exception:
             pass
-    roof_xb = None
-    if xb:   # the backward of the pair as one persistent launch (csrc/xattn_px.hip xattn_px_bwd_kernel + its preparation launch)
-        P_, N_, C_ = 100, a.batch, 1024
-        bb = a.batch * (5 * P_ * C_ + N_ * C_ + 5 * P_ * N_) * 4 + 3 * N_ * C_ * 4
-        bms = sum(r[2] for r in xb) / len(xb)
-        roof_xb = {"bound": "hbm", "achieved": round(bb / (bms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "us": round(bms * 1e3, 1),
-                   "algorithmic_bytes_per_call": bb,
-                   "kernel": "xattn_bwd_planes_kernel + xattn_px_bwd_kernel (dQv, dKv, dVv and both soft-max backwards of the bilateral "
-                             "cross attention in ONE persistent launch cut by pixel rows; the three [N, C] sums over images and pixels "
-                             "follow as split-K products and are in the GEMM family)"}
     out = None
     if rank == 0:
         dtype = {"h2": "f32 storage/accumulate; products h2 = 2 x f16 pieces", "x3": "f32 storage/accumulate; products x3 = 3 x bf16 pieces",
