@@ -333,6 +333,294 @@ __global__ __launch_bounds__(512, 2) void pingpong_kernel(const float* __restric
     }
 }
 
+
+// ---- register-pipelined form: 256 x 128 tile, FOUR waves (2 x 2), wave tile 128 x 64 (FM = 4, FN = 2: 12 KB of fragments per 24 MFMAs instead
+// of 8 KB per 12), three LDS stages, ONE barrier per k tile, fragments double-buffered in registers: the ds_reads of sub-step g + 1 are issued
+// right before the MFMAs of sub-step g, so a wave's own matrix work covers its LDS latency (one wave per SIMD: nobody else would).
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 1) void regpipe_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                         int M, int N, int K, float inv_scale) {
+  constexpr int BM = 256, BN = 128, NW = 4, NST = 3, FM = 4, FN = 2;
+  constexpr int A_ST = BM * 128, B_ST = BN * 128, ST = A_ST + B_ST;
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;        // 8 + 4 LDS-DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(1024))) char lds[NST * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  if (ABL & 8) {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const char* a_src[GA];
+  const char* b_src[GB];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int r = (wave * GA + q) * 8 + lrow;
+    a_src[q] = reinterpret_cast<const char*>(A + (long)min(m0 + r, M - 1) * K) + ((lslot ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const int r = (wave * GB + q) * 8 + lrow;
+    b_src[q] = reinterpret_cast<const char*>(B + (long)min(n0 + r, N - 1) * K) + ((lslot ^ ((r >> 1) & 7)) << 4);
+  }
+  auto issue = [&](int stage, int kt) {
+    char* sa = lds + stage * ST + (wave * GA) * 1024;
+    char* sb = lds + stage * ST + A_ST + (wave * GB) * 1024;
+#pragma unroll
+    for (int q = 0; q < GA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < GB; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + (long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(sb + q * 1024), 16, 0, 0);
+  };
+  f32x16 acc[FM][FN], acx[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
+  const int li = lane & 31, kh = lane >> 5;
+  int a_off[FM], b_off[FN], a_sw[FM], b_sw[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) { const int r = wm * 128 + i * 32 + li; a_off[i] = r * 128; a_sw[i] = (r >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) { const int r = wn * 64 + j * 32 + li; b_off[j] = A_ST + r * 128; b_sw[j] = (r >> 1) & 7; }
+  struct Fr { f16x8 ah[FM], al[FM], bh[FN], bl[FN]; };
+  // ABL & 16: the fragment reads are inline asm (the compiler does not see LDS operations, so it inserts no waits of its own -- its
+  // s_waitcnt lgkmcnt(0) in front of the first MFMA group drains the reads just issued for the NEXT sub-step) and the waits are counted
+  // by hand: LDS returns in order, 12 reads per sub-step
+  auto lds_rd = [&](const char* p) -> f16x8 {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 v;
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+    return __builtin_bit_cast(f16x8, v);
+  };
+  auto read_frags = [&](Fr& f, int stage, int g) {
+    const char* st = lds + stage * ST;
+    const int p0 = 2 * (2 * g + kh);
+    if (ABL & 16) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        f.ah[i] = lds_rd(st + a_off[i] + ((p0 ^ a_sw[i]) << 4));
+        f.al[i] = lds_rd(st + a_off[i] + (((p0 + 1) ^ a_sw[i]) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        f.bh[j] = lds_rd(st + b_off[j] + ((p0 ^ b_sw[j]) << 4));
+        f.bl[j] = lds_rd(st + b_off[j] + (((p0 + 1) ^ b_sw[j]) << 4));
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      f.ah[i] = *reinterpret_cast<const f16x8*>(st + a_off[i] + ((p0 ^ a_sw[i]) << 4));
+      f.al[i] = *reinterpret_cast<const f16x8*>(st + a_off[i] + (((p0 + 1) ^ a_sw[i]) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      f.bh[j] = *reinterpret_cast<const f16x8*>(st + b_off[j] + ((p0 ^ b_sw[j]) << 4));
+      f.bl[j] = *reinterpret_cast<const f16x8*>(st + b_off[j] + (((p0 + 1) ^ b_sw[j]) << 4));
+    }
+  };
+  auto mfmas = [&](const Fr& f) {
+    if (ABL & 1) return;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acx[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acx[i][j], 0, 0, 0);
+      }
+  };
+  const int nk = K / 32;
+  constexpr int GPS = GA + GB;
+  Fr f0, f1;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // tile 0 is in LDS
+  read_frags(f0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt + 1: my pieces landed -> barrier: everyone's landed, and everyone has issued all reads of tile kt - 1 (stage (kt + 2) % 3)
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) issue((kt + 2) % 3, kt + 2);
+    }
+    read_frags(f1, kt % 3, 1);                  // sub-step 1 of this tile: in flight under the MFMAs of sub-step 0
+    if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");   // f0 (the 12 reads before these 12) has arrived
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(f0, (kt + 1) % 3, 0);   // sub-step 0 of the next tile: under the MFMAs of sub-step 1 (unconditional: the last one reads a dead stage)
+    if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");   // f1 has arrived
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < M && col < N) C[(long)row * N + col] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]) * inv_scale;
+      }
+    }
+}
+
+
+// ---- the same 4-wave form with SIX stages of 16 k each (24 KB per stage): four stages in flight while one is consumed -- the three-stage
+// form above has ONE 48 KB tile in flight per CU, and at ~1.6 us of LDS-DMA round trip that is a quarter of what the matrix pipe eats.
+// A stage row is 16 k of both planes = 64 bytes = 4 pieces [hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15]; one DMA instruction moves 16 rows; swizzle
+// piece ^= (row >> 2) & 3 on the source side (the 16 lanes of a b128 service group hit 16 distinct slots of the 256-byte bank row).
+template <int ABL = 0, int NST = 6>
+__global__ __launch_bounds__(256, 1) void regpipe16_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                           int M, int N, int K, float inv_scale) {
+  constexpr int BM = 256, BN = 128, NW = 4, FM = 4, FN = 2;
+  constexpr int A_ST = BM * 64, B_ST = BN * 64, ST = A_ST + B_ST;     // 24 KB
+  constexpr int GA = BM / 16 / NW, GB = BN / 16 / NW;               // 4 + 2 LDS-DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(1024))) char lds[NST * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  if (ABL & 8) {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int lrow = lane >> 2, lslot = lane & 3;
+  const char* a_src[GA];
+  const char* b_src[GB];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int r = (wave * GA + q) * 16 + lrow;
+    a_src[q] = reinterpret_cast<const char*>(A + (long)min(m0 + r, M - 1) * K) + ((lslot ^ ((r >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const int r = (wave * GB + q) * 16 + lrow;
+    b_src[q] = reinterpret_cast<const char*>(B + (long)min(n0 + r, N - 1) * K) + ((lslot ^ ((r >> 2) & 3)) << 4);
+  }
+  auto issue = [&](int stage, int kt) {       // kt counts 16-k tiles: 64 bytes along a row of the plane tensor
+    char* sa = lds + stage * ST + (wave * GA) * 1024;
+    char* sb = lds + stage * ST + A_ST + (wave * GB) * 1024;
+#pragma unroll
+    for (int q = 0; q < GA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (long)kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < GB; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + (long)kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sb + q * 1024), 16, 0, 0);
+  };
+  f32x16 acc[FM][FN], acx[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
+  const int li = lane & 31, kh = lane >> 5;
+  unsigned a_ad[FM][2], b_ad[FN][2];       // LDS byte offsets inside a stage: [fragment][hi | lo]
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int r = wm * 128 + i * 32 + li, sw = (r >> 2) & 3;
+    a_ad[i][0] = r * 64 + (((2 * kh) ^ sw) << 4);
+    a_ad[i][1] = r * 64 + (((2 * kh + 1) ^ sw) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int r = wn * 64 + j * 32 + li, sw = (r >> 2) & 3;
+    b_ad[j][0] = A_ST + r * 64 + (((2 * kh) ^ sw) << 4);
+    b_ad[j][1] = A_ST + r * 64 + (((2 * kh + 1) ^ sw) << 4);
+  }
+  struct Fr { f16x8 ah[FM], al[FM], bh[FN], bl[FN]; };
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds;
+  auto lds_rd = [&](unsigned a) -> f16x8 {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+    return __builtin_bit_cast(f16x8, v);
+  };
+  auto read_frags = [&](Fr& f, int stage) {
+    const unsigned st = lds0 + stage * ST;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) { f.ah[i] = lds_rd(st + a_ad[i][0]); f.al[i] = lds_rd(st + a_ad[i][1]); }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { f.bh[j] = lds_rd(st + b_ad[j][0]); f.bl[j] = lds_rd(st + b_ad[j][1]); }
+  };
+  auto mfmas = [&](const Fr& f) {
+    if (ABL & 1) return;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acx[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acx[i][j], 0, 0, 0);
+      }
+  };
+  const int nk = K / 16;                      // 16-k tiles
+  constexpr int GPS = GA + GB;                // 6 DMA instructions per wave and tile
+  constexpr int AHEAD = NST - 2;              // tiles in flight behind the one being read and the one being consumed from registers
+  // prologue: tiles 0 .. AHEAD
+#pragma unroll
+  for (int t = 0; t <= AHEAD; ++t) if (t < nk) issue(t, t);
+  // wait for tile 0 (everything but the AHEAD newest tiles), barrier, read it
+  if (nk > AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS * AHEAD) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Fr f0, f1;
+  read_frags(f0, 0);
+  // steady state, two tiles per trip (f0: even tiles, f1: odd tiles).  At the top of the half-trip for tile t: tiles t + 1 .. t + AHEAD are in
+  // flight (or landed); wait for t + 1, barrier (everyone's t + 1 landed; everyone has issued its reads of tile t, i.e. is done with tile
+  // t - 1's stage), issue tile t + AHEAD + 1 into that stage, read tile t + 1 under the MFMAs of tile t.
+  auto half = [&](Fr& cur, Fr& nxt, int t) {
+    if (t + 1 < nk) {
+      if (t + AHEAD < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS * (AHEAD - 1)) : "memory");   // t + 1 .. t + AHEAD are outstanding
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          // the tail: fewer are
+      __builtin_amdgcn_s_barrier();
+      if (t + AHEAD + 1 < nk) issue((t + AHEAD + 1) % NST, t + AHEAD + 1);
+      else { /* keep the counter arithmetic uniform: nothing to issue, later waits are then stricter than needed */ }
+    }
+    read_frags(nxt, (t + 1) % NST);
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");       // cur's 12 reads (issued before these 12) have arrived
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(cur);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    half(f0, f1, t);
+    half(f1, f0, t + 1);
+  }
+  if (t < nk) half(f0, f1, t);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < M && col < N) C[(long)row * N + col] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]) * inv_scale;
+      }
+    }
+}
+
 static float host_scale(float amax) {
   int e;
   frexpf(amax, &e);          // amax = f * 2^e, f in [0.5, 1)  ->  floor(log2 amax) = e - 1
@@ -403,6 +691,68 @@ static void run_pp(const char* name, const float* Ap, const float* Bp, float* C,
   fflush(stdout);
 }
 
+template <int ABL>
+static void run_rp(const char* name, const float* Ap, const float* Bp, float* C, const float* Cref, int M, int N, int K, float inv,
+                   int ref_rows_n) {
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  auto launch = [&]() { hipLaunchKernelGGL((regpipe_kernel<ABL>), dim3(tiles), dim3(256), 0, 0, Ap, Bp, C, M, N, K, inv); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  const int it = 10;
+  for (int i = 0; i < it; ++i) launch();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= it;
+  double err = -1.0;
+  if ((ABL & 7) == 0 && Cref) {
+    std::vector<float> h((size_t)ref_rows_n * N), r((size_t)ref_rows_n * N);
+    hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), Cref, r.size() * 4, hipMemcpyDeviceToHost);
+    double num = 0, den = 0;
+    for (size_t i = 0; i < h.size(); ++i) { num = fmax(num, fabs((double)h[i] - r[i])); den = fmax(den, fabs((double)r[i])); }
+    err = num / den;
+  }
+  printf("%-44s M%-7d N%-5d K%-5d %9.1f us %7.1f TF/s  err/max %.2e\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) * 1e-12, err);
+  fflush(stdout);
+}
+
+template <int ABL>
+static void run_rp16(const char* name, const float* Ap, const float* Bp, float* C, const float* Cref, int M, int N, int K, float inv,
+                     int ref_rows_n) {
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  auto launch = [&]() { hipLaunchKernelGGL((regpipe16_kernel<ABL, 6>), dim3(tiles), dim3(256), 0, 0, Ap, Bp, C, M, N, K, inv); };
+  for (int i = 0; i < 3; ++i) launch();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  const int it = 10;
+  for (int i = 0; i < it; ++i) launch();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= it;
+  double err = -1.0;
+  if ((ABL & 7) == 0 && Cref) {
+    std::vector<float> h((size_t)ref_rows_n * N), r((size_t)ref_rows_n * N);
+    hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), Cref, r.size() * 4, hipMemcpyDeviceToHost);
+    double num = 0, den = 0;
+    for (size_t i = 0; i < h.size(); ++i) { num = fmax(num, fabs((double)h[i] - r[i])); den = fmax(den, fabs((double)r[i])); }
+    err = num / den;
+  }
+  printf("%-44s M%-7d N%-5d K%-5d %9.1f us %7.1f TF/s  err/max %.2e\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) * 1e-12, err);
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; };
   std::vector<Shape> shapes = {{4096, 4096, 4096}, {76800, 256, 2304}, {19200, 512, 4608}, {19200, 1024, 1024}, {19200, 1024, 256}, {4800, 2048, 1024},
@@ -429,6 +779,14 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     const float inv = 1.0f / (sA * sB);
 #define RUN(BM, BN, NWM, NWN, NST, OCC, ABL, NAME) run<BM, BN, NWM, NWN, NST, OCC, ABL>(NAME, Ap, Bp, C, Cref, M, N, K, inv, RR)
+    run_rp16<0>("256x128 4w k16 x 6 stages, 4 in flight", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp16<8>("256x128 4w k16 x 6 stages, 4 in flight xcd", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp16<1>("256x128 4w k16 x 6 stages -mfma", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp<16>("256x128 4w reg-pipelined 3st asm-waits", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp<24>("256x128 4w reg-pipelined asm-waits xcd", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp<0>("256x128 4w reg-pipelined 3st", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp<8>("256x128 4w reg-pipelined 3st xcd", Ap, Bp, C, Cref, M, N, K, inv, RR);
+    run_rp<1>("256x128 4w reg-pipelined -mfma", Ap, Bp, C, Cref, M, N, K, inv, RR);
     run_pp<0, 1>("256x128 8w ping-pong 3st prio", Ap, Bp, C, Cref, M, N, K, inv, RR);
     run_pp<0, 0>("256x128 8w ping-pong 3st", Ap, Bp, C, Cref, M, N, K, inv, RR);
     run_pp<8, 1>("256x128 8w ping-pong 3st prio xcd", Ap, Bp, C, Cref, M, N, K, inv, RR);
