@@ -925,6 +925,43 @@ def test_xattn_pixel_row_launch_replays_from_a_graph(ops):
     assert not ops.xattn_timed_out()
 
 
+def test_xattn_forward_and_backward_replay_from_a_graph(ops):
+    """Forward AND backward persistent launches share the sync words (epoch, flags): captured together in one graph they must replay
+    with new operand values and hand the gradients of the eager call, bit for bit; no wait may time out."""
+    if ops.get_gemm_mode() == "f32":
+        pytest.skip("the single-launch forms are split-bf16 / h2 kernels")
+    B, P, N, C = 48, 100, 48, 1024
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *sh: torch.randn(*sh, generator=g).cuda().requires_grad_(True)
+    q = [mk(B, P, C), mk(B, P, C), mk(B, P, C), mk(N, C), mk(N, C), mk(N, C)]
+    wv, wl = torch.randn(B, P, C, generator=g).cuda(), torch.randn(B, N, C, generator=g).cuda()
+
+    def fb():
+        nv, nl = ops.xattn(*q)
+        return torch.autograd.grad([nv, nl], q, [wv, wl])
+    side = torch.cuda.Stream()
+    ops.profile_begin()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fb()
+    side.synchronize()
+    kinds = {r[0] for r in ops.profile_end()}
+    assert {"xattn_fwd_px", "xattn_bwd_px"} <= kinds, kinds      # (both persistent launches are what runs at this shape)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        grads = fb()
+    for it in range(3):
+        with torch.no_grad():
+            for t in q + [wv, wl]:
+                t.copy_(torch.randn(t.shape, generator=g).cuda() * (1.0 + it))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = fb()
+        for a_, b_ in zip(grads, want):
+            assert torch.equal(a_, b_), f"replay {it}"
+    assert not ops.xattn_timed_out()
+
+
 @pytest.mark.parametrize("B,P,N,C", [(3, 100, 5, 1024), (48, 100, 48, 1024), (1, 100, 1, 1024), (2, 37, 64, 128), (2, 25, 17, 64),
                                      (7, 104, 33, 1024), (33, 57, 17, 1024), (40, 97, 64, 512), (60, 103, 64, 1024), (5, 8, 3, 512)])
 def test_xattn_fused(ops, B, P, N, C):
