@@ -307,6 +307,54 @@ def test_bottleneck_stack_with_planes_matches_without(ops):
         assert float((g1[n_] - g0[n_]).norm() / g0[n_].norm().clamp_min(1e-12)) < 5e-5, n_
 
 
+def test_two_forwards_then_one_backward_outside_an_explicit_step(ops):
+    """gradient accumulation -- two training forwards issued outside a train_step bracket, ONE backward of the
+    summed losses -- is legal PyTorch and must work with operand planes on.  Each such forward begins a pool of its own
+    (h2_auto_step, as TRIS.forward / ModifiedResNet.forward_cl do); the earlier forward's pool is retired, not cleared, so the plane
+    tensors its autograd graph saved keep their scale words (ops.h2_begin_step).  The gradients equal the sum of two separate
+    forward + backward runs of the same inputs (BatchNorm running statistics aside, nothing couples the two forwards)."""
+    xa = torch.relu(torch.randn(4, 16, 16, 64, device="cuda"))
+    xb = torch.relu(torch.randn(4, 16, 16, 64, device="cuda")) * 3.0
+    wv = torch.linspace(-1, 1, 256, device="cuda")
+
+    def fwd(net, x):
+        assert ops.h2_auto_step() or ops._H2["next"] == ops._H2.get("base", -1)
+        return (ops.unplanes(net(x)) * wv).sum()
+    net = _stack(3)
+    ops.h2_end_step()
+    ops._H2["next"] = ops._H2.get("base", 0) + 1          # (something was handed out since the last begin: the next forward starts a step)
+    before = dict(ops.PL_STATS)
+    x1, x2 = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+    l1 = fwd(net, x1)
+    step1 = ops._H2["step"]
+    l2 = fwd(net, x2)
+    assert ops._H2["step"] != step1 and step1 in ops._H2["auto_pools"]      # a pool each; the first one retired, alive
+    (l1 + l2).backward()
+    torch.cuda.synchronize()
+    d = {k: ops.PL_STATS[k] - before[k] for k in before if not k.startswith("last")}
+    assert d["products"] >= 2 * 3 * 4 * 3 and d["dx_planes"] == d["dy_planes"] > 0, d   # both graphs ran their products on planes
+    got = (x1.grad.clone(), x2.grad.clone(), {n_: p.grad.clone() for n_, p in net.named_parameters()})
+    ref_g, ref_x = {}, []
+    for x0 in (xa, xb):
+        net = _stack(3)
+        ops.h2_begin_step()
+        x = x0.clone().requires_grad_()
+        (ops.unplanes(net(x)) * wv).sum().backward()
+        ref_x.append(x.grad.clone())
+        for n_, p in net.named_parameters():
+            ref_g[n_] = p.grad.clone() + ref_g.get(n_, 0)
+        ops.h2_end_step()
+    torch.cuda.synchronize()
+    for g, r in zip(got[:2], ref_x):
+        assert float((g - r).norm() / r.norm()) < 2e-5
+    for n_ in ref_g:
+        assert float((got[2][n_] - ref_g[n_]).norm() / ref_g[n_].norm().clamp_min(1e-12)) < 5e-5, n_
+    # a fifth-oldest forward's planes are gone (H2_AUTO_KEEP retired pools), and an explicit step drops them all
+    ops.h2_begin_step()
+    assert not ops._H2["auto_pools"]
+    ops.h2_end_step()
+
+
 def test_training_step_with_planes_against_the_golden_step(ops, golden):
     """the B = 2 step of tests/test_gpu_parity.py (G5) with operand planes on: the trunk's products run on planes (counted), nothing
     falls back to rebuilt fp32 tensors on the hot path, every plane gradient finds its one consumer, and the losses are the

@@ -428,6 +428,10 @@ def profile_end():
     return [(k, f, a.elapsed_time(b), nb) for k, f, a, b, nb in rec]
 
 
+def _shape_tag(text):
+    return text if _PROF_SHAPES else None
+
+
 def _timed(kind, flops, fn, tag=None, nbytes=0):
     """nbytes: ALGORITHMIC HBM bytes of the launch -- every operand read once, every output written once"""
     if _PROF is None:
@@ -608,6 +612,7 @@ H2_SLOTS = 4096          # amax words per step; a word is H2_SUB unsigned words 
 H2_SUB = 2048
 H2_CONST_SLOTS = 1024
 H2_PREPASS_MAX = 1 << 25
+H2_AUTO_KEEP = 4         # retired pools of gradient-mode forwards issued outside an explicit step (h2_begin_step)
 
 
 def h2_on():
@@ -704,10 +709,24 @@ def h2_begin_step(explicit=True):
     _H2["in_step"] = bool(explicit)
     wgrad_join()
     dev = torch.device("cuda", torch.cuda.current_device())
+    # A forward issued OUTSIDE an explicit step with gradients on may still have its autograd graph -- and the plane tensors saved in
+    # it -- alive when the next such forward begins (gradient accumulation, a drop-in user summing the losses of two forwards before
+    # one backward: legal PyTorch).  Its pool is then RETIRED, not cleared: the words stay what the saved plane tensors were written
+    # under (pl_word accepts the H2_AUTO_KEEP most recent retired steps) and the new forward gets a fresh pool.
+    live = _H2.setdefault("auto_pools", {})
     if _H2["pool"] is None or _H2["pool"].device != dev:
         _H2["pool"] = torch.zeros(H2_SLOTS * H2_SUB, device=dev, dtype=torch.int32)
+        live.clear()
+    elif not explicit and _H2.get("auto_grad") and not _H2.get("private") and not torch.cuda.is_current_stream_capturing():
+        live[_H2["step"]] = _H2["pool"]
+        while len(live) > H2_AUTO_KEEP:
+            live.pop(next(iter(live)))
+        _H2["pool"] = torch.zeros(H2_SLOTS * H2_SUB, device=dev, dtype=torch.int32)
     else:
+        if explicit:
+            live.clear()
         _H2["pool"].zero_()
+    _H2["auto_grad"] = (not explicit) and torch.is_grad_enabled() and not _H2.get("private")
     _H2["step"] = _h2_new_step_id()
     _H2["plane_numel"] = {}
     _PL_GRAD.clear()
@@ -934,7 +953,7 @@ def pl_word(t):
     tag = getattr(t, "_pl", None) if t is not None else None
     if tag is None:
         return None
-    if tag[0] != _H2["step"] or tag[2] != t.data_ptr():
+    if (tag[0] != _H2["step"] and tag[0] not in _H2.get("auto_pools", ())) or tag[2] != t.data_ptr():
         raise RuntimeError("a plane tensor outlived the step whose amax pool scales it")
     return tag[1]
 
@@ -1157,7 +1176,7 @@ class LinearFn(torch.autograd.Function):
             _launch_with_stats(y, M, N, lambda part, rows: _timed(
                 "gemm", 2.0 * M * N * K, lambda: (lambda pp: call("tris_gemm_bnstat_f32", pp[0], pp[1], P(y), M, N, K,
                                                                   part.data_ptr(), rows, _stream()))(h2_pp(x, w, w_b=True, k_red=K)),
-                nbytes=4.0 * (M * K + K * N + M * N)))
+                nbytes=4.0 * (M * K + K * N + M * N), tag=_shape_tag(f"bnstat M{M} N{N} K{K}")))
         else:
             gemm(x, w, y, M, N, K, K, K, N, False, True, bias=b, bias_mode=1 if b is not None else 0, resid=resid,
                  ldr=N, act=act, w_b=True)
@@ -1222,7 +1241,7 @@ class LinearFn(torch.autograd.Function):
                         call("tris_gemm_bnbwd_f32", pp[0], pp[1], P(dx), M, K, N, P(extra), K, P(link.x), by,
                              P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream())
                         return rows.value > 0     # (False: the entry point declined the shape, nothing was launched)
-                    _timed("gemm_bnbwd", 2.0 * M * N * K, launch,
+                    _timed("gemm_bnbwd", 2.0 * M * N * K, launch, tag=_shape_tag(f"M{M} N{K} K{N}"),
                            nbytes=4.0 * (M * N + N * K + M * K * (2 + int(link.from_y) + int(extra is not None))))
                     if rows.value > 0:
                         fused = True
@@ -1441,7 +1460,8 @@ class Conv3x3Fn(torch.autograd.Function):
                 def launch(part, rows):
                     return _timed("conv3x3_fwd", fl, lambda: (bound is not None and h2_arm(None, ctx.params[0], a_slot=bound), call(
                         "tris_conv3x3_fwd_bnin_f32", P(xr), P(mean), P(invstd), P(gamma), P(beta), P(w), P(y), B, H, W, Cin, Cout,
-                        None if part is None else part.data_ptr(), rows, _stream()))[1], nbytes=nb)
+                        None if part is None else part.data_ptr(), rows, _stream()))[1], nbytes=nb,
+                        tag=_shape_tag(f"bnin B{B} {H}x{W} {Cin}->{Cout}"))
                 if stats:
                     _launch_with_stats(y, B * H * W, Cout, launch)
                 else:
@@ -1462,11 +1482,11 @@ class Conv3x3Fn(torch.autograd.Function):
             _launch_with_stats(y, B * Ho * Wo, Cout, lambda part, rows: _timed(
                 "conv3x3_fwd", fl, lambda: (lambda pp: call("tris_conv3x3_fwd_bnstat_f32", pp[0], pp[1], P(y), B, H, W, Cin, Cout,
                                                             stride, part.data_ptr(), rows, _stream()))(_conv_pp(x, ctx.params[0], w)),
-                nbytes=nb))
+                nbytes=nb, tag=_shape_tag(f"bnstat B{B} {H}x{W} {Cin}->{Cout} s{stride}")))
         else:
             _timed("conv3x3_fwd", fl,
                    lambda: (lambda pp: call("tris_conv3x3_fwd_f32", pp[0], pp[1], P(y), B, H, W, Cin, Cout, stride, _stream()))(
-                       _conv_pp(x, ctx.params[0], w)), nbytes=nb)
+                       _conv_pp(x, ctx.params[0], w)), nbytes=nb, tag=_shape_tag(f"B{B} {H}x{W} {Cin}->{Cout} s{stride}"))
         ctx.save_for_backward(x, w)
         return y
 
@@ -1505,14 +1525,14 @@ class Conv3x3Fn(torch.autograd.Function):
                     call("tris_conv3x3_dgrad_bnbwd_f32", pp[0], pp[1], P(dx), B, H, W, Cin, Cout, P(link.x), P(link.mean), P(link.invstd),
                          P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream())
                     return rows.value > 0
-                _timed("conv3x3_dgrad_bnbwd", fl, launch, nbytes=4.0 * (B * H * W * (Cout + 2 * Cin) + 9 * Cin * Cout))
+                _timed("conv3x3_dgrad_bnbwd", fl, launch, tag=_shape_tag(f"B{B} {H}x{W} {Cin}<-{Cout}"), nbytes=4.0 * (B * H * W * (Cout + 2 * Cin) + 9 * Cin * Cout))
                 if rows.value > 0:
                     fused = True
                     link.fill(dx, part, rows.value, dzw)
             if not fused:
                 _timed("conv3x3_dgrad", fl,
                        lambda: (lambda pp: call("tris_conv3x3_dgrad_f32", pp[0], pp[1], P(dx), B, H, W, Cin, Cout, _stream()))(
-                           _conv_pp(dy, ctx.params[0], w)),
+                           _conv_pp(dy, ctx.params[0], w)), tag=_shape_tag(f"B{B} {H}x{W} {Cin}<-{Cout}"),
                        nbytes=4.0 * (B * H * W * (Cout + Cin) + 9 * Cin * Cout))
 
         def wgrad(o):
@@ -1524,13 +1544,14 @@ class Conv3x3Fn(torch.autograd.Function):
                 if conv3x3_bnin_ok(x.shape, Cout):
                     return _timed("conv3x3_wgrad", fl, lambda: (ctx.h2_in is not None and h2_arm(dy, None, b_slot=ctx.h2_in), call(
                         "tris_conv3x3_wgrad_bnin_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(dy), P(o), B, H, W, Cin,
-                        Cout, P(ws), ws.numel() * 4, _stream()))[1], nbytes=nb)
+                        Cout, P(ws), ws.numel() * 4, _stream()))[1], nbytes=nb, tag=_shape_tag(f"bnin B{B} {H}x{W} {Cin}->{Cout}"))
                 xin = torch.empty_like(x)   # materialise relu(bn(x)) after all
                 h2_mark_next(xin)
                 call("tris_bn_apply_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), None, P(xin), B * H * W, Cin, 1, _stream())
             return _timed("conv3x3_wgrad", fl, lambda: (lambda pp: call(
                 "tris_conv3x3_wgrad_f32", pp[1], pp[0], P(o), B, H, W, Cin, Cout, ctx.stride, P(ws), ws.numel() * 4, _stream()))(
-                    h2_pp(dy, xin, k_red=dy.shape[0] * dy.shape[1] * dy.shape[2])), nbytes=nb)
+                    h2_pp(dy, xin, k_red=dy.shape[0] * dy.shape[1] * dy.shape[2])), nbytes=nb,
+                tag=_shape_tag(f"B{B} {H}x{W} {Cin}->{Cout} s{ctx.stride}"))
         dw = None
         if ctx.needs_input_grad[1]:
             sk = _sink(ctx.params[0])
