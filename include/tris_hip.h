@@ -47,6 +47,18 @@ int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
  * when the fast kernel does not serve its operands. */
 int tris_gemm_epilogue_next(float* pre_out, const float* dact_x);
 
+/* One-shot: the NEXT tris_gemm_f32 launched from the calling thread may finish a split-K product INSIDE its own launch: each tile's
+ * k slices take a ticket from tickets[tile], and the block that arrives last sums the tile's slabs in slice order (the result is
+ * the separate reduce launch's, bit for bit, whichever block that is), applies bias / activation / residual and writes C.  Used for
+ * up to 8 slices (developer option FUSE_SPLITK = n, 0 = never), one batch, the fast kernels.  `tickets`: `count` ints in device
+ * memory, ZERO when handed over; every launch leaves them zero; private to the stream of the launch (two products in flight at
+ * once must not share an array; a captured launch keeps reading the same array at every replay).  Without it, or with fewer ints
+ * than the product has tiles, the slabs are summed by a second launch.  (The small products of the transformer towers and of the
+ * late trunk stages -- reference CLIP/clip/model.py:366-397 -- are ~190 such pairs of launches per training step.) */
+int tris_splitk_tickets_next(int* tickets, int count);
+/* how many product launches of this process took the fused finish so far (tests, bench.py) */
+long tris_splitk_fused_launches(void);
+
 /* Arithmetic of the dense-product kernels.  tris_set_gemm_mode sets the process-wide DEFAULT; tris_set_gemm_mode_thread
  * sets an override for the calling thread only (-1 = none) -- e.g. the autograd thread running the weight-gradient
  * products in another mode -- so that concurrent launches from other threads are unaffected.  Both are host-side values

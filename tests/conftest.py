@@ -47,5 +47,5 @@ def _reset_library_options(request):
     yield
     if request.node.get_closest_marker("gpu") is not None and "tris_amd.ops" in sys.modules:
         o = sys.modules["tris_amd.ops"]
-        for name in ("FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS"):
+        for name in ("FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "FUSE_SPLITK"):
             o.set_option(name, None)

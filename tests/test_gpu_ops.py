@@ -102,6 +102,37 @@ def test_gemm_epilogue_variants(ops):
             close(C.view(B, M, N), ref, name=f"bias_mode {mode} offset {off}")
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB,slices", [(2048, 512, 4096, False, True, 8), (2048, 1024, 4096, False, False, 4),
+                                                 (4096, 1024, 4096, False, True, 2), (1024, 2048, 4800, True, False, 4),
+                                                 (2044, 508, 4096, False, True, 8)])
+def test_fused_splitk_finish_equals_the_reduce_launch(ops, M, N, K, tA, tB, slices):
+    """Split-K products armed with a ticket array (tris_splitk_tickets_next: ops.gemm does it) finish inside their own launch: the
+    last-arriving block of each tile sums the slabs.  The result is the two-launch form's BIT FOR BIT (same slice order), with bias,
+    QuickGELU / ReLU, residual and alpha in the finish; the ticket array is zero again afterwards; the launch counter says the fused
+    form ran (static cost model: these shapes split into `slices`); FUSE_SPLITK=0 restores the reduce launch."""
+    from tris_amd import _lib
+    g = torch.Generator().manual_seed(5 + M + N)
+    A = torch.randn((K, M) if tA else (M, K), generator=g).cuda()
+    B = (torch.randn((N, K) if tB else (K, N), generator=g) * 0.05).cuda()
+    bias, R = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    ref = 0.5 * ((A.t() if tA else A).double().cpu() @ (B.t() if tB else B).double().cpu()) + bias.double().cpu()
+    ref = (ref * torch.sigmoid(1.702 * ref) + R.double().cpu()).float()
+    out = {}
+    for fused in (True, False):
+        ops.set_option("FUSE_SPLITK", None if fused else "0")
+        n0 = _lib.query("tris_splitk_fused_launches")
+        C = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(A, B, C, M, N, K, M if tA else K, K if tB else N, N, tA, tB, bias=bias, bias_mode=1, resid=R, ldr=N, act=2, alpha=0.5)
+        torch.cuda.synchronize()
+        took = _lib.query("tris_splitk_fused_launches") - n0
+        assert took == (1 if fused else 0), (fused, took, slices)
+        out[fused] = C
+    ops.set_option("FUSE_SPLITK", None)
+    assert torch.equal(out[True], out[False])
+    close(out[True], ref, tol=3e-4)
+    assert int(ops.splitk_tickets().abs().sum()) == 0
+
+
 def test_linear_relu_and_gelu_epilogues(ops):
     x, w, b = leaf(70, 96), leaf(40, 96, scale=0.2), leaf(40)
     y = F.relu(x @ w.t() + b)

@@ -35,6 +35,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
   own_stream         TRIS_OWN_STREAM           the trainer / bench compute on a non-default stream (the default stream serialises with hipGraphs elsewhere)
   h2_planes          TRIS_H2_PLANES            h2 arithmetic: the RN50 trunk's activations / gradients / weights travel as fp16 operand planes
+  fuse_splitk        TRIS_FUSE_SPLITK_PY       split-K products are armed with a ticket array: the last block of a tile sums the slabs in the product's own launch
 """
 import contextlib
 import os
@@ -76,6 +77,7 @@ class _Config:
         self.random_init = e("TRIS_RANDOM_INIT") == "1"
         self.h2_planes = _flag("TRIS_H2_PLANES", True)
         self.own_stream = _flag("TRIS_OWN_STREAM", True)
+        self.fuse_splitk = _flag("TRIS_FUSE_SPLITK_PY", True)
 
     @contextlib.contextmanager
     def override(self, **kw):

@@ -29,6 +29,10 @@ extern __attribute__((visibility("hidden"))) int tris_internal_fin_block;
 __attribute__((visibility("hidden"))) int tris_internal_reduce_wide = 4;
 // XCD_ORDER: -1 = the tuner's choice (LDS-DMA products only), 0 = never, 1 = every fast-kernel launch (gemm_core.h run_cfg)
 __attribute__((visibility("hidden"))) int tris_internal_xcd_order = -1;
+// FUSE_SPLITK: largest slice count whose slabs are summed by the last-arriving block of each tile inside the product's own launch
+// (gemm_fast.h "fused split-K finish"; needs tris_splitk_tickets_next); 0 = always the separate reduce launch
+__attribute__((visibility("hidden"))) int tris_internal_fuse_splitk = 8;
+__attribute__((visibility("hidden"))) long tris_internal_fused_count = 0;
 // option that lives in xattn_px.hip's translation unit
 extern __attribute__((visibility("hidden"))) int tris_internal_xattn_px_slots;
 }
@@ -82,6 +86,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "FIN_BLOCK")) tris_internal_fin_block = unset ? 256 : (atoi(v) >= 1024 ? 1024 : atoi(v) >= 512 ? 512 : 256);
   else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 4 : std::max(0, atoi(v));
   else if (!strcmp(name, "XCD_ORDER")) tris_internal_xcd_order = unset ? -1 : (atoi(v) > 0 ? 1 : 0);
+  else if (!strcmp(name, "FUSE_SPLITK")) tris_internal_fuse_splitk = unset ? TRIS_FUSE_SPLITK_DEFAULT : std::max(0, atoi(v));
   else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }
   else return false;
@@ -89,7 +94,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
 }
 static Options init_options() {
   Options o;
-  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "XCD_ORDER", "TUNE_LOG"}) {
+  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "XCD_ORDER", "FUSE_SPLITK", "TUNE_LOG"}) {
     char env[64];
     snprintf(env, sizeof(env), "TRIS_%s", n);
     if (const char* v = getenv(env)) set_option(o, n, v);
@@ -492,6 +497,17 @@ extern "C" int tris_gemm_epilogue_next(float* pre_out, const float* dact_x) {
   return 0;
 }
 
+// One-shot arming of the NEXT tris_gemm_f32 of the calling thread with a ticket array for the fused split-K finish (gemm_fast.h):
+// `count` ints, ZERO when handed over and left zero by every launch; private to the stream the product is launched on (two
+// products in flight at once must not share one).  Without it a split-K product sums its slabs in a second launch, as before.
+struct TicketsNext { int* t; int n; };
+static thread_local TicketsNext g_tickets_next = {nullptr, 0};
+extern "C" long tris_splitk_fused_launches(void) { return __atomic_load_n(&tris_internal_fused_count, __ATOMIC_RELAXED); }
+extern "C" int tris_splitk_tickets_next(int* tickets, int count) {
+  g_tickets_next = {count > 0 ? tickets : nullptr, count > 0 ? count : 0};
+  return 0;
+}
+
 extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
                              long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
                              const float* bias, int bias_mode, const float* resid, long ldr, long sR, int act,
@@ -500,10 +516,14 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   unsigned* amax_out = tris_internal_take_amax_next();   // (one-shot by-product: the amax word of C, tris_amax_next)
   const EpiNext epi = g_epi_next;
   g_epi_next.armed = false;
+  const TicketsNext tkn = g_tickets_next;
+  g_tickets_next = {nullptr, 0};
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0) return (int)hipErrorInvalidValue;
   GemmParams p = {};
   p.amax_out = amax_out;
+  p.tickets = tkn.t;
+  p.tickets_n = tkn.n;
   if (epi.armed) { p.pre_out = epi.pre; p.dact_x = epi.dact; }
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;

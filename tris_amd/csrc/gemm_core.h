@@ -391,6 +391,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_reduce_wide; }   // option REDUCE_WIDE (gemm_conv.hip)
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_xcd_order; }     // option XCD_ORDER (gemm_conv.hip)
+extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_fuse_splitk; }   // option FUSE_SPLITK (gemm_conv.hip)
+extern "C" { extern __attribute__((visibility("hidden"))) long tris_internal_fused_count; }   // launches that took the fused finish
 // The same sum for outputs too SMALL to fill the chip with one thread per four columns (a 64 x 64 weight gradient cut into 128
 // slabs is 4 blocks of the kernel above, each thread walking 128 slabs four at a time: ~30 us of latency for 2 MB): a block of
 // G waves owns 64 float4 columns, wave w takes the slabs s = w, w + G, ..., the partial sums meet in LDS in a fixed order
@@ -481,6 +483,21 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   if (tris_internal_xcd_order >= 0 && fast && p.xcd_remap != 1)
     p.xcd_remap = (tris_internal_xcd_order && tiles_m * tiles_n >= 16 && tiles_n > 1) ? 2 : 0;
   float* Cfinal = p.C;
+  // fused split-K finish (gemm_fast.h): the fast kernels, one batch, few slices, an armed ticket array with a slot per tile
+  int* const tk = p.tickets;
+  p.tickets = nullptr;
+  // (not where the wide reduce kernel would run -- many slices of a small output: its summation order differs, and the fused finish
+  //  is to be the separate launch's result bit for bit: static-tile runs and their tests see no change in arithmetic)
+  const bool wide = (p.N & 3) == 0 && al16(ws) && al16(Cfinal) && splitk >= 8 && (long)p.M * p.N / 4 < 128 * 256 && tris_internal_reduce_wide;
+  const bool fuse = splitk > 1 && splitk <= tris_internal_fuse_splitk && splitk <= TRIS_FUSE_SPLITK_MAX && tk != nullptr && fast &&
+                    batch == 1 && tiles_m * tiles_n <= p.tickets_n && !wide;
+  if (fuse) {
+    __atomic_fetch_add(&tris_internal_fused_count, 1L, __ATOMIC_RELAXED);
+    p.tickets = tk;
+    p.Cfin = Cfinal;
+    p.vecCfin = (p.N % 4 == 0) && al16(Cfinal) && (p.ldc % 4 == 0) && (!p.resid || (al16(p.resid) && p.ldr % 4 == 0)) &&
+                (p.bias_mode != 1 || al16(p.bias));
+  }
   if (splitk > 1)
     p.vecC = (p.N % 4 == 0) && al16(ws);
   else
@@ -576,7 +593,7 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
 #undef TRIS_FAST
 #undef TRIS_NW
   TRIS_LAUNCH_CHECK();
-  if (splitk > 1) {
+  if (splitk > 1 && !fuse) {
     p.C = Cfinal;
     long total = (long)p.M * p.N;
     if ((p.N & 3) == 0 && al16(ws) && al16(p.C) && splitk >= 8 && total / 4 < 128 * 256 && tris_internal_reduce_wide)

@@ -1133,4 +1133,95 @@ void gemm_fast_kernel(GemmParams p) {
       o[p.N + n0 + tid] = q;
     }
   }
+  // ---- fused split-K finish (EPI_SLAB, p.tickets != NULL: run_cfg, S <= 8 slices) ------------------------------------------------
+  // The slab of this block is in the workspace.  Every block of a tile takes a ticket; the LAST arriver sums the tile's S slabs in
+  // the fixed order s = 0 .. S - 1 (the order of splitk_reduce_kernel: the result does not depend on who arrives last, and equals
+  // the separate reduce launch bit for bit), applies the standard epilogue and stores C -- one launch instead of two for the ~190
+  // small split-K products of a step.  Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): plain
+  // stores -> every wave waits for its own stores -> barrier -> one lane: agent-scope release (writes the XCD's L2 back), wait,
+  // relaxed agent-scope ticket; last arriver: one agent-scope acquire (drops this CU's L1) -> barrier -> plain loads.  The last
+  // arriver leaves its ticket at zero: the array is zero again when the launch ends (the next launch on the stream, or the next
+  // replay of a captured one, finds it so).  Placement-independent: nothing assumes which XCD ran which slice.
+  if constexpr (EPI == EPI_SLAB) {
+    if (p.tickets != nullptr) {   // (uniform)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        As[0] = __builtin_bit_cast(float, old);
+      }
+      __syncthreads();
+      const int old = __builtin_bit_cast(int, As[0]);
+      if (old != p.splitk - 1) return;
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const int S = p.splitk;
+      const long total = (long)p.M * p.N;
+      const float* __restrict__ slab = p.C;
+      float* __restrict__ Cf = p.Cfin;
+      unsigned am = 0u;
+      if (p.vecC && p.vecCfin) {
+        constexpr int VPR = BN / 4;
+        for (int e = tid; e < BM * VPR; e += NTHR) {
+          const int row = grow(e / VPR), col = n0 + (e % VPR) * 4;
+          if (row >= p.M || col >= p.N) continue;
+          const long idx = (long)row * p.N + col;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          int s2 = 0;
+          for (; s2 + 3 < S; s2 += 4) {   // (four slabs in flight per trip; the additions in slice order)
+            const float4 a = ld4(slab + (long)s2 * total + idx), b = ld4(slab + (long)(s2 + 1) * total + idx);
+            const float4 c = ld4(slab + (long)(s2 + 2) * total + idx), d = ld4(slab + (long)(s2 + 3) * total + idx);
+            v[0] = (((v[0] + a.x) + b.x) + c.x) + d.x;
+            v[1] = (((v[1] + a.y) + b.y) + c.y) + d.y;
+            v[2] = (((v[2] + a.z) + b.z) + c.z) + d.z;
+            v[3] = (((v[3] + a.w) + b.w) + c.w) + d.w;
+          }
+          for (; s2 < S; ++s2) {
+            const float4 a = ld4(slab + (long)s2 * total + idx);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+          }
+          float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias_mode == 1) bc = ld4(p.bias + col);
+          else if (p.bias_mode == 2) { const float bb = p.bias[row]; bc = make_float4(bb, bb, bb, bb); }
+          const float bcv[4] = {bc.x, bc.y, bc.z, bc.w};
+          float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.resid) rr = ld4(p.resid + (long)row * p.ldr + col);
+          const float rrv[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float x = v[t] * p.alpha;
+            if (p.bias_mode) x += bcv[t];
+            if (p.act == 1) x = fmaxf(x, 0.f);
+            else if (p.act == 2) x = x / (1.0f + expf(-1.702f * x));
+            if (p.resid) x += rrv[t];
+            v[t] = x;
+            am = max(am, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
+          }
+          *reinterpret_cast<float4*>(Cf + (long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+        for (int e = tid; e < BM * BN; e += NTHR) {
+          const int row = grow(e / BN), col = n0 + (e % BN);
+          if (row >= p.M || col >= p.N) continue;
+          const long idx = (long)row * p.N + col;
+          float x = 0.f;
+          for (int s2 = 0; s2 < S; ++s2) x += slab[(long)s2 * total + idx];
+          x *= p.alpha;
+          if (p.bias_mode == 1) x += p.bias[col];
+          else if (p.bias_mode == 2) x += p.bias[row];
+          if (p.act == 1) x = fmaxf(x, 0.f);
+          else if (p.act == 2) x = x / (1.0f + expf(-1.702f * x));
+          if (p.resid) x += p.resid[(long)row * p.ldr + col];
+          Cf[(long)row * p.ldc + col] = x;
+          am = max(am, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
+        }
+      }
+      if (p.amax_out != nullptr) amax_commit(am, p.amax_out);   // (every lane of every wave reaches this point)
+    }
+  }
 }

@@ -58,7 +58,16 @@ struct GemmParams {
   float* pre_out;
   const float* dact_x;
   int nt;   // EPI_STD vector epilogue: C stores and the residual / bnb_x / bnb_y loads are nontemporal (set per launch: stream_nt)
+  // fused split-K finish (EPI_SLAB, fast kernel, batch 1, at most TRIS_FUSE_SPLITK_MAX slices; armed by tris_splitk_tickets_next):
+  // one int per output tile, zero between launches; the last-arriving block of a tile sums the slabs and writes Cfin
+  // (gemm_fast.h "fused split-K finish"); NULL: the slabs are summed by splitk_reduce_kernel in a launch of its own
+  int* tickets;
+  int tickets_n;    // (host: capacity of the armed array; run_cfg keeps `tickets` only where the fused form is launched)
+  float* Cfin;
+  int vecCfin;      // 16-byte stores / loads legal for Cfin, the residual and the bias
 };
+#define TRIS_FUSE_SPLITK_MAX 8
+#define TRIS_FUSE_SPLITK_DEFAULT 8
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 typedef float gp_f32x4 __attribute__((ext_vector_type(4)));

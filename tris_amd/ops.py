@@ -68,6 +68,22 @@ def workspace(nbytes):
     return cur
 
 
+_TICKETS = {}
+TICKET_SLOTS = 1 << 14
+
+
+def splitk_tickets():
+    """ticket array of the fused split-K finish (tris_splitk_tickets_next) for the current (device, stream): zero when created, left
+    zero by every launch; products launched on one stream run in order, so they share it"""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    cur = _TICKETS.get(key)
+    if cur is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None        # (never allocated under capture: the product then takes the two-launch form)
+        cur = _TICKETS[key] = torch.zeros(TICKET_SLOTS, dtype=torch.int32, device="cuda")
+    return cur
+
+
 # ---- arithmetic of the dense products --------------------------------------------------------------------------------------
 # 'h2' (default since round 5 -- the arithmetic bench.py reports and the trainer runs are one and the same): two fp16 pieces per
 #   operand (the residual pre-scaled by 2^11), three f16 MFMAs per product, one power-of-two scale per TENSOR formed on the device from
@@ -510,6 +526,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
         tB, ldb = True, K
     if mark:
         h2_mark_next(C)  # (h2: the product also leaves the amax of what it writes -- another product may consume C directly)
+    if ws is not None and cfg.fuse_splitk:
+        tk = splitk_tickets()
+        if tk is not None:
+            call("tris_splitk_tickets_next", tk.data_ptr(), tk.numel())
     _timed("gemm", 2.0 * M * N * K * batch, lambda: call(
         "tris_gemm_f32", pA, pB, P(C), M, N, K, lda, ldb, ldc, int(tA), int(tB), batch, sA, sB, sC, P(bias),
         bias_mode, P(resid), ldr, sR, act, float(alpha), P(ws), 0 if ws is None else ws.numel() * 4, _stream()),
