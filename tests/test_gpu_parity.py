@@ -695,6 +695,31 @@ def test_vit_spatial_trunk_matches_reference_modules(golden):
     assert err(gw.reshape(-1)[:512], g["d_conv1.weight_head"]) <= 2e-3 * float(np.abs(g["d_conv1.weight_head"]).max())
 
 
+def test_vit_tower_read_at_token0_skips_dead_rows_of_its_last_block(aux):
+    """cfg.vit_token0: the aux ViT-B/32 is read at its class token only (reference CLIP/clip/model.py:443-446), so the last block's
+    out_proj / ln_2 / MLP run on that row alone.  Features and the gradient with respect to the input image equal the all-rows form
+    (row-wise ops on the same row; a product of fewer rows may pick another tile: round-off)."""
+    from tris_amd import ops
+    from tris_amd.config import cfg
+    torch.manual_seed(11)
+    img = torch.rand(6, 3, 224, 224, device="cuda")
+    wv = torch.randn(512, device="cuda")
+    res = {}
+    for on in (True, False):
+        with cfg.override(vit_token0=on):
+            cam = torch.rand(6, 1, 224, 224, device="cuda").requires_grad_() if not res else res[True][2].detach().clone().requires_grad_()
+            ops.h2_begin_step()
+            f = aux.visual.forward_patches(ops.fg_patches(cam, img, aux.visual.patch_size))   # (the loss block's call: gradients go to the map)
+            (f * wv).sum().backward()
+            ops.wgrad_join()
+            ops.h2_end_step()
+            res[on] = (f.detach().clone(), cam.grad.clone(), cam)
+    f1, g1, _ = res[True]
+    f0, g0, _ = res[False]
+    assert float((f1 - f0).abs().max()) <= 2e-5 * max(1.0, float(f0.abs().max()))
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-5
+
+
 def test_vit_b16_trunk_losses_at_the_headline_batch_48(aux):
     """BASELINE configs[4] at its real size -- 48 images, 401 tokens per image, ViT-B/16 trunk: cls_out, the sigmoid map and the four
     losses of the HIP forward against the oracle's restatement of the same model (tris_forward(vit_trunk=True) + stage1_loss_block) on

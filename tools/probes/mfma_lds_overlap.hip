@@ -33,6 +33,34 @@ __global__ __launch_bounds__(NT, NT / 256) void k(const float* __restrict__ src,
 #pragma unroll
   for (int q = 0; q < 12; ++q) f[q] = (u4){0u, 0u, 0u, 0u};
   const char* g = reinterpret_cast<const char*>(src) + ((size_t)blockIdx.x * NT + tid) * 16;
+  if constexpr ((MODE & 8) != 0) {
+    // FINE INTERLEAVE (round 6; VERDICT r5: the rows above issue all reads, wait, then all MFMAs -- a serial schedule): the same work per
+    // trip with ONE ds_read_b128 in front of every PAIR of MFMAs and one LDS-DMA piece per FOUR, the order pinned by sched_barrier; a
+    // fragment is consumed one trip after it was read (11 younger reads outstanding -> lgkmcnt(11)); DMA three trips deep (vmcnt(18)).
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        if (MODE & 2) {
+          asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(f[q]));
+          x ^= f[q];
+          asm volatile("ds_read_b128 %0, %1" : "=v"(f[q]) : "v"(base + (unsigned)(((t + q) & 7) * 1024)));
+        }
+        if ((MODE & 4) && (q & 1) == 0) {
+          const int d = q >> 1;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)((t * 6 + d) & 63) * 65536 * 4),
+                                           (__attribute__((address_space(3))) void*)(lds + wave * 8192 + ((t * 6 + d) % 8) * 1024), 16, 0, 0);
+          if (d == 5) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE & 1) {
+          const int i = q >> 2, j = (q >> 1) & 1, h = q & 1;    // 12 pairs = the 24 MFMAs of a trip, consecutive ones on different accumulators
+          acc[(2 * q) & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + h) & 3], b[j], acc[(2 * q) & 7], 0, 0, 0);
+          acc[(2 * q + 1) & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + 2) & 3], b[j ^ h], acc[(2 * q + 1) & 7], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else
   for (int t = 0; t < trips; ++t) {
     if (MODE & 4) {   // LDS-DMA: 6 x 1 KB per wave and trip into the wave's 24 KB ring
 #pragma unroll
@@ -104,7 +132,10 @@ int main() {
   run<4, NT>("D  6 LDS-DMA x 1 KB per trip", src, out);           \
   run<5, NT>("E  A + D", src, out);                               \
   run<6, NT>("   B + D", src, out);                               \
-  run<7, NT>("F  A + B + D", src, out);
-  ALL(256) ALL(512) ALL(1024)
+  run<7, NT>("F  A + B + D", src, out);                            \
+  run<11, NT>("C' A + B, 1 read per 2 MFMAs (interleaved)", src, out);   \
+  run<13, NT>("E' A + D, 1 DMA per 4 MFMAs (interleaved)", src, out);    \
+  run<15, NT>("F' A + B + D interleaved", src, out);
+  ALL(256) ALL(512)
   return 0;
 }

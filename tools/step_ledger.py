@@ -5,7 +5,9 @@ pass) is bracketed by HIP events and logged with its shape, its algorithmic FLOP
 read once, every output written once).  Rows are grouped by (kind, shape) and ranked by the time they spend ABOVE their own floor
     floor = max(bytes / 6.3 TB/s (achievable HBM), FLOPs / 600 TFLOP/s (the h2 core's MFMA-only rate under load))
 so the top of the list is where kernel time can actually be taken back, and the column says from which side.
-usage: python tools/step_ledger.py [batch=48] [out.txt]    (join with PMC bytes: tools/pmc_summary.py --ledger)"""
+usage: python tools/step_ledger.py [batch=48] [out.txt]
+LEDGER_ORDER=<file>: also write the launches in issue order (kind:shape, FLOPs, algorithmic bytes, ms) -- run under
+`rocprofv3 --kernel-trace --pmc FETCH_SIZE` (and again with WRITE_SIZE) and join with tools/pmc_ledger.py."""
 import os
 import sys
 import warnings
@@ -55,6 +57,10 @@ def main():
         ops.profile_begin()
         step()
         rec = ops.profile_end()
+    if os.environ.get("LEDGER_ORDER"):      # the launches in issue order: tools/pmc_ledger.py joins them with a rocprofv3 --pmc pass of this run
+        with open(os.environ["LEDGER_ORDER"], "w") as fh:
+            for k, fl, ms, nb in rec:
+                fh.write(f"{k}\t{fl:.0f}\t{nb:.0f}\t{ms:.6f}\n")
     rows = {}
     for k, fl, ms, nb in rec:
         e = rows.setdefault(k, [0, 0.0, 0.0, 0.0])

@@ -309,6 +309,25 @@ class ResidualAttentionBlock(nn.Module):
         return self.mlp.c_proj(f, resid=x, grad_box_res=b2)
 
 
+    def forward_token0(self, x):
+        """The block as the LAST one of a tower that is read at token 0 only (VisionTransformer.forward_patches: ln_post(x[:, 0]) @ proj,
+        reference CLIP/clip/model.py:443-446): keys and values need every token, but everything behind the attention is row-wise, and
+        only the class token's row of the block output is ever read -- out_proj, ln_2 and the MLP run on [N, W] instead of [N, L, W].
+        Same values for that row as forward(x)[:, 0] (row-wise ops; a product of fewer rows may pick another tile: fp32 round-off).
+        Returns [N, W].  (No GradBoxes: the residual gradient here belongs to one row of x, autograd adds it.)"""
+        h = self.ln_1(x)
+        qkv = ops.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        a = ops.token0(ops.mha(qkv, self.attn.num_heads, self.causal))
+        x0 = self.attn.out_proj(a, resid=ops.token0(x))
+        h = self.ln_2(x0)
+        if torch.is_grad_enabled() and cfg.mlp_fuse:
+            f = ops.linear_qgelu(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias)
+            return ops.linear(f, self.mlp.c_proj.weight, self.mlp.c_proj.bias, x0, 0, act_link=True)
+        if torch.is_grad_enabled():
+            return self.mlp.c_proj(self.mlp.gelu(self.mlp.c_fc(h)), resid=x0)
+        return self.mlp.c_proj(self.mlp.c_fc(h, act=2), resid=x0)
+
+
 class Transformer(nn.Module):
     def __init__(self, width, layers, heads, attn_mask=None):
         super().__init__()
@@ -319,6 +338,13 @@ class Transformer(nn.Module):
         for blk in self.resblocks:
             x = ops.cut(blk(x))        # (segment boundary of a segmented capture of the trunk; otherwise x itself)
         return x
+
+    def forward_token0(self, x):
+        """forward(x)[:, 0] without the rows of the last block's output that nobody reads (ResidualAttentionBlock.forward_token0)"""
+        blocks = list(self.resblocks)
+        for blk in blocks[:-1]:
+            x = ops.cut(blk(x))
+        return blocks[-1].forward_token0(x)
 
 
 class VisionTransformer(nn.Module):
@@ -346,8 +372,10 @@ class VisionTransformer(nn.Module):
         emb = ops.linear(patches, self.conv1.weight)   # [W, 3, ps, ps] contiguous = the [W, 3*ps*ps] GEMM operand; sunk gradient
         x = ops.vit_assemble(emb, self.class_embedding, self.positional_embedding)
         x = self.ln_pre(x)
-        x = self.transformer(x)
-        cls = self.ln_post(ops.token0(x))
+        if cfg.vit_token0:
+            cls = self.ln_post(self.transformer.forward_token0(x))
+        else:
+            cls = self.ln_post(ops.token0(self.transformer(x)))
         return ops.matmul(cls, self.proj)
 
     def forward_spatial(self, x):

@@ -533,6 +533,8 @@ class SegmentedTrainStep:
         opt.push_hyper()
         ev[0].record(main)
         fm = self.fwd_marks
+        from .config import cfg as _cfg
+        aux_early = bool(_cfg.aux_text_early)
         for i, g in enumerate(self.fwd):
             if i == fm.get("text", 0):          # the TRIS text encoder starts behind this point of the trunk
                 if i:
@@ -542,10 +544,17 @@ class SegmentedTrainStep:
                     self.g_ftext.replay()
                     ev[1].record(text)
                     mark("text_fwd_done", text)
+                    if aux_early:
+                        # the frozen aux text tower depends on the token ids alone: right behind the TRIS text encoder, under the trunk's
+                        # large kernels, instead of under the aux ViT -- a chain of small products that is the step's critical path there
+                        # and runs faster alone (cfg.aux_text_early; 0: behind the TRIS forward, the eager step's issue point)
+                        self.g_faux.replay()
+                        ev[7 + len(self.back)].record(text)
+                        mark("aux_text_done", text)
             if i == fm["trunk"]:                # trunk issued: the heads need the sentence features
                 mark("trunk_fwd_done")
                 main.wait_event(ev[1])
-            if i == fm["heads"]:                # TRIS forward issued: the frozen aux text tower goes under the aux ViT
+            if i == fm["heads"] and not aux_early:   # TRIS forward issued: the frozen aux text tower goes under the aux ViT
                 e = ev[6 + len(self.back)]
                 e.record(main)
                 text.wait_event(e)
