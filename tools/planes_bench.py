@@ -103,6 +103,21 @@ def conv(B, H, C1, C2):
 
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+if len(sys.argv) > 1 and sys.argv[1] == "vit":
+    # round 6: the frozen aux ViT-B/32's products at the headline batch (48 x 50 tokens): would "convert A to planes, then the plane
+    # product on once-converted weight planes" beat the product that splits both operands in its loop?  (+ the cost of the conversion)
+    for n in (768, 2304, 3072):
+        x = torch.randn(2400, n, device=DEV)
+        w = word_of(x)
+        o = torch.empty_like(x)
+        print(f"convert [2400, {n}] fp32 -> planes: {timed(lambda: call('tris_h2_planes_f32', P(x), P(o), x.numel(), w.data_ptr(), _stream())):6.1f} us"
+              f"   amax pre-pass: {timed(lambda: call('tris_amax_bits_f32', P(x), x.numel(), w.data_ptr(), _stream())):6.1f} us", flush=True)
+    for (M, N, K) in [(2400, 2304, 768), (2400, 768, 768), (2400, 3072, 768), (2400, 768, 3072), (2400, 768, 2304), (3840, 1536, 512),
+                      (3840, 512, 512), (3840, 2048, 512), (3840, 512, 2048)]:
+        gemm(M, N, K)
+    for (M, N, K) in [(2400, 768, 2304), (2400, 768, 768), (2400, 768, 3072), (2400, 3072, 768)]:
+        gemm(M, N, K, False, False)
+    sys.exit(0)
 # the four shapes VERDICT r4 names, then the trunk's 1x1 products (forward NT, data gradient NN, weight gradient TN) and the 3x3 stages
 gemm(76800, 256, 2304)
 gemm(19200, 512, 4608)

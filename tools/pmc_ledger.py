@@ -12,7 +12,7 @@ import csv
 import re
 import sys
 
-MAIN = re.compile(r"gemm_fast_kernel|gemm_kernel<|wgrad3x3_direct_kernel|stem_wgrad_kernel|stem_conv1_kernel|mha_\w*fwd|xattn_px_kernel|xattn_px_bwd_kernel|"
+MAIN = re.compile(r"gemm_fast_kernel|gemm_kernel<|wgrad3x3_direct_kernel|stem_wgrad_kernel|stem_conv1_kernel|mha_mfma_fwd|mha_h2_fwd|xattn_px_kernel|xattn_px_bwd_kernel|"
                   r"xattn_fused|xattn_pair")
 HELPER = re.compile(r"splitk_reduce|slab_reduce|stem_wgrad_reduce|xattn_text_planes|xattn_bwd_prep|xattn_prep")
 
@@ -44,7 +44,12 @@ def main():
         sys.exit(f"join refused: {R} ledger records, {len(f)} / {len(w)} main dispatches in the PMC passes")
     f, w = f[-R:], w[-R:]
     agg = collections.OrderedDict()
+    klass = {"gemm": "gemm_fast_kernel|gemm_kernel<", "conv3x3_fwd": "gemm_fast_kernel|gemm_kernel<|stem_conv1", "conv3x3_dgrad": "gemm_fast_kernel|gemm_kernel<",
+             "conv3x3_wgrad": "gemm_fast_kernel|gemm_kernel<|wgrad3x3_direct|stem_wgrad", "mha_fwd": "mha_", "xattn_fwd": "xattn", "xattn_bwd": "xattn_px_bwd"}
     for (k, fl, nb, ms), (fn, fb), (wn, wb) in zip(order, f, w):
+        want = next(v for kk, v in klass.items() if k.split(":")[0].startswith(kk))
+        if not re.search(want, fn):
+            sys.exit(f"join refused: record {k} landed on kernel {fn[:70]}")
         if fn != wn:
             sys.exit(f"join refused: the two PMC passes disagree on the kernel of a record ({fn[:60]} vs {wn[:60]})")
         e = agg.setdefault(k, [0, 0.0, 0.0, 0.0, fn])

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include "x3_split.h"
 #include "planes.h"
 
@@ -395,6 +396,7 @@ int main(int argc, char** argv) {
   std::vector<Shape> shapes = {{4096, 4096, 4096}, {76800, 256, 2304}, {19200, 512, 4608}, {19248, 3072, 768}, {19248, 768, 3072},
                                {19200, 1024, 1024}, {19200, 1024, 256}, {4800, 2048, 1024}, {76800, 512, 256}, {2400, 3072, 768}};
   const int reps = argc > 1 ? atoi(argv[1]) : 1;
+  if (argc > 2) shapes.resize(std::min((size_t)atoi(argv[2]), shapes.size()));   // (counter passes: the first shapes only)
   for (int rep = 0; rep < reps; ++rep)
   for (const Shape& s : shapes) {
     const int M = s.M, N = s.N, K = s.K;

@@ -85,7 +85,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "LN_BWD_BLOCKS")) tris_internal_ln_bwd_blocks = unset ? 512 : std::min(512, std::max(1, atoi(v)));
   else if (!strcmp(name, "FIN_BLOCK")) tris_internal_fin_block = unset ? 256 : (atoi(v) >= 1024 ? 1024 : atoi(v) >= 512 ? 512 : 256);
   else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 4 : std::max(0, atoi(v));
-  else if (!strcmp(name, "XCD_ORDER")) tris_internal_xcd_order = unset ? -1 : (atoi(v) > 0 ? 1 : 0);
+  else if (!strcmp(name, "XCD_ORDER")) tris_internal_xcd_order = unset ? -1 : std::min(2, std::max(0, atoi(v)));
   else if (!strcmp(name, "FUSE_SPLITK")) tris_internal_fuse_splitk = unset ? TRIS_FUSE_SPLITK_DEFAULT : std::max(0, atoi(v));
   else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "TUNE_LOG")) { strncpy(o.tune_log, unset ? "" : v, sizeof(o.tune_log) - 1); o.tune_log[sizeof(o.tune_log) - 1] = 0; }

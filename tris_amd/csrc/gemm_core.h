@@ -480,7 +480,8 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
   if (glds && cfg.pipe >= 4) p.xcd_remap = 2;
   // developer option XCD_ORDER = 1: the XCD-contiguous tile order for EVERY fast-kernel launch with at least two tiles per XCD that has
   // no placement of its own (consecutive tiles share their A rows: one L2 instead of eight fetches them); 0: never
-  if (tris_internal_xcd_order >= 0 && fast && p.xcd_remap != 1)
+  // (2: only the products that split their operands in the kernel -- the transformer towers' -- keep the tuner's choice for the plane products)
+  if (tris_internal_xcd_order >= 0 && fast && p.xcd_remap != 1 && !(tris_internal_xcd_order == 2 && mode == 4))
     p.xcd_remap = (tris_internal_xcd_order && tiles_m * tiles_n >= 16 && tiles_n > 1) ? 2 : 0;
   float* Cfinal = p.C;
   // fused split-K finish (gemm_fast.h): the fast kernels, one batch, few slices, an armed ticket array with a slot per tile
