@@ -240,11 +240,14 @@ def main():
     # ---- live roofline measurement of the dominant kernel family (one extra, untimed, instrumented step) ----
     # (kernels are timed one at a time: the stream overlap of the production step is switched off for this pass so that a
     # launch's HIP-event bracket measures that kernel alone, not whatever else shares the GPU with it)
+    from tris_amd import _lib as _tl
     with cfg.override(step_graph="0", text_stream=False, wgrad_stream=False):
         step()
+        fused0 = _tl.query("tris_splitk_fused_launches")
         ops.profile_begin()
         step()
         rec_all = ops.profile_end()
+        fused_per_step = int(_tl.query("tris_splitk_fused_launches") - fused0)   # split-K products finished inside their own launch
     xa = [r for r in rec_all if r[0].startswith("xattn_fwd")]
     xb = [r for r in rec_all if r[0] == "xattn_bwd_px"]
     rec = [r for r in rec_all if not r[0].startswith("xattn")]
@@ -277,7 +280,7 @@ def main():
             "peak_f32_mfma": F32_MFMA_PEAK_TFLOPS, "frac_vs_f32_mfma": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
             "arithmetic": _arith_text(mode),
             "kernel": "gemm_fast_kernel<BM,BN,A,B,EPI,PREC> + wgrad3x3_direct_kernel (MFMA GEMM / implicit-GEMM / direct 3x3 family)",
-            "launches_per_step": len(rec), "kernel_ms_per_step": round(ms, 3),
+            "launches_per_step": len(rec), "kernel_ms_per_step": round(ms, 3), "fused_splitk_products_per_step": fused_per_step,
             "fused_epilogue_note": ("kinds *_bnbwd are data-gradient products whose epilogue also does the reduction pass of the "
                                     "BatchNorm backward that consumes them (their extra activation-sized streams are in the byte "
                                     "counts, no FLOPs are counted for them)"),
@@ -290,11 +293,11 @@ def main():
     # PMC-derived HBM traffic / matrix-pipe utilisation of the same kernel family: separate rocprofv3 --pmc passes of THIS command
     # (tools/closing_profiles.sh), committed under profiles/ -- read, not measured here; the files are named in the notes
     def _prof(name):   # this round's committed profile if present, else the last round's (the note names the file that was read)
-        for rd in ("r5", "r4"):
+        for rd in ("r6", "r5", "r4"):
             p = os.path.join(ROOT, "profiles", f"{rd}_{name}")
             if os.path.exists(p):
                 return p, f"{rd}_{name}"
-        return os.path.join(ROOT, "profiles", f"r5_{name}"), f"r5_{name}"
+        return os.path.join(ROOT, "profiles", f"r6_{name}"), f"r6_{name}"
     for tag in ((mode,) if mode in ("h2", "x3") else ()):
         try:
             pfile, pname = _prof(f"{tag}_pmc_hbm_traffic.json")

@@ -122,7 +122,8 @@ def test_fused_splitk_finish_equals_the_reduce_launch(ops, M, N, K, tA, tB, slic
         ops.set_option("FUSE_SPLITK", None if fused else "0")
         n0 = _lib.query("tris_splitk_fused_launches")
         C = torch.full((M, N), float("nan"), device="cuda")
-        ops.gemm(A, B, C, M, N, K, M if tA else K, K if tB else N, N, tA, tB, bias=bias, bias_mode=1, resid=R, ldr=N, act=2, alpha=0.5)
+        with CFG.override(fuse_splitk=True):      # (opt-in since the round-6 measurement: ops.gemm arms the ticket array only then)
+            ops.gemm(A, B, C, M, N, K, M if tA else K, K if tB else N, N, tA, tB, bias=bias, bias_mode=1, resid=R, ldr=N, act=2, alpha=0.5)
         torch.cuda.synchronize()
         took = _lib.query("tris_splitk_fused_launches") - n0
         assert took == (1 if fused else 0), (fused, took, slices)

@@ -51,6 +51,26 @@ def test_g1_text(sd, batch, golden):
     assert abs(float(x.sum()) - g["text_x_sum"][0]) < 1e-2
 
 
+def test_tokens_behind_eot_cannot_reach_hidden(aux, batch):
+    """What a packed text pass would rest on, stated against the oracle's restatement of CLIP.encode_text
+    (reference CLIP/clip/model.py:537-564): `hidden` is the row at argmax(ids) = the EOT token, the mask is causal, every other op
+    is row-wise -- so nothing at a position behind EOT can reach it.  Rewriting those positions with arbitrary token ids (below the
+    EOT id, so the argmax stays) leaves `hidden` BIT-identical; 42 % of the synthetic batches' rows are such positions."""
+    ids = torch.cat([batch["word_ids"], batch["neg_word_ids"].reshape(-1, batch["word_ids"].shape[1])], 0).long()
+    eot = ids.argmax(-1)
+    assert int(eot.min()) >= 1 and int(eot.max()) <= ids.shape[1] - 1
+    behind = torch.arange(ids.shape[1])[None, :] > eot[:, None]
+    assert behind.float().mean() > 0.2
+    junk = ids.clone()
+    g = torch.Generator().manual_seed(3)
+    junk[behind] = torch.randint(1, 40000, (int(behind.sum()),), generator=g)
+    assert torch.equal(junk.argmax(-1), eot)
+    with torch.no_grad():
+        _, h0 = O.encode_text(aux, "", ids)
+        x1, h1 = O.encode_text(aux, "", junk)
+    assert torch.equal(h0, h1)
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_g2_image(sd, batch, golden, mode):
     g = golden("g1_g2_encoders.npz")
