@@ -359,6 +359,11 @@ class VisionTransformer(nn.Module):
         self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
         self.ln_pre = LayerNorm(width)
         self.transformer = Transformer(width, layers, heads)
+        for blk in self.transformer.resblocks:
+            # the tower's Linear weights also exist as operand planes (ops._pl_weight_ok): its products at a few thousand rows and more
+            # run on the LDS-DMA loop with the activation converted once per product (ops._a_planes, cfg.gemm_convert)
+            for w in (blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight):
+                w._tris_linear_w = True
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self.spacial_dim = 7

@@ -37,6 +37,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   h2_planes          TRIS_H2_PLANES            h2 arithmetic: the RN50 trunk's activations / gradients / weights travel as fp16 operand planes
   aux_text_early     TRIS_AUX_TEXT_EARLY       replayed step: the frozen aux text tower right behind the TRIS text encoder (under the trunk), 0: behind the TRIS forward
   vit_token0         TRIS_VIT_TOKEN0           ViT image tower read at its class token: the last block's out_proj / MLP on that row only (0: all 50 rows)
+  gemm_convert       TRIS_GEMM_CONVERT         h2 planes: products of a ViT tower with at least this many rows convert their fp32 A operand to planes first (0 = default: never -- measured slower in both configurations, profiles/r6_gemm_convert_ab.txt)
   fuse_splitk        TRIS_FUSE_SPLITK_PY       split-K products armed with a ticket array: the last block of a tile sums the slabs in the product's own launch (default 0: measured slower)
 """
 import contextlib
@@ -81,6 +82,7 @@ class _Config:
         self.own_stream = _flag("TRIS_OWN_STREAM", True)
         self.fuse_splitk = _flag("TRIS_FUSE_SPLITK_PY", False)
         self.aux_text_early = _flag("TRIS_AUX_TEXT_EARLY", True)
+        self.gemm_convert = int(e("TRIS_GEMM_CONVERT", "0"))
         self.vit_token0 = _flag("TRIS_VIT_TOKEN0", True)
 
     @contextlib.contextmanager

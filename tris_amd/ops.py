@@ -527,6 +527,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0, bia
         C.reshape(M, N).copy_(C4[:M])
         return C
     ws = workspace(0) if (use_ws and batch == 1 and not _BATCH_INVARIANT) else None   # (no workspace = no split-K)
+    if (w_b and batch == 1 and not tA and M >= cfg.gemm_convert and cfg.gemm_convert > 0 and K % 32 == 0 and lda == K and getattr(B, "_tris_linear_w", False)
+            and planes_on() and pl_word(A) is None and A.is_contiguous() and A.data_ptr() % 16 == 0 and _pl_weight_ok(B)):
+        A = _a_planes(A, M, K)
     pA, pB = h2_pp(A, B, w_a=w_a, w_b=w_b, k_red=K, w_bt=w_bt and not tB) if batch == 1 else (P(A), P(B))
     if batch == 1 and PL_STATS["last_t"]:    # B = W [K][N] arrived as the planes of its transpose [N][K]
         tB, ldb = True, K
@@ -712,13 +715,32 @@ def h2_weights_amax(arenas=None):
 
 def _pl_weight_t_ok(p):
     """a 1x1-convolution weight [Cout, Cin, 1, 1] whose transposed planes exist (64 x 64 tiles of the transposing pass)"""
+    if p.dim() == 2:     # a Linear weight [N, K] of a tower whose products run on planes (VisionTransformer marks them)
+        return cfg.gemm_convert > 0 and getattr(p, "_tris_linear_w", False) and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
     return p.dim() == 4 and p.shape[2] * p.shape[3] == 1 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
 
 
 def _pl_weight_ok(p):
     """a parameter that dense products of the trunk read as fp16 operand planes: a convolution weight [Cout, Cin, kh, kw] whose
     contiguous dimension (Cin: channels_last memory) is a multiple of 8"""
+    if p.dim() == 2:     # (round 6) a Linear weight [N, K], K contiguous: the same geometry as a 1x1 convolution's
+        return cfg.gemm_convert > 0 and getattr(p, "_tris_linear_w", False) and p.shape[1] % 8 == 0 and p.is_contiguous()
     return p.dim() == 4 and p.shape[1] % 8 == 0 and (p.is_contiguous(memory_format=torch.channels_last) or p.shape[2] * p.shape[3] == 1)
+
+
+def _a_planes(A, M, K):
+    """(round 6, cfg.gemm_convert) The row-major A operand [M, K] of a large product against a weight that exists as planes, converted
+    to planes ONCE in a pass of its own (tris_h2_planes_f32: 4 bytes read + 4 written per element) so that the product runs on the
+    LDS-DMA loop with no split in its K loop -- every column tile of the product would otherwise re-split the same rows (a ViT-B/16
+    trunk product has 6 ... 24 of them).  Measured per shape in profiles/r6_vit_planes_bench.txt (x1.2 ... 1.57 for the product, 5 ... 13 us
+    for the pass at 2400 rows).  Returns the plane tensor (tagged with A's amax word) or A itself where A has no word."""
+    slot = _h2_amax(A)
+    if slot is None:
+        return A
+    t = torch.empty_like(A)
+    call("tris_h2_planes_f32", P(A), P(t), A.numel(), slot, _stream())
+    PL_STATS["converted"] = PL_STATS.get("converted", 0) + 1
+    return pl_tag(t, slot)
 
 
 def _h2_new_step_id():
