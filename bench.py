@@ -149,7 +149,7 @@ def main():
     if "TRIS_STEP_GRAPH" not in os.environ:
         cfg.step_graph = "seg"                   # `value` = the step as the trainer issues it (train_stage1.main): segmented hipGraph replay
     mode = ops.get_gemm_mode()
-    QL = 20
+    QL = int(os.environ.get("TRIS_BENCH_QL", "20"))   # (20 = the metric's query length; the override exists for what-if experiments only)
 
     def build(backbone, distributed=False, force=False):
         args = get_parser().parse_args(["--backbone", backbone, "--size", "320", "--max_query_len", str(QL),

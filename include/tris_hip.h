@@ -330,6 +330,23 @@ int tris_mha_h2_fwd_f32(const float* qkv, float* out, float* lse, const unsigned
 int tris_mha_h2_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
                         const unsigned* amax_qkv, const unsigned* amax_dout, int N, int L, int W, int heads, int causal,
                         void* stream);
+/* Packed text rows (round 6).  A causal text tower is read at the EOT row of every sentence (reference CLIP/clip/model.py:552-564: the row at
+ * argmax(ids)); under the causal mask (:537-543) no position behind it can reach that row, so the packed pass keeps rows 0 .. eot_n of
+ * sentence n back to back and drops the rest (42 % of a RefCOCOg-shaped batch).  Extents live in DEVICE memory -- a captured pass is
+ * valid for any ids.  Every packed buffer has R = N L rounded up to 256 rows.  plan (3 + N + R ints) <- tris_text_pack_plan_i64: [0] rows
+ * in use P, [1] P rounded up to 256 = the row limit (<= R), [2 + n] first row of sentence n (n = 0 .. N), then the source token of
+ * every packed row (-1 behind P).
+ * tris_embed_packed_fwd_f32 writes rows < plan[1] of out [R, W] (zeros for P .. plan[1] - 1); tris_mha_packed_fwd_f32 is
+ * tris_mha_fwd_f32 over the sentences' row ranges of the packed qkv [R, 3 W] (L <= 64; it keeps rows P .. plan[1] - 1 of out zero);
+ * tris_eot_gather_packed_f32 reads each sentence's last row.  tris_rows_limit_thread(limit) makes the calling thread's following
+ * tris_gemm_f32 (row-major A, one batch) and tris_layernorm_fwd_f32 launches skip rows >= *limit (a device word, normally &plan[1];
+ * a multiple of 256 so that tiles are whole or absent); NULL clears it.  Forward only (the frozen aux tower). */
+int tris_text_pack_plan_i64(const long* ids, int N, int L, int* plan, void* stream);
+int tris_embed_packed_fwd_f32(const long* ids, const float* tok, const float* pos, const int* plan, float* out, int N, int L, int W,
+                              void* stream);
+int tris_mha_packed_fwd_f32(const float* qkv, float* out, const int* plan, int N, int Lmax, int W, int heads, int causal, void* stream);
+int tris_eot_gather_packed_f32(const float* x, const int* plan, float* out, int N, int W, void* stream);
+int tris_rows_limit_thread(const int* limit);
 /* token_embedding(ids) + positional_embedding[:L]  (model.py:553-554).  bwd: dtok must be zero-filled by the caller */
 int tris_embed_fwd_f32(const long* ids, const float* tok, const float* pos, float* out, int N, int L, int W,
                        void* stream);

@@ -695,6 +695,50 @@ def test_vit_spatial_trunk_matches_reference_modules(golden):
     assert err(gw.reshape(-1)[:512], g["d_conv1.weight_head"]) <= 2e-3 * float(np.abs(g["d_conv1.weight_head"]).max())
 
 
+def test_packed_text_pass_equals_the_padded_pass(aux):
+    """cfg.text_pack: the frozen aux text tower on PACKED rows -- positions behind every sentence's EOT token are
+    not computed, extents are device words -- gives the padded pass's `hidden` (same rows through the same row-wise kernels; fewer
+    rows may pick another tile: round-off), for ragged lengths incl. the shortest (SOT EOT) and the longest sentence, whatever sits
+    behind EOT; replayed from its hipGraph with OTHER ids it follows them (the plan is rebuilt on the device inside the graph)."""
+    from tris_amd import ops
+    from tris_amd.config import cfg
+    from tris_amd.graphs import GraphedFrozenText
+    from tris_amd.utils.synth import synthetic_batch
+    outs = {}
+    for seed in (7, 8):
+        b = synthetic_batch(48, 32, 20, 3, seed=seed)
+        ids = torch.cat([b["word_ids"], b["neg_word_ids"].reshape(-1, 20)], 0).long()
+        ids[0, :] = 0
+        ids[0, 0], ids[0, 1] = 49406, 49407                     # the shortest sentence
+        ids[1, 1:19] = 1000
+        ids[1, 0], ids[1, 19] = 49406, 49407                    # the longest
+        outs[seed] = ids.cuda()
+    ids = outs[7]
+    with torch.no_grad():
+        with cfg.override(text_pack=False):
+            ref = aux.encode_text_hidden(ids)
+        got = aux.encode_text_hidden(ids)
+        junk = ids.clone()
+        eot = ids.argmax(-1)
+        behind = torch.arange(20, device="cuda")[None, :] > eot[:, None]
+        junk[behind] = 31337
+        got_junk = aux.encode_text_hidden(junk)
+        plan = ops.text_pack_plan(ids)
+        torch.cuda.synchronize()
+        P_rows = int(plan[0])
+        assert P_rows == int((eot + 1).sum()) and int(plan[1]) == (P_rows + 255) // 256 * 256 and P_rows < 0.75 * ids.numel()
+        tol = 2e-5 * float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= tol
+        assert torch.equal(got_junk, got)
+        g = GraphedFrozenText(aux, ids.shape[0], 20)
+        a = g(ids)
+        b2 = g(outs[8])
+        with cfg.override(text_pack=False):
+            ref8 = aux.encode_text_hidden(outs[8])
+        torch.cuda.synchronize()
+        assert float((a - ref).abs().max()) <= tol and float((b2 - ref8).abs().max()) <= 2e-5 * float(ref8.abs().max())
+
+
 def test_vit_tower_read_at_token0_skips_dead_rows_of_its_last_block(aux):
     """cfg.vit_token0: the aux ViT-B/32 is read at its class token only (reference CLIP/clip/model.py:443-446), so the last block's
     out_proj / ln_2 / MLP run on that row alone.  Features and the gradient with respect to the input image equal the all-rows form

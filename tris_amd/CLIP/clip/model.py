@@ -309,6 +309,16 @@ class ResidualAttentionBlock(nn.Module):
         return self.mlp.c_proj(f, resid=x, grad_box_res=b2)
 
 
+    def forward_packed(self, x, plan, N, L):
+        """the block on PACKED text rows [N L, W] (no gradient; CLIP.encode_text_hidden): every op but the attention is row-wise and
+        runs under the row limit of the plan; the attention walks each sentence's own row range"""
+        h = self.ln_1(x)
+        qkv = ops.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        a = ops.mha_packed(qkv, plan, N, L, self.attn.num_heads, self.causal)
+        x = self.attn.out_proj(a, resid=x)
+        h = self.ln_2(x)
+        return self.mlp.c_proj(self.mlp.c_fc(h, act=2), resid=x)
+
     def forward_token0(self, x):
         """The block as the LAST one of a tower that is read at token 0 only (VisionTransformer.forward_patches: ln_post(x[:, 0]) @ proj,
         reference CLIP/clip/model.py:443-446): keys and values need every token, but everything behind the attention is row-wise, and
@@ -485,6 +495,27 @@ class CLIP(nn.Module):
         x = self.ln_final(x)
         hidden = ops.matmul(ops.eot_gather(ids, x), self.text_projection)
         return x, hidden
+
+    def encode_text_hidden(self, text):
+        """encode_text(text)[1] -- what every caller of the Stage-1 path uses.  Without gradients (the frozen aux tower: 4 of 5 sentence
+        passes of a training step) the pass runs on PACKED rows (cfg.text_pack): `hidden` is the row at each sentence's EOT token and
+        the mask is causal, so the positions behind EOT -- 42 % of a RefCOCOg-shaped batch -- cannot reach it
+        (tests/test_oracle_golden.py::test_tokens_behind_eot_cannot_reach_hidden) and are not computed.  All extents are device words
+        (ops.text_pack_plan): a captured pass replays for any token ids.  Same values as the padded pass up to the tile choice of the
+        products (fewer rows)."""
+        ids = text.long()
+        if (not cfg.text_pack or torch.is_grad_enabled() or not ops.text_packable(ids.shape[1]) or ids.shape[1] > self.txt_length
+                or not ids.is_cuda):
+            return self.encode_text(text)[1]
+        ids = ids.contiguous()
+        N, L = ids.shape
+        plan = ops.text_pack_plan(ids)
+        x = ops.embed_packed(ids, self.token_embedding.weight, self.positional_embedding, plan)
+        with ops.rows_limit(plan):
+            for blk in self.transformer.resblocks:
+                x = blk.forward_packed(x, plan, N, L)
+            x = self.ln_final(x)
+        return ops.matmul(ops.eot_gather_packed(x, plan, N), self.text_projection)
 
     def forward(self, image, text):
         raise NotImplementedError("CLIP.forward (zero-shot logits) is not on the Stage-1 path")

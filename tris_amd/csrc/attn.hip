@@ -269,6 +269,137 @@ __global__ void eot_gather_kernel(const long* __restrict__ ids, const float* __r
   }
 }
 
+// ---- packed text rows (round 6; reference CLIP/clip/model.py:537-564) -------------------------------------------------------------
+// A causal text tower is read at the EOT row of every sentence only, and under the causal mask nothing behind that row can reach it
+// (tests/test_oracle_golden.py::test_tokens_behind_eot_cannot_reach_hidden): the rows behind EOT -- 42 % of a RefCOCOg-shaped batch --
+// need not exist.  The packed pass keeps the rows 0 .. eot_n of sentence n back to back.  All extents live in a device array `plan`
+// so that a captured pass stays valid for any token ids:
+//   plan[0] = P   rows in use            plan[1] = P rounded up to 256 = the ROW LIMIT of the row-wise launches (tris_rows_limit_thread)
+//   plan[2 + n], n = 0 .. N: first packed row of sentence n (plan[2 + N] = P)
+//   plan[3 + N + r], r = 0 .. R - 1 (R = N L rounded up to 256 = the row count of every packed buffer): the source token n L + l of
+//   packed row r, -1 for r >= P
+// Rows P .. plan[1] - 1 are kept ZERO at the input (and by the attention kernel): row-wise launches compute them like any row --
+// finite values of ordinary size, never read by a sentence -- so tiles and amax by-products need no masks; rows >= plan[1] are never
+// touched.
+__global__ __launch_bounds__(256) void text_pack_plan_kernel(const long* __restrict__ ids, int N, int L, int* __restrict__ plan) {
+  extern __shared__ int len[];     // [N]
+  for (int n = threadIdx.x; n < N; n += 256) {
+    int best = 0;
+    long bv = ids[(long)n * L];
+    for (int l = 1; l < L; ++l) {
+      const long vv = ids[(long)n * L + l];
+      if (vv > bv) { bv = vv; best = l; }
+    }
+    len[n] = best + 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int n = 0; n < N; ++n) { plan[2 + n] = acc; acc += len[n]; }
+    plan[2 + N] = acc;
+    plan[0] = acc;
+    plan[1] = ((acc + 255) / 256) * 256;
+  }
+  __syncthreads();
+  int* map = plan + 3 + N;
+  const int P = plan[0];
+  const int R = ((N * L + 255) / 256) * 256;      // the packed buffers have R rows: plan[1] <= R
+  for (int r = P + threadIdx.x; r < R; r += 256) map[r] = -1;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const int o = plan[2 + n];
+    for (int l = 0; l < len[n]; ++l) map[o + l] = n * L + l;
+  }
+}
+
+__global__ void embed_packed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                        const int* __restrict__ plan, float* __restrict__ out, long NL, int N, int L, int W) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W4 = W >> 2;
+  if (i >= NL * W4) return;
+  const long r = i / W4;
+  if (r >= plan[1]) return;
+  const int c = (int)(i - r * W4) * 4;
+  const int t = plan[3 + N + r];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t >= 0) {
+    const float4 a = *reinterpret_cast<const float4*>(tok + ids[t] * W + c);
+    const float4 b = *reinterpret_cast<const float4*>(pos + (long)(t % L) * W + c);
+    o = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+  *reinterpret_cast<float4*>(out + r * W + c) = o;
+}
+
+// mha_fwd_kernel over packed rows: workgroup (head, n) owns the plan[2 + n + 1] - plan[2 + n] rows of sentence n; the extra workgroups
+// n == N keep the rows P .. plan[1] - 1 of `out` zero (the next product reads them).  LDS sized for Lmax rows.
+__global__ __launch_bounds__(256) void mha_packed_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                             const int* __restrict__ plan, int N, int Lmax, int W, int causal,
+                                                             float scale, unsigned* __restrict__ amax) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  if (n == N) {
+    const int P = plan[0], P2 = plan[1];
+    for (int idx = tid; idx < (P2 - P) * (HD / 4); idx += 256) {
+      const int i = P + (idx >> 4), d = (idx & 15) * 4;
+      *reinterpret_cast<float4*>(out + (long)i * W + h * HD + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (amax != nullptr) amax_commit_block(0u, amax);
+    return;
+  }
+  const int r0 = plan[2 + n], L = plan[2 + n + 1] - r0;
+  float* q = sm;
+  float* k = q + Lmax * HP;
+  float* v = k + Lmax * HP;
+  float* s = v + Lmax * HP;  // [L][L+1]
+  const int LP = L + 1;
+  const float* base = qkv + (long)r0 * 3 * W + h * HD;
+  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
+    const int l = idx >> 4, d = (idx & 15) * 4;
+    const float* r = base + (long)l * 3 * W + d;
+    *reinterpret_cast<float4*>(&q[l * HP + d]) = *reinterpret_cast<const float4*>(r);
+    *reinterpret_cast<float4*>(&k[l * HP + d]) = *reinterpret_cast<const float4*>(r + W);
+    *reinterpret_cast<float4*>(&v[l * HP + d]) = *reinterpret_cast<const float4*>(r + 2 * W);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * L; idx += 256) {
+    const int i = idx / L, j = idx - i * L;
+    float acc = -INFINITY;
+    if (!causal || j <= i) {
+      acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) acc += dot4(lds4(&q[i * HP + d]), lds4(&k[j * HP + d]));
+      acc *= scale;
+    }
+    s[i * LP + j] = acc;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int i = wv; i < L; i += 4) {
+    float x = lane < L ? s[i * LP + lane] : -INFINITY;
+    float m = wave_max(x);
+    float e = lane < L ? expf(x - m) : 0.f;
+    float sum = wave_sum(e);
+    if (lane < L) s[i * LP + lane] = e / sum;
+  }
+  __syncthreads();
+  float* ob = out + (long)r0 * W + h * HD;
+  unsigned am = 0u;
+  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
+    const int i = idx >> 4, d = (idx & 15) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < L; ++j) fma4(acc, s[i * LP + j], lds4(&v[j * HP + d]));
+    *reinterpret_cast<float4*>(&ob[(long)i * W + d]) = acc;
+    am = max(am, abits4(acc));
+  }
+  if (amax != nullptr) amax_commit_block(am, amax);
+}
+
+// out[n] = x[last packed row of sentence n]
+__global__ void eot_gather_packed_kernel(const float* __restrict__ x, const int* __restrict__ plan, float* __restrict__ out, int W) {
+  const int n = blockIdx.x;
+  const long r = plan[2 + n + 1] - 1;
+  for (int c = threadIdx.x; c < W; c += blockDim.x) out[(long)n * W + c] = x[r * W + c];
+}
+
 // both kernels may need more than the default 64 KB of dynamic LDS (L = 50..64)
 int mha_init() {
   static int state = -1;
@@ -299,6 +430,43 @@ extern "C" int tris_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv
   if (int e = mha_init()) return e;
   hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, qkv, dout, dqkv, L, W, causal,
                      0.125f, tris_internal_take_amax_next());
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_text_pack_plan_i64(const long* ids, int N, int L, int* plan, void* stream) {
+  if (N < 1 || L < 1 || N > 8192) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream, ids, N, L, plan);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_embed_packed_fwd_f32(const long* ids, const float* tok, const float* pos, const int* plan, float* out, int N, int L,
+                                         int W, void* stream) {
+  if (W % 4) return (int)hipErrorInvalidValue;
+  const long R = (((long)N * L + 255) / 256) * 256;      // rows of `out`
+  const long n = R * (W / 4);
+  hipLaunchKernelGGL(embed_packed_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, tok, pos, plan, out,
+                     R, N, L, W);
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_mha_packed_fwd_f32(const float* qkv, float* out, const int* plan, int N, int Lmax, int W, int heads, int causal,
+                                       void* stream) {
+  if (W != heads * HD || Lmax > 64 || Lmax < 1) return (int)hipErrorInvalidValue;
+  static int st = -1;
+  if (st < 0) st = (int)hipFuncSetAttribute((const void*)mha_packed_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (st) return st;
+  const size_t lds = (size_t)(3 * Lmax * HP + Lmax * (Lmax + 1)) * sizeof(float);
+  hipLaunchKernelGGL(mha_packed_fwd_kernel, dim3(heads, N + 1), dim3(256), lds, (hipStream_t)stream, qkv, out, plan, N, Lmax, W, causal,
+                     0.125f, tris_internal_take_amax_next());
+  TRIS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tris_eot_gather_packed_f32(const float* x, const int* plan, float* out, int N, int W, void* stream) {
+  hipLaunchKernelGGL(eot_gather_packed_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, plan, out, W);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -492,6 +492,7 @@ static bool stats_eligible(const GemmParams& p) { return gemm_fast_ok(p) && p.M 
 // One-shot arming of the NEXT tris_gemm_f32 of the calling thread with two epilogue extras (GemmParams::pre_out / dact_x)
 struct EpiNext { float* pre; const float* dact; bool armed; };
 static thread_local EpiNext g_epi_next = {nullptr, nullptr, false};
+extern "C" __attribute__((visibility("hidden"))) const int* tris_internal_rows_limit();   // (norm.hip: tris_rows_limit_thread)
 extern "C" int tris_gemm_epilogue_next(float* pre_out, const float* dact_x) {
   g_epi_next = {pre_out, dact_x, pre_out != nullptr || dact_x != nullptr};
   return 0;
@@ -524,6 +525,7 @@ extern "C" int tris_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.amax_out = amax_out;
   p.tickets = tkn.t;
   p.tickets_n = tkn.n;
+  if (!transA && batch == 1) p.m_limit = tris_internal_rows_limit();
   if (epi.armed) { p.pre_out = epi.pre; p.dact_x = epi.dact; }
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;

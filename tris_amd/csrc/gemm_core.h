@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int tile = blockIdx.x;
   const int m0 = (tile / p.tiles_n) * BM;
   const int n0 = (tile % p.tiles_n) * BN;
+  if (p.m_limit != nullptr && m0 >= *p.m_limit) return;   // (packed text rows: uniform exit before the first barrier)
   const int zb = blockIdx.z / p.splitk;  // batch index
   const int zs = blockIdx.z % p.splitk;  // k slice
   const int kbeg = zs * p.kchunk;
@@ -340,7 +341,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmParams p) {
   const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   const long total = (long)p.M * p.N;
-  if (idx >= total) {
+  if (idx >= total || (p.m_limit != nullptr && idx / p.N >= (long)*p.m_limit)) {
     if (p.amax_out != nullptr) amax_commit(0u, p.amax_out);   // (all lanes of the wave take part in the shuffles)
     return;
   }
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(64 * G) void splitk_reduce_wide_kernel(const float*
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long total = (long)p.M * p.N;
   const long idx = ((long)blockIdx.x * 64 + c) * 4;
-  const bool in = idx < total;
+  const bool in = idx < total && !(p.m_limit != nullptr && idx / p.N >= (long)*p.m_limit);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (in) {
     int s = g;

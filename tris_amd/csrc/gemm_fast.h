@@ -174,6 +174,7 @@ void gemm_fast_kernel(GemmParams p) {
   const int tile = bid_x;
   const int m0 = (tile / p.tiles_n) * BM;
   const int n0 = (tile % p.tiles_n) * BN;
+  if (p.m_limit != nullptr && m0 >= *p.m_limit) return;   // (uniform: the whole workgroup leaves before its first barrier)
   const int zb = bid_z / p.splitk;
   const int zs = bid_z % p.splitk;
   const int kbeg = zs * p.kchunk;

@@ -61,6 +61,9 @@ struct GemmParams {
   // fused split-K finish (EPI_SLAB, fast kernel, batch 1, at most TRIS_FUSE_SPLITK_MAX slices; armed by tris_splitk_tickets_next):
   // one int per output tile, zero between launches; the last-arriving block of a tile sums the slabs and writes Cfin
   // (gemm_fast.h "fused split-K finish"); NULL: the slabs are summed by splitk_reduce_kernel in a launch of its own
+  // packed text rows (tris_rows_limit_thread): a device word; tiles whose first row is >= *m_limit leave at once, the split-K reduce
+  // skips those rows (row-major A only; the limit is a multiple of every tile height, so a tile is either whole or absent)
+  const int* m_limit;
   int* tickets;
   int tickets_n;    // (host: capacity of the armed array; run_cfg keeps `tickets` only where the fused form is launched)
   float* Cfin;

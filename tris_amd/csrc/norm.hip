@@ -573,10 +573,12 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ Y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            long rows, int W, float eps, unsigned* __restrict__ amax = nullptr) {
+                                                            long rows, int W, float eps, unsigned* __restrict__ amax = nullptr,
+                                                            const int* __restrict__ limit = nullptr) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (limit != nullptr && row >= (long)*limit) return;   // (packed text rows: nothing lives behind the limit; a whole wave leaves)
   unsigned am = 0u;
   const int W4 = W >> 2;
   float4 v[4];
@@ -847,6 +849,14 @@ static unsigned* take_amax_next() {
 }
 // (the other translation units that can produce an amax -- attention kernels, the GEMM epilogue -- take the arming through this)
 extern "C" __attribute__((visibility("hidden"))) unsigned* tris_internal_take_amax_next() { return take_amax_next(); }
+// Row limit of the calling thread (tris_rows_limit_thread, include/tris_hip.h "packed text rows"): a device word; launches of
+// tris_gemm_f32 (row-major A) and tris_layernorm_fwd_f32 skip rows >= *limit.  Persistent until cleared with NULL.
+static thread_local const int* g_rows_limit = nullptr;
+extern "C" __attribute__((visibility("hidden"))) const int* tris_internal_rows_limit() { return g_rows_limit; }
+extern "C" int tris_rows_limit_thread(const int* limit) {
+  g_rows_limit = limit;
+  return 0;
+}
 extern "C" int tris_amax_next(unsigned* out) {
   g_amax_next = out;
   return 0;
@@ -1123,7 +1133,7 @@ extern "C" int tris_layernorm_fwd_f32(const float* X, const float* gamma, const 
                                       float* rstd, long rows, int W, float eps, void* stream) {
   if (W % 4 || W > 1024) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, X, gamma, beta, Y,
-                     mean, rstd, rows, W, eps, take_amax_next());
+                     mean, rstd, rows, W, eps, take_amax_next(), g_rows_limit);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -67,7 +67,7 @@ class GraphedFrozenText:
         dev = next(clip_model.parameters()).device
         self.s_ids = torch.zeros(n, L, device=dev, dtype=torch.int64)
         self.s_ids[:, 0] = 49406
-        self.s_ids[:, 1] = 49407
+        self.s_ids[:, L - 1] = 49407      # (full-length sentences: the warm-up calls -- and the autotuner behind them -- see every row in use)
         from . import ops
         # (h2 products tag their operands with words of a PER-STEP amax pool: a graph that outlives the step must not hold such
         # pointers -- this tower owns its words, cleared inside the graph; its frozen weights have constant words)
@@ -77,14 +77,14 @@ class GraphedFrozenText:
             cap.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cap):
                 for _ in range(warmup):
-                    clip_model.encode_text(self.s_ids)
+                    clip_model.encode_text_hidden(self.s_ids)
             torch.cuda.current_stream().wait_stream(cap)
             self.g = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (the collective backend's watchdog, the autograd engine of a previous
             # step) may touch the device while this stream is capturing
             with torch.cuda.graph(self.g, capture_error_mode="thread_local"):
                 self.h2.reset()
-                self.out = clip_model.encode_text(self.s_ids)[1]
+                self.out = clip_model.encode_text_hidden(self.s_ids)
 
     def __call__(self, ids):
         """replay on the CURRENT stream; returns a COPY of the static [n, E] output (a few hundred KB): the loss keeps it for
@@ -327,7 +327,7 @@ class SegmentedTrainStep:
             self.g_faux = G()
             with torch.no_grad(), self.h2_aux:
                 ids_all, f_all = _capture(self.g_faux, self.text, pool_t,
-                                          lambda: (self.h2_aux.reset(), (lambda i: (i, clip_model.encode_text(i)[1]))(ids_all_()))[1])
+                                          lambda: (self.h2_aux.reset(), (lambda i: (i, clip_model.encode_text_hidden(i)))(ids_all_()))[1])
             at = "layer2"   # the TRIS text encoder starts behind this trunk stage (measured best of stem / layer1..3)
             fwd = _Chain(self.cap, pool_c)
             marks = {}
@@ -627,10 +627,10 @@ def frozen_text(clip_model, ids):
     from . import ops
     from .config import cfg
     if not cfg.hipgraph or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
-        return clip_model.encode_text(ids)[1]
+        return clip_model.encode_text_hidden(ids)
     n, L = ids.shape
     cache = clip_model.__dict__.setdefault("_tris_text_graphs", {})
-    key = (n, L, clip_model.token_embedding.weight.data_ptr(), ops.get_gemm_mode())
+    key = (n, L, clip_model.token_embedding.weight.data_ptr(), ops.get_gemm_mode(), cfg.text_pack)
     g = cache.get(key)
     if g is None:
         if len(cache) >= 4:

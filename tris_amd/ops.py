@@ -2189,6 +2189,61 @@ def eot_gather(ids, x):
     return EotGatherFn.apply(ids, x)
 
 
+# ---- packed text rows (csrc/attn.hip "packed text rows"; include/tris_hip.h) -- forward only, no autograd: the frozen aux tower
+class rows_limit:
+    """inside: this thread's tris_gemm_f32 (row-major A) and LayerNorm-forward launches skip rows >= plan[1] (a device word)"""
+
+    def __init__(self, plan):
+        self.ptr = plan.data_ptr() + 4
+
+    def __enter__(self):
+        call("tris_rows_limit_thread", self.ptr)
+
+    def __exit__(self, *exc):
+        call("tris_rows_limit_thread", None)
+        return False
+
+
+def packed_rows(N, L):
+    """rows of every packed buffer: N L rounded up to the 256-row granule of the row limit"""
+    return (N * L + 255) // 256 * 256
+
+
+def text_packable(L):
+    return not _BATCH_INVARIANT and 1 <= L <= 64
+
+
+def text_pack_plan(ids):
+    """ids int64 [N, L] -> plan (int32 device array: rows in use, row limit, first row of every sentence, source token of every row)"""
+    N, L = ids.shape
+    plan = torch.empty(3 + N + packed_rows(N, L), device=ids.device, dtype=torch.int32)
+    call("tris_text_pack_plan_i64", P(ids), N, L, plan.data_ptr(), _stream())
+    return plan
+
+
+def embed_packed(ids, tok, pos, plan):
+    N, L = ids.shape
+    W = tok.shape[1]
+    out = torch.empty(packed_rows(N, L), W, device=tok.device, dtype=torch.float32)
+    call("tris_embed_packed_fwd_f32", P(ids), P(tok), P(pos), plan.data_ptr(), P(out), N, L, W, _stream())
+    return out
+
+
+def mha_packed(qkv, plan, N, L, heads, causal):
+    """qkv [N L, 3 W] packed rows -> out [N L, W]; sentence n attends inside its own row range (L: the longest possible sentence)"""
+    W = qkv.shape[-1] // 3
+    out = torch.empty(qkv.shape[0], W, device=qkv.device, dtype=torch.float32)
+    h2_mark_next(out)
+    call("tris_mha_packed_fwd_f32", P(qkv), P(out), plan.data_ptr(), N, L, W, heads, int(causal), _stream())
+    return out
+
+
+def eot_gather_packed(x, plan, N):
+    out = torch.empty(N, x.shape[-1], device=x.device, dtype=torch.float32)
+    call("tris_eot_gather_packed_f32", P(x), plan.data_ptr(), P(out), N, x.shape[-1], _stream())
+    return out
+
+
 def token0(x):
     """x[:, 0, :] of [N, L, W] as a copy, with its own backward kernel (the ViT class token, CLIP/clip/model.py:443)"""
     return EotGatherFn.apply(None, x)

@@ -78,7 +78,7 @@ def stage1_loss_block(clip_model, img, cls, sig_out, f_all, ids_all, K, args):
     f_i = vit.forward_patches(ops.fg_patches(cam, im, vit.patch_size))
     with torch.no_grad():
         if f_all is None:
-            f_all = clip_model.encode_text(ids_all)[1]
+            f_all = clip_model.encode_text_hidden(ids_all)
         elif callable(f_all):
             f_all = f_all()
         f_t = f_all[:B].contiguous()
