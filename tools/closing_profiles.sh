@@ -1,7 +1,7 @@
 # measurement set of a round for ONE arithmetic (run on the GPU box through gpurun):
 #   TAG=r5 MODE=h2 bash tools/closing_profiles.sh      -> gpurun_out/${TAG}_${MODE}_*   (MODE = h2 | x3; copy what is to be kept into profiles/)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-TAG=${TAG:-r5}; MODE=${MODE:-h2}; P=${TAG}_${MODE}
+TAG=${TAG:-r6}; MODE=${MODE:-h2}; P=${TAG}_${MODE}
 export TRIS_GEMM_MODE=$MODE
 B="python bench.py --steps 2 --warmup 1 --headline-only"
 # 1. kernel trace of the production configuration (autotuned, three streams, the step replayed from its graphs), the timed steps only.

@@ -1,6 +1,6 @@
 # closing run of a round (on the GPU box: gpurun -- bash tools/closing_run.sh): full GPU test suite, smoke, bench (with CPU baseline and every side leg; autotuner log per arithmetic), the cross-attention phase table, then the profile sets of tools/closing_profiles.sh for h2 and x3; outputs under gpurun_out/, copied to profiles/ by hand
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-export TAG=${TAG:-r5}
+export TAG=${TAG:-r6}
 timeout 1800 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/${TAG}_gputests.log 2>&1 < /dev/null; echo "tests rc=$?"; grep -E "passed|failed" gpurun_out/${TAG}_gputests.log | tail -2
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1 < /dev/null; tail -1 gpurun_out/${TAG}_smoke.log
 TRIS_TUNE_LOG=gpurun_out/${TAG}_autotune_log_all.txt timeout 1200 python bench.py > gpurun_out/${TAG}_bench.log 2>&1 < /dev/null; grep "^{" gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; cut -c1-300 gpurun_out/${TAG}_bench.json
