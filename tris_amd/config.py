@@ -51,9 +51,16 @@ def _flag(name, default):
 
 
 class _Config:
+    def __setattr__(self, name, value):
+        # (the trainer may pick its own default for step_graph only while nobody -- environment or code -- has chosen one)
+        if name == "step_graph" and "step_graph" in self.__dict__:
+            self.__dict__["step_graph_chosen"] = True
+        self.__dict__[name] = value
+
     def __init__(self):
         e = os.environ.get
         self.step_graph = e("TRIS_STEP_GRAPH", "0")
+        self.step_graph_chosen = "TRIS_STEP_GRAPH" in os.environ
         self.hipgraph = _flag("TRIS_HIPGRAPH", True)
         self.text_stream = _flag("TRIS_TEXT_STREAM", True)
         self.wgrad_stream = _flag("TRIS_WGRAD_STREAM", True)
@@ -101,7 +108,7 @@ class _Config:
     def key(self):
         """what a captured step depends on: tris_amd.train_stage1.train_step records the step again when this (or the arithmetic, the
         optimiser, the reducer, the aux model) changes; a batch of another shape runs eagerly next to the kept recording"""
-        return tuple(sorted(self.__dict__.items()))
+        return tuple(sorted((k, v) for k, v in self.__dict__.items() if k != "step_graph_chosen"))
 
 
 cfg = _Config()

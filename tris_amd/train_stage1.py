@@ -308,7 +308,8 @@ def _main(args, tokenizer=None):
         local_rank = 0
         if cfg.own_stream and torch.cuda.is_available():
             torch.cuda.set_stream(ops.compute_stream())   # (never compute on the default stream: ops.compute_stream)
-    if "TRIS_STEP_GRAPH" not in os.environ:
+    if not cfg.step_graph_chosen:
+        # (neither the environment nor the caller chose an issue form -- cfg.step_graph still holds its default)
         # the trainer replays its steps from the segmented hipGraphs (what bench.py reports as `value`): the host issues a step in
         # ~2 ms instead of ~30 ms of eager launches; batches of another shape (the last one of an epoch) run eagerly (train_step)
         cfg.step_graph = "seg"
