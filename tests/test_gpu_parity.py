@@ -962,7 +962,7 @@ def test_rccl_code_path_single_rank(model, aux, batch, golden):
         refill(model)
 
 
-def test_three_step_training_trajectory_matches_oracle(model, aux):
+def test_three_step_training_trajectory_matches_oracle(model, aux, arith):
     """Training dynamics, not just one step: three optimisation steps on three different batches, HIP path vs the CPU
     oracle from the same initial weights -- the loss of every step agrees (the later ones depend on the earlier AdamW
     updates), and the two trained models then produce the same evaluation masks (mask IoU >= 0.98; the mIoU criterion of
@@ -992,7 +992,10 @@ def test_three_step_training_trajectory_matches_oracle(model, aux):
                 # apart slowly -- the bound is 1e-3 for the first step, 3e-3 for the second, 1e-2 for the third: a change of
                 # summation order in ONE kernel moved step 3 by 6e-3 (fp32 instead of fp64 partial statistics of the stem's first
                 # convolution) and step 2 by 1.1e-3 (x3: the cross-attention backward as one launch instead of a chain of products))
-                tol = (1e-3, 3e-3, 1e-2)[step] * max(1.0, abs(ref[k]))
+                # (the second step's looser bound only where it is needed -- measured in round 6, as fractions of max(1, |ref|):
+                #  x3 <= 6e-5 at steps 1-2, 4e-3 / 20 at step 3; h2 1.7e-3 / 2.3 on l4 at step 2)
+                tol = (1e-3, 1e-3 if arith == "x3" else 3e-3, 1e-2)[step] * max(1.0, abs(ref[k]))
+                print(f"trajectory[{arith}] step {step} {k}: |hip - oracle| = {abs(hip[i] - ref[k]):.2e} (bound {tol:.0e})")
                 assert abs(hip[i] - ref[k]) < tol, (step, k, hip[i], ref[k])
         model.eval()
         b = synthetic_batch(2, 320, 20, 3, seed=7)

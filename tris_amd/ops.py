@@ -1104,10 +1104,30 @@ def _retag(t, tag):
 _PL_GRAD = {}   # data_ptr -> (step, word, shape): gradients a BatchNorm backward wrote as planes, until their one consumer takes them
 
 
+_PL_GRAD_CB = [False]
+
+
+def _pl_grad_end_of_backward():
+    """ runs when the autograd pass that registered plane gradients ends: an entry that is still there found no
+    plane-aware consumer -- its bytes were read as fp32 by whoever took the tensor, and the address-keyed tag would wait for an
+    unrelated gradient that reuses the address.  Never silent: drop the entries and raise."""
+    _PL_GRAD_CB[0] = False
+    if _PL_GRAD:
+        left = [(hex(k), v[2]) for k, v in _PL_GRAD.items()]
+        _PL_GRAD.clear()
+        raise RuntimeError(f"plane gradients without a plane-aware consumer at the end of backward: {left[:4]}")
+
+
 def pl_grad_out(t, word):
     pl_tag(t, word)
     _PL_GRAD[t.data_ptr()] = (_H2["step"], word, tuple(t.shape))
     PL_STATS["dx_planes"] += 1
+    if not _PL_GRAD_CB[0]:
+        try:   # (inside an autograd pass: BatchNormFn.backward calls this)
+            torch.autograd.Variable._execution_engine.queue_callback(_pl_grad_end_of_backward)
+            _PL_GRAD_CB[0] = True
+        except RuntimeError:
+            pass
     return t
 
 
