@@ -199,6 +199,12 @@ int tris_h2_next(const unsigned* amaxA, const unsigned* amaxB, float scaleA, flo
  * the same scales.  flags bit 0: the bn_y operand of tris_gemm_bnbwd_f32 is a plane tensor as well; bit 1: the weight operand of
  * tris_gemm_bnbwd_f32 is given TRANSPOSED ([N][K] = W^T, tris_h2_planes_t_segments_f32).  A product the fast kernels do not
  * serve FAILS (hipErrorInvalidValue): there is no fp32 operand to fall back on; the *_bnin forms refuse planes. */
+/* Bit masks (round 6): tris_bn_mask_next(mask) arms the calling thread's NEXT tris_bn_apply_pl_f32 to write, beside its plane output
+ * [M, C], the ReLU mask of that output as one BYTE per 8 channels (M C / 8 bytes; bit t <=> channel 8 g + t is positive, decided as a
+ * reader of the planes would); tris_h2_next_planes flags bit 2 tells tris_gemm_bnbwd_f32 that its bn_y argument IS that byte array
+ * (1 bit per element read in the fused BatchNorm-backward epilogue instead of the 4-byte plane element: model.py:42-55's
+ * relu(bn3(..) + identity) outputs are the widest tensors of a Bottleneck). */
+int tris_bn_mask_next(unsigned char* mask);
 int tris_h2_planes_f32(const float* x, float* planes_out, long n, const unsigned* word, void* stream);
 int tris_h2_planes_segments_f32(const float* base, const long* offs, const long* sizes, const long* slot_index, int nseg,
                                 const unsigned* slots, float* out_base, void* stream);

@@ -355,6 +355,62 @@ def test_two_forwards_then_one_backward_outside_an_explicit_step(ops):
     ops.h2_end_step()
 
 
+def test_relu_byte_mask_equals_the_mask_read_from_the_planes(ops):
+    """cfg.bn_bitmask: relu(bn3(..) + identity) leaves, beside its plane output, its ReLU mask as one byte per 8 channels
+    (tris_bn_mask_next) and the next block's conv1 data-gradient epilogue masks with that byte instead of the plane element
+    (tris_h2_next_planes flag 4).  The bits are decided exactly as a reader of the planes decides -- so the whole training step is
+    BIT-identical with the option on and off (losses, every gradient), and the masks were really used (the link carries one)."""
+    import warnings
+    from tris_amd.args import get_parser
+    from tris_amd.CLIP import clip
+    from tris_amd.config import cfg
+    from tris_amd.model.model_stage1 import TRIS
+    from tris_amd.optim import FusedAdamW
+    from tris_amd.train_stage1 import freeze_aux, stage1_forward_losses
+    from tris_amd.utils.synth import seed_fill, synthetic_batch
+    args = get_parser().parse_args(["--backbone", "clip-RN50", "--size", "320", "--max_query_len", "20", "--negative_samples", "3",
+                                    "--batch_size", "2"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        aux, _ = clip.load("ViT-B-32", device="cuda", txt_length=20)
+    seed_fill(aux.state_dict(), 4321)
+    aux = freeze_aux(aux)
+    batch = synthetic_batch(2, 320, 20, 3, seed=7)
+    res = {}
+    made = []
+    orig = ops._BnBwdLink.fill
+
+    def spy(self, *a, **k):
+        made.append(self.mask is not None)
+        return orig(self, *a, **k)
+    for on in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = TRIS(args).cuda().train()
+        seed_fill(model.state_dict(), 1234)
+        bb, new = model.trainable_parameters()
+        opt = FusedAdamW([{"params": bb, "lr": args.lr * args.lr_multi}, {"params": new}], lr=args.lr, weight_decay=args.weight_decay)
+        made.clear()
+        ops._BnBwdLink.fill = spy
+        try:
+            with cfg.override(bn_bitmask=on):
+                ops.h2_begin_step()
+                losses, _, _ = stage1_forward_losses(model, aux, batch["img"].cuda(), batch["word_ids"].cuda(), batch["neg_word_ids"].cuda(), args)
+                opt.zero_grad()
+                losses[0].backward()
+                ops.wgrad_join()
+                ops.h2_end_step()
+        finally:
+            ops._BnBwdLink.fill = orig
+        torch.cuda.synchronize()
+        res[on] = (losses.detach().clone(), [a.g.clone() for a in opt.arenas], sum(made))
+        del model, opt
+    assert res[True][2] >= 8 and res[False][2] == 0, (res[True][2], res[False][2])     # fused epilogues that masked from the byte array
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_training_step_with_planes_against_the_golden_step(ops, golden):
     """the B = 2 step of tests/test_gpu_parity.py (G5) with operand planes on: the trunk's products run on planes (counted), nothing
     falls back to rebuilt fp32 tensors on the hot path, every plane gradient finds its one consumer, and the losses are the

@@ -39,6 +39,8 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   vit_token0         TRIS_VIT_TOKEN0           ViT image tower read at its class token: the last block's out_proj / MLP on that row only (0: all 50 rows)
   gemm_convert       TRIS_GEMM_CONVERT         h2 planes: products of a ViT tower with at least this many rows convert their fp32 A operand to planes first (0 = default: never -- measured slower in both configurations, profiles/r6_gemm_convert_ab.txt)
   text_pack          TRIS_TEXT_PACK            no-gradient text passes (the frozen aux tower) on packed rows: positions behind EOT are not computed
+  bn_bitmask         TRIS_BN_BITMASK           operand planes: relu(bn(x) + identity) also leaves its ReLU mask as one byte per 8 channels; the consumer's fused
+                                               BatchNorm-backward epilogue reads that instead of the plane element
   fuse_splitk        TRIS_FUSE_SPLITK_PY       split-K products armed with a ticket array: the last block of a tile sums the slabs in the product's own launch (default 0: measured slower)
 """
 import contextlib
@@ -91,6 +93,7 @@ class _Config:
         self.fuse_splitk = _flag("TRIS_FUSE_SPLITK_PY", False)
         self.aux_text_early = _flag("TRIS_AUX_TEXT_EARLY", True)
         self.text_pack = _flag("TRIS_TEXT_PACK", True)
+        self.bn_bitmask = _flag("TRIS_BN_BITMASK", True)
         self.gemm_convert = int(e("TRIS_GEMM_CONVERT", "0"))
         self.vit_token0 = _flag("TRIS_VIT_TOKEN0", True)
 

@@ -160,7 +160,7 @@ struct H2Guard {
     if (!gemm_fast_ok(p)) { bad = n.planes; return; }
     p.h2_amaxA = n.a; p.h2_amaxB = n.b; p.h2_sA = n.sa; p.h2_sB = n.sb;
     g_mode_thread = n.planes ? 4 : 3;
-    p.bnb_y_pl = (n.planes && (n.flags & 1)) ? 1 : 0;
+    p.bnb_y_pl = (n.planes && (n.flags & 4)) ? 2 : (n.planes && (n.flags & 1)) ? 1 : 0;   // (4: bn_y is the BYTE mask of tris_bn_mask_next)
     on = true;
   }
   ~H2Guard() { if (on) g_mode_thread = saved; }

@@ -956,7 +956,15 @@ void gemm_fast_kernel(GemmParams p) {
               if (p.bnb_x != nullptr) {
                 const long o = (long)row * p.ldc + col;
                 const float4 xx = ld4s(p.bnb_x + o, nt_e);
-                if (p.bnb_y != nullptr && p.bnb_y_pl) {
+                if (p.bnb_y != nullptr && p.bnb_y_pl == 2) {
+                  // the ReLU mask as one BYTE per 8 columns, written by the forward pass beside the planes (tris_bn_mask_next): 1 bit
+                  // per element instead of re-reading the 4-byte plane element
+                  const unsigned mb = reinterpret_cast<const unsigned char*>(p.bnb_y)[((long)row * p.ldc + col) >> 3] >> (col & 4);
+                  if (!(mb & 1u)) v.x = 0.f;
+                  if (!(mb & 2u)) v.y = 0.f;
+                  if (!(mb & 4u)) v.z = 0.f;
+                  if (!(mb & 8u)) v.w = 0.f;
+                } else if (p.bnb_y != nullptr && p.bnb_y_pl) {
                   // y = relu(..) as fp16 piece planes (8 columns = 16 bytes of hi pieces, then 16 of lo pieces): y > 0 <=> a piece is non-zero
                   const char* yb = reinterpret_cast<const char*>(p.bnb_y + (long)row * p.ldc + (col & ~7)) + (col & 4) * 2;
                   const uint2 yh = *reinterpret_cast<const uint2*>(yb), yl = *reinterpret_cast<const uint2*>(yb + 16);
@@ -1024,7 +1032,9 @@ void gemm_fast_kernel(GemmParams p) {
               const long o = (long)row * p.ldc + col;
               const float xx = p.bnb_x[o], mu1 = p.bnb_mean[col], is1 = p.bnb_invstd[col];
               bool on;
-              if (p.bnb_y != nullptr && p.bnb_y_pl) {
+              if (p.bnb_y != nullptr && p.bnb_y_pl == 2) {
+                on = (reinterpret_cast<const unsigned char*>(p.bnb_y)[((long)row * p.ldc + col) >> 3] >> (col & 7)) & 1u;
+              } else if (p.bnb_y != nullptr && p.bnb_y_pl) {
                 const unsigned short* yb = reinterpret_cast<const unsigned short*>(p.bnb_y + (long)row * p.ldc + (col & ~7)) + (col & 7);
                 on = ((yb[0] | yb[8]) & 0x7fffu) != 0;
               } else

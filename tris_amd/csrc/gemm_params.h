@@ -43,7 +43,8 @@ struct GemmParams {
   // sum(dz), sum(dz * xhat) per column into stat_part [tiles_m][2][N] (fp64 across lanes / waves / tiles), i.e. exactly what
   // col_partial_kernel<1> computes in a pass of its own.
   const float *bnb_x, *bnb_y, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
-  int bnb_y_pl;   // bnb_y is an fp16-plane tensor (PREC 4 callers): its ReLU mask is "either piece non-zero"
+  int bnb_y_pl;   // 1: bnb_y is an fp16-plane tensor (PREC 4 callers): its ReLU mask is "either piece non-zero"; 2: bnb_y is that mask itself, one
+                  // byte per 8 columns (tris_bn_mask_next: written by the forward pass beside the planes)
   // PREC 3 ("h2": two fp16 pieces per operand, three f16 MFMAs per product): per-operand power-of-two scales, either derived in
   // the kernel from the bit pattern of the tensor's largest magnitude -- or of an upper bound of it -- in device memory (h2_amaxA /
   // h2_amaxB: amax words, include/tris_hip.h) or, where that pointer is NULL, given by the host (h2_sA / h2_sB; 0 = 1.0)

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ resid, int rk,
                                                           const unsigned* __restrict__ resid_word, float* __restrict__ Y,
-                                                          const unsigned* __restrict__ out_word, long n8, int C, int relu) {
+                                                          const unsigned* __restrict__ out_word, long n8, int C, int relu,
+                                                          unsigned char* __restrict__ mask_out = nullptr) {
   const float s = pl_scale(out_word);
   const float rinv = rk == 2 ? 1.0f / pl_scale(resid_word) : 1.0f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,6 +222,12 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
     if (relu) { y0 = relu4(y0); y1 = relu4(y1); }
     below += pl_below_floor(y0, y1, s);
     Pl8 o = pl8_split(y0, y1, s);
+    if (mask_out != nullptr) {
+      // the ReLU mask of this group of 8 channels as ONE byte (bit t <=> element t has a non-zero piece: exactly what a reader of the
+      // planes would decide, pl8_positive): the backward reads 1 bit per element instead of the 4-byte plane element (tris_bn_mask_next)
+      const long eg = (e0 - lane * 4) + (odd ? 256 : 0) + 8 * (lane >> 1);    // first element of this thread's group
+      if (eg < n) mask_out[eg >> 3] = (unsigned char)pl8_positive(o.hi, o.lo);
+    }
     pair_xchg(o.hi, o.lo, odd);
     if (e0 < n) stu<BIG>(Y + e0, o.hi);
     if (e1 < n) stu<BIG>(Y + e1, o.lo);
@@ -474,19 +481,28 @@ inline int pl_grid(long n8, int C) {   // one unit (64 groups) per wave and trip
 }
 }  // namespace
 
+// one-shot: the next tris_bn_apply_pl_f32 of the calling thread also writes the ReLU mask of its output, one byte per 8 channels
+static thread_local unsigned char* g_bn_mask_next = nullptr;
+extern "C" int tris_bn_mask_next(unsigned char* mask) {
+  g_bn_mask_next = mask;
+  return 0;
+}
+
 extern "C" int tris_bn_apply_pl_f32(const float* X, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                     const float* resid, int resid_kind, const unsigned* resid_word, float* Ypl, const unsigned* out_word,
                                     long M, int C, int relu, void* stream) {
   if (C % 8 || 2048 % C || out_word == nullptr || (resid_kind != 0 && resid == nullptr) || (resid_kind == 2 && resid_word == nullptr) ||
       resid_kind < 0 || resid_kind > 2 || !al16p(X) || !al16p(Ypl) || !al16p(resid))
     return (int)hipErrorInvalidValue;
+  unsigned char* const mask = g_bn_mask_next;
+  g_bn_mask_next = nullptr;
   const long n8 = M * C / 8;
   if (pl_big(n8, C, resid_kind ? 3 : 2))
     hipLaunchKernelGGL(bn_apply_pl_kernel<true>, dim3(pl_big_grid(n8)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta,
-                       resid, resid_kind, resid_word, Ypl, out_word, n8, C, relu);
+                       resid, resid_kind, resid_word, Ypl, out_word, n8, C, relu, mask);
   else
     hipLaunchKernelGGL(bn_apply_pl_kernel<false>, dim3(pl_grid(n8, C)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta,
-                       resid, resid_kind, resid_word, Ypl, out_word, n8, C, relu);
+                       resid, resid_kind, resid_word, Ypl, out_word, n8, C, relu, mask);
   TRIS_LAUNCH_CHECK();
   return 0;
 }

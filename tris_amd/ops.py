@@ -1145,7 +1145,7 @@ def pl_grad_in(dy):
     return dy
 
 
-def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False, k_red=32, w_bt=False):
+def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False, k_red=32, w_bt=False, y_mask=False):
     """Arm the next dense product for h2 (as h2_arm) and return the pointers of its operands A, B to hand to the entry point.  With
     operand planes on: if one operand IS a plane tensor and the other one is too, or is a convolution weight (w_a / w_b: that
     operand is a parameter), the product runs on planes; a plane tensor next to an fp32 operand is rebuilt (counted in PL_STATS).
@@ -1169,7 +1169,7 @@ def h2_pp(A, B, a_slot=None, b_slot=None, y_planes=False, w_a=False, w_b=False, 
                 pb = (tt[1], tt[2])
                 PL_STATS["last_t"] = True
         if pa is not None and pb is not None:
-            call("tris_h2_next_planes", pa[1], pb[1], (1 if y_planes else 0) | (2 if PL_STATS["last_t"] else 0))
+            call("tris_h2_next_planes", pa[1], pb[1], (1 if y_planes else 0) | (2 if PL_STATS["last_t"] else 0) | (4 if y_mask else 0))
             PL_STATS["products"] += 1
             PL_STATS["last"] = True
             return pa[0], pb[0]
@@ -1192,13 +1192,14 @@ class _BnBwdLink:
     on whatever arrived, which is why the masked gradient is only ever produced when the BatchNorm is known to be behind it.
     The model marks the BatchNorms whose output has exactly one autograd consumer (Bottleneck: bn2 -> conv3; bn3 -> the next
     block's conv1, the residual branch rides a GradBox) with bwd_link=True."""
-    __slots__ = ("x", "mean", "invstd", "gamma", "beta", "from_y", "dz", "part", "rows", "dzw")
+    __slots__ = ("x", "mean", "invstd", "gamma", "beta", "from_y", "dz", "part", "rows", "dzw", "mask")
 
     def __init__(self, x, mean, invstd, gamma, beta, from_y):
         # (no reference to the BatchNorm's OUTPUT, which carries this object: the consumer has that tensor as its own input)
         self.x, self.mean, self.invstd, self.gamma, self.beta, self.from_y = x, mean, invstd, gamma, beta, from_y
         self.dz = self.part = self.dzw = None
         self.rows = 0
+        self.mask = None      # (cfg.bn_bitmask) the ReLU mask of the BatchNorm's plane output, one byte per 8 channels (tris_bn_mask_next)
 
     def fill(self, dz, part, rows, dzw=None):
         # (identity of the gradient tensor, not a reference to it: autograd hands a sole-owner gradient on without a copy)
@@ -1302,10 +1303,13 @@ class LinearFn(torch.autograd.Function):
                     dzw = _h2_slot() if planes_on() else None   # (the masked gradient's amax: the bound of that BatchNorm's dx)
 
                     def launch():
-                        pp = h2_pp(dy, w, w_b=True, y_planes=ypl, k_red=N, w_bt=True)
+                        bits = ypl and link.mask is not None
+                        pp = h2_pp(dy, w, w_b=True, y_planes=ypl, k_red=N, w_bt=True, y_mask=bits)
                         if dzw is not None:
                             call("tris_amax_next", dzw)
                         by = (P(x) if (PL_STATS["last"] or not ypl) else P(unplanes(x))) if link.from_y else None
+                        if bits and PL_STATS["last"]:
+                            by = link.mask.data_ptr()       # (the product took planes and was armed with flag 4: bn_y is the byte mask)
                         call("tris_gemm_bnbwd_f32", pp[0], pp[1], P(dx), M, K, N, P(extra), K, P(link.x), by,
                              P(link.mean), P(link.invstd), P(link.gamma), P(link.beta), part.data_ptr(), ctypes.byref(rows), _stream())
                         return rows.value > 0     # (False: the entry point declined the shape, nothing was launched)
@@ -1664,6 +1668,7 @@ class BatchNormFn(torch.autograd.Function):
         """planes: the output is WRITTEN as fp16 operand planes (every consumer is a product, a plane-aware BatchNorm / pool, or goes
         through ops.unplanes); dx_planes: so is the input gradient (its one consumer is the backward of the convolution before)."""
         _chk(x, gamma, beta, rmean, rvar, resid)
+        y_mask = None
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
@@ -1759,6 +1764,11 @@ class BatchNormFn(torch.autograd.Function):
                 call("tris_bn_apply_pool_pl_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(y), word, x.shape[0], x.shape[1],
                      x.shape[2], C, _stream())
             else:
+                if cfg.bn_bitmask and training and bwd_link and relu and resid is not None:
+                    # out = relu(bn(x) + identity) with ONE consumer whose data-gradient epilogue will mask with it (_BnBwdLink.from_y):
+                    # the pass also leaves the mask as one byte per 8 channels, so that epilogue reads a bit, not the plane element
+                    y_mask = torch.empty(M * C // 8, device=x.device, dtype=torch.uint8)
+                    call("tris_bn_mask_next", y_mask.data_ptr())
                 call("tris_bn_apply_pl_f32", P(x), P(mean), P(invstd), P(gamma), P(beta), P(resid), rk, rw if rk == 2 else None, P(y),
                      word, M, C, int(relu), _stream())
             pl_tag(y, word)
@@ -1787,6 +1797,7 @@ class BatchNormFn(torch.autograd.Function):
             if bwd_link and relu and not pool:
                 # the consumer (ops.linear) may reduce this BatchNorm's backward sums in its data-gradient epilogue: _BnBwdLink
                 ctx.link = y._bn_link = _BnBwdLink(x, mean, invstd, gamma, beta, keep_y)
+                ctx.link.mask = y_mask if keep_y else None
         return y
 
     @staticmethod
