@@ -27,11 +27,11 @@ PER_RANK = 2
 WORLD = 2
 
 
-def _worker(rank, world, port, tmp, issue, arith, backend="gloo"):
+def _worker(rank, world, port, tmp, issue, arith, backend="gloo", poison=False):
     """backend "gloo": every rank on cuda:0 (one-GPU box); "nccl": rank r on cuda:r over real RCCL (a box with >= world devices)"""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRIS_AUTOTUNE="0", TRIS_RANDOM_INIT="1",
-                      TRIS_STEP_GRAPH=issue, TRIS_GEMM_MODE=arith)
+                      TRIS_STEP_GRAPH=issue, TRIS_GEMM_MODE=arith, TRIS_DDP_SEG_POISON="1" if poison else "0")
     import warnings
     import torch.distributed as dist
     dev = rank if backend == "nccl" else 0
@@ -77,6 +77,8 @@ def _worker(rank, world, port, tmp, issue, arith, backend="gloo"):
         assert ("_tris_step_graph" in net.__dict__) == (issue == "seg")      # the step really was (not) replayed from graphs
         out = {"losses": losses.cpu(), "launch_log": list(red.launch_log), "backend": dist.get_backend(), "device": torch.cuda.current_device(),
                "params": [a.p.detach().cpu() for a in opt.arenas]}
+        sg = net.__dict__.get("_tris_step_graph")
+        out["poisoned"] = sg[1].poisoned_segments if sg is not None and sg[1] is not None else 0
         if rank == 0:
             names = {id(p): n for n, p in net.named_parameters()}
             out["grads"] = {names[id(p)]: p.grad.detach().cpu().clone() for a in opt.arenas for p in a.params}
@@ -119,14 +121,24 @@ def test_two_ranks_on_two_devices_over_rccl(tmp_path, issue, arith):
     _two_rank_check(tmp_path, issue, arith, "nccl")
 
 
-def _two_rank_check(tmp_path, issue, arith, backend):
+@pytest.mark.parametrize("arith", ["h2", "x3"])
+def test_no_launch_reads_a_parameter_behind_its_early_update(tmp_path, arith):
+    """the replayed data-parallel step updates every reducer segment right behind its all-reduce, while the backward is still
+    being issued (cfg.ddp_seg_opt) -- correct only if nothing issued later reads that segment's parameters.  Here the same two-rank
+    step runs with cfg.ddp_seg_poison: each early-updated segment is NaN from its update to the end of the step.  Losses, reduced
+    gradients (finite, cosine with the oracle's), running statistics and the replicas' parameters (finite, bit-identical) are
+    checked exactly as in the plain run; x3 reads the fp32 parameters in every data gradient, h2 reads the trunk's through planes."""
+    _two_rank_check(tmp_path, "seg", arith, "gloo", poison=True)
+
+
+def _two_rank_check(tmp_path, issue, arith, backend, poison=False):
     import torch.multiprocessing as mp
     from oracle import tris_oracle as O
     from tris_amd.utils.shapes import aux_state_dict_spec, empty_state_dict, tris_state_dict_spec
     from tris_amd.utils.synth import seed_fill, synthetic_batch
     ctx = mp.get_context("spawn")
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), issue, arith, backend)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), issue, arith, backend, poison)) for r in range(WORLD)]
     for p in procs:
         p.start()
     # the oracle runs on the host cores while the ranks run on the GPU
@@ -150,6 +162,9 @@ def _two_rank_check(tmp_path, issue, arith, backend):
     assert r0["syncbn_transport"] == r1["syncbn_transport"] == os.environ.get("TRIS_EXPECT_SYNCBN", "mailbox")
     assert r0["backend"] == r1["backend"] == backend
     assert (r0["device"], r1["device"]) == ((0, 1) if backend == "nccl" else (0, 0))
+    if poison:
+        assert r0["poisoned"] >= 4 and r0["poisoned"] == r1["poisoned"], (r0["poisoned"], r1["poisoned"])
+        assert all(torch.isfinite(a).all() for a in r0["params"]) and all(torch.isfinite(g).all() for g in r0["grads"].values())
     # (1) per-rank losses vs the oracle's per-shard losses
     for r, got in enumerate((r0["losses"], r1["losses"])):
         want = torch.stack([t.detach() for t in ref["per_rank"][r]])

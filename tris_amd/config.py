@@ -31,6 +31,8 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   ddp_check          TRIS_DDP_CHECK            NaN-poison check of the gradient reducer's release order
   syncbn_bound       TRIS_SYNCBN_BOUND         SyncBatchNorm mailbox exchanges also leave the bound word of the plane tensor written next (0: separate launches)
   ddp_seg_opt        TRIS_DDP_SEG_OPT          replayed data-parallel step: AdamW per reducer segment right behind its all-reduce (0: one AdamW behind the join)
+  ddp_seg_poison     TRIS_DDP_SEG_POISON       checking mode of the above: a segment's parameters are NaN from its early AdamW until the end of the step (then the updated
+                                               values are put back): any launch that still reads them shows up as NaN gradients / losses
   ddp_sparse_embed   TRIS_DDP_SPARSE_EMBED     token-embedding gradient as a sparse (ids, rows) exchange
   random_init        TRIS_RANDOM_INIT          clip.load may build an architecture without a weights file
   own_stream         TRIS_OWN_STREAM           the trainer / bench compute on a non-default stream (the default stream serialises with hipGraphs elsewhere)
@@ -41,6 +43,8 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
   text_pack          TRIS_TEXT_PACK            no-gradient text passes (the frozen aux tower) on packed rows: positions behind EOT are not computed
   bn_bitmask         TRIS_BN_BITMASK           operand planes: relu(bn(x) + identity) also leaves its ReLU mask as one byte per 8 channels; the consumer's fused
                                                BatchNorm-backward epilogue reads that instead of the plane element
+  step_graph_rerecord TRIS_STEP_GRAPH_RERECORD replayed step: a batch shape other than the recorded one, seen this many steps IN A ROW, is recorded in its place
+                                               (default 3: a recording made on a ragged first batch does not leave the run eager; 0: never)
   fuse_splitk        TRIS_FUSE_SPLITK_PY       split-K products armed with a ticket array: the last block of a tile sums the slabs in the product's own launch (default 0: measured slower)
 """
 import contextlib
@@ -76,6 +80,7 @@ class _Config:
         self.mha = e("TRIS_MHA", "auto")
         self.mha_h2 = _flag("TRIS_MHA_H2", True)
         self.ddp_seg_opt = _flag("TRIS_DDP_SEG_OPT", True)
+        self.ddp_seg_poison = _flag("TRIS_DDP_SEG_POISON", False)
         self.syncbn_bound = _flag("TRIS_SYNCBN_BOUND", True)
         self.xattn_fused = _flag("TRIS_XATTN_FUSED", True)
         self.xattn_px = _flag("TRIS_XATTN_PX", True)
@@ -95,6 +100,7 @@ class _Config:
         self.text_pack = _flag("TRIS_TEXT_PACK", True)
         self.bn_bitmask = _flag("TRIS_BN_BITMASK", True)
         self.gemm_convert = int(e("TRIS_GEMM_CONVERT", "0"))
+        self.step_graph_rerecord = int(e("TRIS_STEP_GRAPH_RERECORD", "3"))
         self.vit_token0 = _flag("TRIS_VIT_TOKEN0", True)
 
     @contextlib.contextmanager
@@ -111,7 +117,7 @@ class _Config:
     def key(self):
         """what a captured step depends on: tris_amd.train_stage1.train_step records the step again when this (or the arithmetic, the
         optimiser, the reducer, the aux model) changes; a batch of another shape runs eagerly next to the kept recording"""
-        return tuple(sorted((k, v) for k, v in self.__dict__.items() if k != "step_graph_chosen"))
+        return tuple(sorted((k, v) for k, v in self.__dict__.items() if k not in ("step_graph_chosen", "step_graph_rerecord")))
 
 
 cfg = _Config()

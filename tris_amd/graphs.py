@@ -402,8 +402,9 @@ class SegmentedTrainStep:
             # on the reducer's stream, while the backward goes on; only what is reduced in finish() (and the sparsely exchanged
             # embedding table) is left for the AdamW graph behind the join.  (A parameter a later-issued launch still reads -- the
             # gamma / beta a folded BatchNorm's weight-gradient launch re-normalises with -- belongs to a LATER segment, whose
-            # collective waits for that launch.)
-            self.g_opt_seg = {}
+            # collective waits for that launch.  Checked, not only argued: cfg.ddp_seg_poison keeps an updated segment's parameters NaN
+            # until the step ends, tests/test_gpu_ddp.py runs the two-rank step that way and finds no NaN.)
+            self.g_opt_seg, self.g_opt_ranges, self._poisoned, self.poisoned_segments = {}, {}, [], 0
             red = self.reducer
             from .config import cfg
             if red is not None and cfg.ddp_seg_opt and red.segments:
@@ -417,6 +418,7 @@ class SegmentedTrainStep:
                     g = G()
                     _capture(g, self.cap, pool_o, lambda: optimizer.step(device_hyper=True, ranges=segs))
                     self.g_opt_seg[k] = g
+                    self.g_opt_ranges[k] = segs
                     for ai, s_, e_ in segs:
                         covered.setdefault(ai, []).append((s_, e_))
                 if self.g_opt_seg:
@@ -458,6 +460,17 @@ class SegmentedTrainStep:
                     h.wait()              # (RCCL: the reducer's stream waits for the backend's, no host synchronisation)
                 red.scale_now(key)        # (a backend without an averaging all-reduce: the mean of this segment, now)
                 g.replay()
+                from .config import cfg
+                if cfg.ddp_seg_poison:
+                    # Checking mode: this update is only correct if nothing issued from here on reads the segment's
+                    # parameters -- the backward goes on while it runs.  The updated values are set aside and the parameters are NaN
+                    # until the step's last launch (__call__ puts them back): a later data-gradient or weight-gradient launch that
+                    # read one of them would leave NaN in the gradients, which tests/test_gpu_ddp.py looks for.
+                    for ai, s_, e_ in self.g_opt_ranges[key]:
+                        v = self.optimizer.arenas[ai].p[s_:e_]
+                        self._poisoned.append((v, v.clone()))
+                        v.fill_(float("nan"))
+                    self.poisoned_segments += 1
 
     @staticmethod
     def _late_spans(optimizer, touched):
@@ -614,6 +627,11 @@ class SegmentedTrainStep:
         if red is not None:
             red.finish()                     # what is left (embedding, stem), then the compute stream waits for the collectives
         self.g_opt.replay()
+        if self._poisoned:                   # (cfg.ddp_seg_poison; red.finish() has joined the reducer's stream)
+            for v, saved in self._poisoned:
+                v.copy_(saved)
+                saved.record_stream(main)
+            self._poisoned = []
         mark("opt_done")
         for m in self.bns:
             m._nbt_pending += 1

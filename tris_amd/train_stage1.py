@@ -150,6 +150,19 @@ def train_step(model, clip_model, optimizer, img, word_ids, neg_word_ids, args, 
             # the ragged last batch of an epoch: it runs eagerly below and the recording for the main shape is kept.)
             net.__dict__.pop("_tris_step_graph")
             slot = None
+        if slot is not None and slot[1] is not None and slot[0] != key:
+            # the same configuration, another batch shape.  Once in a while that is the ragged last batch of an epoch; several
+            # steps in a row mean the recording was made on the odd one (a short first batch): record this shape in its place
+            seen = net.__dict__.get("_tris_step_graph_other")
+            n = seen[1] + 1 if seen is not None and seen[0] == key[:5] else 1
+            net.__dict__["_tris_step_graph_other"] = (key[:5], n)
+            if 0 < cfg.step_graph_rerecord <= n:
+                net.__dict__.pop("_tris_step_graph")
+                net.__dict__.pop("_tris_step_graph_other")
+                net.__dict__.pop("_tris_step_graph_warned", None)
+                slot = None
+        elif slot is not None:
+            net.__dict__.pop("_tris_step_graph_other", None)
         if slot is None:
             from .graphs import GraphedTrainStep, NotCapturable, SegmentedTrainStep
             cls = SegmentedTrainStep if cfg.step_graph == "seg" else GraphedTrainStep
