@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(mode, steps=4, B=3, backbone="clip-RN50", Bs=None):
+def _run(mode, steps=4, B=3, backbone="clip-RN50", Bs=None, **over):
     from tris_amd.args import get_parser
     from tris_amd.CLIP import clip
     from tris_amd.model.model_stage1 import TRIS
@@ -18,7 +18,7 @@ def _run(mode, steps=4, B=3, backbone="clip-RN50", Bs=None):
     from tris_amd.train_stage1 import freeze_aux, train_step
     from tris_amd.utils.synth import seed_fill, synthetic_batch
     from tris_amd.config import cfg
-    with cfg.override(step_graph=mode):
+    with cfg.override(step_graph=mode, **over):
         args = get_parser().parse_args(["--backbone", backbone, "--size", "320", "--negative_samples", "3", "--max_query_len", "20"])
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -55,6 +55,16 @@ def eager():
     losses, state, replayed = _run("0")
     assert not replayed
     return losses, state
+
+
+def test_parameter_gradients_on_the_side_stream_change_nothing(eager):
+    """cfg.side_param_grads (round 6): the bias / InstanceNorm-parameter column sums of the heads are issued on the weight-gradient
+    stream; the same launches, only elsewhere -- four eager steps with the switch off end in the state of four steps with it on"""
+    losses, state, _ = _run("0", side_param_grads=False)
+    assert torch.equal(losses, eager[0])
+    for k in ("p", "m", "v"):
+        for a, b in zip(state[k], eager[1][k]):
+            assert torch.equal(a, b), (k, float((a - b).abs().max()))
 
 
 def test_a_recording_made_on_an_odd_first_batch_is_replaced():

@@ -45,6 +45,7 @@ assigning to it (`cfg.step_graph = "seg"`, `monkeypatch.setattr(cfg, "bn_pool", 
                                                BatchNorm-backward epilogue reads that instead of the plane element
   step_graph_rerecord TRIS_STEP_GRAPH_RERECORD replayed step: a batch shape other than the recorded one, seen this many steps IN A ROW, is recorded in its place
                                                (default 3: a recording made on a ragged first batch does not leave the run eager; 0: never)
+  side_param_grads   TRIS_SIDE_PARAM_GRADS     bias / InstanceNorm-parameter gradients (column sums nothing in the backward waits for) on the weight-gradient stream
   fuse_splitk        TRIS_FUSE_SPLITK_PY       split-K products armed with a ticket array: the last block of a tile sums the slabs in the product's own launch (default 0: measured slower)
 """
 import contextlib
@@ -101,6 +102,7 @@ class _Config:
         self.bn_bitmask = _flag("TRIS_BN_BITMASK", True)
         self.gemm_convert = int(e("TRIS_GEMM_CONVERT", "0"))
         self.step_graph_rerecord = int(e("TRIS_STEP_GRAPH_RERECORD", "3"))
+        self.side_param_grads = _flag("TRIS_SIDE_PARAM_GRADS", True)
         self.vit_token0 = _flag("TRIS_VIT_TOKEN0", True)
 
     @contextlib.contextmanager

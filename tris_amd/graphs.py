@@ -251,6 +251,7 @@ class SegmentedTrainStep:
 
     def __init__(self, model, clip_model, optimizer, args, example, lr_scheduler=None, priming=2, reducer=None):
         from . import ops
+        from .config import cfg
         from .CLIP.clip.model import BatchNorm2d
         from .train_stage1 import stage1_loss_block
         img, ids, neg = example
@@ -282,7 +283,9 @@ class SegmentedTrainStep:
         def wgrad_graphs(split=False):
             """the deferred weight-gradient launches of the segment just captured, as a graph for their stream (split: every
             other one goes into a second graph for the text stream, idle by then -- used for the last segments, whose weight
-            gradients nothing is left to hide behind) -> (graph | None, graph | None, [arena views written])"""
+            gradients nothing is left to hide behind) -> (graph | None, graph | None, [arena views written])
+            (Round 6: the one-launch segments of the stem alternated between the two streams -- no gain: the step's last 0.7 ms are
+            AdamW over everything outside the late span plus the stem's weight gradients, together bound by HBM, not by the queue.)"""
             fns, self.deferred = self.deferred, []
             keep.append(fns)
             parts = [fns[0::2], fns[1::2]] if split and len(fns) > 1 else [fns, []]
@@ -406,7 +409,6 @@ class SegmentedTrainStep:
             # until the step ends, tests/test_gpu_ddp.py runs the two-rank step that way and finds no NaN.)
             self.g_opt_seg, self.g_opt_ranges, self._poisoned, self.poisoned_segments = {}, {}, [], 0
             red = self.reducer
-            from .config import cfg
             if red is not None and cfg.ddp_seg_opt and red.segments:
                 released = [k for (_, _, _, keys) in self.back for k in keys] + list(self.text_released)
                 pool_o = torch.cuda.graph_pool_handle()

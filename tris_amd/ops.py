@@ -411,13 +411,18 @@ def _sink(p):
     return None
 
 
-def _emit(p, make, needs):
-    """Produce a parameter gradient: into the sink (return None) or as a fresh tensor."""
+def _emit(p, make, needs, reads=None):
+    """Produce a parameter gradient: into the sink (return None) or as a fresh tensor.  reads: the tensors `make` reads -- a gradient
+    that lands in the arena and that nothing downstream of the backward pass waits for (a bias or norm-parameter column sum) is then
+    issued on the weight-gradient stream like the weight gradients themselves, off the compute stream's chain (cfg.side_param_grads)."""
     if not needs:
         return None
     s = _sink(p)
     if s is not None:
-        make(s)
+        if reads is not None and cfg.side_param_grads:
+            on_wgrad_stream(lambda: make(s), *reads, sink=s)
+        else:
+            make(s)
         return None
     out = torch.empty_like(p, memory_format=torch.preserve_format)
     make(out)
@@ -1338,7 +1343,7 @@ class LinearFn(torch.autograd.Function):
                 dw = _emit(pw, lambda o: gemm(dy, x, o, N, K, M, N, K, K, True, False, mark=False), True)
         db = None
         if ctx.has_b:
-            db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2])
+            db = _emit(pb, lambda o: colsum(dy, M, N, o), ctx.needs_input_grad[2], reads=(dy,))
         return dx, dw, db, d_res, None, None, None, None, None, None, None
 
 
@@ -1401,7 +1406,7 @@ class LinearQGeluFn(torch.autograd.Function):
                 dw = _emit(pw, lambda o: gemm(dpre, x, o, N, K, M, N, K, K, True, False, mark=False), True)
         db = None
         if ctx.has_b:
-            db = _emit(pb, lambda o: colsum(dpre, M, N, o), ctx.needs_input_grad[2])
+            db = _emit(pb, lambda o: colsum(dpre, M, N, o), ctx.needs_input_grad[2], reads=(dpre,))
         return dx, dw, db
 
 
@@ -2357,8 +2362,8 @@ class InstNormFn(torch.autograd.Function):
         parts = torch.empty(2, B, C, device=x.device, dtype=torch.float32)
         call("tris_instnorm_bwd_f32", P(dy.contiguous()), P(y), P(x), P(g), P(st), P(st, B * C), P(dx), P(parts),
              P(parts, B * C), B, Pp, C, int(ctx.relu), _stream())
-        dg = _emit(ctx.params[0], lambda o: colsum(parts[0], B, C, o), ctx.needs_input_grad[1])
-        db = _emit(ctx.params[1], lambda o: colsum(parts[1], B, C, o), ctx.needs_input_grad[2])
+        dg = _emit(ctx.params[0], lambda o: colsum(parts[0], B, C, o), ctx.needs_input_grad[1], reads=(parts,))
+        db = _emit(ctx.params[1], lambda o: colsum(parts[1], B, C, o), ctx.needs_input_grad[2], reads=(parts,))
         return dx, dg, db, None, None
 
 
