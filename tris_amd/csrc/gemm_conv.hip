@@ -29,6 +29,8 @@ extern __attribute__((visibility("hidden"))) int tris_internal_fin_block;
 __attribute__((visibility("hidden"))) int tris_internal_reduce_wide = 4;
 // XCD_ORDER: -1 = the tuner's choice (LDS-DMA products only), 0 = never, 1 = every fast-kernel launch (gemm_core.h run_cfg)
 __attribute__((visibility("hidden"))) int tris_internal_xcd_order = -1;
+// RED_GRID: most blocks of a split-K reduce launch (grid-stride above that); 0 = one block per 1024 outputs
+__attribute__((visibility("hidden"))) int tris_internal_red_grid = 0;
 // FUSE_SPLITK: largest slice count whose slabs are summed by the last-arriving block of each tile inside the product's own launch
 // (gemm_fast.h "fused split-K finish"; needs tris_splitk_tickets_next); 0 = always the separate reduce launch
 __attribute__((visibility("hidden"))) int tris_internal_fuse_splitk = 8;
@@ -85,6 +87,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "LN_BWD_BLOCKS")) tris_internal_ln_bwd_blocks = unset ? 512 : std::min(512, std::max(1, atoi(v)));
   else if (!strcmp(name, "FIN_BLOCK")) tris_internal_fin_block = unset ? 256 : (atoi(v) >= 1024 ? 1024 : atoi(v) >= 512 ? 512 : 256);
   else if (!strcmp(name, "REDUCE_WIDE")) tris_internal_reduce_wide = unset ? 4 : std::max(0, atoi(v));
+  else if (!strcmp(name, "RED_GRID")) tris_internal_red_grid = unset ? 0 : std::max(0, atoi(v));
   else if (!strcmp(name, "XCD_ORDER")) tris_internal_xcd_order = unset ? -1 : std::min(2, std::max(0, atoi(v)));
   else if (!strcmp(name, "FUSE_SPLITK")) tris_internal_fuse_splitk = unset ? TRIS_FUSE_SPLITK_DEFAULT : std::max(0, atoi(v));
   else if (!strcmp(name, "XATTN_PX_SLOTS")) tris_internal_xattn_px_slots = unset ? 0 : std::max(0, atoi(v));
@@ -94,7 +97,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
 }
 static Options init_options() {
   Options o;
-  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "XCD_ORDER", "FUSE_SPLITK", "TUNE_LOG"}) {
+  for (const char* n : {"FORCE_TILE", "FORCE_PIPE", "PIPE", "CONV_DIRECT", "WGRAD_DIRECT", "BN_FOLD", "STEM_CONV1", "WG_BLOCKS", "STREAM_FORM", "COL_BLOCKS", "XATTN_PX_SLOTS", "LN_BWD_BLOCKS", "FIN_BLOCK", "REDUCE_WIDE", "XCD_ORDER", "FUSE_SPLITK", "RED_GRID", "TUNE_LOG"}) {
     char env[64];
     snprintf(env, sizeof(env), "TRIS_%s", n);
     if (const char* v = getenv(env)) set_option(o, n, v);

@@ -339,57 +339,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // row (16-byte loads, 4 slabs in flight per trip) -- the reduce is a pure HBM/L2 stream and runs a few hundred times per step.
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, GemmParams p) {
-  const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  // grid-stride: the launch may hold fewer blocks than 1024-element pieces (option RED_GRID; a thread's sums are the same either way)
   const long total = (long)p.M * p.N;
-  if (idx >= total || (p.m_limit != nullptr && idx / p.N >= (long)*p.m_limit)) {
-    if (p.amax_out != nullptr) amax_commit(0u, p.amax_out);   // (all lanes of the wave take part in the shuffles)
-    return;
-  }
-  float v[VEC];
+  const long stride = (long)gridDim.x * blockDim.x * VEC;
+  unsigned am = 0u;
+  for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; idx < total; idx += stride) {
+    if (p.m_limit != nullptr && idx / p.N >= (long)*p.m_limit) break;   // (rows ascend with idx)
+    float v[VEC];
 #pragma unroll
-  for (int t = 0; t < VEC; ++t) v[t] = 0.f;
-  if (VEC == 4) {
-    int s = 0;
-    for (; s + 3 < S; s += 4) {  // fixed summation order s = 0, 1, 2, ... (deterministic)
-      const float4 a = ld4(ws + (long)s * total + idx), b = ld4(ws + (long)(s + 1) * total + idx);
-      const float4 c = ld4(ws + (long)(s + 2) * total + idx), d = ld4(ws + (long)(s + 3) * total + idx);
-      v[0] = (((v[0] + a.x) + b.x) + c.x) + d.x;
-      v[1] = (((v[1] + a.y) + b.y) + c.y) + d.y;
-      v[2] = (((v[2] + a.z) + b.z) + c.z) + d.z;
-      v[3] = (((v[3] + a.w) + b.w) + c.w) + d.w;
+    for (int t = 0; t < VEC; ++t) v[t] = 0.f;
+    if (VEC == 4) {
+      int s = 0;
+      for (; s + 3 < S; s += 4) {  // fixed summation order s = 0, 1, 2, ... (deterministic)
+        const float4 a = ld4(ws + (long)s * total + idx), b = ld4(ws + (long)(s + 1) * total + idx);
+        const float4 c = ld4(ws + (long)(s + 2) * total + idx), d = ld4(ws + (long)(s + 3) * total + idx);
+        v[0] = (((v[0] + a.x) + b.x) + c.x) + d.x;
+        v[1] = (((v[1] + a.y) + b.y) + c.y) + d.y;
+        v[2] = (((v[2] + a.z) + b.z) + c.z) + d.z;
+        v[3] = (((v[3] + a.w) + b.w) + c.w) + d.w;
+      }
+      for (; s < S; ++s) {
+        const float4 a = ld4(ws + (long)s * total + idx);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+      }
+    } else {
+      for (int s = 0; s < S; ++s) v[0] += ws[(long)s * total + idx];
     }
-    for (; s < S; ++s) {
-      const float4 a = ld4(ws + (long)s * total + idx);
-      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    const int row = (int)(idx / p.N), col0 = (int)(idx - (long)row * p.N);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      const int col = col0 + t;
+      float x = v[t] * p.alpha;
+      if (p.bias_mode == 1) x += p.bias[col];
+      else if (p.bias_mode == 2) x += p.bias[row];
+      if (p.act == 1) x = fmaxf(x, 0.f);
+      else if (p.act == 2) x = x / (1.0f + expf(-1.702f * x));
+      if (p.resid) x += p.resid[(long)row * p.ldr + col];
+      v[t] = x;
     }
-  } else {
-    for (int s = 0; s < S; ++s) v[0] += ws[(long)s * total + idx];
-  }
-  const int row = (int)(idx / p.N), col0 = (int)(idx - (long)row * p.N);
+    if (VEC == 4 && (p.ldc & 3) == 0)
+      *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+    else
 #pragma unroll
-  for (int t = 0; t < VEC; ++t) {
-    const int col = col0 + t;
-    float x = v[t] * p.alpha;
-    if (p.bias_mode == 1) x += p.bias[col];
-    else if (p.bias_mode == 2) x += p.bias[row];
-    if (p.act == 1) x = fmaxf(x, 0.f);
-    else if (p.act == 2) x = x / (1.0f + expf(-1.702f * x));
-    if (p.resid) x += p.resid[(long)row * p.ldr + col];
-    v[t] = x;
-  }
-  if (VEC == 4 && (p.ldc & 3) == 0)
-    *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
-  else
-#pragma unroll
-    for (int t = 0; t < VEC; ++t) p.C[(long)row * p.ldc + col0 + t] = v[t];
-  if (p.amax_out != nullptr) {
-    unsigned am = 0u;
+      for (int t = 0; t < VEC; ++t) p.C[(long)row * p.ldc + col0 + t] = v[t];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) am = max(am, __builtin_bit_cast(unsigned, v[t]) & 0x7fffffffu);
-    amax_commit(am, p.amax_out);
   }
+  if (p.amax_out != nullptr) amax_commit(am, p.amax_out);   // (every lane arrives here)
 }
 
+extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_red_grid; }      // option RED_GRID (gemm_conv.hip)
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_reduce_wide; }   // option REDUCE_WIDE (gemm_conv.hip)
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_xcd_order; }     // option XCD_ORDER (gemm_conv.hip)
 extern "C" { extern __attribute__((visibility("hidden"))) int tris_internal_fuse_splitk; }   // option FUSE_SPLITK (gemm_conv.hip)
@@ -452,6 +451,8 @@ __global__ __launch_bounds__(64 * G) void splitk_reduce_wide_kernel(const float*
 }
 
 #include "gemm_fast.h"
+
+static inline long red_blocks(long want) { return tris_internal_red_grid > 0 && want > tris_internal_red_grid ? tris_internal_red_grid : want; }
 
 // launch one configuration (+ split-K reduce).  mode: 0 = f32-input MFMA, 1 = split-bf16 x3, 3 = two-piece fp16 h2,
 // 4 = h2 with both operands arriving as fp16 piece planes (gemm_fast.h PREC 4)
@@ -608,9 +609,9 @@ int run_cfg(GemmParams p, int batch, float* ws, hipStream_t st, Cfg cfg, int mod
         hipLaunchKernelGGL(splitk_reduce_wide_kernel<4>, dim3(cdiv(total / 4, 64)), dim3(256), 0, st, ws, splitk, p);
     }
     else if ((p.N & 3) == 0 && al16(ws) && al16(p.C))
-      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, ws, splitk, p);
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(red_blocks(cdiv(total / 4, 256))), dim3(256), 0, st, ws, splitk, p);
     else
-      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, splitk, p);
+      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(red_blocks(cdiv(total, 256))), dim3(256), 0, st, ws, splitk, p);
     TRIS_LAUNCH_CHECK();
   }
   return 0;

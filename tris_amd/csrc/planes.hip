@@ -4,6 +4,8 @@
 // The scale of a plane tensor comes from an amax word that is final BEFORE the writing pass starts: the tensor's true amax where a
 // pass over it exists anyway (weights: tris_amax_segments_f32), otherwise an upper bound (BatchNorm outputs: Samuelson's bound from
 // the affine parameters, tris_bn_out_bound_f32; BatchNorm input gradients: tris_bn_bwd_bound_f32).
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "tris_hip.h"
 
@@ -233,19 +235,24 @@ __global__ __launch_bounds__(256) void bn_apply_pl_kernel(const float* __restric
     if (e1 < n) stu<BIG>(Y + e1, o.lo);
   };
   if (BIG) {
-    float4 x0[2], x1[2], r0[2], r1[2];
+    // (a block takes pieces b, b + gridDim.x, ...: the launch may hold fewer blocks than pieces -- pl_big_blocks)
+    const long units = (n + 511) / 512;
+    for (long pb = blockIdx.x; pb * PL_UPB < units; pb += gridDim.x) {
+      const long u0 = pb * PL_UPB + wave, uend = min(units, (pb + 1) * PL_UPB);
+      float4 x0[2], x1[2], r0[2], r1[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const long e0 = (w.u + 4 * q) * 512 + lane * 4, e1 = e0 + 256;
-      const bool ok0 = (w.u + 4 * q) < w.end && e0 < n, ok1 = (w.u + 4 * q) < w.end && e1 < n;
-      x0[q] = ok0 ? ldx<true>(X + e0) : z4;
-      x1[q] = ok1 ? ldx<true>(X + e1) : z4;
-      r0[q] = (ok0 && rk) ? ldx<true>(resid + e0) : z4;
-      r1[q] = (ok1 && rk) ? ldx<true>(resid + e1) : z4;
+      for (int q = 0; q < 2; ++q) {
+        const long e0 = (u0 + 4 * q) * 512 + lane * 4, e1 = e0 + 256;
+        const bool ok0 = (u0 + 4 * q) < uend && e0 < n, ok1 = (u0 + 4 * q) < uend && e1 < n;
+        x0[q] = ok0 ? ldx<true>(X + e0) : z4;
+        x1[q] = ok1 ? ldx<true>(X + e1) : z4;
+        r0[q] = (ok0 && rk) ? ldx<true>(resid + e0) : z4;
+        r1[q] = (ok1 && rk) ? ldx<true>(resid + e1) : z4;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if ((u0 + 4 * q) < uend) finish((u0 + 4 * q) * 512 + lane * 4, x0[q], x1[q], r0[q], r1[q]);   // (wave-uniform)
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if ((w.u + 4 * q) < w.end) finish((w.u + 4 * q) * 512 + lane * 4, x0[q], x1[q], r0[q], r1[q]);   // (wave-uniform)
   } else {
     for (; w.u < w.end; w.u += w.step) {
       const long e0 = w.u * 512 + lane * 4, e1 = e0 + 256;
@@ -414,26 +421,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pl_kernel(const float* __res
     }
   };
   if (BIG) {
-    float4 g0[2], g1[2], x0[2], x1[2], y0[2], y1[2];
+    const long units = (n + 511) / 512;
+    for (long pb = blockIdx.x; pb * PL_UPB < units; pb += gridDim.x) {     // (pieces b, b + gridDim.x, ...: pl_big_blocks)
+      const long u0 = pb * PL_UPB + wave, uend = min(units, (pb + 1) * PL_UPB);
+      float4 g0[2], g1[2], x0[2], x1[2], y0[2], y1[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const long u = w.u + 4 * q;
-      const long e0 = u * 512 + lane * 4, e1 = e0 + 256;
-      const bool ok0 = u < w.end && e0 < n, ok1 = u < w.end && e1 < n;
-      if (POOL) {
-        if (u < w.end) pooled_g(u, g0[q], g1[q]); else g0[q] = g1[q] = z4;
-      } else {
-        g0[q] = ok0 ? ldx<true>(dY + e0) : z4;
-        g1[q] = ok1 ? ldx<true>(dY + e1) : z4;
+      for (int q = 0; q < 2; ++q) {
+        const long u = u0 + 4 * q;
+        const long e0 = u * 512 + lane * 4, e1 = e0 + 256;
+        const bool ok0 = u < uend && e0 < n, ok1 = u < uend && e1 < n;
+        if (POOL) {
+          if (u < uend) pooled_g(u, g0[q], g1[q]); else g0[q] = g1[q] = z4;
+        } else {
+          g0[q] = ok0 ? ldx<true>(dY + e0) : z4;
+          g1[q] = ok1 ? ldx<true>(dY + e1) : z4;
+        }
+        x0[q] = ok0 ? ldx<true>(X + e0) : z4;
+        x1[q] = ok1 ? ldx<true>(X + e1) : z4;
+        y0[q] = (ok0 && use_y) ? ldx<true>(Ypl + e0) : z4;
+        y1[q] = (ok1 && use_y) ? ldx<true>(Ypl + e1) : z4;
       }
-      x0[q] = ok0 ? ldx<true>(X + e0) : z4;
-      x1[q] = ok1 ? ldx<true>(X + e1) : z4;
-      y0[q] = (ok0 && use_y) ? ldx<true>(Ypl + e0) : z4;
-      y1[q] = (ok1 && use_y) ? ldx<true>(Ypl + e1) : z4;
-    }
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if ((w.u + 4 * q) < w.end) finish((w.u + 4 * q) * 512 + lane * 4, g0[q], g1[q], x0[q], x1[q], y0[q], y1[q]);
+      for (int q = 0; q < 2; ++q)
+        if ((u0 + 4 * q) < uend) finish((u0 + 4 * q) * 512 + lane * 4, g0[q], g1[q], x0[q], x1[q], y0[q], y1[q]);
+    }
   } else {
     for (; w.u < w.end; w.u += w.step) {
       const long e0 = w.u * 512 + lane * 4, e1 = e0 + 256;
@@ -475,9 +486,29 @@ inline bool pl_big(long n8, int C, int streams) {   // (norm.hip big_form: the l
   return n8 * 32 * streams > (256L << 20) && n8 >= 64L * 16 * PL_UPB;
 }
 inline int pl_big_grid(long n8) { return (int)((n8 / 64 + 1 + PL_UPB - 1) / PL_UPB); }   // units = ceil(n8 / 64)
+// blocks of a streaming-form launch: at most 1024 (TRIS_PL_BIG_GRID overrides; 0 = every 4096-element piece its own block, the form of
+// rounds 3-5), each walking pieces gridDim.x apart (a thread then still sees one channel group).  Same reason as pl_grid_cap:
+// 34.54 -> 34.32 ms, means of three A/B rounds (profiles/r6_plane_pass_grid_ab.txt)
+static int pl_big_cap() {
+  static const int cap = [] { const char* e = getenv("TRIS_PL_BIG_GRID"); return e ? std::max(0, atoi(e)) : 1024; }();
+  return cap;
+}
+inline int pl_big_blocks(long n8) {
+  const int g = pl_big_grid(n8), cap = pl_big_cap();
+  return cap > 0 && g > cap ? cap : g;
+}
+// Blocks of the grid-stride form.  Rounds 4-5 launched up to 4096 (one 512-element unit per wave: the fastest on an idle device for
+// the large tensors).  Inside the step these passes run beside the weight-gradient stream's products, and 1024 blocks that each walk
+// several units -- fewer workgroups to place among another stream's -- take 0.4 ms off the step (36.33 -> 35.87 ms, means of three
+// A/B rounds; 768 and 2048 the same, 512 and 256 slower: profiles/r6_plane_pass_grid_ab.txt).  TRIS_PL_GRID overrides (read once).
+static int pl_grid_cap() {
+  static const int cap = [] { const char* e = getenv("TRIS_PL_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  return cap;
+}
 inline int pl_grid(long n8, int C) {   // one unit (64 groups) per wave and trip, four waves per block
   long g = (n8 + 255) / 256;
-  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+  const int cap = pl_grid_cap();
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 }  // namespace
 
@@ -498,7 +529,7 @@ extern "C" int tris_bn_apply_pl_f32(const float* X, const float* mean, const flo
   g_bn_mask_next = nullptr;
   const long n8 = M * C / 8;
   if (pl_big(n8, C, resid_kind ? 3 : 2))
-    hipLaunchKernelGGL(bn_apply_pl_kernel<true>, dim3(pl_big_grid(n8)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL(bn_apply_pl_kernel<true>, dim3(pl_big_blocks(n8)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta,
                        resid, resid_kind, resid_word, Ypl, out_word, n8, C, relu, mask);
   else
     hipLaunchKernelGGL(bn_apply_pl_kernel<false>, dim3(pl_grid(n8, C)), dim3(256), 0, (hipStream_t)stream, X, mean, invstd, gamma, beta,
@@ -529,7 +560,7 @@ extern "C" int tris_bn_bwd_apply_pl_f32(const float* dY, const float* Ypl, const
   const long n8 = M * C / 8;
   const int streams = 3 + ((Ypl && !beta_mask) ? 1 : 0) + (dZ ? 1 : 0);
   if (pl_big(n8, C, streams))
-    hipLaunchKernelGGL((bn_bwd_apply_pl_kernel<false, true>), dim3(pl_big_grid(n8)), dim3(256), 0, (hipStream_t)stream, dY, Ypl, X, mean,
+    hipLaunchKernelGGL((bn_bwd_apply_pl_kernel<false, true>), dim3(pl_big_blocks(n8)), dim3(256), 0, (hipStream_t)stream, dY, Ypl, X, mean,
                        invstd, gamma, sum_dz, sum_dzx, inv_count, dXpl, out_word, dZ, n8, C, beta_mask, 0, 0);
   else
     hipLaunchKernelGGL((bn_bwd_apply_pl_kernel<false, false>), dim3(pl_grid(n8, C)), dim3(256), 0, (hipStream_t)stream, dY, Ypl, X, mean,
