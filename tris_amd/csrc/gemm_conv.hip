@@ -62,7 +62,8 @@ struct Options {
   int wgrad_direct = -1;  // WGRAD_DIRECT=0 keeps the implicit GEMM, 1..5 forces a direct configuration
   int bn_fold = 1;        // BN_FOLD=0: BatchNorm + ReLU never folded into the direct convolutions
   int stem_conv1 = 1;     // STEM_CONV1=0: the stem's first convolution through the generic kernels
-  int wg_blocks = 512;    // WG_BLOCKS: blocks the direct weight gradient aims for (two per CU)
+  int wg_blocks = 256;    // WG_BLOCKS: blocks the direct weight gradient aims for (one per CU; 512 until round 6: on an idle device the same, inside the
+                          // step -0.25 ms, means of two A/B sweeps -- profiles/r6_wg_blocks_ab.txt: fewer slabs to sum, fewer workgroups among the compute stream's)
   // (STREAM_FORM=0: element-wise passes never take the nontemporal one-piece-per-block form, n > 1: they do above n MB (1 = default = 256); COL_BLOCKS: blocks a column
   //  reduction aims for -- both live in norm.hip's translation unit: tris_internal_stream_form / tris_internal_col_blocks;
   //  XATTN_PX_SLOTS=n: workgroups per image of the pixel-row cross attention, 0 = as many as fit one per CU -- xattn_px.hip)
@@ -81,7 +82,7 @@ static bool set_option(Options& o, const char* name, const char* v) {
   else if (!strcmp(name, "WGRAD_DIRECT")) o.wgrad_direct = unset ? -1 : atoi(v);
   else if (!strcmp(name, "BN_FOLD")) o.bn_fold = unset ? 1 : (v[0] != '0');
   else if (!strcmp(name, "STEM_CONV1")) o.stem_conv1 = unset ? 1 : (v[0] != '0');
-  else if (!strcmp(name, "WG_BLOCKS")) o.wg_blocks = unset ? 512 : std::max(1, atoi(v));
+  else if (!strcmp(name, "WG_BLOCKS")) o.wg_blocks = unset ? 256 : std::max(1, atoi(v));
   else if (!strcmp(name, "STREAM_FORM")) tris_internal_stream_form = unset ? 256 : (atoi(v) == 1 ? 256 : std::max(0, atoi(v)));
   else if (!strcmp(name, "COL_BLOCKS")) tris_internal_col_blocks = unset ? 512 : std::max(1, atoi(v));
   else if (!strcmp(name, "LN_BWD_BLOCKS")) tris_internal_ln_bwd_blocks = unset ? 512 : std::min(512, std::max(1, atoi(v)));
