@@ -264,7 +264,8 @@ int tris_bn_bwd_apply_f32(const float* dY, const float* Y, const float* X, const
 /* out[n] = sum_m X[m*ld+n]  (bias gradients).  workspace: tris_col_workspace_bytes(M, N) */
 int tris_colsum_f32(const float* X, long M, int N, long ld, float* out, float* workspace, void* stream);
 
-/* ---- InstanceNorm2d(affine) [+ReLU] on [B, P, C]  (model/attn.py:75,80,85,106) ---------------------------------------- */
+/* ---- InstanceNorm2d(affine) [+ReLU] on [B, P, C]  (model/attn.py:75,80,85,106) ----------------------------------------
+ * (both honour tris_amax_next: the amax word of Y / dX as a by-product) */
 int tris_instnorm_fwd_f32(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* invstd,
                           int B, int P, int C, float eps, int relu, void* stream);
 int tris_instnorm_bwd_f32(const float* dY, const float* Y, const float* X, const float* gamma, const float* mean,

@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ Y,
                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                           int P, int C, float eps, int relu) {
+                                                           int P, int C, float eps, int relu,
+                                                           unsigned* __restrict__ amax = nullptr) {
   __shared__ float red[4][64];
   const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
   const bool ok = c < C;
@@ -520,15 +521,19 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
   __syncthreads();
   float var = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)P;
   float is = rsqrtf(var + eps);
-  if (!ok) return;
-  float g = gamma[c], be = beta[c];
-  float* y = Y + (long)b * P * C + c;
-  for (int p = pg; p < P; p += 4) {
-    float o = (x[(long)p * C] - mean) * is * g + be;
-    if (relu) o = fmaxf(o, 0.f);
-    y[(long)p * C] = o;
+  unsigned am = 0u;   // (h2: the amax of Y as a by-product, tris_amax_next; every lane reaches the commit)
+  if (ok) {
+    float g = gamma[c], be = beta[c];
+    float* y = Y + (long)b * P * C + c;
+    for (int p = pg; p < P; p += 4) {
+      float o = (x[(long)p * C] - mean) * is * g + be;
+      if (relu) o = fmaxf(o, 0.f);
+      y[(long)p * C] = o;
+      am = max(am, __builtin_bit_cast(unsigned, o) & 0x7fffffffu);
+    }
+    if (pg == 0) { mean_out[(long)b * C + c] = mean; invstd_out[(long)b * C + c] = is; }
   }
-  if (pg == 0) { mean_out[(long)b * C + c] = mean; invstd_out[(long)b * C + c] = is; }
+  if (amax != nullptr) amax_commit(am, amax);
 }
 
 __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
                                                            const float* __restrict__ mean_in,
                                                            const float* __restrict__ invstd_in, float* __restrict__ dX,
                                                            float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
-                                                           int P, int C, int relu) {
+                                                           int P, int C, int relu, unsigned* __restrict__ amax = nullptr) {
   __shared__ float r0[4][64];
   __shared__ float r1[4][64];
   const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, pg = threadIdx.x >> 6;
@@ -556,15 +561,20 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
   __syncthreads();
   s0 = r0[0][cl] + r0[1][cl] + r0[2][cl] + r0[3][cl];
   s1 = r1[0][cl] + r1[1][cl] + r1[2][cl] + r1[3][cl];
-  if (!ok) return;
-  float ga = gamma[c], ip = 1.0f / (float)P;
-  for (int p = pg; p < P; p += 4) {
-    float g = dY[base + (long)p * C];
-    if (relu && !(Y[base + (long)p * C] > 0.f)) g = 0.f;
-    float xh = (X[base + (long)p * C] - mean) * is;
-    dX[base + (long)p * C] = ga * is * (g - s0 * ip - xh * s1 * ip);
+  unsigned am = 0u;   // (h2: the amax of dX as a by-product; every lane reaches the commit)
+  if (ok) {
+    float ga = gamma[c], ip = 1.0f / (float)P;
+    for (int p = pg; p < P; p += 4) {
+      float g = dY[base + (long)p * C];
+      if (relu && !(Y[base + (long)p * C] > 0.f)) g = 0.f;
+      float xh = (X[base + (long)p * C] - mean) * is;
+      const float d = ga * is * (g - s0 * ip - xh * s1 * ip);
+      dX[base + (long)p * C] = d;
+      am = max(am, __builtin_bit_cast(unsigned, d) & 0x7fffffffu);
+    }
+    if (pg == 0) { dgamma_part[(long)b * C + c] = s1; dbeta_part[(long)b * C + c] = s0; }
   }
-  if (pg == 0) { dgamma_part[(long)b * C + c] = s1; dbeta_part[(long)b * C + c] = s0; }
+  if (amax != nullptr) amax_commit(am, amax);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1115,7 +1125,7 @@ extern "C" int tris_colsum_f32(const float* X, long M, int N, long ld, float* ou
 extern "C" int tris_instnorm_fwd_f32(const float* X, const float* gamma, const float* beta, float* Y, float* mean,
                                      float* invstd, int B, int P, int C, float eps, int relu, void* stream) {
   hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, X, gamma, beta, Y,
-                     mean, invstd, P, C, eps, relu);
+                     mean, invstd, P, C, eps, relu, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }
@@ -1124,7 +1134,7 @@ extern "C" int tris_instnorm_bwd_f32(const float* dY, const float* Y, const floa
                                      const float* mean, const float* invstd, float* dX, float* dgamma_part,
                                      float* dbeta_part, int B, int P, int C, int relu, void* stream) {
   hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, dY, Y, X, gamma,
-                     mean, invstd, dX, dgamma_part, dbeta_part, P, C, relu);
+                     mean, invstd, dX, dgamma_part, dbeta_part, P, C, relu, take_amax_next());
   TRIS_LAUNCH_CHECK();
   return 0;
 }

@@ -2348,6 +2348,7 @@ class InstNormFn(torch.autograd.Function):
         B, Pp, C = x.shape
         y = torch.empty_like(x)
         st = torch.empty(2, B, C, device=x.device, dtype=torch.float32)
+        h2_mark_next(y)     # (h2: the launch leaves y's amax -- its consumers are dense products)
         call("tris_instnorm_fwd_f32", P(x), P(g), P(b), P(y), P(st), P(st, B * C), B, Pp, C, eps, int(relu), _stream())
         ctx.relu = bool(relu)
         ctx.params = (g, b)
@@ -2360,6 +2361,7 @@ class InstNormFn(torch.autograd.Function):
         B, Pp, C = x.shape
         dx = torch.empty_like(x)
         parts = torch.empty(2, B, C, device=x.device, dtype=torch.float32)
+        h2_mark_next(dx)
         call("tris_instnorm_bwd_f32", P(dy.contiguous()), P(y), P(x), P(g), P(st), P(st, B * C), P(dx), P(parts),
              P(parts, B * C), B, Pp, C, int(ctx.relu), _stream())
         dg = _emit(ctx.params[0], lambda o: colsum(parts[0], B, C, o), ctx.needs_input_grad[1], reads=(parts,))
